@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI in ``include/anatomix_amd.h`` (libanatomix_amd.so, built in-tree by
+``anatomix_amd/csrc/Makefile``).  There is no CPU implementation behind these symbols: if the
+shared library is missing the import of the HIP path fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libanatomix_amd.so")
+
+NORM = {"none": 0, "batch": 1, "instance": 2, "instance_affine": 3}
+ACT = {"none": 0, "relu": 1, "lrelu": 2}
+POOL = {"Max": 0, "Avg": 1}
+INTERP = {"nearest": 0, "trilinear": 1}
+PRECISION = {"f16": 0, "fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1}
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [
+        ("input_nc", C.c_int32), ("output_nc", C.c_int32), ("num_downs", C.c_int32), ("ngf", C.c_int32),
+        ("norm", C.c_int32), ("norm_eps", C.c_float), ("activation", C.c_int32), ("act_slope", C.c_float),
+        ("final_act", C.c_int32), ("pooling", C.c_int32), ("interp", C.c_int32), ("doubleconv", C.c_int32),
+        ("use_skip", C.c_int32), ("precision", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/anatomix_amd.h declares.
+_P = C.c_void_p
+_I = C.c_int
+SYMBOLS = {
+    "amx_version": (_I, []),
+    "amx_last_error": (C.c_char_p, []),
+    "amx_unet_create": (_I, [C.POINTER(_P), C.POINTER(UnetCfg)]),
+    "amx_unet_destroy": (None, [_P]),
+    "amx_unet_num_modules": (_I, [_P]),
+    "amx_unet_num_convs": (_I, [_P]),
+    "amx_unet_conv_info": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "amx_unet_load_conv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "amx_unet_workspace_bytes": (C.c_size_t, [_P, _I, _I, _I, _I]),
+    "amx_unet_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, _P]),
+    "amx_unet_forward_window": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
+    "amx_sw_normalize": (_I, [_P, _P, _I, C.c_longlong, _P]),
+    "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
+    "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_pool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class AmxError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and declare prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmxError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C anatomix_amd/csrc).  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        raise AmxError(f"anatomix_amd error {status}: {load().amx_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

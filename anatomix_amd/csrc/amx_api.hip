@@ -1,0 +1,477 @@
+// anatomix_amd -- C ABI (include/anatomix_amd.h) over the gfx950 kernels: layer plan, parameter
+// folding/packing, activation arena and the launch schedule of one UNet forward.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/anatomix_amd.h"
+#include "amx_common.h"
+
+namespace amx {
+hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st);
+hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
+                               int Cout, int Q, int precision, hipStream_t st);
+hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
+                            const float* conv_bias, float eps, int C, float* scale, float* shift,
+                            hipStream_t st);
+hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo, int C, int avg,
+                        int precision, hipStream_t st);
+hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long long voxels, hipStream_t st);
+hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
+                           int rw, const float* wmap, hipStream_t st);
+int conv_pick_q(int Cout, int W);
+}  // namespace amx
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define AMX_HIP(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(AMX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+enum Kind { K_CONV, K_NORM, K_ACT, K_POOL, K_UP, K_FINAL_ACT };
+
+struct ConvLayer {
+  int module_idx = 0, cin = 0, cout = 0, norm_idx = -1;
+  bool has_act = false, is_final = false;
+  int level = 0;          // resolution level the conv runs at (0 = full)
+  int q = 1;              // MFMA tiles per workgroup the weights are packed for
+  int cin_pad = 0;
+  void* wpk = nullptr;    // packed A fragments
+  float* scale = nullptr; // folded norm gain (applied to the weights at pack time)
+  float* shift = nullptr; // epilogue bias
+  bool loaded = false;
+};
+
+}  // namespace
+
+struct amx_unet {
+  amx_unet_cfg cfg;
+  std::vector<int> kinds;
+  std::vector<ConvLayer> convs;
+  std::vector<int> encoder_idx, decoder_idx;
+  int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Mirrors the list the reference constructor builds (anatomix/model/network.py:309-465): same
+// module order, hence the same integer indices in state_dict keys and encoder/decoder ids.
+void build_plan(amx_unet* h) {
+  const amx_unet_cfg& c = h->cfg;
+  const bool has_norm = c.norm != AMX_NORM_NONE, has_act = c.activation != AMX_ACT_NONE;
+  auto add_block = [&](int cin, int cout, int level) {
+    ConvLayer L;
+    L.module_idx = (int)h->kinds.size();
+    L.cin = cin;
+    L.cout = cout;
+    L.level = level;
+    h->kinds.push_back(K_CONV);
+    if (has_norm) {
+      L.norm_idx = (int)h->kinds.size();
+      h->kinds.push_back(K_NORM);
+    }
+    if (has_act) {
+      L.has_act = true;
+      h->kinds.push_back(K_ACT);
+    }
+    h->convs.push_back(L);
+  };
+  add_block(c.input_nc, c.ngf, 0);
+  int in_ngf = c.ngf;
+  for (int i = 0; i < c.num_downs; ++i) {
+    const int mult = i == 0 ? 1 : 2;
+    add_block(in_ngf, in_ngf * mult, i);
+    if (c.doubleconv) add_block(in_ngf * mult, in_ngf * mult, i);
+    h->encoder_idx.push_back((int)h->kinds.size() - 1);
+    h->kinds.push_back(K_POOL);
+    in_ngf *= mult;
+  }
+  add_block(in_ngf, in_ngf * 2, c.num_downs);
+  if (c.doubleconv) add_block(in_ngf * 2, in_ngf * 2, c.num_downs);
+  int mult = 1 << c.num_downs;
+  for (int i = 0; i < c.num_downs; ++i) {
+    h->decoder_idx.push_back((int)h->kinds.size());
+    h->kinds.push_back(K_UP);
+    const int m = c.use_skip ? mult + mult / 2 : mult;
+    const int level = c.num_downs - 1 - i;
+    add_block(c.ngf * m, c.ngf * (mult / 2), level);
+    if (c.doubleconv) add_block(c.ngf * (mult / 2), c.ngf * (mult / 2), level);
+    mult /= 2;
+  }
+  ConvLayer F;
+  F.module_idx = (int)h->kinds.size();
+  F.cin = c.ngf * mult;
+  F.cout = c.output_nc;
+  F.level = 0;
+  F.is_final = true;
+  h->kinds.push_back(K_CONV);
+  h->convs.push_back(F);
+  if (c.final_act != AMX_ACT_NONE) h->kinds.push_back(K_FINAL_ACT);
+}
+
+int level_channels(const amx_unet* h, int level) { return h->cfg.ngf << level; }
+
+struct Arena {
+  char* base;
+  size_t bytes;
+  std::vector<std::vector<char*>> slot;        // [level][3]
+  std::vector<std::vector<bool>> used;
+};
+
+size_t level_bytes(const amx_unet* h, int level, int n, int d, int hh, int w) {
+  const size_t vox = (size_t)(d >> level) * (hh >> level) * (w >> level);
+  return align_up((size_t)n * vox * level_channels(h, level) * 2, 256);
+}
+
+int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
+  const int L = h->cfg.num_downs;
+  if (n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  const int m = 1 << L;
+  if (d % m || hh % m || w % m)
+    return fail(AMX_ERR_SHAPE, "spatial dims (%d,%d,%d) must be divisible by 2^num_downs = %d", d, hh, w, m);
+  if ((d >> L) < 2 || (hh >> L) < 2 || (w >> L) < 2)
+    return fail(AMX_ERR_SHAPE, "bottleneck would be smaller than 2 voxels: reflect padding undefined");
+  return AMX_OK;
+}
+
+// One forward.  in_*: fp32 single-channel input view (byte strides); out: fp32 planar output view.
+int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
+                float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
+                const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
+                hipStream_t st) {
+  const amx_unet_cfg& c = h->cfg;
+  if (int e = check_shape(h, n, d, hh, w)) return e;
+  for (const ConvLayer& L : h->convs)
+    if (!L.loaded) return fail(AMX_ERR_NOT_LOADED, "conv model.%d has no parameters", L.module_idx);
+  const int NL = c.num_downs + 1;
+  size_t need = 0;
+  for (int l = 0; l < NL; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
+  if (ws_bytes < need || ((uintptr_t)ws & 255))
+    return fail(AMX_ERR_WORKSPACE, "workspace needs %zu bytes, 256-byte aligned (got %zu)", need, ws_bytes);
+
+  Arena A;
+  A.base = (char*)ws;
+  A.slot.resize(NL);
+  A.used.assign(NL, std::vector<bool>(3, false));
+  {
+    char* pcur = A.base;
+    for (int l = 0; l < NL; ++l)
+      for (int s = 0; s < 3; ++s) {
+        A.slot[l].push_back(pcur);
+        pcur += level_bytes(h, l, n, d, hh, w);
+      }
+  }
+  auto grab = [&](int level) -> int {
+    for (int s = 0; s < 3; ++s)
+      if (!A.used[level][s]) {
+        A.used[level][s] = true;
+        return s;
+      }
+    return -1;
+  };
+
+  struct Tensor { int level = 0, slot = -1, C = 0; };
+  Tensor cur;              // current activation (slot -1: the fp32 network input)
+  bool have_cur_up = false;  // cur is to be read through a x2 upsample by the next conv
+  std::vector<Tensor> skips;
+  Tensor pend_skip;
+  bool have_skip = false;
+  size_t conv_i = 0;
+
+  for (size_t i = 0; i < h->kinds.size(); ++i) {
+    const int kind = h->kinds[i];
+    if (kind == K_CONV) {
+      const ConvLayer& L = h->convs[conv_i++];
+      const int lv = L.level;
+      const int dd = d >> lv, dh = hh >> lv, dw = w >> lv;
+      amx::ConvParams p;
+      memset(&p, 0, sizeof p);
+      p.N = n; p.D = dd; p.H = dh; p.W = dw; p.Cout = L.cout;
+      if (cur.slot < 0) {  // stem: fp32 single-channel input
+        p.src0 = (const char*)x;
+        p.s0n = xs_n; p.s0z = xs_z; p.s0y = xs_y; p.s0x = 4;
+        p.C0 = 16; p.C1 = 0; p.src0_f32c1 = 1;
+      } else if (have_cur_up) {
+        const Tensor& lo = cur;
+        const long long lx = (long long)lo.C * 2, ly = lx * (dw / 2), lz = ly * (dh / 2);
+        if (have_skip) {
+          const long long sx = (long long)pend_skip.C * 2, sy = sx * dw, sz = sy * dh;
+          p.src0 = A.slot[pend_skip.level][pend_skip.slot];
+          p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = pend_skip.C;
+          p.src1 = A.slot[lo.level][lo.slot];
+          p.s1n = lz * (dd / 2); p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+        } else {  // no skip connection: the whole input is the upsampled tensor
+          p.src0 = A.slot[lo.level][lo.slot];  // unused segment of zero channels
+          p.C0 = 0;
+          p.src1 = A.slot[lo.level][lo.slot];
+          p.s1n = lz * (dd / 2); p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+        }
+      } else {
+        const long long sx = (long long)cur.C * 2, sy = sx * dw, sz = sy * dh;
+        p.src0 = A.slot[cur.level][cur.slot];
+        p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = cur.C; p.C1 = 0;
+      }
+      if (p.C0 + p.C1 != L.cin_pad)
+        return fail(AMX_ERR_INVALID, "internal: conv model.%d expects %d channels, schedule has %d",
+                    L.module_idx, L.cin_pad, p.C0 + p.C1);
+      p.wpk = (const char*)L.wpk;
+      p.bias = L.shift;
+      p.act = L.has_act ? c.activation : AMX_ACT_NONE;
+      p.slope = c.act_slope;
+      Tensor out;
+      out.level = lv; out.C = L.cout;
+      if (L.is_final) {
+        if (c.final_act != AMX_ACT_NONE) p.act = c.final_act;
+        p.out32 = y;
+        p.pn = ys_n; p.pc = ys_c; p.pz = ys_z; p.py = ys_y;
+        p.wmap = wmap;
+      } else {
+        out.slot = grab(lv);
+        if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
+        p.out = A.slot[lv][out.slot];
+        p.ox = (long long)L.cout * 2; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
+      }
+      AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
+      // inputs are dead once their consumer is enqueued (stream order)
+      if (cur.slot >= 0) A.used[cur.level][cur.slot] = false;
+      if (have_skip) A.used[pend_skip.level][pend_skip.slot] = false;
+      have_skip = false;
+      have_cur_up = false;
+      cur = out;
+      // skip to past the fused norm / activation modules
+      if (L.norm_idx >= 0) ++i;
+      if (L.has_act) ++i;
+      // encoder_idx marks the module AFTER which the skip is pushed (network.py:546-547)
+      for (int e : h->encoder_idx)
+        if (e == (int)i && c.use_skip) {
+          skips.push_back(cur);
+          // keep it alive: mark as used by skip (cur release below must not free it)
+        }
+    } else if (kind == K_POOL) {
+      const int lv = cur.level + 1;
+      Tensor out;
+      out.level = lv; out.C = cur.C; out.slot = grab(lv);
+      if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
+      AMX_HIP(amx::launch_pool2(A.slot[cur.level][cur.slot], A.slot[lv][out.slot], n, d >> lv, hh >> lv,
+                                w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st));
+      // the pooled-from tensor stays alive only if it was pushed as a skip
+      bool is_skip = false;
+      for (const Tensor& s : skips)
+        if (s.level == cur.level && s.slot == cur.slot) is_skip = true;
+      if (!is_skip) A.used[cur.level][cur.slot] = false;
+      cur = out;
+    } else if (kind == K_UP) {
+      if (c.interp != AMX_INTERP_NEAREST)
+        return fail(AMX_ERR_INVALID, "interp='trilinear' is not implemented in the HIP path yet");
+      have_cur_up = true;
+      if (c.use_skip) {
+        pend_skip = skips.back();
+        skips.pop_back();
+        have_skip = true;
+      }
+    } else if (kind == K_FINAL_ACT) {
+      // fused into the last conv's epilogue
+    }
+  }
+  return AMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amx_version(void) { return AMX_VERSION; }
+const char* amx_last_error(void) { return g_err.c_str(); }
+
+int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
+  if (!out || !cfg) return fail(AMX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->num_downs < 1 || cfg->num_downs > 7 || cfg->ngf < 16 || cfg->ngf % 16)
+    return fail(AMX_ERR_INVALID, "ngf must be a positive multiple of 16 and 1 <= num_downs <= 7 (got ngf=%d num_downs=%d)",
+                cfg->ngf, cfg->num_downs);
+  if (cfg->input_nc != 1) return fail(AMX_ERR_INVALID, "HIP path supports input_nc == 1 (got %d)", cfg->input_nc);
+  if (cfg->output_nc < 16 || cfg->output_nc % 16)
+    return fail(AMX_ERR_INVALID, "output_nc must be a multiple of 16 (got %d)", cfg->output_nc);
+  if (cfg->norm != AMX_NORM_NONE && cfg->norm != AMX_NORM_BATCH_EVAL)
+    return fail(AMX_ERR_INVALID, "norm mode %d is not implemented in the HIP path yet (batch/eval and none are)", cfg->norm);
+  if (cfg->activation < AMX_ACT_NONE || cfg->activation > AMX_ACT_LRELU || cfg->final_act < AMX_ACT_NONE ||
+      cfg->final_act > AMX_ACT_LRELU)
+    return fail(AMX_ERR_INVALID, "unsupported activation");
+  if (cfg->precision != AMX_PREC_F16 && cfg->precision != AMX_PREC_BF16)
+    return fail(AMX_ERR_INVALID, "unsupported precision %d", cfg->precision);
+  amx_unet* h = new amx_unet();
+  h->cfg = *cfg;
+  build_plan(h);
+  h->pack_w = 128;
+  for (ConvLayer& L : h->convs) {
+    L.cin_pad = (L.cin + 15) / 16 * 16;
+    // Q is chosen for the reference operating point (128^3 windows): level l runs at W = 128>>l.
+    const int w_at = h->pack_w >> L.level;
+    L.q = amx::conv_pick_q(L.cout, w_at > 0 ? w_at : 1);
+    const size_t wbytes = (size_t)L.cout * L.cin_pad * 28 * 2;
+    hipError_t e = hipMalloc(&L.wpk, wbytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
+    if (e != hipSuccess) {
+      amx_unet_destroy(h);
+      return fail(AMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
+  }
+  *out = h;
+  return AMX_OK;
+}
+
+void amx_unet_destroy(amx_unet_t* h) {
+  if (!h) return;
+  for (ConvLayer& L : h->convs) {
+    if (L.wpk) (void)hipFree(L.wpk);
+    if (L.scale) (void)hipFree(L.scale);
+    if (L.shift) (void)hipFree(L.shift);
+  }
+  delete h;
+}
+
+int amx_unet_num_modules(const amx_unet_t* h) { return h ? (int)h->kinds.size() : fail(AMX_ERR_INVALID, "null handle"); }
+int amx_unet_num_convs(const amx_unet_t* h) { return h ? (int)h->convs.size() : fail(AMX_ERR_INVALID, "null handle"); }
+
+int amx_unet_conv_info(const amx_unet_t* h, int conv, int* module_idx, int* cin, int* cout, int* norm_module_idx) {
+  if (!h || conv < 0 || conv >= (int)h->convs.size()) return fail(AMX_ERR_INVALID, "bad conv index %d", conv);
+  const ConvLayer& L = h->convs[conv];
+  if (module_idx) *module_idx = L.module_idx;
+  if (cin) *cin = L.cin;
+  if (cout) *cout = L.cout;
+  if (norm_module_idx) *norm_module_idx = L.norm_idx;
+  return AMX_OK;
+}
+
+int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, const float* d_bias,
+                       const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var,
+                       void* stream) {
+  if (!h || !d_weight) return fail(AMX_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (ConvLayer& L : h->convs) {
+    if (L.module_idx != module_idx) continue;
+    const bool bn = L.norm_idx >= 0 && h->cfg.norm == AMX_NORM_BATCH_EVAL;
+    if (bn && (!d_mean || !d_var)) return fail(AMX_ERR_INVALID, "model.%d: BatchNorm running stats required", module_idx);
+    AMX_HIP(amx::launch_fold_norm(bn ? d_gamma : nullptr, bn ? d_beta : nullptr, bn ? d_mean : nullptr,
+                                  bn ? d_var : nullptr, d_bias, h->cfg.norm_eps, L.cout, L.scale, L.shift, st));
+    AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
+                                     h->cfg.precision, st));
+    L.loaded = true;
+    return AMX_OK;
+  }
+  return fail(AMX_ERR_INVALID, "model.%d is not a convolution of this network", module_idx);
+}
+
+size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int hh, int w) {
+  if (!h) return 0;
+  size_t need = 0;
+  for (int l = 0; l <= h->cfg.num_downs; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
+  return need;
+}
+
+int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                     void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !d_x || !d_y || !d_workspace) return fail(AMX_ERR_INVALID, "null argument");
+  const long long vox = (long long)d * hh * w;
+  return run_forward(h, d_x, vox * 4, (long long)hh * w * 4, (long long)w * 4, d_y,
+                     vox * h->cfg.output_nc, vox, (long long)hh * w, w, nullptr, n, d, hh, w, d_workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+int amx_unet_forward_window(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int oz, int oy,
+                            int ox, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                            void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !d_vol || !d_acc || !d_wmap || !d_workspace) return fail(AMX_ERR_INVALID, "null argument");
+  if (oz < 0 || oy < 0 || ox < 0 || oz + rd > vd || oy + rh > vh || ox + rw > vw)
+    return fail(AMX_ERR_SHAPE, "window (%d,%d,%d)+(%d,%d,%d) outside volume (%d,%d,%d)", oz, oy, ox, rd, rh, rw, vd, vh, vw);
+  const long long vvox = (long long)vd * vh * vw;
+  const long long off = ((long long)oz * vh + oy) * vw + ox;
+  return run_forward(h, d_vol + off, vvox * 4, (long long)vh * vw * 4, (long long)vw * 4, d_acc + off,
+                     vvox * h->cfg.output_nc, vvox, (long long)vh * vw, vw, d_wmap, 1, rd, rh, rw,
+                     d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream) {
+  if (!d_acc || !d_cnt || channels < 1 || voxels < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_sw_normalize(d_acc, d_cnt, channels, voxels, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_sw_count(float* d_cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh, int rw,
+                 const float* d_wmap, void* stream) {
+  if (!d_cnt || !d_wmap) return fail(AMX_ERR_INVALID, "null argument");
+  if (oz < 0 || oy < 0 || ox < 0 || oz + rd > vd || oy + rh > vh || ox + rw > vw)
+    return fail(AMX_ERR_SHAPE, "window outside volume");
+  AMX_HIP(amx::launch_sw_count(d_cnt, vd, vh, vw, oz, oy, ox, rd, rh, rw, d_wmap, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_conv3d_packed_bytes(int cin, int cout) {
+  const int cin_pad = (cin + 15) / 16 * 16;
+  return (size_t)cout * cin_pad * 28 * 2;
+}
+
+int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
+                          const float* d_scale, const float* d_shift, int cout, int n, int d, int hh, int w,
+                          int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
+                          void* stream) {
+  if (!d_x0 || !d_weight || !d_wpk || (!d_out16 == !d_out32)) return fail(AMX_ERR_INVALID, "bad pointer arguments");
+  if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16)
+    return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
+  if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
+  if (d < 2 || hh < 2 || w < 2) return fail(AMX_ERR_SHAPE, "reflect padding needs >= 2 voxels per axis");
+  hipStream_t st = (hipStream_t)stream;
+  const int q = amx::conv_pick_q(cout, w);
+  if (d_out32 && (q > 2 || w < 32)) return fail(AMX_ERR_INVALID, "fp32 planar output needs cout <= 32 and w >= 32");
+  AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, c0 + c1, c0 + c1, cout, q, precision, st));
+  amx::ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
+  p.src0 = (const char*)d_x0; p.C0 = c0;
+  p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
+  if (c1) {
+    p.src1 = (const char*)d_x1; p.C1 = c1;
+    p.s1x = (long long)c1 * 2; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
+  }
+  p.wpk = (const char*)d_wpk;
+  p.bias = d_shift;
+  p.act = act; p.slope = slope;
+  if (d_out16) {
+    p.out = (char*)d_out16;
+    p.ox = (long long)cout * 2; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+  } else {
+    p.out32 = d_out32;
+    p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
+  }
+  AMX_HIP(amx::launch_conv(p, precision, q, st));
+  return AMX_OK;
+}
+
+int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout, int c, int avg, int precision,
+              void* stream) {
+  if (!d_in || !d_out || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_pool2(d_in, d_out, n, dout, hout, wout, c, avg, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// anatomix_amd -- internal shared declarations (device + host) for the gfx950 UNet path.
+// Not part of the public C ABI (that is include/anatomix_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amx {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// 3x3x3 taps are consumed two at a time (K = 32 = 2 taps x 16 channels per MFMA step).
+// Step s pairs tap A (lane groups 0,1) with tap B (lane groups 2,3); the pairing is chosen so
+// that B's LDS address is A's plus a per-step-class constant (1 voxel, one halo row, one halo
+// slab), which lets every ds_read use a lane-constant base + immediate offset.
+//   s 0..8  : (kz,ky,0) + (kz,ky,1)        kz = s/3, ky = s%3     delta = 1 voxel
+//   s 9..11 : (kz,0,2)  + (kz,1,2)         kz = s-9               delta = halo row
+//   s 12    : (0,2,2)   + (1,2,2)                                 delta = halo slab
+//   s 13    : (2,2,2)   + <zero weights>                          delta = 0
+constexpr int kSteps = 14;
+
+__host__ __device__ constexpr int tapA_index(int s) {           // index into [kz][ky][kx]
+  return s < 9 ? s * 3 : (s < 12 ? (s - 9) * 9 + 2 : (s == 12 ? 8 : 26));
+}
+__host__ __device__ constexpr int tapB_index(int s) {           // -1: no tap (zero weights)
+  return s < 9 ? s * 3 + 1 : (s < 12 ? (s - 9) * 9 + 5 : (s == 12 ? 17 : -1));
+}
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+// Parameters of one 3x3x3 reflect-padded convolution launch.  All tensors are channels-last
+// (N, D, H, W, C) 16-bit unless noted.  Strides are in BYTES.
+struct ConvParams {
+  const char* src0;            // first Cin segment (skip / sole input), full resolution
+  const char* src1;            // second Cin segment, HALF resolution, read through nearest x2
+  long long s0n, s0z, s0y, s0x;
+  long long s1n, s1z, s1y, s1x;
+  int C0, C1;                  // channels per segment (multiples of 16); Cin = C0 + C1
+  int src0_f32c1;              // 1: src0 is a single-channel fp32 volume (network input)
+  const char* wpk;             // packed A fragments [cout_group][chunk][step][q][lane][8]
+  const float* bias;           // [Cout] fp32 (folded norm shift / conv bias)
+  char* out;                   // 16-bit NDHWC output (OUTMODE 0)
+  long long on, oz, oy, ox;
+  float* out32;                // fp32 planar output (OUTMODE 1): [n][c][z][y][x], x contiguous
+  long long pn, pc, pz, py;    // element strides of out32
+  const float* wmap;           // optional importance map [D][H][W]: out32 += wmap * value
+  int N, D, H, W, Cout;
+  int act;
+  float slope;
+  int nbz, nby, nbx;           // bricks per axis
+  float* stats;                // optional per-(n,c) {sum, sumsq} fp32 accumulators (instance norm)
+};
+
+}  // namespace amx

@@ -1,0 +1,53 @@
+"""Variant registry and checkpoint loading with the surface of
+``anatomix.model.load_from_hf`` (reference: anatomix/model/load_from_hf.py:11-79).
+
+The Hub download itself needs network access; everything after it (variant -> constructor kwargs,
+``_orig_mod.`` prefix stripping, ``load_state_dict(strict=True)``) is reproduced so that a local
+``.pth`` can be loaded with ``load_from_hf(variant, weights_path=...)``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .network import Unet
+
+DEFAULT_REPO = "neeldey/anatomix"
+
+# load_from_hf.py:11-36 -- constructor kwargs per published variant.
+ANATOMIX_VARIANTS = {
+    "anatomix": {
+        "unet_kwargs": dict(dimension=3, input_nc=1, output_nc=16, num_downs=4, ngf=16),
+        "output_channels": 16,
+    },
+    "anatomix-dev": {
+        "unet_kwargs": dict(dimension=3, input_nc=1, output_nc=32, num_downs=5, ngf=32, norm="instance",
+                            pooling="Avg", interp="trilinear", norm_eps=1e-2),
+        "output_channels": 32,
+    },
+}
+
+
+def _load_handling_compile(model, state_dict):
+    """load_from_hf.py:39-49: accept checkpoints saved from a torch.compile()-wrapped module."""
+    if state_dict and next(iter(state_dict)).startswith("_orig_mod."):
+        state_dict = {k.removeprefix("_orig_mod."): v for k, v in state_dict.items()}
+    model.load_state_dict(state_dict, strict=True)
+    return model
+
+
+def build_variant(variant):
+    """Un-initialised model of a registered variant."""
+    if variant not in ANATOMIX_VARIANTS:
+        raise ValueError(f"Unknown variant {variant!r}. Known: {sorted(ANATOMIX_VARIANTS)}")
+    return Unet(**ANATOMIX_VARIANTS[variant]["unet_kwargs"])
+
+
+def load_from_hf(variant, repo_id=DEFAULT_REPO, revision=None, map_location="cpu", weights_path=None):
+    """load_from_hf.py:52-79.  ``weights_path`` (extension) loads a local ``<variant>.pth`` instead of
+    downloading it."""
+    model = build_variant(variant)
+    if weights_path is None:
+        from huggingface_hub import hf_hub_download   # needs network access
+        weights_path = hf_hub_download(repo_id, f"{variant}.pth", revision=revision)
+    state_dict = torch.load(weights_path, map_location=map_location)
+    return _load_handling_compile(model, state_dict)

@@ -1,0 +1,313 @@
+"""Drop-in mirror of ``anatomix.model.network`` (reference: anatomix/model/network.py) whose
+inference forward runs on hand-written gfx950 kernels through the C ABI of
+``include/anatomix_amd.h``.
+
+What is kept from the reference surface:
+  * ``Unet(dimension, input_nc, output_nc, num_downs, ngf=24, norm='batch', final_act='none',
+    activation='relu', pad_type='reflect', doubleconv=True, residual_connection=False,
+    pooling='Max', interp='nearest', use_skip_connection=True, norm_eps=1e-5)`` -- same
+    positional order and defaults as network.py:262-279;
+  * ``.model`` is an ``nn.Sequential`` of real ``nn.Conv3d / nn.BatchNorm3d / nn.ReLU / nn.MaxPool3d /
+    nn.Upsample`` children at the same integer indices, so ``state_dict`` keys, ``load_state_dict(
+    strict=True)``, ``.apply(init_fn)``, ``for i, layer in enumerate(net.model)`` all behave
+    identically (network.py:465);
+  * ``encoder_idx / decoder_idx / res_source / res_dest / use_bias / use_skip_connection /
+    residual_connection`` attributes and the two constructor prints (network.py:447-448);
+  * ``forward(input, layers=[], encode_only=False, verbose=False)`` (network.py:467).
+
+What is different: for CUDA(ROCm) inputs under ``torch.no_grad()``/eval the forward is ONE call
+into libanatomix_amd.so (20 fused conv launches + 4 pools for the 6M model) instead of 66 module
+calls.  Anything the HIP path does not cover yet (autograd, train-mode BatchNorm, ``layers`` taps,
+CPU tensors) raises, unless the stock-module path is explicitly enabled with
+``model.allow_torch_path = True`` (or env AMX_ALLOW_TORCH_PATH=1).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import warnings
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+def get_norm_layer(ndims, norm="batch", eps=1e-5):
+    """Same contract as network.py:127-168: returns a callable ``Norm(num_features)`` or None."""
+    table = {
+        "batch": lambda: partial(getattr(nn, f"BatchNorm{ndims}d"), eps=eps),
+        "instance": lambda: partial(getattr(nn, f"InstanceNorm{ndims}d"), eps=eps),
+        "instance_affine": lambda: partial(getattr(nn, f"InstanceNorm{ndims}d"), affine=True, eps=eps),
+        "none": lambda: None,
+    }
+    if norm not in table:
+        raise ValueError(f"Currently unsupported normalization: {norm}")
+    return table[norm]()
+
+
+def get_actvn_layer(activation="relu"):
+    """Same contract as network.py:171-204 (one module instance, shared by every site)."""
+    makers = {
+        "relu": lambda: nn.ReLU(inplace=True),
+        "lrelu": lambda: nn.LeakyReLU(0.3, inplace=True),
+        "elu": nn.ELU,
+        "prelu": nn.PReLU,
+        "selu": lambda: nn.SELU(inplace=True),
+        "tanh": nn.Tanh,
+        "none": lambda: None,
+    }
+    assert activation in makers, "Unsupported activation: {}".format(activation)
+    return makers[activation]()
+
+
+class Unet(nn.Module):
+    """MI355X-native U-Net with the constructor / state_dict / forward surface of the reference
+    ``anatomix.model.network.Unet`` (network.py:210-548)."""
+
+    def __init__(self, dimension, input_nc, output_nc, num_downs, ngf=24, norm="batch", final_act="none",
+                 activation="relu", pad_type="reflect", doubleconv=True, residual_connection=False,
+                 pooling="Max", interp="nearest", use_skip_connection=True, norm_eps=1e-5):
+        super().__init__()
+        assert dimension in [1, 2, 3], "ndims should be 1--3. found: %d" % dimension
+        self.use_bias = norm == "instance"          # network.py:292
+        self.residual_connection = residual_connection
+        self.use_skip_connection = use_skip_connection
+        self.res_source, self.res_dest = [], []
+        self.encoder_idx, self.decoder_idx = [], []
+        self._cfg = dict(dimension=dimension, input_nc=input_nc, output_nc=output_nc, num_downs=num_downs,
+                         ngf=ngf, norm=norm, final_act=final_act, activation=activation, pad_type=pad_type,
+                         doubleconv=doubleconv, residual_connection=residual_connection, pooling=pooling,
+                         interp=interp, use_skip_connection=use_skip_connection, norm_eps=norm_eps)
+
+        Conv = getattr(nn, "Conv%dd" % dimension)
+        Pool = getattr(nn, "%sPool%dd" % (pooling, dimension))
+        Norm = get_norm_layer(dimension, norm, eps=norm_eps)
+        act = get_actvn_layer(activation)          # ONE shared instance, as in the reference
+        final = get_actvn_layer(final_act)
+        seq = []
+
+        def block(cin, cout):
+            """conv -> norm -> act, recording the residual source/destination indices."""
+            seq.append(Conv(cin, cout, kernel_size=3, stride=1, bias=self.use_bias, padding="same",
+                            padding_mode=pad_type))
+            self.res_source.append(len(seq) - 1)
+            if Norm is not None:
+                seq.append(Norm(cout))
+            if act is not None:
+                seq.append(act)
+            self.res_dest.append(len(seq) - 1)
+
+        block(input_nc, ngf)                                        # stem
+        width = ngf
+        for level in range(num_downs):                              # encoder
+            grow = 1 if level == 0 else 2
+            block(width, width * grow)
+            if doubleconv:
+                block(width * grow, width * grow)
+            self.encoder_idx.append(len(seq) - 1)
+            seq.append(Pool(2))
+            width *= grow
+        block(width, width * 2)                                     # bottleneck
+        if doubleconv:
+            block(width * 2, width * 2)
+        mult = 2 ** num_downs
+        for _ in range(num_downs):                                  # decoder
+            self.decoder_idx.append(len(seq))
+            seq.append(nn.Upsample(scale_factor=2, mode=interp))
+            cat_mult = mult + mult // 2 if use_skip_connection else mult
+            block(ngf * cat_mult, ngf * (mult // 2))
+            if doubleconv:
+                block(ngf * (mult // 2), ngf * (mult // 2))
+            mult //= 2
+        print("Encoder skip connect id", self.encoder_idx)
+        print("Decoder skip connect id", self.decoder_idx)
+        seq.append(Conv(ngf * mult, output_nc, kernel_size=3, stride=1, bias=self.use_bias, padding="same",
+                        padding_mode=pad_type))                    # bare output conv
+        if final is not None:
+            seq.append(final)
+        self.model = nn.Sequential(*seq)
+
+        # ---- HIP-path state (not part of the reference surface)
+        self.precision = os.environ.get("AMX_PRECISION", "f16")
+        self.allow_torch_path = os.environ.get("AMX_ALLOW_TORCH_PATH", "0") == "1"
+        self._handle = None
+        self._handle_key = None
+        self._weights_dirty = True
+        self._workspace = None
+        self._warned = False
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+
+    # ------------------------------------------------------------------------------------------
+    # bookkeeping: repack weights whenever parameters may have changed
+    # ------------------------------------------------------------------------------------------
+    def _mark_dirty(self):
+        self._weights_dirty = True
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place (e.g. a manual ``param.data.copy_``)."""
+        self._mark_dirty()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._mark_dirty()
+        self._workspace = None
+        return out
+
+    def train(self, mode=True):
+        self._mark_dirty()
+        return super().train(mode)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().amx_unet_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    # HIP path
+    # ------------------------------------------------------------------------------------------
+    def hip_unsupported_reason(self, x, layers=()):
+        """None if this call can run on the HIP kernels, else a human-readable reason."""
+        c = self._cfg
+        if not x.is_cuda:
+            return "input is not on a GPU device"
+        if len(layers) > 0:
+            return "feature taps (`layers`) are not implemented in the HIP path yet"
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return "autograd is enabled (wrap inference in torch.no_grad()); backward kernels are not implemented yet"
+        if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
+            return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
+        if c["norm"] == "batch" and self.training:
+            return "BatchNorm in train mode (batch statistics) is not implemented in the HIP path yet; call .eval()"
+        if c["norm"] not in ("batch", "none"):
+            return f"norm='{c['norm']}' is not implemented in the HIP path yet"
+        if c["activation"] not in _lib.ACT or c["final_act"] not in _lib.ACT:
+            return "activation not implemented in the HIP path"
+        if c["interp"] != "nearest":
+            return f"interp='{c['interp']}' is not implemented in the HIP path yet"
+        if c["input_nc"] != 1 or c["ngf"] % 16 or c["output_nc"] % 16:
+            return "HIP path needs input_nc == 1 and ngf, output_nc multiples of 16"
+        if x.dim() != 5 or x.shape[1] != 1:
+            return "expected input of shape [N, 1, D, H, W]"
+        return None
+
+    def _ensure_handle(self, device):
+        lib = _lib.load()
+        key = (device.index, self.precision)
+        if self._handle is not None and self._handle_key == key:
+            return lib
+        if self._handle is not None:
+            lib.amx_unet_destroy(self._handle)
+            self._handle = None
+        c = self._cfg
+        cfg = _lib.UnetCfg(
+            input_nc=c["input_nc"], output_nc=c["output_nc"], num_downs=c["num_downs"], ngf=c["ngf"],
+            norm=_lib.NORM[c["norm"]], norm_eps=float(c["norm_eps"]), activation=_lib.ACT[c["activation"]],
+            act_slope=0.3, final_act=_lib.ACT[c["final_act"]], pooling=_lib.POOL[c["pooling"]],
+            interp=_lib.INTERP[c["interp"]], doubleconv=int(bool(c["doubleconv"])),
+            use_skip=int(bool(c["use_skip_connection"])), precision=_lib.PRECISION[self.precision])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.amx_unet_create(ctypes.byref(h), ctypes.byref(cfg)))
+        self._handle, self._handle_key = h, key
+        self._weights_dirty = True
+        return lib
+
+    def _upload_weights(self, lib, device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        keep = []   # fp32 staging copies must outlive the enqueued pack kernels (same stream => safe)
+        nconv = lib.amx_unet_num_convs(self._handle)
+        mi, ci, co, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+
+        def dev32(t):
+            if t is None:
+                return None
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        for k in range(nconv):
+            _lib.check(lib.amx_unet_conv_info(self._handle, k, ctypes.byref(mi), ctypes.byref(ci),
+                                              ctypes.byref(co), ctypes.byref(ni)))
+            conv = self.model[mi.value]
+            w, b = dev32(conv.weight), dev32(conv.bias)
+            g = be = mu = var = None
+            if ni.value >= 0:
+                nm = self.model[ni.value]
+                g, be = dev32(getattr(nm, "weight", None)), dev32(getattr(nm, "bias", None))
+                mu, var = dev32(getattr(nm, "running_mean", None)), dev32(getattr(nm, "running_var", None))
+            _lib.check(lib.amx_unet_load_conv(self._handle, mi.value, _lib.ptr(w), _lib.ptr(b), _lib.ptr(g),
+                                              _lib.ptr(be), _lib.ptr(mu), _lib.ptr(var), stream))
+        self._weights_dirty = False
+
+    def _get_workspace(self, lib, n, d, h, w, device):
+        need = lib.amx_unet_workspace_bytes(self._handle, n, d, h, w)
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws, need
+
+    def forward_hip(self, x):
+        """[N,1,D,H,W] -> [N,output_nc,D,H,W] fp32, all work enqueued on the current HIP stream."""
+        device = x.device
+        lib = self._ensure_handle(device)
+        with torch.cuda.device(device):
+            if self._weights_dirty:
+                self._upload_weights(lib, device)
+            xin = x.detach()
+            if xin.dtype != torch.float32 or not xin.is_contiguous():
+                xin = xin.float().contiguous()
+            n, _, d, h, w = xin.shape
+            ws, need = self._get_workspace(lib, n, d, h, w, device)
+            y = torch.empty((n, self._cfg["output_nc"], d, h, w), dtype=torch.float32, device=device)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.amx_unet_forward(self._handle, _lib.ptr(xin), _lib.ptr(y), n, d, h, w, _lib.ptr(ws),
+                                            need, stream))
+        return y if x.dtype == torch.float32 else y.to(x.dtype)
+
+    # ------------------------------------------------------------------------------------------
+    # stock-module path (explicit opt-in): same traversal as network.py:467-548
+    # ------------------------------------------------------------------------------------------
+    def _forward_torch(self, x, layers, encode_only, verbose):
+        feat, feats, pending_skips = x, [], []
+        saved = None
+        want = len(layers) > 0
+        for idx, layer in enumerate(self.model):
+            feat = layer(feat)
+            if verbose and want:
+                print(idx, layer.__class__.__name__, feat.size())
+            if self.residual_connection and idx in self.res_source:
+                saved = feat
+            if self.residual_connection and idx in self.res_dest:
+                assert saved.size() == feat.size()
+                feat = feat + 0.1 * saved
+            if self.use_skip_connection:
+                if idx in self.decoder_idx:
+                    feat = torch.cat((pending_skips.pop(), feat), dim=1)
+                if idx in self.encoder_idx:
+                    pending_skips.append(feat)
+            if want:
+                if idx in layers:
+                    feats.append(feat)
+                if encode_only and idx == layers[-1]:
+                    return feats
+        return (feat, feats) if want else feat
+
+    def forward(self, input, layers=[], encode_only=False, verbose=False):
+        """Same call contract as network.py:467: tensor without ``layers``; ``(out, feats)`` with
+        ``layers``; ``feats`` alone with ``encode_only``."""
+        reason = self.hip_unsupported_reason(input, layers)
+        if reason is None:
+            return self.forward_hip(input)
+        if not self.allow_torch_path:
+            raise RuntimeError(
+                "anatomix_amd.Unet: this call cannot run on the HIP kernels (" + reason + "). Set "
+                "model.allow_torch_path = True (or AMX_ALLOW_TORCH_PATH=1) to run it on the stock torch modules.")
+        if not self._warned:
+            warnings.warn("anatomix_amd.Unet: running on stock torch modules: " + reason)
+            self._warned = True
+        return self._forward_torch(input, layers, encode_only, verbose)

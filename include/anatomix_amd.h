@@ -1,0 +1,131 @@
+/* anatomix_amd -- public C ABI of the MI355X (gfx950) anatomix UNet feature-extraction path.
+ *
+ * The reference (neel-dey/anatomix) is pure Python and has no FFI: its boundary for this path is
+ * the nn.Module surface of anatomix.model.network.Unet.  Each entry point below names the
+ * reference interface it stands in for (paths relative to the reference checkout).  The Python
+ * mirror anatomix_amd.model.network.Unet binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (PyTorch's allocator);
+ *     the library owns only its packed-weight buffers (allocated at amx_unet_create/load);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it and
+ *     the library never synchronises, so calls are capturable in a hipGraph;
+ *   - every function returns 0 on success or a negative amx_status; amx_last_error() gives the
+ *     message of the last failure on the calling thread.  Nothing aborts or throws;
+ *   - a handle is not thread-safe; use one handle per module per device.
+ */
+#ifndef ANATOMIX_AMD_H
+#define ANATOMIX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMX_VERSION 100 /* 0.1.0 */
+
+typedef enum amx_status {
+  AMX_OK = 0,
+  AMX_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+  AMX_ERR_SHAPE = -2,       /* spatial size not divisible by 2^num_downs, bottleneck < 2, ... */
+  AMX_ERR_NOT_LOADED = -3,  /* forward before every conv received its parameters */
+  AMX_ERR_WORKSPACE = -4,   /* workspace too small / misaligned */
+  AMX_ERR_HIP = -5          /* a HIP runtime call failed */
+} amx_status;
+
+enum { AMX_NORM_NONE = 0, AMX_NORM_BATCH_EVAL = 1, AMX_NORM_INSTANCE = 2, AMX_NORM_INSTANCE_AFFINE = 3 };
+enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_LRELU = 2 };
+enum { AMX_POOL_MAX = 0, AMX_POOL_AVG = 1 };
+enum { AMX_INTERP_NEAREST = 0, AMX_INTERP_TRILINEAR = 1 };
+enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1 };
+
+/* Constructor arguments of anatomix/model/network.py:262-279 (Unet.__init__) that shape the
+ * arithmetic.  dimension is fixed at 3, pad_type at 'reflect', residual_connection at False. */
+typedef struct amx_unet_cfg {
+  int32_t input_nc;       /* network.py:265 */
+  int32_t output_nc;      /* network.py:266 */
+  int32_t num_downs;      /* network.py:267 */
+  int32_t ngf;            /* network.py:268 */
+  int32_t norm;           /* AMX_NORM_*   <- norm=      network.py:269,127-168 */
+  float norm_eps;         /*              <- norm_eps=  network.py:278 */
+  int32_t activation;     /* AMX_ACT_*    <- activation= network.py:271,171-204 */
+  float act_slope;        /* 0.3 for 'lrelu' (network.py:191) */
+  int32_t final_act;      /* AMX_ACT_*    <- final_act= network.py:270 */
+  int32_t pooling;        /* AMX_POOL_*   <- pooling=   network.py:275,297 */
+  int32_t interp;         /* AMX_INTERP_* <- interp=    network.py:276,407 */
+  int32_t doubleconv;     /* network.py:273 */
+  int32_t use_skip;       /* network.py:277 */
+  int32_t precision;      /* AMX_PREC_*: storage type of activations / weights (fp32 accumulate) */
+} amx_unet_cfg;
+
+typedef struct amx_unet amx_unet_t;
+
+int amx_version(void);
+const char* amx_last_error(void);
+
+/* Unet.__init__ (network.py:262-465): builds the layer plan (same module indices as the
+ * reference's nn.Sequential) and allocates packed-weight storage on the current device. */
+int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg);
+void amx_unet_destroy(amx_unet_t* h);
+
+/* Layer plan queries: number of children of Unet.model, and per conv its module index
+ * (the `i` of state_dict key `model.{i}.weight`), channel counts and the index of the norm
+ * module that follows it (-1 if none). */
+int amx_unet_num_modules(const amx_unet_t* h);
+int amx_unet_num_convs(const amx_unet_t* h);
+int amx_unet_conv_info(const amx_unet_t* h, int conv, int* module_idx, int* cin, int* cout, int* norm_module_idx);
+
+/* nn.Module.load_state_dict for one Conv3d (+ the BatchNorm3d that follows it), see
+ * anatomix/model/load_from_hf.py:39-49.  d_weight is fp32 [Cout][Cin][3][3][3]; d_bias (conv
+ * bias), d_gamma/d_beta (norm affine), d_mean/d_var (BatchNorm running stats) are fp32 [Cout]
+ * or NULL.  Eval-mode BatchNorm is folded into the packed weights here. */
+int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, const float* d_bias,
+                       const float* d_gamma, const float* d_beta, const float* d_mean,
+                       const float* d_var, void* stream);
+
+/* Bytes of scratch the forward needs for a batch of n volumes of d x h x w. */
+size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int w_h, int w_w);
+
+/* Unet.forward(input) standard branch (network.py:530-548), eval mode.
+ * d_x: fp32 [n][input_nc][d][h][w]; d_y: fp32 [n][output_nc][d][h][w] (both NCDHW contiguous). */
+int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                     void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* One sliding-window step of monai.inferers.sliding_window_inference as called from
+ * anatomix/registration/convex_adam_utils.py:202-219: runs the forward on the roi-sized window of
+ * volume d_vol (fp32 [vd][vh][vw], single channel) whose corner is (oz,oy,ox) and accumulates
+ *   d_acc[c][oz+z][oy+y][ox+x] += d_wmap[z][y][x] * feature[c][z][y][x]
+ * (d_acc fp32 [output_nc][vd][vh][vw]).  Windows that overlap must be issued on one stream. */
+int amx_unet_forward_window(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int oz, int oy,
+                            int ox, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Final step of sliding_window_inference: d_acc[c][v] /= d_cnt[v] in place. */
+int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream);
+
+/* d_cnt[oz+z][oy+y][ox+x] += d_wmap[z][y][x] for one window (the count map of
+ * sliding_window_inference). */
+int amx_sw_count(float* d_cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh, int rw,
+                 const float* d_wmap, void* stream);
+
+/* Single-layer entry (per-kernel parity / roofline tests): y = act(conv3x3x3_reflect(cat(x0,
+ * up2_nearest(x1))) * scale + shift).  x0: 16-bit NDHWC [n][d][h][w][c0]; x1: 16-bit NDHWC
+ * [n][d/2][h/2][w/2][c1] or NULL (c1 = 0); d_weight fp32 [cout][c0+c1][27]; d_scale/d_shift fp32
+ * [cout] or NULL; output 16-bit NDHWC (d_out16) or fp32 NCDHW (d_out32), exactly one non-NULL.
+ * d_wpk is scratch for the packed weights: amx_conv3d_packed_bytes(c0+c1, cout) bytes. */
+size_t amx_conv3d_packed_bytes(int cin, int cout);
+int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
+                          const float* d_scale, const float* d_shift, int cout, int n, int d, int hh,
+                          int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
+                          float* d_out32, void* stream);
+
+/* nn.MaxPool3d(2) / nn.AvgPool3d(2) on a 16-bit NDHWC tensor (network.py:297,368). */
+int amx_pool2(const void* d_in, void* d_out, int n, int d_out_, int h_out, int w_out, int c, int avg,
+              int precision, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANATOMIX_AMD_H */

@@ -1,0 +1,82 @@
+"""GPU parity of the single-layer entry amx_conv3d_k3_reflect against a CPU fp64-accumulated
+reference fed the same fp16/bf16-rounded operands.  Covers every tile configuration the
+launcher can pick (W >= 32 / 16 / <= 8 x Q in {1,2,4}), reflect borders, partial bricks, the
+fused nearest-upsample + concat input and the fp32 planar epilogue."""
+import numpy as np
+import pytest
+import torch
+
+from _util import TORCH_T, max_rel, ref_conv, rel_l2, run_conv
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (c0, c1, cout, (d,h,w), n, act)   -- shapes from SURVEY.md section 8c(iii) plus edge cases
+    (16, 0, 16, (32, 32, 32), 1, 1),
+    (16, 0, 16, (8, 16, 32), 2, 0),
+    (16, 0, 32, (16, 16, 32), 1, 1),      # Q=2, W>=32
+    (32, 0, 32, (8, 8, 64), 1, 1),
+    (16, 32, 16, (16, 16, 32), 1, 1),     # skip || up  (48 -> 16)
+    (32, 64, 32, (8, 8, 32), 1, 1),       # 96 -> 32
+    (64, 0, 64, (8, 8, 32), 1, 1),        # Q=4, W>=32
+    (32, 0, 64, (8, 8, 16), 1, 1),        # W=16 class
+    (64, 128, 64, (8, 8, 16), 1, 2),      # 192 -> 64 @16, leaky relu
+    (128, 0, 128, (16, 16, 16), 1, 1),    # Q=2 NCH=2 @16
+    (128, 256, 128, (4, 8, 16), 1, 1),    # 384 -> 128
+    (128, 0, 256, (8, 8, 8), 1, 1),       # bottleneck 8^3, Q=1 NCH=4
+    (256, 0, 256, (8, 8, 8), 2, 1),
+    (48, 0, 16, (6, 10, 20), 1, 1),       # ragged: partial bricks on every axis, 3 chunks
+    (16, 0, 16, (2, 2, 2), 1, 1),         # minimum legal size for reflect
+    (64, 0, 128, (4, 4, 4), 1, 1),        # tiny level of a 32^3 network
+    (16, 0, 16, (33, 17, 35), 1, 1),      # odd sizes
+]
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d+%d_o%d_%dx%dx%d_n%d_a%d" % (c[0], c[1], c[2], *c[3], c[4], c[5]))
+def test_conv_matches_cpu(device, case, precision):
+    c0, c1, cout, (d, h, w), n, act = case
+    rs = np.random.RandomState(hash((c0, c1, cout, d, h, w)) & 0xFFFF)
+    x0 = torch.from_numpy(rs.randn(n, c0, d, h, w).astype(np.float32))
+    x1 = None
+    if c1:
+        x1 = torch.from_numpy(rs.randn(n, c1, d // 2, h // 2, w // 2).astype(np.float32))
+    wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy((rs.randn(cout) * 0.1).astype(np.float32))
+    got = run_conv(device, x0, x1, wgt, scale, shift, act, precision)
+    ref = ref_conv(x0, x1, wgt, scale, shift, act, precision)
+    assert torch.isfinite(got).all()
+    # output is stored in the 16-bit type: allow one rounding of the result
+    ulp = 2.0 ** -10 if precision == "f16" else 2.0 ** -7
+    err = (got.double() - ref.double()).abs()
+    tol = ulp * ref.abs().double() + 1e-3 * ulp + 2e-5
+    assert (err <= tol).all(), f"max err {err.max().item():.3e} rel_l2 {rel_l2(got, ref):.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("cout,c0,c1", [(16, 16, 0), (32, 32, 0), (16, 16, 32)])
+def test_conv_planar_fp32_output(device, cout, c0, c1, precision):
+    """Final-layer epilogue: fp32 NCDHW, no output rounding -> tight tolerance."""
+    rs = np.random.RandomState(7)
+    d, h, w = 8, 12, 40
+    x0 = torch.from_numpy(rs.randn(2, c0, d, h, w).astype(np.float32))
+    x1 = torch.from_numpy(rs.randn(2, c1, d // 2, h // 2, w // 2).astype(np.float32)) if c1 else None
+    wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
+    got = run_conv(device, x0, x1, wgt, None, None, 0, precision, planar=True)
+    ref = ref_conv(x0, x1, wgt, None, None, 0, precision)
+    assert torch.isfinite(got).all()
+    assert max_rel(got, ref) < 2e-5, max_rel(got, ref)
+
+
+def test_conv_transpose_detecting(device):
+    """A = I style check with an asymmetric operand: one-hot weight moves channel 3 at tap
+    (kz,ky,kx) = (0,1,2) to output channel 5 -- catches swapped MFMA rows/cols or tap order."""
+    c, d, h, w = 16, 4, 6, 32
+    rs = np.random.RandomState(3)
+    x0 = torch.from_numpy(rs.randn(1, c, d, h, w).astype(np.float32))
+    wgt = torch.zeros(16, c, 3, 3, 3)
+    wgt[5, 3, 0, 1, 2] = 1.0
+    got = run_conv(device, x0, None, wgt, None, None, 0, "f16")
+    ref = ref_conv(x0, None, wgt, None, None, 0, "f16")
+    assert torch.equal(got, ref.half().float())

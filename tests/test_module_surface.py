@@ -1,0 +1,91 @@
+"""CPU: the drop-in boundary.  anatomix_amd.Unet keeps the reference's constructor signature,
+module indices, state_dict keys/dtypes and forward contract, and the C-ABI
+library exports every symbol include/anatomix_amd.h declares."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+import anatomix_amd
+from anatomix_amd import _lib
+from oracle import unet_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_constructor_signature_matches_reference():
+    sig = inspect.signature(anatomix_amd.Unet.__init__)
+    names = list(sig.parameters)[1:]
+    assert names == ["dimension", "input_nc", "output_nc", "num_downs", "ngf", "norm", "final_act", "activation",
+                     "pad_type", "doubleconv", "residual_connection", "pooling", "interp", "use_skip_connection",
+                     "norm_eps"]                                     # network.py:262-279
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == dict(ngf=24, norm="batch", final_act="none", activation="relu", pad_type="reflect", doubleconv=True,
+                     residual_connection=False, pooling="Max", interp="nearest", use_skip_connection=True,
+                     norm_eps=1e-5)
+    fsig = inspect.signature(anatomix_amd.Unet.forward)
+    assert list(fsig.parameters)[1:] == ["input", "layers", "encode_only", "verbose"]
+
+
+@pytest.mark.parametrize("variant", ["anatomix", "anatomix-dev"])
+def test_state_dict_keys_and_strict_load(variant, capsys):
+    kw = R.VARIANTS[variant]
+    m = anatomix_amd.Unet(**kw)
+    printed = capsys.readouterr().out
+    assert "Encoder skip connect id" in printed and "Decoder skip connect id" in printed   # network.py:447-448
+    sd = R.synthetic_state_dict(kw, 0)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    for k, v in m.state_dict().items():
+        assert v.shape == sd[k].shape and v.dtype == sd[k].dtype, k
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        bad = dict(sd); bad.pop(next(iter(bad)))
+        m.load_state_dict(bad, strict=True)
+    plan = R.build_plan(**{k: v for k, v in kw.items() if k != "dimension"})
+    assert m.encoder_idx == plan.encoder_idx and m.decoder_idx == plan.decoder_idx
+    assert len(m.model) == len(plan.kinds)
+    assert sum(p.numel() for p in m.parameters()) == {"anatomix": 5899344, "anatomix-dev": 94369568}[variant]
+    assert m.model[2] is m.model[5]          # one shared activation instance (network.py:188-189)
+
+
+def test_compiled_checkpoint_prefix_is_stripped():
+    from anatomix_amd.model.load_from_hf import _load_handling_compile, build_variant
+    kw = R.VARIANTS["anatomix"]
+    sd = {"_orig_mod." + k: v for k, v in R.synthetic_state_dict(kw, 0).items()}
+    m = _load_handling_compile(build_variant("anatomix"), sd)
+    assert torch.equal(m.model[0].weight, sd["_orig_mod.model.0.weight"])
+    with pytest.raises(ValueError):
+        build_variant("nope")
+
+
+def test_stock_module_path_equals_oracle_when_opted_in():
+    kw = R.VARIANTS["anatomix"]
+    sd = R.synthetic_state_dict(kw, 0)
+    m = anatomix_amd.Unet(**kw)
+    m.load_state_dict(sd)
+    m.eval()
+    x = R.synthetic_input(3, 1, (32, 32, 32))
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="HIP kernels"):
+            m(x)                              # CPU tensor: loud, no silent fallback
+        m.allow_torch_path = True
+        with pytest.warns(UserWarning):
+            y = m(x)
+        out, feats = m(x, [27, 31], False)
+        enc = m(x, [27, 31], True)
+        ref, rfeats = R.forward(x, sd, kw, layers=[27, 31])
+    assert torch.allclose(y, ref, atol=1e-6) and torch.equal(out, y)
+    assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(feats, rfeats)) and len(enc) == 2
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "anatomix_amd.h")).read()
+    body = hdr.split('extern "C" {', 1)[1]
+    declared = set(re.findall(r"\b(amx_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()                          # raises if the .so is missing or lacks a symbol
+    assert lib.amx_version() == 100
+    for name in declared:
+        assert hasattr(lib, name)

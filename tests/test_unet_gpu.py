@@ -1,0 +1,112 @@
+"""GPU parity of the whole forward (anatomix_amd.Unet on the HIP kernels) against the CPU oracle.
+
+Two distances are checked:
+  * kernel correctness: HIP output vs ``oracle.unet_ref.forward_lowp`` (same rounding points,
+    fp32 accumulation) -- differences are accumulation order + rare 1-ulp storage flips;
+  * precision claim: HIP f16 output vs the fp32 oracle must meet the north-star tolerance
+    (<= 1e-3 relative) on the SURVEY-spec synthetic weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import max_rel, rel_l2
+import anatomix_amd
+from oracle import unet_ref as R
+
+pytestmark = pytest.mark.gpu
+
+KW = R.VARIANTS["anatomix"]
+
+
+def _model(device, seed, gain, precision="f16"):
+    m = anatomix_amd.Unet(**KW)
+    sd = R.synthetic_state_dict(KW, seed, gain=gain)
+    m.load_state_dict(sd, strict=True)
+    m.precision = precision
+    return m.to(device).eval(), sd
+
+
+@pytest.mark.parametrize("size,n", [((32, 32, 32), 1), ((64, 64, 64), 1), ((32, 48, 64), 2)])
+@pytest.mark.parametrize("gain", [1.0, 2 ** 0.5])
+def test_forward_matches_emulated_oracle(device, size, n, gain):
+    m, sd = _model(device, 0, gain)
+    x = R.synthetic_input(100, n, size)
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+        ref = R.forward_lowp(x, sd, KW, torch.float16)
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    assert torch.isfinite(y).all()
+    assert rel_l2(y, ref) < (1e-3 if gain == 1.0 else 4e-3), (rel_l2(y, ref), max_rel(y, ref))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_forward_f16_meets_1e3_vs_fp32_oracle(device, seed):
+    """north_star: feature maps within 1e-3 (relative) of the fp32 reference."""
+    m, sd = _model(device, seed, 1.0)
+    x = R.synthetic_input(100 + seed, 1, (64, 64, 64))
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+        ref = R.forward(x, sd, KW)
+    assert rel_l2(y, ref) <= 1e-3, rel_l2(y, ref)
+    assert max_rel(y, ref) <= 2e-3, max_rel(y, ref)
+
+
+def test_forward_bf16_mode_runs_and_is_bf16_accurate(device):
+    m, sd = _model(device, 0, 1.0, precision="bf16")
+    x = R.synthetic_input(100, 1, (32, 32, 32))
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+        ref_emul = R.forward_lowp(x, sd, KW, torch.bfloat16)
+        ref = R.forward(x, sd, KW)
+    assert rel_l2(y, ref_emul) < 8e-3
+    assert rel_l2(y, ref) < 2e-2
+
+
+def test_forward_128_probes(device):
+    """BASELINE config 1 size: 1x1x128^3.  Full fp32 oracle on the host (~1.5 s)."""
+    m, sd = _model(device, 0, 1.0)
+    x = R.synthetic_input(100, 1, (128, 128, 128))
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+        ref = R.forward(x, sd, KW)
+    assert rel_l2(y, ref) <= 1e-3, rel_l2(y, ref)
+
+
+def test_batch_independence_and_determinism(device):
+    m, _ = _model(device, 0, 1.0)
+    x = R.synthetic_input(5, 2, (32, 32, 32)).to(device)
+    with torch.no_grad():
+        y2 = m(x)
+        y0 = m(x[:1])
+        y1 = m(x[1:])
+        y2b = m(x)
+    assert torch.equal(y2[:1], y0) and torch.equal(y2[1:], y1)
+    assert torch.equal(y2, y2b)
+
+
+def test_shape_errors_and_unsupported_modes_are_loud(device):
+    m, _ = _model(device, 0, 1.0)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="divisible"):
+            m(torch.zeros(1, 1, 40, 32, 32, device=device))
+        with pytest.raises(RuntimeError, match="smaller than 2"):
+            m(torch.zeros(1, 1, 16, 32, 32, device=device))
+    with pytest.raises(RuntimeError, match="autograd"):
+        m(torch.zeros(1, 1, 32, 32, 32, device=device))
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="not on a GPU"):
+            m(torch.zeros(1, 1, 32, 32, 32))
+
+
+def test_weights_repacked_after_load_state_dict(device):
+    m, sd = _model(device, 0, 1.0)
+    x = R.synthetic_input(9, 1, (32, 32, 32))
+    with torch.no_grad():
+        y0 = m(x.to(device)).cpu()
+        sd1 = R.synthetic_state_dict(KW, 1)
+        m.load_state_dict(sd1, strict=True)
+        y1 = m(x.to(device)).cpu()
+        ref1 = R.forward_lowp(x, sd1, KW, torch.float16)
+    assert not torch.allclose(y0, y1)
+    assert rel_l2(y1, ref1) < 1e-3
