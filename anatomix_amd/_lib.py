@@ -25,7 +25,16 @@ class UnetCfg(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); every symbol include/anatomix_amd.h declares.
+_P = C.c_void_p
+_I = C.c_int
+
+
+class LaunchRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("module_idx", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("n", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ms", C.c_float),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 SYMBOLS = {
@@ -39,6 +48,8 @@ SYMBOLS = {
     "amx_unet_load_conv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "amx_unet_workspace_bytes": (C.c_size_t, [_P, _I, _I, _I, _I]),
     "amx_unet_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, _P]),
+    "amx_unet_forward_profiled": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, _P, C.POINTER(LaunchRecord), _I,
+                                        C.POINTER(_I)]),
     "amx_unet_forward_window": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_sw_normalize": (_I, [_P, _P, _I, C.c_longlong, _P]),
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -23,6 +23,7 @@ hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long 
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
 int conv_pick_q(int Cout, int W);
+const char* last_conv_kernel_name();
 }  // namespace amx
 
 namespace {
@@ -130,6 +131,19 @@ void build_plan(amx_unet* h) {
 
 int level_channels(const amx_unet* h, int level) { return h->cfg.ngf << level; }
 
+struct Profiler {
+  std::vector<hipEvent_t> ev;
+  std::vector<amx_launch_record> rec;
+  hipStream_t st;
+  int mark(const amx_launch_record& r) {   // call BEFORE the launch it describes
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) return -1;
+    ev.push_back(e);
+    rec.push_back(r);
+    return 0;
+  }
+};
+
 struct Arena {
   char* base;
   size_t bytes;
@@ -157,7 +171,7 @@ int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
 int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
                 float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
                 const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
-                hipStream_t st) {
+                hipStream_t st, Profiler* prof = nullptr) {
   const amx_unet_cfg& c = h->cfg;
   if (int e = check_shape(h, n, d, hh, w)) return e;
   for (const ConvLayer& L : h->convs)
@@ -250,7 +264,19 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         p.out = A.slot[lv][out.slot];
         p.ox = (long long)L.cout * 2; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
       }
+      if (prof) {
+        amx_launch_record r;
+        memset(&r, 0, sizeof r);
+        r.module_idx = L.module_idx; r.cin = L.cin; r.cout = L.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
+        const double vox = (double)n * dd * dh * dw;
+        r.flops = 2.0 * 27.0 * L.cin * L.cout * vox;
+        const double in_b = cur.slot < 0 ? 4.0 * vox : (p.C0 * vox + p.C1 * vox / 8.0) * 2.0;
+        const double out_b = L.is_final ? 4.0 * L.cout * vox : 2.0 * L.cout * vox;
+        r.bytes = in_b + out_b + 2.0 * 27.0 * L.cin * L.cout;
+        if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
+      }
       AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
+      if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_kernel_name());
       // inputs are dead once their consumer is enqueued (stream order)
       if (cur.slot >= 0) A.used[cur.level][cur.slot] = false;
       if (have_skip) A.used[pend_skip.level][pend_skip.slot] = false;
@@ -271,6 +297,14 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       Tensor out;
       out.level = lv; out.C = cur.C; out.slot = grab(lv);
       if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
+      if (prof) {
+        amx_launch_record r;
+        memset(&r, 0, sizeof r);
+        snprintf(r.kernel, sizeof r.kernel, "pool2<%s>", c.pooling == AMX_POOL_AVG ? "avg" : "max");
+        r.module_idx = (int)i; r.cin = r.cout = cur.C; r.n = n; r.d = d >> lv; r.h = hh >> lv; r.w = w >> lv;
+        r.bytes = 2.0 * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 9.0;
+        if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
+      }
       AMX_HIP(amx::launch_pool2(A.slot[cur.level][cur.slot], A.slot[lv][out.slot], n, d >> lv, hh >> lv,
                                 w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st));
       // the pooled-from tensor stays alive only if it was pushed as a skip
@@ -396,6 +430,35 @@ int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, 
   return run_forward(h, d_x, vox * 4, (long long)hh * w * 4, (long long)w * 4, d_y,
                      vox * h->cfg.output_nc, vox, (long long)hh * w, w, nullptr, n, d, hh, w, d_workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+int amx_unet_forward_profiled(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                              void* d_workspace, size_t workspace_bytes, void* stream,
+                              amx_launch_record* records, int max_records, int* n_records) {
+  if (!h || !d_x || !d_y || !d_workspace || !records || !n_records) return fail(AMX_ERR_INVALID, "null argument");
+  Profiler prof;
+  prof.st = (hipStream_t)stream;
+  const long long vox = (long long)d * hh * w;
+  int rc = run_forward(h, d_x, vox * 4, (long long)hh * w * 4, (long long)w * 4, d_y, vox * h->cfg.output_nc, vox,
+                       (long long)hh * w, w, nullptr, n, d, hh, w, d_workspace, workspace_bytes, prof.st, &prof);
+  if (rc == AMX_OK) {
+    amx_launch_record endr;
+    memset(&endr, 0, sizeof endr);
+    if (prof.mark(endr)) rc = fail(AMX_ERR_HIP, "hipEventRecord failed");
+  }
+  if (hipStreamSynchronize(prof.st) != hipSuccess && rc == AMX_OK) rc = fail(AMX_ERR_HIP, "hipStreamSynchronize failed");
+  int cnt = 0;
+  if (rc == AMX_OK) {
+    for (size_t k = 0; k + 1 < prof.ev.size() && cnt < max_records; ++k) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, prof.ev[k], prof.ev[k + 1]);
+      prof.rec[k].ms = ms;
+      records[cnt++] = prof.rec[k];
+    }
+  }
+  for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+  *n_records = cnt;
+  return rc;
 }
 
 int amx_unet_forward_window(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int oz, int oy,

@@ -52,6 +52,7 @@ struct ConvParams {
   float slope;
   int nbz, nby, nbx;           // bricks per axis
   float* stats;                // optional per-(n,c) {sum, sumsq} fp32 accumulators (instance norm)
+  int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
 };
 
 }  // namespace amx

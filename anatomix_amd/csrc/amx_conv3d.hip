@@ -16,36 +16,11 @@
 // Reflect padding, the nearest-x2 upsample of the low-resolution segment and the skip||up
 // channel concat are all resolved in the per-lane global address of the halo gather; none of
 // them is ever materialised in HBM.
-#include "amx_common.h"
+#include <stdio.h>
+
+#include "amx_device.h"
 
 namespace amx {
-
-template <typename T> struct Ops;
-template <> struct Ops<f16> {
-  typedef f16x8 vec8;
-  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Ops<bf16> {
-  typedef bf16x8 vec8;
-  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ int reflect_clamp(int g, int n) {
-  g = g < 0 ? -g : g;                 // -1 -> 1
-  g = g >= n ? 2 * n - 2 - g : g;     //  n -> n-2
-  g = g < 0 ? 0 : g;                  // only reachable for masked (out-of-volume) voxels
-  return g >= n ? n - 1 : g;
-}
-
-template <typename T>
-__device__ __forceinline__ unsigned short to_bits(float v) {
-  T t = (T)v;
-  return __builtin_bit_cast(unsigned short, t);
-}
 
 template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
 struct ConvCfg {
@@ -343,9 +318,14 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
 // -------------------------------------------------------------------------------------------
 // host-side launchers
 // -------------------------------------------------------------------------------------------
+static thread_local char g_kernel_name[64] = "";
+const char* last_conv_kernel_name() { return g_kernel_name; }
+
 template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
 static hipError_t launch_cfg(ConvParams p, hipStream_t st) {
   typedef ConvCfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
+  snprintf(g_kernel_name, sizeof g_kernel_name, "conv3d_k3<%s,%dx%dx%d,q%d,nch%d,o%d>", __is_same(T, f16) ? "f16" : "bf16",
+           C::TZ, C::TY, C::TX, Q, NCH, OUTMODE);
   auto kern = conv3d_k3_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -396,8 +376,24 @@ static hipError_t launch_conv_t(const ConvParams& p, int Q, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
+hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);
+const char* last_conv_v2_kernel_name();
+bool conv_zmarch_eligible(const ConvParams& p);
+hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st);
+const char* last_conv_zm_kernel_name();
+
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
+  if (conv_zmarch_eligible(p) && Q == 1) {   // HBM-bound 16->16 full-resolution layers: z-marching ring kernel
+    hipError_t e = launch_conv_zmarch(p, precision, st);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
+    return e;
+  }
+  if (!p.src0_f32c1) {   // everything but the fp32 single-channel stem runs on the persistent DMA kernel
+    hipError_t e = launch_conv_v2(p, precision, Q, st);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_v2_kernel_name());
+    return e;
+  }
   if (precision == 0) {
     return planar ? launch_conv_t<f16, 1>(p, Q, st) : launch_conv_t<f16, 0>(p, Q, st);
   }

@@ -1,0 +1,437 @@
+// anatomix_amd -- conv3d 3x3x3 reflect, second-generation kernel: persistent workgroups,
+// LDS-DMA halo gather, double-buffered stages, deferred output stores.
+//
+// Same arithmetic formulation as amx_conv3d.hip (weights = MFMA A operand, activations = B operand,
+// plane-major LDS halo image, 14 paired-tap steps per 16 input channels).  What changes is the
+// data movement and the per-item overhead, which is what bounded the first kernel:
+//   * every workgroup is persistent over a contiguous run of (brick, cout-group) items and over
+//     the 16*NCH-channel stages of each item; the flattened (item, stage) sequence is software
+//     pipelined with two LDS buffers -- while stage t is multiplied out of buffer t&1, the halo
+//     rows (+ packed weights + bias) of stage t+1 stream into the other buffer;
+//   * the gather uses LDS-DMA (global_load_lds_dwordx4): one instruction moves one halo row of one
+//     8-channel plane (<= 64 voxels x 16 B) HBM/L2 -> LDS with no VGPR round trip.  The row's
+//     (z, y) reflect/upsample/concat address is wave-uniform SCALAR math; only the x offset is
+//     per lane and it is computed once per stage;
+//   * when a layer has a single stage and a single cout group (all 16->16 layers) the packed
+//     weights and the bias are loaded once per workgroup and stay resident;
+//   * one barrier per stage: [s_waitcnt vmcnt(0) ; s_barrier] -> issue DMA(t+1) -> store the
+//     PREVIOUS item's packed outputs -> MFMA sweep(t).  The stores therefore drain under the sweep
+//     instead of in front of the next barrier;
+//   * item coordinates advance by increment-and-carry on the scalar unit (no integer divisions
+//     in the loop); accumulators start from the bias, so the epilogue is activation + pack.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "amx_device.h"
+
+namespace amx {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+struct Conv2Cfg {
+  static constexpr int NW = NWZ * NWY;
+  static constexpr int TZ = WZ * NWZ, TY = WY * NWY, TX = WX;
+  static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  static constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;
+  static constexpr int HALO = 2 * PLANE;              // bytes per 16-channel sub-chunk
+  static constexpr int WSUB = kSteps * Q * 1024;      // packed weight bytes per sub-chunk
+  static constexpr int WOFF = NCH * HALO;
+  static constexpr int BIASOFF = WOFF + NCH * WSUB;   // 16*Q fp32 (256 B reserved)
+  static constexpr int BUF = BIASOFF + 256;           // one pipeline buffer
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int LX = WX >= 16 ? 16 : 8;
+  static constexpr int LY = 16 / LX;
+  static constexpr int XT = WX / LX;
+  static constexpr int YT = WY / LY;
+  static constexpr int CTW = WZ * YT * XT;
+  static constexpr int RR = 64 / HX;                  // halo rows per DMA instruction
+  static constexpr int NROW = HZ * HY;
+  static constexpr int NINST = (NROW + RR - 1) / RR;
+  static_assert(HX <= 64, "halo row must fit one wave");
+  static_assert(WY % LY == 0 && WX % LX == 0, "wave sub-brick must tile into 16-voxel columns");
+  static_assert(LDS_BYTES <= 160 * 1024, "two pipeline buffers must fit the 160 KiB LDS");
+};
+
+struct ItemCoord {   // all members wave-uniform
+  int bx, by, bz, n, cg;
+};
+
+__device__ __forceinline__ void advance_item(ItemCoord& c, const ConvParams& p) {
+  if (++c.bx < p.nbx) return;
+  c.bx = 0;
+  if (++c.by < p.nby) return;
+  c.by = 0;
+  if (++c.bz < p.nbz) return;
+  c.bz = 0;
+  if (++c.n < p.N) return;
+  c.n = 0;
+  ++c.cg;
+}
+
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+__global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvParams p) {
+  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
+  typedef typename Ops<T>::vec8 vec8;
+  constexpr int HY = C::HY, HX = C::HX, PLANE = C::PLANE, HALO = C::HALO, NW = C::NW;
+  constexpr int WOFF = C::WOFF, CTW = C::CTW, LX = C::LX, LY = C::LY, XT = C::XT, YT = C::YT;
+  constexpr int NPEND = OUTMODE == 0 ? 2 * Q : 4 * Q;   // 32-bit words kept per column tile until the store
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+
+  // ---- this workgroup's contiguous run of items; XCD b%8 gets a contiguous span of runs
+  const int nbricks = p.nbz * p.nby * p.nbx * p.N;
+  const int ncg = p.Cout / (16 * Q);
+  const long long items = (long long)nbricks * ncg;
+  const int G = gridDim.x;
+  int jw = blockIdx.x;
+  if ((G & 7) == 0) jw = (jw & 7) * (G >> 3) + (jw >> 3);
+  const int it0 = (int)(items * jw / G), it1 = (int)(items * (jw + 1) / G);
+  const int nchunk = (p.C0 + p.C1) >> 4;
+  const int nstage = nchunk / NCH;
+  const int T_total = (it1 - it0) * nstage;
+  if (T_total <= 0) return;
+  const bool resident = nstage == 1 && ncg == 1;     // weights + bias loaded once per workgroup
+
+  // ---- lane-constant LDS read bases (relative to the pipeline buffer)
+  const int wz = wave / NWY, wy = wave % NWY;
+  const int dy = (LX == 16) ? 0 : (li >> 3);
+  const int dx = (LX == 16) ? li : (li & 7);
+  const int lanehv = ((wz * WZ) * HY + wy * WY + dy) * HX + dx;
+  const int lanebase = (g & 1) * PLANE + lanehv * 16;
+  const int hi = g >> 1;
+  const int base_d1 = lanebase + hi * 16;
+  const int base_dx = lanebase + hi * 16 * HX;
+  const int base_dz = lanebase + hi * 16 * HX * HY;
+  const int base_d0 = lanebase;
+
+  // ---- DMA lane constants: lane -> (row within instruction, x within halo row)
+  const int dl = lane / HX, hxl = lane - dl * HX;
+  const bool dma_lane = dl < C::RR;
+
+  ItemCoord nx;   // next item to issue DMA for (one-time decode; afterwards increment-and-carry)
+  {
+    nx.cg = it0 / nbricks;
+    int b = it0 - nx.cg * nbricks;
+    nx.bx = b % p.nbx;
+    b /= p.nbx;
+    nx.by = b % p.nby;
+    b /= p.nby;
+    nx.bz = b % p.nbz;
+    nx.n = b / p.nbz;
+  }
+  ItemCoord cu = nx;   // item being multiplied
+  int nx_stage = 0, cu_stage = 0;
+
+  // ---- issue the LDS-DMA of one (item, stage) into pipeline buffer `bsel01`
+  auto issue = [&](const ItemCoord& it, int stage, int bsel01, bool with_weights) {
+    char* buf = smem + bsel01 * C::BUF;
+    const int z0 = it.bz * C::TZ, y0 = it.by * C::TY, x0 = it.bx * C::TX;
+    const int gx = reflect_clamp(x0 + hxl - 1, p.W);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = (stage * NCH + k) << 4;                // wave-uniform
+      const bool second = ch >= p.C0;
+      const int sh = second ? 1 : 0;
+      const char* base = second ? p.src1 + (long long)it.n * p.s1n + (ch - p.C0) * 2
+                                : p.src0 + (long long)it.n * p.s0n + ch * 2;
+      const long long sz = second ? p.s1z : p.s0z, sy = second ? p.s1y : p.s0y;
+      const int xoff = (gx >> sh) * (int)(second ? p.s1x : p.s0x);
+      if (C::RR == 1) {
+        // one halo row per instruction: (z, y) addressing stays on the scalar unit
+        for (int j = wave; j < C::NROW; j += NW) {
+          const int hz = j / HY, hy = j - hz * HY;
+          const int gz = reflect_clamp(z0 + hz - 1, p.D) >> sh;
+          const int gy = reflect_clamp(y0 + hy - 1, p.H) >> sh;
+          const char* row = base + gz * sz + gy * sy;         // uniform
+          char* dst = buf + k * HALO + j * (HX * 16);          // uniform LDS row base
+          if (dma_lane) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+          }
+        }
+      } else {
+        for (int j = wave; j < C::NINST; j += NW) {
+          const int r = j * C::RR + dl;
+          const int hz = r / HY, hy = r - hz * HY;
+          const int gz = reflect_clamp(z0 + hz - 1, p.D) >> sh;
+          const int gy = reflect_clamp(y0 + hy - 1, p.H) >> sh;
+          const char* src = base + gz * sz + gy * sy + xoff;
+          char* dst = buf + k * HALO + j * (C::RR * HX * 16);   // uniform
+          if (dma_lane && r < C::NROW) {
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+          }
+        }
+      }
+    }
+    if (with_weights) {
+      // packed weights of these sub-chunks: linear copy, 1 KiB per instruction
+      const char* ws = p.wpk + ((long long)it.cg * nchunk + (long long)stage * NCH) * C::WSUB;
+      constexpr int NWI = NCH * C::WSUB / 1024;
+      for (int j = wave; j < NWI; j += NW)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ws + j * 1024 + lane * 16), (lptr_t)(buf + WOFF + j * 1024), 16,
+                                         0, 0);
+      if (wave == NW - 1 && stage == 0 && p.bias) {     // bias rides with the item's first stage
+        if (lane < 4 * Q)
+          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.bias + (it.cg * 16 * Q) * 4 + lane * 16),
+                                           (lptr_t)(buf + C::BIASOFF), 16, 0, 0);
+      }
+    }
+  };
+  auto step_next = [&]() {
+    if (++nx_stage == nstage) {
+      nx_stage = 0;
+      advance_item(nx, p);
+    }
+  };
+
+  // ---- deferred store of a finished item's packed outputs
+  unsigned pend[CTW][NPEND];
+  ItemCoord pd = cu;
+  bool pending = false;
+  auto flush = [&]() {
+    const int z0 = pd.bz * C::TZ, y0 = pd.by * C::TY, x0 = pd.bx * C::TX;
+    const int cb = pd.cg * 16 * Q + g * 4 * Q;
+    const bool full = (z0 + C::TZ <= p.D) & (y0 + C::TY <= p.H) & (x0 + C::TX <= p.W);
+    const int zl = z0 + wz * WZ, yl = y0 + wy * WY + dy, xl = x0 + dx;
+    if (OUTMODE == 0) {
+      char* lbase = p.out + (long long)pd.n * p.on + (long long)zl * p.oz + (long long)yl * p.oy +
+                    (long long)xl * p.ox + cb * 2;
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+        if (!full && !((zl + cz < p.D) & (yl + cy * LY < p.H) & (xl + cx * LX < p.W))) continue;
+        char* dst = lbase + cz * p.oz + (cy * LY) * p.oy + (cx * LX) * p.ox;
+        if (Q == 1) {
+          *(uint2*)dst = make_uint2(pend[c][0], pend[c][1]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < Q / 2; ++j)
+            *(uint4*)(dst + j * 16) = make_uint4(pend[c][4 * j], pend[c][4 * j + 1], pend[c][4 * j + 2], pend[c][4 * j + 3]);
+        }
+      }
+    } else {
+      float* lbase = p.out32 + (long long)pd.n * p.pn + (long long)cb * p.pc + (long long)zl * p.pz +
+                     (long long)yl * p.py + xl;
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+        if (!full && !((zl + cz < p.D) & (yl + cy * LY < p.H) & (xl + cx * LX < p.W))) continue;
+        float* dst = lbase + cz * p.pz + (cy * LY) * p.py + cx * LX;
+        if (p.wmap) {
+          const float wgt = p.wmap[((long long)(zl + cz) * p.H + (yl + cy * LY)) * p.W + xl + cx * LX];
+#pragma unroll
+          for (int j = 0; j < 4 * Q; ++j) dst[(long long)j * p.pc] += wgt * __builtin_bit_cast(float, pend[c][j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4 * Q; ++j) dst[(long long)j * p.pc] = __builtin_bit_cast(float, pend[c][j]);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[CTW][Q];
+
+  // optional cycle trace (AMX_TRACE=1): wave 0 of each workgroup stamps s_memtime per phase
+  unsigned long long* trace = (p.dbg & 8) ? (unsigned long long*)p.stats + (long long)blockIdx.x * 128 : nullptr;
+  int tcount = 0;
+#define AMX_STAMP()                                                               \
+  do {                                                                            \
+    if (trace && wave == 0 && lane == 0 && tcount < 128) trace[tcount] = __builtin_readcyclecounter(); \
+    ++tcount;                                                                     \
+  } while (0)
+
+  AMX_STAMP();
+  issue(nx, nx_stage, 0, true);
+  step_next();
+  AMX_STAMP();
+  for (int t = 0; t < T_total; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(t) pieces (and older stores) are done
+    AMX_STAMP();
+    __syncthreads();                                   // every wave's DMA(t) landed; buffer (t+1)&1 is free
+    AMX_STAMP();
+    if (t + 1 < T_total && !(p.dbg & 1)) {
+      issue(nx, nx_stage, (t + 1) & 1, !resident);
+      step_next();
+    }
+    AMX_STAMP();
+    if (pending) {                                     // previous item's outputs drain under this sweep
+      if (!(p.dbg & 4)) flush();
+      pending = false;
+    }
+    AMX_STAMP();
+    const char* buf = smem + (t & 1) * C::BUF;
+    const char* wbuf = resident ? smem : buf;          // resident weights/bias live in buffer 0
+    if (cu_stage == 0) {
+      // accumulators start from the bias (folded norm shift): lane holds channels cb .. cb+4Q-1
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const f32x4 bv = p.bias ? *(const f32x4*)(wbuf + C::BIASOFF + (g * Q + q) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) acc[c][q] = bv;
+      }
+    }
+
+    // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
+    if (!(p.dbg & 2)) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+          const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
+          const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
+          const int kx = s < 9 ? 0 : 2;
+          const int tapoff = ((kz * HY + ky) * HX + kx) * 16;
+          const int bsel = s < 9 ? base_d1 : (s < 12 ? base_dx : (s == 12 ? base_dz : base_d0));
+          vec8 a[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q)
+            a[q] = *(const vec8*)(wbuf + WOFF + ((k * kSteps + s) * Q + q) * 1024 + lane * 16);
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+            const int coff = ((cz * HY + cy * LY) * HX + cx * LX) * 16;
+            const vec8 bf = *(const vec8*)(buf + bsel + k * HALO + tapoff + coff);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(a[q], bf, acc[c][q]);
+          }
+        }
+      }
+    }
+    AMX_STAMP();
+    if (++cu_stage < nstage) continue;
+    cu_stage = 0;
+
+    // ---- item finished: activation + pack into the pending registers (stored next iteration)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      float v[4 * Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f = acc[c][q][j];
+          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
+          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          v[q * 4 + j] = f;
+        }
+      if (OUTMODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * Q; ++j)
+          pend[c][j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4 * Q; ++j) pend[c][j] = __builtin_bit_cast(unsigned, v[j]);
+      }
+    }
+    pd = cu;
+    pending = true;
+    advance_item(cu, p);
+  }
+  if (pending && !(p.dbg & 4)) flush();
+}
+
+// -------------------------------------------------------------------------------------------
+// launcher
+// -------------------------------------------------------------------------------------------
+static thread_local char g_kernel_name2[64] = "";
+const char* last_conv_v2_kernel_name() { return g_kernel_name2; }
+
+static int g_num_cus = 0;
+
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
+  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
+  snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
+           __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
+  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  p.nbz = (p.D + C::TZ - 1) / C::TZ;
+  p.nby = (p.H + C::TY - 1) / C::TY;
+  p.nbx = (p.W + C::TX - 1) / C::TX;
+  static int dbg = -1;
+  static unsigned long long* trace_buf = nullptr;
+  if (dbg < 0) {
+    const char* e = getenv("AMX_DBG");
+    dbg = e ? atoi(e) : 0;
+    if (getenv("AMX_TRACE")) dbg |= 8;
+  }
+  p.dbg = dbg;
+  const long long items = (long long)p.nbz * p.nby * p.nbx * p.N * (p.Cout / (16 * Q));
+  const int per_cu = C::LDS_BYTES <= 80 * 1024 ? 2 : 1;
+  long long grid = items < (long long)g_num_cus * per_cu ? items : (long long)g_num_cus * per_cu;
+  if (dbg & 8) {   // debug only: per-phase cycle stamps of a few workgroups, printed after a sync
+    if (!trace_buf && hipMalloc((void**)&trace_buf, 1024 * 128 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(trace_buf, 0, 1024 * 128 * 8, st);
+    p.stats = (float*)trace_buf;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NW * 64), C::LDS_BYTES, st, p);
+  if (dbg & 8) {
+    static int printed = 0;
+    (void)hipStreamSynchronize(st);
+    if (printed++ == 3) {
+      static unsigned long long hostbuf[1024 * 128];
+      (void)hipMemcpy(hostbuf, trace_buf, sizeof hostbuf, hipMemcpyDeviceToHost);
+      const int wgs[4] = {0, 1, (int)grid / 2, (int)grid - 1};
+      for (int wi = 0; wi < 4; ++wi) {
+        const unsigned long long* tr = hostbuf + (long long)wgs[wi] * 128;
+        fprintf(stderr, "[trace %s wg %d] start %llu :", g_kernel_name2, wgs[wi], tr[0]);
+        for (int k = 1; k < 128 && tr[k]; ++k) fprintf(stderr, " %llu", tr[k] - tr[k - 1]);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  return hipGetLastError();
+}
+
+template <typename T, int OUTMODE>
+static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
+  const int nch = (p.C0 + p.C1) / 16;
+  if (p.W >= 32) {
+    if (Q == 1) return launch_cfg2<T, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
+    if (Q == 2) return launch_cfg2<T, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
+    if (OUTMODE == 0 && Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 1, 4, 1, 0>(p, st);  // brick 4x2x16, 4 waves
+    return hipErrorInvalidValue;
+  }
+  if (OUTMODE == 1) return hipErrorInvalidValue;
+  if (p.W >= 16) {
+    if (Q == 1) return launch_cfg2<T, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
+    if (Q == 2) return launch_cfg2<T, 1, 2, 16, 4, 1, 2, 1, 0>(p, st);
+    if (Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 1, 4, 1, 0>(p, st);
+  }
+  if (Q == 1) {
+    if (nch % 2 == 0) return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
+    return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
+  }
+  if (Q == 2) {
+    if (nch % 2 == 0) return launch_cfg2<T, 1, 2, 8, 4, 1, 2, 2, 0>(p, st);
+    return launch_cfg2<T, 1, 2, 8, 4, 1, 2, 1, 0>(p, st);
+  }
+  if (Q == 4) return launch_cfg2<T, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st) {
+  const bool planar = p.out32 != nullptr;
+  if (precision == 0) return planar ? launch_conv2_t<f16, 1>(p, Q, st) : launch_conv2_t<f16, 0>(p, Q, st);
+  return planar ? launch_conv2_t<bf16, 1>(p, Q, st) : launch_conv2_t<bf16, 0>(p, Q, st);
+}
+
+}  // namespace amx

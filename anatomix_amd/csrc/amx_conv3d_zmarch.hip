@@ -1,0 +1,351 @@
+// anatomix_amd -- conv3d 3x3x3 reflect for the HBM-bound 16 -> 16 channel layers at full
+// resolution (network.py modules 3, 6, 62, 65 of the 6M model): z-marching streaming kernel with
+// producer / consumer wave specialisation.
+//
+// Roofline: 216 FLOP/B -- these layers are bound by HBM, not MFMA, so the
+// design minimises bytes moved per output voxel and keeps the memory pipeline continuously full:
+//   * a workgroup owns an in-plane tile TY x TX and marches along z through a segment of the
+//     volume.  Input z-planes (with their 1-voxel in-plane halo) live in an LDS RING of R planes;
+//     every input plane is fetched ONCE per workgroup (read amplification (TY+2)(TX+2)/(TY*TX) =
+//     1.33 instead of the 1.99 of a 4x8x32 brick with a full 3-D halo);
+//   * NL loader waves do nothing but LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B, per-lane
+//     reflect offsets precomputed once per march): a VMEM instruction blocks its wave while the
+//     memory queue is full, so issuing from the MFMA waves serialised streaming and math.  Loaders
+//     run R - (TZ+2) planes ahead with counted waits (s_waitcnt vmcnt(N), never 0 in steady state);
+//   * NC consumer waves only sweep and store: the packed weights (14 A fragments = 56 VGPRs) and
+//     the bias live in registers for the whole march, so the sweep issues exactly one
+//     ds_read_b128 (the activation fragment) per MFMA; outputs are stored straight from the
+//     accumulators and never waited for;
+//   * one raw s_barrier per step hands planes from loaders to consumers and ring slots back.
+// Arithmetic is identical to amx_conv3d.hip (same packed-weight layout, same 14 paired-tap steps).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "amx_device.h"
+
+namespace amx {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int TY, int TX, int TZ, int NC, int R>
+struct ZmCfg {
+  static constexpr int NL = 2;                                     // loader waves: one per 8-channel plane
+  static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;    // halo voxels of one z-plane
+  static constexpr int PPL = ((HVP * 16 + 255) / 256) * 256;       // one 8-channel plane of one z-plane
+  static constexpr int PLSZ = 2 * PPL;                             // one z-plane (16 channels)
+  static constexpr int LDS_BYTES = R * PLSZ;
+  static constexpr int XT = TX / 16;
+  static constexpr int TILES = TZ * TY * XT;                       // column tiles per step
+  static constexpr int CTW = TILES / NC;                           // per consumer wave
+  static constexpr int WPZ = NC / TZ;                              // consumer waves per output z-plane
+  static constexpr int ROWS_W = TY / WPZ;                          // y rows per consumer wave
+  static constexpr int NDMA = (HVP + 63) / 64;                     // DMA instructions per (z-plane, channel plane)
+  static constexpr int AHEAD = R - (TZ + 2);                       // planes issued beyond the current step's needs
+  static_assert(TILES % NC == 0 && NC % TZ == 0 && TY % WPZ == 0, "tile/wave decomposition");
+  static_assert(CTW == ROWS_W * XT, "consumer wave owns ROWS_W rows x XT column tiles of one plane");
+  static_assert(AHEAD > TZ, "ring must hold more than one step of prefetch");
+  static_assert(R * NDMA <= 60, "loader wave must not exceed the 6-bit vmcnt range");
+  static_assert(LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
+};
+
+// One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
+template <typename T, int TY, int TX, int TZ, int NC, int R, int OUTMODE>
+__global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef ZmCfg<TY, TX, TZ, NC, R> C;
+  typedef typename Ops<T>::vec8 vec8;
+  constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NDMA = C::NDMA;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- work item: (n, z segment, y tile, x tile); x fastest so XCD-neighbours share halos in L2
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  const int bx = b % p.nbx;
+  b /= p.nbx;
+  const int by = b % p.nby;
+  b /= p.nby;
+  const int sg = b % nseg;
+  const int n = b / nseg;
+  const int y0 = by * TY, x0 = bx * TX;
+  const int zs = sg * zseg;
+  const int ze = (zs + zseg < p.D) ? zs + zseg : p.D;      // output planes [zs, ze)
+  const int nplanes = ze - zs + 2;                          // input planes q = 0 .. nplanes-1 <-> z = zs-1+q
+  const int nsteps = (ze - zs + TZ - 1) / TZ;
+
+  unsigned long long* trace = (p.dbg & 8) ? (unsigned long long*)p.stats + (long long)blockIdx.x * 256 : nullptr;
+  int tcount = 0;
+#define ZM_STAMP(W, BASE)                                                                                        \
+  do {                                                                                                           \
+    if (trace && wave == (W) && lane == 0 && tcount < 128) trace[(BASE) + tcount] = __builtin_readcyclecounter(); \
+    ++tcount;                                                                                                    \
+  } while (0)
+
+  if (wave >= NC) {
+    // =========================== loader wave: channel plane cp = wave - NC ===========================
+    const int cp = wave - NC;
+    int off[NDMA];                     // per-lane source offset of halo voxel hv = 64*j + lane (fixed for the march)
+    bool valid[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int hv = j * 64 + lane;
+      const int hy = hv / HX, hx = hv - hy * HX;
+      valid[j] = hv < C::HVP;
+      off[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x + cp * 16;
+    }
+    const char* src_n = p.src0 + (long long)n * p.s0n;
+    auto issue_plane = [&](int q) {
+      const char* plane = src_n + (long long)reflect_clamp(zs - 1 + q, p.D) * p.s0z;   // uniform
+      char* dstp = smem + (q % R) * PLSZ + cp * PPL;                                    // uniform
+#pragma unroll
+      for (int j = 0; j < NDMA; ++j)
+        if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 1024), 16, 0, 0);
+    };
+    int issued = 0;
+    {
+      const int first = nplanes < R ? nplanes : R;
+      for (; issued < first; ++issued) issue_plane(issued);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      // step s reads planes q <= s*TZ + TZ + 1.  In steady state AHEAD - TZ newer planes are in flight
+      // behind them (this step's refill comes after the barrier); loads retire in order.
+      const int need_hi = s * TZ + TZ + 1;
+      ZM_STAMP(NC, 128);
+      if (issued - 1 - need_hi >= C::AHEAD - TZ) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEAD - TZ) * NDMA) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      ZM_STAMP(NC, 128);
+      __builtin_amdgcn_s_barrier();      // planes of step s are in LDS; consumers have finished step s-1
+      asm volatile("" ::: "memory");
+      ZM_STAMP(NC, 128);
+      const int lim = s * TZ + R < nplanes ? s * TZ + R : nplanes;   // slots of planes q < s*TZ are free
+      for (; issued < lim; ++issued) issue_plane(issued);
+    }
+    return;
+  }
+
+  // ================================= consumer wave =================================
+  const int li = lane & 15, g = lane >> 4, hi = g >> 1;
+  // resident weights (A fragments) and bias
+  vec8 wreg[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) wreg[s] = *(const vec8*)(p.wpk + s * 1024 + lane * 16);
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *(const f32x4*)(p.bias + g * 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // wave -> tiles: one output plane tz, ROWS_W rows, XT column tiles
+  const int tz = wave / C::WPZ;
+  const int wrow = (wave % C::WPZ) * C::ROWS_W;
+  const int lanebase = (g & 1) * PPL + ((wrow * HX) + li) * 16;
+  const int base_d1 = lanebase + hi * 16;
+  const int base_dx = lanebase + hi * 16 * HX;
+  const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
+
+  // per-lane output base (plane z added per step)
+  const int yl = y0 + wrow, xl = x0 + li;
+  char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 : nullptr;
+  float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4) * p.pc + (long long)yl * p.py + xl
+                                : nullptr;
+
+  for (int s = 0; s < nsteps; ++s) {
+    ZM_STAMP(0, 0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ZM_STAMP(0, 0);
+
+    const int zo = zs + s * TZ + tz;                 // this wave's output plane
+    // ring slots of the three input planes zo-1, zo, zo+1  (q = s*TZ + tz + kz)
+    int sl[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) sl[kz] = ((s * TZ + tz + kz) % R) * PLSZ;
+    int b1[3], bx3[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      b1[kz] = base_d1 + sl[kz];
+      bx3[kz] = base_dx + sl[kz];
+    }
+    const int bz = lanebase + (hi ? sl[1] : sl[0]);
+    const int b0 = lanebase + sl[2];
+
+    f32x4 acc[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[c] = bias;
+
+    if (!(p.dbg & 2)) {
+      // The (kx=0,kx=1) fragment of input row r serves every (cy, ky) with cy + ky = r, so each plane
+      // needs only ROWS_W+2 row fragments per column tile.  Fragments are fetched in batches one batch
+      // ahead of the MFMAs that consume them (explicit software pipeline; sched_barrier pins the phases).
+      constexpr int RW = C::ROWS_W, NR = RW + 2;
+      vec8 F[2][NR][XT];     // double-buffered d1 batches (one input plane each)
+      vec8 H[3][RW][XT];     // steps 9..11: (kz,0,2)+(kz,1,2)
+      vec8 S[2][RW][XT];     // steps 12, 13
+      auto load_F = [&](int buf, int kz) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int cx = 0; cx < XT; ++cx) F[buf][r][cx] = *(const vec8*)(smem + b1[kz] + (r * HX + cx * 16) * 16);
+      };
+      auto mma_F = [&](int buf, int kz) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < XT; ++cx)
+              acc[cy * XT + cx] = Ops<T>::mfma(wreg[kz * 3 + ky], F[buf][cy + ky][cx], acc[cy * XT + cx]);
+      };
+      load_F(0, 0);
+      load_F(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_F(0, 0);
+      load_F(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_F(1, 1);
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < XT; ++cx)
+            H[kz][cy][cx] = *(const vec8*)(smem + bx3[kz] + 2 * 16 + (cy * HX + cx * 16) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_F(0, 2);
+#pragma unroll
+      for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < XT; ++cx) {
+          S[0][cy][cx] = *(const vec8*)(smem + bz + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
+          S[1][cy][cx] = *(const vec8*)(smem + b0 + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < XT; ++cx)
+            acc[cy * XT + cx] = Ops<T>::mfma(wreg[9 + kz], H[kz][cy][cx], acc[cy * XT + cx]);
+#pragma unroll
+      for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < XT; ++cx) {
+          acc[cy * XT + cx] = Ops<T>::mfma(wreg[12], S[0][cy][cx], acc[cy * XT + cx]);
+          acc[cy * XT + cx] = Ops<T>::mfma(wreg[13], S[1][cy][cx], acc[cy * XT + cx]);
+        }
+    }
+
+    ZM_STAMP(0, 0);
+    // ---- epilogue: activation + store (never waited for)
+    if (zo < ze && !(p.dbg & 4)) {
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = c / XT;
+        if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f = acc[c][j];
+          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
+          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          v[j] = f;
+        }
+        if (OUTMODE == 0) {
+          char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
+          *(uint2*)dst = make_uint2((unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16),
+                                    (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16));
+        } else {
+          float* dst = out32_l + (long long)zo * p.pz + cy * p.py + cx * 16;
+          if (p.wmap) {
+            const float wgt = p.wmap[((long long)zo * p.H + yl + cy) * p.W + xl + cx * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(long long)j * p.pc] += wgt * v[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(long long)j * p.pc] = v[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+static thread_local char g_kernel_name3[64] = "";
+const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
+
+template <typename T, int OUTMODE>
+static hipError_t launch_zm(ConvParams p, hipStream_t st) {
+  constexpr int TY = 8, TX = 32, TZ = 2, NC = 8, R = 10;
+  typedef ZmCfg<TY, TX, TZ, NC, R> C;
+  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%dx%dx%d,c%d+l%d,r%d,o%d>",
+           __is_same(T, f16) ? "f16" : "bf16", TZ, TY, TX, NC, C::NL, R, OUTMODE);
+  auto kern = conv3d_k3_zmarch_kernel<T, TY, TX, TZ, NC, R, OUTMODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  static int dbg = -1;
+  static unsigned long long* trace_buf = nullptr;
+  if (dbg < 0) {
+    const char* e = getenv("AMX_DBG");
+    dbg = e ? atoi(e) : 0;
+    if (getenv("AMX_TRACE")) dbg |= 8;
+  }
+  p.dbg = dbg;
+  if (dbg & 8) {
+    if (!trace_buf && hipMalloc((void**)&trace_buf, 1024 * 256 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(trace_buf, 0, 1024 * 256 * 8, st);
+    p.stats = (float*)trace_buf;
+  }
+  p.nby = (p.H + TY - 1) / TY;
+  p.nbx = (p.W + TX - 1) / TX;
+  // z segments: enough workgroups to fill 256 CUs, each segment a multiple of TZ planes, >= 8 planes
+  const int tiles = p.nby * p.nbx * p.N;
+  int nseg = (256 + tiles - 1) / tiles;
+  if (nseg < 1) nseg = 1;
+  int zseg = (p.D + nseg - 1) / nseg;
+  zseg = (zseg + TZ - 1) / TZ * TZ;
+  if (zseg < 8) zseg = 8;
+  nseg = (p.D + zseg - 1) / zseg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((NC + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
+  if (dbg & 8) {
+    static int printed = 0;
+    (void)hipStreamSynchronize(st);
+    if (printed++ == 3) {
+      static unsigned long long hostbuf[1024 * 256];
+      (void)hipMemcpy(hostbuf, trace_buf, sizeof hostbuf, hipMemcpyDeviceToHost);
+      const int wgs[2] = {0, 100};
+      for (int wi = 0; wi < 2; ++wi)
+        for (int role = 0; role < 2; ++role) {
+          const unsigned long long* tr = hostbuf + (long long)wgs[wi] * 256 + role * 128;
+          fprintf(stderr, "[trace %s wg %d %s] :", g_kernel_name3, wgs[wi], role ? "loader(wait,barrier,refill+loop)" : "consumer(barrier,sweep,epilogue)");
+          for (int k = 1; k < 128 && tr[k]; ++k) fprintf(stderr, " %llu", tr[k] - tr[k - 1]);
+          fprintf(stderr, "\n");
+        }
+    }
+  }
+  return hipGetLastError();
+}
+
+// Eligibility: one 16-channel input segment at full resolution, 16 output channels, W >= 32.
+bool conv_zmarch_eligible(const ConvParams& p) {
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_ZMARCH") ? 1 : 0;
+  return !off && !p.src0_f32c1 && p.C0 == 16 && p.C1 == 0 && p.Cout == 16 && p.W >= 32 && p.H >= 8 && p.D >= 8;
+}
+
+hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
+  const bool planar = p.out32 != nullptr;
+  if (precision == 0) return planar ? launch_zm<f16, 1>(p, st) : launch_zm<f16, 0>(p, st);
+  return planar ? launch_zm<bf16, 1>(p, st) : launch_zm<bf16, 0>(p, st);
+}
+
+}  // namespace amx

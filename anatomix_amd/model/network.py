@@ -269,6 +269,32 @@ class Unet(nn.Module):
                                             need, stream))
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
+    def profile_forward(self, x):
+        """One forward with a hipEvent around every launch (amx_unet_forward_profiled).  Returns
+        (output, [dict(kernel, module_idx, cin, cout, n, d, h, w, ms, flops, bytes), ...])."""
+        reason = self.hip_unsupported_reason(x)
+        if reason is not None:
+            raise RuntimeError("profile_forward needs the HIP path: " + reason)
+        device = x.device
+        lib = self._ensure_handle(device)
+        with torch.cuda.device(device):
+            if self._weights_dirty:
+                self._upload_weights(lib, device)
+            xin = x.detach().float().contiguous()
+            n, _, d, h, w = xin.shape
+            ws, need = self._get_workspace(lib, n, d, h, w, device)
+            y = torch.empty((n, self._cfg["output_nc"], d, h, w), dtype=torch.float32, device=device)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            recs = (_lib.LaunchRecord * 256)()
+            cnt = ctypes.c_int(0)
+            _lib.check(lib.amx_unet_forward_profiled(self._handle, _lib.ptr(xin), _lib.ptr(y), n, d, h, w,
+                                                     _lib.ptr(ws), need, stream, recs, 256, ctypes.byref(cnt)))
+        out = []
+        for r in recs[:cnt.value]:
+            out.append(dict(kernel=r.kernel.decode(), module_idx=r.module_idx, cin=r.cin, cout=r.cout, n=r.n,
+                            d=r.d, h=r.h, w=r.w, ms=r.ms, flops=r.flops, bytes=r.bytes))
+        return y, out
+
     # ------------------------------------------------------------------------------------------
     # stock-module path (explicit opt-in): same traversal as network.py:467-548
     # ------------------------------------------------------------------------------------------

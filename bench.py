@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 128^3 volumes/sec of anatomix 6M-UNet feature extraction on MI355X.
+
+Contract (see task prompt): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
+launches one rank per GPU with torch.distributed.run.  A *step* is one pass of the hot path over
+one batch of synthetic windows already resident in HBM: `Unet.forward` on a [B,1,128,128,128] fp32
+batch (B = 2 = the sw_batch_size the reference's sliding_window_inference feeds the predictor,
+anatomix/registration/convex_adam_utils.py:202-219), fp32 [B,16,128,128,128] features written to
+HBM.  Ranks are independent replicas on different windows (no data-path collective): weak scaling.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- dominant kernel (largest share of the step), ALGORITHMIC flops per launch /
+                  hipEvent-measured average launch duration, against the dense 16-bit MFMA peak;
+  cpu_baseline -- the CPU restatement (oracle, torch.nn.functional = the ATen/oneDNN kernels the
+                  reference dispatches to) timed on the host cores of this box on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_VOLUME_6M = 346.986381312
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="128^3 windows per step per GPU (sw_batch_size)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, forwards):
+    """oracle (CPU restatement) on one [1,1,S,S,S] volume, all host threads, fp32 eval."""
+    import torch
+    from oracle import unet_ref as R
+    kw = R.VARIANTS["anatomix"]
+    sd = R.synthetic_state_dict(kw, 0)
+    x = R.synthetic_input(100, 1, (size,) * 3)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # pick the thread count on a 1/8-size probe (oneDNN on a many-core host is not fastest with every
+    # hardware thread), then time the full-size volume with it; the whole leg is bounded to ~30 s.
+    xs = R.synthetic_input(100, 1, (max(size // 2, 32),) * 3)
+    cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}) or [avail]
+    probe = {}
+    with torch.no_grad():
+        for c in cands:
+            torch.set_num_threads(c)
+            R.forward(xs, sd, kw)
+            t0 = time.perf_counter()
+            R.forward(xs, sd, kw)
+            probe[c] = time.perf_counter() - t0
+        cores = min(probe, key=probe.get)
+        torch.set_num_threads(cores)
+        R.forward(x, sd, kw)                       # warm-up (oneDNN primitive creation)
+        ts = []
+        t_start = time.perf_counter()
+        for _ in range(forwards):
+            t0 = time.perf_counter()
+            R.forward(x, sd, kw)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 20.0:
+                break
+    best = min(ts)
+    return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts)} forwards of one 1x1x{size}^3 volume, fp32 eval, torch CPU (oneDNN) with {cores} of "
+                      f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import anatomix_amd
+    from oracle import unet_ref as R      # only for the synthetic weights/input generators + cpu_baseline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kw = R.VARIANTS["anatomix"]
+    sys.stdout.flush()
+    devnull = open(os.devnull, "w")
+    so, sys.stdout = sys.stdout, devnull             # the constructor prints two lines (reference parity)
+    model = anatomix_amd.Unet(**kw)
+    sys.stdout = so
+    model.load_state_dict(R.synthetic_state_dict(kw, 0), strict=True)
+    model.precision = args.precision
+    model = model.to(dev).eval()
+    S, B = args.size, args.batch
+    x = R.synthetic_input(100 + rank, B, (S, S, S)).to(dev)      # resident before the timed region
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+        barrier()
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            y = model(x)
+        e1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    assert torch.isfinite(y).all()
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: hipEvents around every launch (not the timed region)
+        with torch.no_grad():
+            agg = {}
+            reps = 5
+            for _ in range(reps):
+                _, recs = model.profile_forward(x)
+                for r in recs:
+                    a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        a = agg[dom]
+        avg_ms = a["ms"] / a["launches"]
+        flops_per_launch = a["flops"] / a["launches"]
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        total_ms = sum(v["ms"] for v in agg.values()) / reps
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["launches"] // reps,
+                    "flops_per_launch": flops_per_launch, "share_of_step": round(a["ms"] / reps / total_ms, 3),
+                    "hbm_alg_GBps": round(a["bytes"] / a["launches"] / (avg_ms * 1e-3) / 1e9, 1),
+                    "traffic": None}
+        gflop_vol = GFLOP_PER_VOLUME_6M * (S / 128.0) ** 3
+        result = {
+            "metric": "128^3 volumes/sec feature-extraction (6M UNet)", "value": round(value, 2), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic (uniform [0,1) volumes, seeded random weights of the anatomix 6M architecture)",
+            "config": {"workload": f"anatomix 6M UNet (ngf=16,num_downs=4) forward on sw_batch={B} windows of "
+                                   f"1x{S}^3 (the predictor call of sliding_window_inference, BASELINE configs[1]); "
+                                   "fp32 NCDHW in/out, 16-bit channels-last activations, fp32 accumulate",
+                       "batch_per_gpu": B, "window": S, "parallelism": f"replicas x{world} (no data-path collective)"},
+            "end_to_end_TFLOPs": round(value * gflop_vol / 1e3, 1),
+            "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(S, args.cpu_forwards)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,17 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
                        const float* d_gamma, const float* d_beta, const float* d_mean,
                        const float* d_var, void* stream);
 
+/* One record per kernel launch of a profiled forward (amx_unet_forward_profiled). */
+typedef struct amx_launch_record {
+  char kernel[64];      /* kernel template instance, e.g. "conv3d_k3<f16,1x8x32,q1,nch1,o0>" */
+  int32_t module_idx;   /* index of the conv / pool module in Unet.model */
+  int32_t cin, cout;    /* logical input / output channels */
+  int32_t n, d, h, w;   /* output extent of the launch */
+  float ms;             /* hipEvent time from this launch to the next (includes the boundary) */
+  double flops;         /* algorithmic: 2*27*cin*cout*voxels (0 for pools) */
+  double bytes;         /* algorithmic: input read once + output written once + weights */
+} amx_launch_record;
+
 /* Bytes of scratch the forward needs for a batch of n volumes of d x h x w. */
 size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int w_h, int w_w);
 
@@ -92,6 +103,13 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int w_h, int 
  * d_x: fp32 [n][input_nc][d][h][w]; d_y: fp32 [n][output_nc][d][h][w] (both NCDHW contiguous). */
 int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
                      void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Same forward, with a hipEvent recorded on `stream` around every launch; synchronises the
+ * stream before returning and fills up to max_records records (profiling aid for bench.py's
+ * roofline figures -- not used in the timed region). */
+int amx_unet_forward_profiled(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                              void* d_workspace, size_t workspace_bytes, void* stream,
+                              amx_launch_record* records, int max_records, int* n_records);
 
 /* One sliding-window step of monai.inferers.sliding_window_inference as called from
  * anatomix/registration/convex_adam_utils.py:202-219: runs the forward on the roi-sized window of
