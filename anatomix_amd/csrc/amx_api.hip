@@ -23,6 +23,14 @@ hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long 
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
 int conv_pick_q(int Cout, int W);
+hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st);
+hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st);
+const char* last_conv_stem_kernel_name();
+size_t conv_upcat16_packed_bytes();
+bool conv_upcat16_eligible(const ConvParams& p);
+hipError_t launch_conv_upcat16(const ConvParams& p, int precision, hipStream_t st);
+hipError_t launch_pack_upcat16(const float* w, const float* scale, void* wpk, int precision, hipStream_t st);
+const char* last_conv_upcat_kernel_name();
 const char* last_conv_kernel_name();
 }  // namespace amx
 
@@ -55,6 +63,7 @@ struct ConvLayer {
   int q = 1;              // MFMA tiles per workgroup the weights are packed for
   int cin_pad = 0;
   void* wpk = nullptr;    // packed A fragments
+  void* wpk_up = nullptr; // second packing for the 16+32 -> 16 merged-tap kernel (amx_conv3d_upcat.hip)
   float* scale = nullptr; // folded norm gain (applied to the weights at pack time)
   float* shift = nullptr; // epilogue bias
   bool loaded = false;
@@ -275,8 +284,19 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         r.bytes = in_b + out_b + 2.0 * 27.0 * L.cin * L.cout;
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
-      AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
-      if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_kernel_name());
+      if (p.src0_f32c1) {
+        if (L.is_final || L.cout > 32)
+          return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
+        AMX_HIP(amx::launch_conv_stem(p, c.precision, st));
+        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_stem_kernel_name());
+      } else if (L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p)) {
+        p.wpk = (const char*)L.wpk_up;
+        AMX_HIP(amx::launch_conv_upcat16(p, c.precision, st));
+        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_upcat_kernel_name());
+      } else {
+        AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
+        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_kernel_name());
+      }
       // inputs are dead once their consumer is enqueued (stream order)
       if (cur.slot >= 0) A.used[cur.level][cur.slot] = false;
       if (have_skip) A.used[pend_skip.level][pend_skip.slot] = false;
@@ -363,6 +383,8 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     L.q = amx::conv_pick_q(L.cout, w_at > 0 ? w_at : 1);
     const size_t wbytes = (size_t)L.cout * L.cin_pad * 28 * 2;
     hipError_t e = hipMalloc(&L.wpk, wbytes);
+    if (e == hipSuccess && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
+      e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
     if (e != hipSuccess) {
@@ -378,6 +400,7 @@ void amx_unet_destroy(amx_unet_t* h) {
   if (!h) return;
   for (ConvLayer& L : h->convs) {
     if (L.wpk) (void)hipFree(L.wpk);
+    if (L.wpk_up) (void)hipFree(L.wpk_up);
     if (L.scale) (void)hipFree(L.scale);
     if (L.shift) (void)hipFree(L.shift);
   }
@@ -408,8 +431,13 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
     if (bn && (!d_mean || !d_var)) return fail(AMX_ERR_INVALID, "model.%d: BatchNorm running stats required", module_idx);
     AMX_HIP(amx::launch_fold_norm(bn ? d_gamma : nullptr, bn ? d_beta : nullptr, bn ? d_mean : nullptr,
                                   bn ? d_var : nullptr, d_bias, h->cfg.norm_eps, L.cout, L.scale, L.shift, st));
-    AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
-                                     h->cfg.precision, st));
+    if (L.cin == 1 && &L == &h->convs[0]) {   // stem: 27 taps packed into one K = 32 MFMA step
+      AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout, h->cfg.precision, st));
+    } else {
+      AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
+                                       h->cfg.precision, st));
+      if (L.wpk_up) AMX_HIP(amx::launch_pack_upcat16(d_weight, L.scale, L.wpk_up, h->cfg.precision, st));
+    }
     L.loaded = true;
     return AMX_OK;
   }
@@ -491,7 +519,9 @@ int amx_sw_count(float* d_cnt, int vd, int vh, int vw, int oz, int oy, int ox, i
 
 size_t amx_conv3d_packed_bytes(int cin, int cout) {
   const int cin_pad = (cin + 15) / 16 * 16;
-  return (size_t)cout * cin_pad * 28 * 2;
+  size_t bytes = (size_t)cout * cin_pad * 28 * 2;
+  if (cin == 48 && cout == 16) bytes = (bytes + 255) / 256 * 256 + amx::conv_upcat16_packed_bytes();
+  return bytes;
 }
 
 int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
@@ -525,6 +555,13 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
   } else {
     p.out32 = d_out32;
     p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
+  }
+  if (c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
+    char* up = (char*)d_wpk + ((size_t)cout * (c0 + c1) * 28 * 2 + 255) / 256 * 256;
+    AMX_HIP(amx::launch_pack_upcat16(d_weight, d_scale, up, precision, st));
+    p.wpk = up;
+    AMX_HIP(amx::launch_conv_upcat16(p, precision, st));
+    return AMX_OK;
   }
   AMX_HIP(amx::launch_conv(p, precision, q, st));
   return AMX_OK;

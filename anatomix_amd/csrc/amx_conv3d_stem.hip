@@ -1,0 +1,234 @@
+// anatomix_amd -- stem convolution: fp32 single-channel volume -> 16*Q channels, 3x3x3 reflect
+// (network.py module 0: nn.Conv3d(input_nc=1, ngf, 3, padding='same', padding_mode='reflect') +
+// folded BatchNorm + ReLU).  25 FLOP/B: purely output-bandwidth bound (4 B in, 32*Q B out per voxel).
+//
+// Same z-marching structure as amx_conv3d_zmarch.hip: a workgroup owns an in-plane tile and marches
+// along z; the fp32 input planes (with halo) stream into an LDS ring by 4-byte LDS-DMA from one
+// loader wave.  The whole 27-tap stencil is ONE MFMA per 16 voxels x 16 channels: K = 32 holds the
+// 27 taps (k = 8*g + e: lane groups g = 0,1,2 carry the 8 first taps of plane kz = g, group 3
+// carries the three (ky,kx) = (2,2) taps and five zero weights).  Each lane gathers its 8 taps
+// from the fp32 ring, rounds them to the 16-bit storage type (the same round-to-nearest the
+// reference numerics emulation applies to the network input) and feeds them as the B fragment.
+// The input may be a strided window of a larger volume (sliding-window caller): nothing is
+// gathered or converted in HBM.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "amx_device.h"
+
+namespace amx {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int TY, int TX, int TZ, int NC, int R>
+struct StemCfg {
+  static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
+  static constexpr int PLSZ = ((HVP * 4 + 255) / 256) * 256;      // one fp32 z-plane with halo
+  static constexpr int LDS_BYTES = R * PLSZ;
+  static constexpr int XT = TX / 16;
+  static constexpr int TILES = TZ * TY * XT;
+  static constexpr int CTW = TILES / NC;
+  static constexpr int WPZ = NC / TZ;
+  static constexpr int ROWS_W = TY / WPZ;
+  static constexpr int NDMA = (HVP + 63) / 64;                     // 4-byte DMA instructions per plane
+  static constexpr int AHEAD = R - (TZ + 2);
+  static_assert(TILES % NC == 0 && NC % TZ == 0 && TY % WPZ == 0 && CTW == ROWS_W * XT, "tile/wave decomposition");
+  static_assert(AHEAD > TZ && R * NDMA <= 60, "ring / vmcnt range");
+};
+
+template <typename T, int Q, int TY, int TX, int TZ, int NC, int R>
+__global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef StemCfg<TY, TX, TZ, NC, R> C;
+  typedef typename Ops<T>::vec8 vec8;
+  constexpr int HX = C::HX, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NDMA = C::NDMA;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  const int bx = b % p.nbx;
+  b /= p.nbx;
+  const int by = b % p.nby;
+  b /= p.nby;
+  const int sg = b % nseg;
+  const int n = b / nseg;
+  const int y0 = by * TY, x0 = bx * TX;
+  const int zs = sg * zseg;
+  const int ze = (zs + zseg < p.D) ? zs + zseg : p.D;
+  const int nplanes = ze - zs + 2;
+  const int nsteps = (ze - zs + TZ - 1) / TZ;
+
+  if (wave >= NC) {
+    // ================================ loader wave ================================
+    int off[NDMA];
+    bool valid[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int hv = j * 64 + lane;
+      const int hy = hv / HX, hx = hv - hy * HX;
+      valid[j] = hv < C::HVP;
+      off[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x;
+    }
+    const char* src_n = p.src0 + (long long)n * p.s0n;
+    auto issue_plane = [&](int q) {
+      const char* plane = src_n + (long long)reflect_clamp(zs - 1 + q, p.D) * p.s0z;
+      char* dstp = smem + (q % R) * PLSZ;
+#pragma unroll
+      for (int j = 0; j < NDMA; ++j)
+        if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 256), 4, 0, 0);
+    };
+    int issued = 0;
+    {
+      const int first = nplanes < R ? nplanes : R;
+      for (; issued < first; ++issued) issue_plane(issued);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      const int need_hi = s * TZ + TZ + 1;
+      if (issued - 1 - need_hi >= C::AHEAD - TZ) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEAD - TZ) * NDMA) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int lim = s * TZ + R < nplanes ? s * TZ + R : nplanes;
+      for (; issued < lim; ++issued) issue_plane(issued);
+    }
+    return;
+  }
+
+  // ================================ consumer wave ================================
+  const int li = lane & 15, g = lane >> 4;
+  vec8 wreg[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) wreg[q] = *(const vec8*)(p.wpk + q * 1024 + lane * 16);
+  f32x4 bias[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) bias[q] = p.bias ? *(const f32x4*)(p.bias + g * 4 * Q + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int tz = wave / C::WPZ;
+  const int wrow = (wave % C::WPZ) * C::ROWS_W;
+  const int lanepos = ((wrow * HX) + li) * 4;
+  const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
+  const int yl = y0 + wrow, xl = x0 + li;
+  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 * Q;
+
+  for (int s = 0; s < nsteps; ++s) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int zo = zs + s * TZ + tz;
+    int sl[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) sl[kz] = ((s * TZ + tz + kz) % R) * PLSZ;
+    // lane-group bases: groups 0..2 read plane kz = g at taps e = ky*3+kx; group 3 reads tap (2,2) of planes 0,1,2
+    const int own = (g == 0 ? sl[0] : (g == 1 ? sl[1] : (g == 2 ? sl[2] : sl[0]))) + lanepos;
+    int be[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) be[e] = g < 3 ? own : sl[e] + lanepos + ((2 * HX + 2) - ((e / 3) * HX + e % 3)) * 4;
+
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int cx = c % XT, cy = c / XT;
+      const int toff = (cy * HX + cx * 16) * 4;
+      vec8 bf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int imm = ((e / 3) * HX + e % 3) * 4 + toff;
+        const float f = *(const float*)(smem + (e < 3 ? be[e] : own) + imm);
+        bf[e] = (T)f;
+      }
+      float v[4 * Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        f32x4 acc = bias[q];
+        if (!(p.dbg & 2)) acc = Ops<T>::mfma(wreg[q], bf, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f = acc[j];
+          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
+          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          v[q * 4 + j] = f;
+        }
+      }
+      if (zo >= ze || (p.dbg & 4)) continue;
+      if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
+      char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
+      unsigned w[2 * Q];
+#pragma unroll
+      for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+      if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
+      else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+// Stem weights: fp32 [Cout][1][3][3][3] (* folded norm gain) -> [q][lane 64][8] A fragments with
+// k = 8*g + e <-> tap as described above; row m of tile q is channel (m>>2)*4Q + q*4 + (m&3).
+template <typename T>
+__global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk,
+                                 int Q) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Q * 512) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, q = idx >> 9;
+  const int m = lane & 15, g = lane >> 4;
+  const int cout = (m >> 2) * 4 * Q + q * 4 + (m & 3);
+  int tap = -1;
+  if (g < 3) tap = g * 9 + e;
+  else if (e < 3) tap = e * 9 + 8;
+  float v = 0.f;
+  if (tap >= 0) v = w[cout * 27 + tap] * (scale ? scale[cout] : 1.f);
+  wpk[idx] = (T)v;
+}
+
+static thread_local char g_kernel_name4[64] = "";
+const char* last_conv_stem_kernel_name() { return g_kernel_name4; }
+
+template <typename T, int Q>
+static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
+  constexpr int TY = 8, TX = 32, TZ = 2, NC = 8, R = 10;
+  typedef StemCfg<TY, TX, TZ, NC, R> C;
+  snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem<%s,q%d,%dx%dx%d,c%d+l1,r%d>", __is_same(T, f16) ? "f16" : "bf16", Q,
+           TZ, TY, TX, NC, R);
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("AMX_DBG");
+    dbg = e ? atoi(e) : 0;
+  }
+  p.dbg = dbg;
+  p.nby = (p.H + TY - 1) / TY;
+  p.nbx = (p.W + TX - 1) / TX;
+  const int tiles = p.nby * p.nbx * p.N;
+  int nseg = (512 + tiles - 1) / tiles;       // tiny LDS footprint: two workgroups per CU
+  if (nseg < 1) nseg = 1;
+  int zseg = (p.D + nseg - 1) / nseg;
+  zseg = (zseg + TZ - 1) / TZ * TZ;
+  if (zseg < 8) zseg = 8;
+  nseg = (p.D + zseg - 1) / zseg;
+  hipLaunchKernelGGL((conv3d_stem_kernel<T, Q, TY, TX, TZ, NC, R>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
+                     C::LDS_BYTES, st, p, zseg, nseg);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st) {
+  const int Q = p.Cout / 16;
+  if (Q != 1 && Q != 2) return hipErrorInvalidValue;
+  if (precision == 0) return Q == 1 ? launch_stem_t<f16, 1>(p, st) : launch_stem_t<f16, 2>(p, st);
+  return Q == 1 ? launch_stem_t<bf16, 1>(p, st) : launch_stem_t<bf16, 2>(p, st);
+}
+
+hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st) {
+  const int Q = Cout / 16;
+  if (precision == 0)
+    hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((Q * 512 + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q);
+  else
+    hipLaunchKernelGGL(pack_stem_kernel<bf16>, dim3((Q * 512 + 255) / 256), dim3(256), 0, st, w, scale, (bf16*)wpk, Q);
+  return hipGetLastError();
+}
+
+}  // namespace amx

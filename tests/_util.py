@@ -75,3 +75,43 @@ def ref_conv(x0, x1, w, scale, shift, act, precision, slope=0.3):
     elif act == 2:
         y = F.leaky_relu(y, slope)
     return y.float()
+
+
+def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3):
+    """Reference for the merged-tap kernel (amx_conv3d_upcat.hip): the skip segment is a plain
+    reflect-padded 3x3x3 convolution with rounded weights; the nearest-upsampled segment is, per
+    output parity class, a 2x2x2 convolution over the REPLICATE-padded low-res tensor whose weights
+    are the fp32 sums of the original taps that hit the same low-res voxel, rounded once."""
+    tdt = TORCH_T[precision]
+    q = lambda t: t.to(tdt).float()
+    c0 = x0.shape[1]
+    wf = w.float()
+    sc = torch.ones(w.shape[0]) if scale is None else scale.float()
+    xs = q(x0).double()
+    y = F.conv3d(F.pad(xs, (1,) * 6, mode="reflect"), q(wf[:, :c0] * sc[:, None, None, None, None]).double())
+    lo = F.pad(q(x1).double(), (1,) * 6, mode="replicate")
+    wu = wf[:, c0:]                                     # merged in fp32 first, gain applied to the sum (kernel order)
+    sets = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}          # parity -> taps merged into low offset e = 0, 1
+    n, _, d, h, ww = x0.shape
+    for pz in (0, 1):
+        for py in (0, 1):
+            for px in (0, 1):
+                wm = torch.zeros(w.shape[0], wu.shape[1], 2, 2, 2)
+                for ez in (0, 1):
+                    for ey in (0, 1):
+                        for ex in (0, 1):
+                            acc = torch.zeros(w.shape[0], wu.shape[1])
+                            for kz in sets[pz][ez]:
+                                for ky in sets[py][ey]:
+                                    for kx in sets[px][ex]:
+                                        acc = acc + wu[:, :, kz, ky, kx]
+                            wm[:, :, ez, ey, ex] = acc
+                sub = lo[:, :, pz:pz + d // 2 + 1, py:py + h // 2 + 1, px:px + ww // 2 + 1]
+                y[:, :, pz::2, py::2, px::2] += F.conv3d(sub, q(wm * sc[:, None, None, None, None]).double())
+    if shift is not None:
+        y = y + shift.double()[None, :, None, None, None]
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, slope)
+    return y.float()

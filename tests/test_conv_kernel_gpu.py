@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import TORCH_T, max_rel, ref_conv, rel_l2, run_conv
+from _util import TORCH_T, max_rel, ref_conv, ref_conv_upcat_merged, rel_l2, run_conv
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,9 @@ CASES = [
     (16, 0, 16, (8, 16, 32), 2, 0),
     (16, 0, 32, (16, 16, 32), 1, 1),      # Q=2, W>=32
     (32, 0, 32, (8, 8, 64), 1, 1),
-    (16, 32, 16, (16, 16, 32), 1, 1),     # skip || up  (48 -> 16)
+    (16, 32, 16, (16, 16, 32), 1, 1),     # skip || up  (48 -> 16): merged-tap z-march kernel
+    (16, 32, 16, (12, 24, 64), 2, 1),     # same, ragged tile rows, batch 2
+    (16, 32, 16, (6, 6, 16), 1, 1),       # same shape class below the merged kernel's minimum: generic path
     (32, 64, 32, (8, 8, 32), 1, 1),       # 96 -> 32
     (64, 0, 64, (8, 8, 32), 1, 1),        # Q=4, W>=32
     (32, 0, 64, (8, 8, 16), 1, 1),        # W=16 class
@@ -45,7 +47,8 @@ def test_conv_matches_cpu(device, case, precision):
     scale = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
     shift = torch.from_numpy((rs.randn(cout) * 0.1).astype(np.float32))
     got = run_conv(device, x0, x1, wgt, scale, shift, act, precision)
-    ref = ref_conv(x0, x1, wgt, scale, shift, act, precision)
+    merged = (c0, c1, cout) == (16, 32, 16) and w >= 32 and h >= 8 and d >= 4
+    ref = (ref_conv_upcat_merged if merged else ref_conv)(x0, x1, wgt, scale, shift, act, precision)
     assert torch.isfinite(got).all()
     # output is stored in the 16-bit type: allow one rounding of the result
     ulp = 2.0 ** -10 if precision == "f16" else 2.0 ** -7
@@ -64,7 +67,7 @@ def test_conv_planar_fp32_output(device, cout, c0, c1, precision):
     x1 = torch.from_numpy(rs.randn(2, c1, d // 2, h // 2, w // 2).astype(np.float32)) if c1 else None
     wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
     got = run_conv(device, x0, x1, wgt, None, None, 0, precision, planar=True)
-    ref = ref_conv(x0, x1, wgt, None, None, 0, precision)
+    ref = (ref_conv_upcat_merged if c1 else ref_conv)(x0, x1, wgt, None, None, 0, precision)
     assert torch.isfinite(got).all()
     assert max_rel(got, ref) < 2e-5, max_rel(got, ref)
 
