@@ -17,207 +17,11 @@
 // channel concat are all resolved in the per-lane global address of the halo gather; none of
 // them is ever materialised in HBM.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "amx_device.h"
 
 namespace amx {
-
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
-struct ConvCfg {
-  static constexpr int TZ = WZ * NWZ, TY = WY * NWY, TX = WX;
-  static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
-  static constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;
-  static constexpr int HALO = 2 * PLANE;            // bytes per 16-channel sub-chunk
-  static constexpr int WOFF = NCH * HALO;
-  static constexpr int WSUB = kSteps * Q * 1024;    // weight bytes per 16-channel sub-chunk
-  static constexpr int LDS_BYTES = NCH * (HALO + WSUB);
-  static constexpr int LX = WX >= 16 ? 16 : 8;      // column tile: LY rows x LX voxels = 16
-  static constexpr int LY = 16 / LX;
-  static constexpr int XT = WX / LX;
-  static constexpr int YT = WY / LY;
-  static constexpr int CTW = WZ * YT * XT;          // column tiles per wave
-  static_assert(NWZ * NWY == 4, "4 waves per workgroup");
-  static_assert(WY % LY == 0 && WX % LX == 0, "wave sub-brick must tile into 16-voxel columns");
-};
-
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
-__global__ __launch_bounds__(256) void conv3d_k3_kernel(const ConvParams p) {
-  typedef ConvCfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
-  typedef typename Ops<T>::vec8 vec8;
-  constexpr int HY = C::HY, HX = C::HX, HV = C::HV, PLANE = C::PLANE, HALO = C::HALO;
-  constexpr int WOFF = C::WOFF, CTW = C::CTW, LX = C::LX, LY = C::LY, XT = C::XT, YT = C::YT;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-
-  // ---- brick decode; blocks of one XCD (b % 8) get a contiguous run of bricks so that
-  //      neighbouring halos are re-read from that XCD's own L2.
-  const int nb = p.nbz * p.nby * p.nbx * p.N;
-  int b = blockIdx.x;
-  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
-  const int bx = b % p.nbx;
-  int t = b / p.nbx;
-  const int by = t % p.nby;
-  t /= p.nby;
-  const int bz = t % p.nbz;
-  const int n = t / p.nbz;
-  const int z0 = bz * C::TZ, y0 = by * C::TY, x0 = bx * C::TX;
-  const int cgrp = blockIdx.y;
-
-  const int nchunk = (p.C0 + p.C1) >> 4;
-  const int nstage = nchunk / NCH;
-
-  f32x4 acc[CTW][Q];
-#pragma unroll
-  for (int c = 0; c < CTW; ++c)
-#pragma unroll
-    for (int q = 0; q < Q; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- lane-constant LDS read bases
-  const int wz = wave / NWY, wy = wave % NWY;
-  const int dy = (LX == 16) ? 0 : (li >> 3);
-  const int dx = (LX == 16) ? li : (li & 7);
-  const int lanehv = ((wz * WZ) * HY + wy * WY + dy) * HX + dx;
-  const int lanebase = (g & 1) * PLANE + lanehv * 16;
-  const int hi = g >> 1;
-  const int base_d1 = lanebase + hi * 16;
-  const int base_dx = lanebase + hi * 16 * HX;
-  const int base_dz = lanebase + hi * 16 * HX * HY;
-  const int base_d0 = lanebase;
-
-  const long long src0_n = (long long)n * p.s0n;
-  const long long src1_n = (long long)n * p.s1n;
-  const char* wsrc = p.wpk + (long long)cgrp * nchunk * C::WSUB;
-
-  for (int stage = 0; stage < nstage; ++stage) {
-    if (stage > 0) __syncthreads();
-    // ---- stage the halo of NCH x 16 input channels: unit = (halo voxel, sub-chunk, plane)
-    {
-      constexpr int UPV = 2 * NCH;
-      constexpr int NU = HV * UPV;
-#pragma unroll 4
-      for (int u = tid; u < NU; u += 256) {
-        const int hv = u / UPV;
-        const int sub = u % UPV;
-        const int k = sub >> 1, pl = sub & 1;
-        const int hx = hv % HX;
-        const int t2 = hv / HX;
-        const int hy = t2 % HY;
-        const int hz = t2 / HY;
-        const int gz = reflect_clamp(z0 + hz - 1, p.D);
-        const int gy = reflect_clamp(y0 + hy - 1, p.H);
-        const int gx = reflect_clamp(x0 + hx - 1, p.W);
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (p.src0_f32c1) {
-          if (pl == 0 && k == 0 && stage == 0) {
-            const float f =
-                *(const float*)(p.src0 + src0_n + gz * p.s0z + gy * p.s0y + gx * p.s0x);
-            v.x = (unsigned)to_bits<T>(f);
-          }
-        } else {
-          const int ch = ((stage * NCH + k) << 4) + (pl << 3);
-          const bool second = ch >= p.C0;
-          const int sh = second ? 1 : 0;
-          const char* base = second ? p.src1 + src1_n : p.src0 + src0_n;
-          const long long sz = second ? p.s1z : p.s0z;
-          const long long sy = second ? p.s1y : p.s0y;
-          const long long sx = second ? p.s1x : p.s0x;
-          const int cc = second ? ch - p.C0 : ch;
-          v = *(const uint4*)(base + (gz >> sh) * sz + (gy >> sh) * sy + (gx >> sh) * sx + cc * 2);
-        }
-        *(uint4*)(smem + k * HALO + pl * PLANE + hv * 16) = v;
-      }
-    }
-    // ---- stage the packed weights of these sub-chunks (linear copy)
-    {
-      const char* ws = wsrc + (long long)stage * NCH * C::WSUB;
-      constexpr int NW = NCH * kSteps * Q * 64;
-#pragma unroll 4
-      for (int u = tid; u < NW; u += 256)
-        *(uint4*)(smem + WOFF + u * 16) = *(const uint4*)(ws + (long long)u * 16);
-    }
-    __syncthreads();
-
-    // ---- MFMA sweep: 14 steps per 16-channel sub-chunk
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-#pragma unroll
-      for (int s = 0; s < kSteps; ++s) {
-        const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
-        const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
-        const int kx = s < 9 ? 0 : 2;
-        const int tapoff = ((kz * HY + ky) * HX + kx) * 16;
-        const int bsel = s < 9 ? base_d1 : (s < 12 ? base_dx : (s == 12 ? base_dz : base_d0));
-        vec8 a[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-          a[q] = *(const vec8*)(smem + WOFF + ((k * kSteps + s) * Q + q) * 1024 + lane * 16);
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-          const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
-          const int coff = ((cz * HY + cy * LY) * HX + cx * LX) * 16;
-          const vec8 bf = *(const vec8*)(smem + bsel + k * HALO + tapoff + coff);
-#pragma unroll
-          for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(a[q], bf, acc[c][q]);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: bias (folded norm) + activation; lane holds channels cb .. cb+4Q-1 of one voxel
-  const int cb = cgrp * 16 * Q + g * 4 * Q;
-  float bias[4 * Q];
-#pragma unroll
-  for (int j = 0; j < 4 * Q; ++j) bias[j] = p.bias ? p.bias[cb + j] : 0.f;
-
-#pragma unroll
-  for (int c = 0; c < CTW; ++c) {
-    const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
-    const int z = z0 + wz * WZ + cz;
-    const int y = y0 + wy * WY + cy * LY + dy;
-    const int x = x0 + cx * LX + dx;
-    const bool ok = (z < p.D) & (y < p.H) & (x < p.W);
-    float v[4 * Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float f = acc[c][q][j] + bias[q * 4 + j];
-        if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-        else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
-        v[q * 4 + j] = f;
-      }
-    if (!ok) continue;
-    if (OUTMODE == 0) {
-      char* dst = p.out + (long long)n * p.on + (long long)z * p.oz + (long long)y * p.oy +
-                  (long long)x * p.ox + cb * 2;
-      unsigned w[2 * Q];
-#pragma unroll
-      for (int j = 0; j < 2 * Q; ++j)
-        w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
-      if (Q == 1) {
-        *(uint2*)dst = make_uint2(w[0], w[1]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < Q / 2; ++j)
-          *(uint4*)(dst + j * 16) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-      }
-    } else {
-      float* dst = p.out32 + (long long)n * p.pn + (long long)cb * p.pc + (long long)z * p.pz +
-                   (long long)y * p.py + x;
-      if (p.wmap) {
-        const float wgt = p.wmap[((long long)z * p.H + y) * p.W + x];
-#pragma unroll
-        for (int j = 0; j < 4 * Q; ++j) dst[(long long)j * p.pc] += wgt * v[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4 * Q; ++j) dst[(long long)j * p.pc] = v[j];
-      }
-    }
-  }
-}
 
 // -------------------------------------------------------------------------------------------
 // Weight packer: fp32 [Cout][Cin][3][3][3] (+ per-channel scale = folded norm gain) -> A fragments.
@@ -321,27 +125,6 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
 static thread_local char g_kernel_name[64] = "";
 const char* last_conv_kernel_name() { return g_kernel_name; }
 
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
-static hipError_t launch_cfg(ConvParams p, hipStream_t st) {
-  typedef ConvCfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
-  snprintf(g_kernel_name, sizeof g_kernel_name, "conv3d_k3<%s,%dx%dx%d,q%d,nch%d,o%d>", __is_same(T, f16) ? "f16" : "bf16",
-           C::TZ, C::TY, C::TX, Q, NCH, OUTMODE);
-  auto kern = conv3d_k3_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  p.nbz = (p.D + C::TZ - 1) / C::TZ;
-  p.nby = (p.H + C::TY - 1) / C::TY;
-  p.nbx = (p.W + C::TX - 1) / C::TX;
-  dim3 grid((unsigned)(p.nbz * p.nby * p.nbx * p.N), (unsigned)(p.Cout / (16 * Q)));
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
-  return hipGetLastError();
-}
-
 // Tile-shape heuristic.  Returns the Q (16-channel MFMA tiles per workgroup) a layer will be
 // launched with; the packed-weight layout depends on it.
 int conv_pick_q(int Cout, int W) {
@@ -350,30 +133,6 @@ int conv_pick_q(int Cout, int W) {
   if (W >= 32) return 4;      // Cout >= 64 at 32^3 and larger
   if (W >= 16) return 2;      // 16^3: more cout groups to fill the chip
   return 1;
-}
-
-template <typename T, int OUTMODE>
-static hipError_t launch_conv_t(const ConvParams& p, int Q, hipStream_t st) {
-  const int nch = (p.C0 + p.C1) / 16;
-  if (p.W >= 32 && Q == 1) return launch_cfg<T, 1, 8, 32, 4, 1, 1, 1, OUTMODE>(p, st);
-  if (p.W >= 32 && Q == 2) return launch_cfg<T, 1, 4, 32, 4, 1, 2, 1, OUTMODE>(p, st);
-  if (p.W >= 32 && Q == 4) return launch_cfg<T, 1, 2, 16, 4, 1, 4, 1, OUTMODE>(p, st);
-  if (p.W >= 16) {
-    if (Q == 1) return launch_cfg<T, 1, 2, 16, 4, 1, 1, 1, OUTMODE>(p, st);
-    if (Q == 2) {
-      if (nch % 2 == 0) return launch_cfg<T, 1, 2, 16, 4, 1, 2, 2, OUTMODE>(p, st);
-      return launch_cfg<T, 1, 2, 16, 4, 1, 2, 1, OUTMODE>(p, st);
-    }
-    if (Q == 4) return launch_cfg<T, 1, 2, 16, 4, 1, 4, 1, OUTMODE>(p, st);
-  }
-  // W <= 8 (8^3 bottleneck and the tiny levels of small test volumes): 2x8 column tiles
-  if (Q == 1) {
-    if (nch % 4 == 0) return launch_cfg<T, 1, 2, 8, 4, 1, 1, 4, OUTMODE>(p, st);
-    return launch_cfg<T, 1, 2, 8, 4, 1, 1, 1, OUTMODE>(p, st);
-  }
-  if (Q == 2) return launch_cfg<T, 1, 2, 8, 4, 1, 2, 1, OUTMODE>(p, st);
-  if (Q == 4) return launch_cfg<T, 1, 2, 8, 4, 1, 4, 1, OUTMODE>(p, st);
-  return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);
@@ -389,15 +148,11 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
     return e;
   }
-  if (!p.src0_f32c1) {   // everything but the fp32 single-channel stem runs on the persistent DMA kernel
-    hipError_t e = launch_conv_v2(p, precision, Q, st);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_v2_kernel_name());
-    return e;
-  }
-  if (precision == 0) {
-    return planar ? launch_conv_t<f16, 1>(p, Q, st) : launch_conv_t<f16, 0>(p, Q, st);
-  }
-  return planar ? launch_conv_t<bf16, 1>(p, Q, st) : launch_conv_t<bf16, 0>(p, Q, st);
+  if (p.src0_f32c1) return hipErrorInvalidValue;   // the fp32 stem has its own kernel (amx_conv3d_stem.hip)
+  (void)planar;
+  hipError_t e = launch_conv_v2(p, precision, Q, st);   // generic path: persistent double-buffered DMA kernel
+  snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_v2_kernel_name());
+  return e;
 }
 
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,

@@ -16,7 +16,9 @@
 //     the bias live in registers for the whole march, so the sweep issues exactly one
 //     ds_read_b128 (the activation fragment) per MFMA; outputs are stored straight from the
 //     accumulators and never waited for;
-//   * one raw s_barrier per step hands planes from loaders to consumers and ring slots back.
+//   * no workgroup barrier in the march: loaders publish 'planes landed' counters and consumers
+//     publish 'steps done' counters in LDS (amx_device.h), so a wave stalled on VMEM issue only
+//     delays the waves that depend on it and store bursts of different waves de-synchronise.
 // Arithmetic is identical to amx_conv3d.hip (same packed-weight layout, same 14 paired-tap steps).
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,7 +36,8 @@ struct ZmCfg {
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;    // halo voxels of one z-plane
   static constexpr int PPL = ((HVP * 16 + 255) / 256) * 256;       // one 8-channel plane of one z-plane
   static constexpr int PLSZ = 2 * PPL;                             // one z-plane (16 channels)
-  static constexpr int LDS_BYTES = R * PLSZ;
+  static constexpr int FLAGOFF = R * PLSZ;                         // ready[NL] at +0, done[NC] at +32
+  static constexpr int LDS_BYTES = R * PLSZ + 64;
   static constexpr int XT = TX / 16;
   static constexpr int TILES = TZ * TY * XT;                       // column tiles per step
   static constexpr int CTW = TILES / NC;                           // per consumer wave
@@ -77,13 +80,10 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
   const int nplanes = ze - zs + 2;                          // input planes q = 0 .. nplanes-1 <-> z = zs-1+q
   const int nsteps = (ze - zs + TZ - 1) / TZ;
 
-  unsigned long long* trace = (p.dbg & 8) ? (unsigned long long*)p.stats + (long long)blockIdx.x * 256 : nullptr;
-  int tcount = 0;
-#define ZM_STAMP(W, BASE)                                                                                        \
-  do {                                                                                                           \
-    if (trace && wave == (W) && lane == 0 && tcount < 128) trace[(BASE) + tcount] = __builtin_readcyclecounter(); \
-    ++tcount;                                                                                                    \
-  } while (0)
+  int* ready = (int*)(smem + C::FLAGOFF);
+  int* done = (int*)(smem + C::FLAGOFF + 32);
+  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  __syncthreads();
 
   if (wave >= NC) {
     // =========================== loader wave: channel plane cp = wave - NC ===========================
@@ -105,27 +105,22 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
       for (int j = 0; j < NDMA; ++j)
         if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 1024), 16, 0, 0);
     };
-    int issued = 0;
-    {
-      const int first = nplanes < R ? nplanes : R;
-      for (; issued < first; ++issued) issue_plane(issued);
-    }
-    for (int s = 0; s < nsteps; ++s) {
-      // step s reads planes q <= s*TZ + TZ + 1.  In steady state AHEAD - TZ newer planes are in flight
-      // behind them (this step's refill comes after the barrier); loads retire in order.
-      const int need_hi = s * TZ + TZ + 1;
-      ZM_STAMP(NC, 128);
-      if (issued - 1 - need_hi >= C::AHEAD - TZ) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEAD - TZ) * NDMA) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int next_issue = 0, next_pub = 0;
+    const unsigned a_ready = lds_addr(ready + cp), a_done = lds_addr(done);
+    while (next_pub < nplanes) {
+      if (next_issue < nplanes) {
+        static_assert(NC == 8, "done flags are read as two b128");
+        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
+        int lim = R + TZ * md;                              // planes q < TZ*md are dead: their slots are free
+        lim = lim < nplanes ? lim : nplanes;
+        while (next_issue < lim) issue_plane(next_issue++);
       }
-      ZM_STAMP(NC, 128);
-      __builtin_amdgcn_s_barrier();      // planes of step s are in LDS; consumers have finished step s-1
-      asm volatile("" ::: "memory");
-      ZM_STAMP(NC, 128);
-      const int lim = s * TZ + R < nplanes ? s * TZ + R : nplanes;   // slots of planes q < s*TZ are free
-      for (; issued < lim; ++issued) issue_plane(issued);
+      if (next_issue == next_pub) {                         // ring full, everything published: wait for consumers
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      WaitVm<NDMA, R - 1>::run(next_issue - next_pub - 1);  // the oldest unpublished plane has landed
+      flag_store_asm(a_ready, ++next_pub);
     }
     return;
   }
@@ -154,11 +149,24 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
   float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4) * p.pc + (long long)yl * p.py + xl
                                 : nullptr;
 
+  // fp32 planar output with 16-byte stores needs x-quads that never straddle a row and aligned planes
+  const bool vec_planar = OUTMODE == 1 && !(p.W & 3) && !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) &&
+                          !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
+  float* out32_q = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4 + (li & 3)) * p.pc + (long long)yl * p.py +
+                                      x0 + (li & ~3)
+                                : nullptr;
+
   for (int s = 0; s < nsteps; ++s) {
-    ZM_STAMP(0, 0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ZM_STAMP(0, 0);
+    {
+      int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
+      need = need < nplanes ? need : nplanes;
+      while (true) {
+        const int r0 = flag_load(ready), r1 = flag_load(ready + 1);
+        if ((r0 < r1 ? r0 : r1) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
 
     const int zo = zs + s * TZ + tz;                 // this wave's output plane
     // ring slots of the three input planes zo-1, zo, zo+1  (q = s*TZ + tz + kz)
@@ -241,7 +249,9 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
         }
     }
 
-    ZM_STAMP(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
+    flag_store(done + wave, s + 1);
+
     // ---- epilogue: activation + store (never waited for)
     if (zo < ze && !(p.dbg & 4)) {
 #pragma unroll
@@ -260,6 +270,18 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
           char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
           *(uint2*)dst = make_uint2((unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16),
                                     (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16));
+        } else if (vec_planar) {
+          // 4x4 transpose inside each lane quad (DPP, no LDS): lane (li, g) ends up with channel
+          // g*4 + (li&3) at x = (li&~3) .. +3, i.e. ONE 16-byte store per lane instead of four 4-byte ones.
+          quad_transpose4(v, li);
+          float* dst = out32_q + (long long)zo * p.pz + cy * p.py + cx * 16;
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.wmap) {
+            const float4 wg = *(const float4*)(p.wmap + ((long long)zo * p.H + yl + cy) * p.W + x0 + (li & ~3) + cx * 16);
+            const float4 old = *(const float4*)dst;
+            o = make_float4(old.x + wg.x * o.x, old.y + wg.y * o.y, old.z + wg.z * o.z, old.w + wg.w * o.w);
+          }
+          *(float4*)dst = o;
         } else {
           float* dst = out32_l + (long long)zo * p.pz + cy * p.py + cx * 16;
           if (p.wmap) {
@@ -293,18 +315,11 @@ static hipError_t launch_zm(ConvParams p, hipStream_t st) {
     attr_done = true;
   }
   static int dbg = -1;
-  static unsigned long long* trace_buf = nullptr;
   if (dbg < 0) {
     const char* e = getenv("AMX_DBG");
     dbg = e ? atoi(e) : 0;
-    if (getenv("AMX_TRACE")) dbg |= 8;
   }
   p.dbg = dbg;
-  if (dbg & 8) {
-    if (!trace_buf && hipMalloc((void**)&trace_buf, 1024 * 256 * 8) != hipSuccess) return hipErrorOutOfMemory;
-    (void)hipMemsetAsync(trace_buf, 0, 1024 * 256 * 8, st);
-    p.stats = (float*)trace_buf;
-  }
   p.nby = (p.H + TY - 1) / TY;
   p.nbx = (p.W + TX - 1) / TX;
   // z segments: enough workgroups to fill 256 CUs, each segment a multiple of TZ planes, >= 8 planes
@@ -316,22 +331,6 @@ static hipError_t launch_zm(ConvParams p, hipStream_t st) {
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((NC + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
-  if (dbg & 8) {
-    static int printed = 0;
-    (void)hipStreamSynchronize(st);
-    if (printed++ == 3) {
-      static unsigned long long hostbuf[1024 * 256];
-      (void)hipMemcpy(hostbuf, trace_buf, sizeof hostbuf, hipMemcpyDeviceToHost);
-      const int wgs[2] = {0, 100};
-      for (int wi = 0; wi < 2; ++wi)
-        for (int role = 0; role < 2; ++role) {
-          const unsigned long long* tr = hostbuf + (long long)wgs[wi] * 256 + role * 128;
-          fprintf(stderr, "[trace %s wg %d %s] :", g_kernel_name3, wgs[wi], role ? "loader(wait,barrier,refill+loop)" : "consumer(barrier,sweep,epilogue)");
-          for (int k = 1; k < 128 && tr[k]; ++k) fprintf(stderr, " %llu", tr[k] - tr[k - 1]);
-          fprintf(stderr, "\n");
-        }
-    }
-  }
   return hipGetLastError();
 }
 

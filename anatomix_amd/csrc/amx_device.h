@@ -31,4 +31,82 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
   return __builtin_bit_cast(unsigned short, t);
 }
 
+// 4x4 transpose across the four lanes of a quad with DPP quad_perm moves (VALU only):
+// afterwards register j of quad lane i holds what register i of quad lane j held.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], int lane_in_quad_bits) {
+  const bool b0 = lane_in_quad_bits & 1, b1 = lane_in_quad_bits & 2;
+  // exchange with lane ^ 1 (quad_perm [1,0,3,2] = 0xB1): 2x2 blocks of registers (0,1) and (2,3)
+  const float r01 = dpp_quad<0xB1>(b0 ? v[0] : v[1]);
+  const float r23 = dpp_quad<0xB1>(b0 ? v[2] : v[3]);
+  if (b0) { v[0] = r01; v[2] = r23; } else { v[1] = r01; v[3] = r23; }
+  // exchange with lane ^ 2 (quad_perm [2,3,0,1] = 0x4E): registers (0,2) and (1,3)
+  const float r02 = dpp_quad<0x4E>(b1 ? v[0] : v[2]);
+  const float r13 = dpp_quad<0x4E>(b1 ? v[1] : v[3]);
+  if (b1) { v[0] = r02; v[1] = r13; } else { v[2] = r02; v[3] = r13; }
+}
+
+// ---- intra-workgroup producer/consumer flags in LDS (loader waves <-> MFMA waves) --------------
+// A monotonically increasing 32-bit counter per producer / consumer wave replaces the workgroup
+// barrier of the z-marching kernels, so that a wave blocked on a full memory queue (VMEM issue
+// back-pressure) delays only the waves that really depend on it.  LDS is a single in-order
+// memory per CU: a ds_write issued after `s_waitcnt vmcnt` (LDS-DMA data landed) or after
+// `s_waitcnt lgkmcnt(0)` (own ds_reads returned) is observed by other waves after the data.
+__device__ __forceinline__ int flag_load(const int* p) {
+  return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ void flag_store(int* p, int v) {
+  __atomic_store_n(p, v, __ATOMIC_RELAXED);
+}
+
+// Loader-side variants in inline asm: hipcc treats an in-flight LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of every LDS access of the issuing wave, which would drain the whole
+// prefetch queue at each flag access.  The asm forms are invisible to that pass; ordering against the
+// DMA data is provided explicitly by the counted vmcnt wait that precedes the store.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void flag_store_asm(unsigned addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ int flag_load_asm(unsigned addr) {
+  int r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+// min over 8 consecutive int flags (32-byte aligned) with two ds_read_b128 and ONE wait
+__device__ __forceinline__ int flag_min8_asm(unsigned addr) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  i32x4 a, b;
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(addr)
+               : "memory");
+  int m0 = a[0] < a[1] ? a[0] : a[1], m1 = a[2] < a[3] ? a[2] : a[3];
+  int m2 = b[0] < b[1] ? b[0] : b[1], m3 = b[2] < b[3] ? b[2] : b[3];
+  m0 = m0 < m1 ? m0 : m1;
+  m2 = m2 < m3 ? m2 : m3;
+  return m0 < m2 ? m0 : m2;
+}
+
+// s_waitcnt vmcnt(k * PER) for a run-time k in [0, MAXK]; larger k: no wait needed.
+template <int PER, int I>
+struct WaitVm {
+  static __device__ __forceinline__ void run(int k) {
+    if (k == I) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(I * PER) : "memory");
+    } else {
+      WaitVm<PER, I - 1>::run(k);
+    }
+  }
+};
+template <int PER>
+struct WaitVm<PER, -1> {
+  static __device__ __forceinline__ void run(int) {}
+};
+
 }  // namespace amx
