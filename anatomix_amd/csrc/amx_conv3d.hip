@@ -143,7 +143,7 @@ const char* last_conv_zm_kernel_name();
 
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (conv_zmarch_eligible(p) && Q == 1) {   // HBM-bound 16->16 full-resolution layers: z-marching ring kernel
+  if (conv_zmarch_eligible(p) && Q == p.Cout / 16) {   // narrow full/half-resolution layers: z-marching ring kernel
     hipError_t e = launch_conv_zmarch(p, precision, st);
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
     return e;

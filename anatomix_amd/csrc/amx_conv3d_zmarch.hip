@@ -1,25 +1,25 @@
-// anatomix_amd -- conv3d 3x3x3 reflect for the HBM-bound 16 -> 16 channel layers at full
-// resolution (network.py modules 3, 6, 62, 65 of the 6M model): z-marching streaming kernel with
-// producer / consumer wave specialisation.
+// anatomix_amd -- conv3d 3x3x3 reflect for the narrow full/half-resolution layers
+// (16 -> 16 @128^3: network.py modules 3, 6, 62, 65; 16 -> 32 and 32 -> 32 @64^3: modules 10, 13, 55
+// of the 6M model): z-marching streaming kernel with producer / consumer wave specialisation.
 //
-// Roofline: 216 FLOP/B -- these layers are bound by HBM, not MFMA, so the
-// design minimises bytes moved per output voxel and keeps the memory pipeline continuously full:
+// Roofline: 216 .. 431 FLOP/B -- these layers sit at or below the ridge point, so
+// the design minimises bytes moved per output voxel and keeps the memory pipeline continuously full:
 //   * a workgroup owns an in-plane tile TY x TX and marches along z through a segment of the
 //     volume.  Input z-planes (with their 1-voxel in-plane halo) live in an LDS RING of R planes;
-//     every input plane is fetched ONCE per workgroup (read amplification (TY+2)(TX+2)/(TY*TX) =
-//     1.33 instead of the 1.99 of a 4x8x32 brick with a full 3-D halo);
-//   * NL loader waves do nothing but LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B, per-lane
-//     reflect offsets precomputed once per march): a VMEM instruction blocks its wave while the
-//     memory queue is full, so issuing from the MFMA waves serialised streaming and math.  Loaders
-//     run R - (TZ+2) planes ahead with counted waits (s_waitcnt vmcnt(N), never 0 in steady state);
-//   * NC consumer waves only sweep and store: the packed weights (14 A fragments = 56 VGPRs) and
-//     the bias live in registers for the whole march, so the sweep issues exactly one
-//     ds_read_b128 (the activation fragment) per MFMA; outputs are stored straight from the
-//     accumulators and never waited for;
-//   * no workgroup barrier in the march: loaders publish 'planes landed' counters and consumers
-//     publish 'steps done' counters in LDS (amx_device.h), so a wave stalled on VMEM issue only
-//     delays the waves that depend on it and store bursts of different waves de-synchronise.
-// Arithmetic is identical to amx_conv3d.hip (same packed-weight layout, same 14 paired-tap steps).
+//     every input plane is fetched ONCE per workgroup (read amplification (TY+2)(TX+2)/(TY*TX)
+//     instead of the ~2x of a brick with a full 3-D halo);
+//   * 2*NCK loader waves (one per 8-channel plane) do nothing but LDS-DMA (global_load_lds_dwordx4, 64
+//     lanes x 16 B, per-lane reflect offsets precomputed once per march): a VMEM instruction blocks
+//     its wave while the memory queue is full, so issuing from the MFMA waves serialised streaming
+//     and math.  Loaders run up to R - (TZ+2) planes ahead with counted waits (never vmcnt(0));
+//   * NC consumer waves only sweep and store.  Each owns ONE 16-channel output tile q and keeps that
+//     tile's packed weights (14*NCK A fragments) and bias in registers for the whole march: the sweep
+//     issues at most one ds_read_b128 (the activation fragment) per MFMA, and fragments of input rows
+//     shared by neighbouring output rows are read once;
+//   * no workgroup barrier in the march: loaders publish "planes landed" and consumers "steps done"
+//     counters in LDS (amx_device.h), so a wave stalled on VMEM issue only delays the waves that
+//     depend on it and the store bursts of different waves de-synchronise.
+// Arithmetic is identical to the generic kernel (same packed-weight layout, same 14 paired-tap steps).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -30,34 +30,34 @@ namespace amx {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int TY, int TX, int TZ, int NC, int R>
+template <int NCK, int QT, int TY, int TX, int TZ, int NC, int R>
 struct ZmCfg {
-  static constexpr int NL = 2;                                     // loader waves: one per 8-channel plane
+  static constexpr int NL = 2 * NCK;                               // loader waves: one per 8-channel plane
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;    // halo voxels of one z-plane
   static constexpr int PPL = ((HVP * 16 + 255) / 256) * 256;       // one 8-channel plane of one z-plane
-  static constexpr int PLSZ = 2 * PPL;                             // one z-plane (16 channels)
+  static constexpr int PLSZ = NL * PPL;                            // one z-plane (16*NCK channels)
   static constexpr int FLAGOFF = R * PLSZ;                         // ready[NL] at +0, done[NC] at +32
   static constexpr int LDS_BYTES = R * PLSZ + 64;
   static constexpr int XT = TX / 16;
-  static constexpr int TILES = TZ * TY * XT;                       // column tiles per step
-  static constexpr int CTW = TILES / NC;                           // per consumer wave
-  static constexpr int WPZ = NC / TZ;                              // consumer waves per output z-plane
+  static constexpr int WPQ = NC / QT;                              // consumer waves per output tile q
+  static constexpr int WPZ = WPQ / TZ;                             // ... per output z-plane
   static constexpr int ROWS_W = TY / WPZ;                          // y rows per consumer wave
+  static constexpr int CTW = ROWS_W * XT;                          // column tiles per consumer wave
   static constexpr int NDMA = (HVP + 63) / 64;                     // DMA instructions per (z-plane, channel plane)
-  static constexpr int AHEAD = R - (TZ + 2);                       // planes issued beyond the current step's needs
-  static_assert(TILES % NC == 0 && NC % TZ == 0 && TY % WPZ == 0, "tile/wave decomposition");
-  static_assert(CTW == ROWS_W * XT, "consumer wave owns ROWS_W rows x XT column tiles of one plane");
-  static_assert(AHEAD > TZ, "ring must hold more than one step of prefetch");
+  static_assert(NC == 8, "done flags are read as two b128");
+  static_assert(NC % QT == 0 && WPQ % TZ == 0 && TY % WPZ == 0, "tile/wave decomposition");
+  static_assert(R - (TZ + 2) > TZ, "ring must hold more than one step of prefetch");
   static_assert(R * NDMA <= 60, "loader wave must not exceed the 6-bit vmcnt range");
-  static_assert(LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
+  static_assert(NL <= 8 && LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
 };
 
 // One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
-template <typename T, int TY, int TX, int TZ, int NC, int R, int OUTMODE>
-__global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
-  typedef ZmCfg<TY, TX, TZ, NC, R> C;
+template <typename T, int NCK, int QT, int TY, int TX, int TZ, int NC, int R, int OUTMODE>
+__global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef ZmCfg<NCK, QT, TY, TX, TZ, NC, R> C;
   typedef typename Ops<T>::vec8 vec8;
-  constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NDMA = C::NDMA;
+  constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NDMA = C::NDMA, NL = C::NL;
+  constexpr int RW = C::ROWS_W;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,7 +109,6 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
     const unsigned a_ready = lds_addr(ready + cp), a_done = lds_addr(done);
     while (next_pub < nplanes) {
       if (next_issue < nplanes) {
-        static_assert(NC == 8, "done flags are read as two b128");
         const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
         int lim = R + TZ * md;                              // planes q < TZ*md are dead: their slots are free
         lim = lim < nplanes ? lim : nplanes;
@@ -127,32 +126,34 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
 
   // ================================= consumer wave =================================
   const int li = lane & 15, g = lane >> 4, hi = g >> 1;
-  // resident weights (A fragments) and bias
-  vec8 wreg[kSteps];
+  const int wq = wave / C::WPQ;                            // output tile (16 channels) of this wave
+  const int wr = wave % C::WPQ;
+  const int tz = wr / C::WPZ;
+  const int wrow = (wr % C::WPZ) * RW;
+  // resident weights (A fragments of tile wq) and bias
+  vec8 wreg[NCK][kSteps];
 #pragma unroll
-  for (int s = 0; s < kSteps; ++s) wreg[s] = *(const vec8*)(p.wpk + s * 1024 + lane * 16);
+  for (int k = 0; k < NCK; ++k)
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) wreg[k][s] = *(const vec8*)(p.wpk + ((k * kSteps + s) * QT + wq) * 1024 + lane * 16);
+  const int cb = g * 4 * QT + wq * 4;                      // lane holds output channels cb .. cb+3
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bias = *(const f32x4*)(p.bias + g * 4);
+  if (p.bias) bias = *(const f32x4*)(p.bias + cb);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // wave -> tiles: one output plane tz, ROWS_W rows, XT column tiles
-  const int tz = wave / C::WPZ;
-  const int wrow = (wave % C::WPZ) * C::ROWS_W;
   const int lanebase = (g & 1) * PPL + ((wrow * HX) + li) * 16;
   const int base_d1 = lanebase + hi * 16;
   const int base_dx = lanebase + hi * 16 * HX;
   const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
 
-  // per-lane output base (plane z added per step)
+  // per-lane output bases (plane z added per step)
   const int yl = y0 + wrow, xl = x0 + li;
-  char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 : nullptr;
-  float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4) * p.pc + (long long)yl * p.py + xl
-                                : nullptr;
-
+  char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + cb * 2 : nullptr;
+  float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)cb * p.pc + (long long)yl * p.py + xl : nullptr;
   // fp32 planar output with 16-byte stores needs x-quads that never straddle a row and aligned planes
   const bool vec_planar = OUTMODE == 1 && !(p.W & 3) && !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) &&
                           !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
-  float* out32_q = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4 + (li & 3)) * p.pc + (long long)yl * p.py +
+  float* out32_q = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(cb + (li & 3)) * p.pc + (long long)yl * p.py +
                                       x0 + (li & ~3)
                                 : nullptr;
 
@@ -161,8 +162,13 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
       need = need < nplanes ? need : nplanes;
       while (true) {
-        const int r0 = flag_load(ready), r1 = flag_load(ready + 1);
-        if ((r0 < r1 ? r0 : r1) >= need) break;
+        int m = flag_load(ready);
+#pragma unroll
+        for (int i = 1; i < NL; ++i) {
+          const int r = flag_load(ready + i);
+          m = r < m ? r : m;
+        }
+        if (m >= need) break;
         __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");
@@ -187,68 +193,96 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
     for (int c = 0; c < CTW; ++c) acc[c] = bias;
 
     if (!(p.dbg & 2)) {
-      // The (kx=0,kx=1) fragment of input row r serves every (cy, ky) with cy + ky = r, so each plane
-      // needs only ROWS_W+2 row fragments per column tile.  Fragments are fetched in batches one batch
-      // ahead of the MFMAs that consume them (explicit software pipeline; sched_barrier pins the phases).
-      constexpr int RW = C::ROWS_W, NR = RW + 2;
-      vec8 F[2][NR][XT];     // double-buffered d1 batches (one input plane each)
-      vec8 H[3][RW][XT];     // steps 9..11: (kz,0,2)+(kz,1,2)
-      vec8 S[2][RW][XT];     // steps 12, 13
-      auto load_F = [&](int buf, int kz) {
+      // taps (kz, ky, 0)+(kz, ky, 1): the fragment of input row r serves every (cy, ky) with cy + ky = r, so a
+      // (chunk, plane) batch is RW+2 row fragments per column tile for 3*RW*XT MFMAs.  With one input chunk
+      // the batches are double buffered one batch ahead of their MFMAs (sched_barrier pins the phases);
+      // with two chunks the 28 resident weight fragments leave no registers for the second buffer.
+      constexpr int NB = 3 * NCK;
+      constexpr bool DB = NCK == 1;
+      vec8 F[DB ? 2 : 1][RW + 2][XT];
+      auto load_F = [&](int buf, int idx) {
+        const int k = idx / 3, kz = idx - 3 * k;
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+        for (int r = 0; r < RW + 2; ++r)
 #pragma unroll
-          for (int cx = 0; cx < XT; ++cx) F[buf][r][cx] = *(const vec8*)(smem + b1[kz] + (r * HX + cx * 16) * 16);
+          for (int cx = 0; cx < XT; ++cx)
+            F[buf][r][cx] = *(const vec8*)(smem + b1[kz] + k * 2 * PPL + (r * HX + cx * 16) * 16);
       };
-      auto mma_F = [&](int buf, int kz) {
+      auto mma_F = [&](int buf, int idx) {
+        const int k = idx / 3, kz = idx - 3 * k;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int cy = 0; cy < RW; ++cy)
 #pragma unroll
             for (int cx = 0; cx < XT; ++cx)
-              acc[cy * XT + cx] = Ops<T>::mfma(wreg[kz * 3 + ky], F[buf][cy + ky][cx], acc[cy * XT + cx]);
+              acc[cy * XT + cx] = Ops<T>::mfma(wreg[k][kz * 3 + ky], F[buf][cy + ky][cx], acc[cy * XT + cx]);
       };
-      load_F(0, 0);
-      load_F(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_F(0, 0);
-      load_F(0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_F(1, 1);
+      if (DB) {
+        // one chunk: F(kz=0), F(1) | mma F(0), F(2) | mma F(1), H (steps 9-11) | mma F(2), S (steps 12,13) | mma H, S
+        vec8 H[3][RW][XT], S[2][RW][XT];
+        load_F(0, 0);
+        load_F(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_F(0, 0);
+        load_F(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_F(1, 1);
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz)
+        for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-        for (int cy = 0; cy < RW; ++cy)
+          for (int cy = 0; cy < RW; ++cy)
 #pragma unroll
-          for (int cx = 0; cx < XT; ++cx)
-            H[kz][cy][cx] = *(const vec8*)(smem + bx3[kz] + 2 * 16 + (cy * HX + cx * 16) * 16);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_F(0, 2);
-#pragma unroll
-      for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-        for (int cx = 0; cx < XT; ++cx) {
-          S[0][cy][cx] = *(const vec8*)(smem + bz + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
-          S[1][cy][cx] = *(const vec8*)(smem + b0 + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kz = 0; kz < 3; ++kz)
+            for (int cx = 0; cx < XT; ++cx) H[kz][cy][cx] = *(const vec8*)(smem + bx3[kz] + 2 * 16 + (cy * HX + cx * 16) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_F(0, 2);
 #pragma unroll
         for (int cy = 0; cy < RW; ++cy)
 #pragma unroll
-          for (int cx = 0; cx < XT; ++cx)
-            acc[cy * XT + cx] = Ops<T>::mfma(wreg[9 + kz], H[kz][cy][cx], acc[cy * XT + cx]);
+          for (int cx = 0; cx < XT; ++cx) {
+            S[0][cy][cx] = *(const vec8*)(smem + bz + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
+            S[1][cy][cx] = *(const vec8*)(smem + b0 + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
+          }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int cy = 0; cy < RW; ++cy)
+        for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-        for (int cx = 0; cx < XT; ++cx) {
-          acc[cy * XT + cx] = Ops<T>::mfma(wreg[12], S[0][cy][cx], acc[cy * XT + cx]);
-          acc[cy * XT + cx] = Ops<T>::mfma(wreg[13], S[1][cy][cx], acc[cy * XT + cx]);
+          for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < XT; ++cx) acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][9 + kz], H[kz][cy][cx], acc[cy * XT + cx]);
+#pragma unroll
+        for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < XT; ++cx) {
+            acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][12], S[0][cy][cx], acc[cy * XT + cx]);
+            acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][13], S[1][cy][cx], acc[cy * XT + cx]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          load_F(0, i);
+          mma_F(0, i);
         }
+      }
+#pragma unroll
+      for (int k = 0; k < (DB ? 0 : NCK); ++k) {
+        const int koff = k * 2 * PPL;                        // channel planes 2k, 2k+1
+        // taps (kz,0,2)+(kz,1,2), then (0,2,2)+(1,2,2), then (2,2,2)
+#pragma unroll
+        for (int st = 9; st < kSteps; ++st) {
+          const int kz = st < 12 ? st - 9 : 0;
+          const int tapoff = ((st < 12 ? 0 : 2) * HX + 2) * 16;
+          const int bsel = st < 12 ? bx3[kz] : (st == 12 ? bz : b0);
+#pragma unroll
+          for (int cy = 0; cy < RW; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < XT; ++cx) {
+              const vec8 bf = *(const vec8*)(smem + bsel + koff + tapoff + (cy * HX + cx * 16) * 16);
+              acc[cy * XT + cx] = Ops<T>::mfma(wreg[k][st], bf, acc[cy * XT + cx]);
+            }
+        }
+      }
     }
-
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
 
@@ -272,7 +306,7 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
                                     (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16));
         } else if (vec_planar) {
           // 4x4 transpose inside each lane quad (DPP, no LDS): lane (li, g) ends up with channel
-          // g*4 + (li&3) at x = (li&~3) .. +3, i.e. ONE 16-byte store per lane instead of four 4-byte ones.
+          // cb + (li&3) at x = (li&~3) .. +3, i.e. ONE 16-byte store per lane instead of four 4-byte ones.
           quad_transpose4(v, li);
           float* dst = out32_q + (long long)zo * p.pz + cy * p.py + cx * 16;
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -301,13 +335,13 @@ __global__ __launch_bounds__((NC + 2) * 64) void conv3d_k3_zmarch_kernel(const C
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int OUTMODE>
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE>
 static hipError_t launch_zm(ConvParams p, hipStream_t st) {
-  constexpr int TY = 8, TX = 32, TZ = 2, NC = 8, R = 10;
-  typedef ZmCfg<TY, TX, TZ, NC, R> C;
-  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%dx%dx%d,c%d+l%d,r%d,o%d>",
-           __is_same(T, f16) ? "f16" : "bf16", TZ, TY, TX, NC, C::NL, R, OUTMODE);
-  auto kern = conv3d_k3_zmarch_kernel<T, TY, TX, TZ, NC, R, OUTMODE>;
+  constexpr int TX = 32, TZ = 2, NC = 8;
+  typedef ZmCfg<NCK, QT, TY, TX, TZ, NC, R> C;
+  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c%d+l%d,r%d,o%d>",
+           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, NC, C::NL, R, OUTMODE);
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, TZ, NC, R, OUTMODE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -334,17 +368,25 @@ static hipError_t launch_zm(ConvParams p, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Eligibility: one 16-channel input segment at full resolution, 16 output channels, W >= 32.
+// Eligibility: one full-resolution input segment of 16 or 32 channels, 16 or 32 output channels
+// (not 32 -> 16), W >= 32; the packed weights must use Q = Cout/16 tiles per group (conv_pick_q does).
 bool conv_zmarch_eligible(const ConvParams& p) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_ZMARCH") ? 1 : 0;
-  return !off && !p.src0_f32c1 && p.C0 == 16 && p.C1 == 0 && p.Cout == 16 && p.W >= 32 && p.H >= 8 && p.D >= 8;
+  if (off || p.src0_f32c1 || p.C1 != 0 || p.W < 32 || p.H < 8 || p.D < 8) return false;
+  if (p.C0 == 16 && p.Cout == 16) return true;
+  if (p.out32) return false;                                // planar epilogue only instantiated for 16 -> 16
+  return (p.C0 == 16 || p.C0 == 32) && p.Cout == 32;
 }
 
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (precision == 0) return planar ? launch_zm<f16, 1>(p, st) : launch_zm<f16, 0>(p, st);
-  return planar ? launch_zm<bf16, 1>(p, st) : launch_zm<bf16, 0>(p, st);
+  if (p.Cout == 16) {
+    if (precision == 0) return planar ? launch_zm<f16, 1, 1, 8, 10, 1>(p, st) : launch_zm<f16, 1, 1, 8, 10, 0>(p, st);
+    return planar ? launch_zm<bf16, 1, 1, 8, 10, 1>(p, st) : launch_zm<bf16, 1, 1, 8, 10, 0>(p, st);
+  }
+  if (p.C0 == 16) return precision == 0 ? launch_zm<f16, 1, 2, 4, 10, 0>(p, st) : launch_zm<bf16, 1, 2, 4, 10, 0>(p, st);
+  return precision == 0 ? launch_zm<f16, 2, 2, 4, 10, 0>(p, st) : launch_zm<bf16, 2, 2, 4, 10, 0>(p, st);
 }
 
 }  // namespace amx
