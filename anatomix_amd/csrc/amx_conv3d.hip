@@ -131,8 +131,7 @@ int conv_pick_q(int Cout, int W) {
   if (Cout == 16) return 1;
   if (Cout == 32) return 2;
   if (W >= 32) return 4;      // Cout >= 64 at 32^3 and larger
-  if (W >= 16) return 2;      // 16^3: more cout groups to fill the chip
-  return 1;
+  return 2;                   // 16^3 and below: more cout groups to fill the chip, still two tiles per weight read
 }
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);

@@ -46,6 +46,15 @@ struct Conv2Cfg {
   static constexpr int XT = WX / LX;
   static constexpr int YT = WY / LY;
   static constexpr int CTW = WZ * YT * XT;
+  // low-resolution staging of the upsampled segment (one row per output voxel row pair): instead of
+  // gathering the x2-upsampled halo (every low-res voxel fetched up to 8 times) the stage holds the
+  // low-res halo itself and the B-fragment addresses divide by two.  Needs 16-voxel column tiles
+  // in one row and one 16-channel sub-chunk per stage.
+  static constexpr bool LOWUP = WX >= 16 && NCH == 1 && WZ == 1 && (WY % 2) == 0;
+  static constexpr int LZH = TZ / 2 + 2, LYH = TY / 2 + 2, LXH = TX / 2 + 2;   // low-res halo extent
+  static constexpr int RRL = 64 / LXH;                // low-res halo rows per DMA instruction
+  static constexpr int NROWL = LZH * LYH;
+  static constexpr int NINSTL = (NROWL + RRL - 1) / RRL;
   static constexpr int RR = 64 / HX;                  // halo rows per DMA instruction
   static constexpr int NROW = HZ * HY;
   static constexpr int NINST = (NROW + RR - 1) / RR;
@@ -110,6 +119,25 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
   const int base_dz = lanebase + hi * 16 * HX * HY;
   const int base_d0 = lanebase;
 
+  // ---- lane-constant LDS read bases for LOW-RES staged (upsampled) stages.  Output voxel (z,y,x) of the
+  //      brick reads low-res halo voxel ((z+kz-1)>>1, (y+ky-1)>>1, (x+kx-1)>>1) + 1 per axis.
+  int U1[3], U2e[3], U2o[3], Uz = 0;
+  if (C::LOWUP) {
+    constexpr int LXH = C::LXH, LYH = C::LYH;
+    const int Lx0 = ((li - 1) >> 1) + 1, Lx1 = (li >> 1) + 1, Lx2 = ((li + 1) >> 1) + 1;
+    const int ub = (g & 1) * PLANE + ((wy * WY / 2) * LXH) * 16;
+    int zrow[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) zrow[kz] = ((((wz * WZ + kz - 1) >> 1) + 1) * LYH * LXH) * 16;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      U1[kz] = ub + zrow[kz] + (hi ? Lx1 : Lx0) * 16;           // steps 0..8: (kz,ky,0) | (kz,ky,1)
+      U2o[kz] = ub + zrow[kz] + Lx2 * 16;                        // kx = 2, both halves in the same low row
+      U2e[kz] = U2o[kz] + hi * LXH * 16;                         // kx = 2, (ky=0 | ky=1) one low row apart (even cy)
+    }
+    Uz = ub + (hi ? zrow[1] : zrow[0]) + Lx2 * 16;               // step 12: (0,2,2) | (1,2,2)
+  }
+
   // ---- DMA lane constants: lane -> (row within instruction, x within halo row)
   const int dl = lane / HX, hxl = lane - dl * HX;
   const bool dma_lane = dl < C::RR;
@@ -142,7 +170,27 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
                                 : p.src0 + (long long)it.n * p.s0n + ch * 2;
       const long long sz = second ? p.s1z : p.s0z, sy = second ? p.s1y : p.s0y;
       const int xoff = (gx >> sh) * (int)(second ? p.s1x : p.s0x);
-      if (C::RR == 1) {
+      if (C::LOWUP && second) {
+        // low-res halo of the upsampled segment: reflect padding at high resolution == replicate (clamp)
+        // at low resolution; brick origins are even.
+        const int LD = p.D >> 1, LH = p.H >> 1, LW = p.W >> 1;
+        const int dl2 = lane / C::LXH, hx2 = lane - dl2 * C::LXH;
+        int gx2 = (x0 >> 1) - 1 + hx2;
+        gx2 = gx2 < 0 ? 0 : (gx2 >= LW ? LW - 1 : gx2);
+        for (int j = wave; j < C::NINSTL; j += NW) {
+          const int r = j * C::RRL + dl2;
+          const int lz = r / C::LYH, ly = r - lz * C::LYH;
+          int gz = (z0 >> 1) - 1 + lz, gy = (y0 >> 1) - 1 + ly;
+          gz = gz < 0 ? 0 : (gz >= LD ? LD - 1 : gz);
+          gy = gy < 0 ? 0 : (gy >= LH ? LH - 1 : gy);
+          const char* src = base + gz * sz + gy * sy + gx2 * (int)p.s1x;
+          char* dst = buf + k * HALO + j * (C::RRL * C::LXH * 16);   // uniform
+          if (dl2 < C::RRL && r < C::NROWL) {
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+          }
+        }
+      } else if (C::RR == 1) {
         // one halo row per instruction: (z, y) addressing stays on the scalar unit
         for (int j = wave; j < C::NROW; j += NW) {
           const int hz = j / HY, hy = j - hz * HY;
@@ -279,7 +327,28 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
     }
 
     // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
-    if (!(p.dbg & 2)) {
+    const bool up_stage = C::LOWUP && ((cu_stage * NCH) << 4) >= p.C0;
+    if (!(p.dbg & 2) && up_stage) {
+      // the stage buffer holds the LOW-RES halo of 16 upsampled channels
+      constexpr int LXH = C::LXH;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) {
+        const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
+        const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
+        vec8 a[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a[q] = *(const vec8*)(wbuf + WOFF + (s * Q + q) * 1024 + lane * 16);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          const int cx = c % XT, cy = (c / XT) % YT;
+          const int rowc = ((cy + ky - 1) >> 1) + 1;               // low row of the tile for tap ky (lo lanes)
+          const int ubase = s < 9 ? U1[kz] : (s < 12 ? ((cy & 1) ? U2o[kz] : U2e[kz]) : (s == 12 ? Uz : U2o[2]));
+          const vec8 bf = *(const vec8*)(buf + ubase + (rowc * LXH + cx * 8) * 16);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(a[q], bf, acc[c][q]);
+        }
+      }
+    } else if (!(p.dbg & 2)) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
 #pragma unroll
@@ -407,23 +476,20 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   if (p.W >= 32) {
     if (Q == 1) return launch_cfg2<T, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
     if (Q == 2) return launch_cfg2<T, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
-    if (OUTMODE == 0 && Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 1, 4, 1, 0>(p, st);  // brick 4x2x16, 4 waves
+    if (OUTMODE == 0 && Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
     return hipErrorInvalidValue;
   }
   if (OUTMODE == 1) return hipErrorInvalidValue;
   if (p.W >= 16) {
     if (Q == 1) return launch_cfg2<T, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
-    if (Q == 2) return launch_cfg2<T, 1, 2, 16, 4, 1, 2, 1, 0>(p, st);
-    if (Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 1, 4, 1, 0>(p, st);
+    if (Q == 2) return launch_cfg2<T, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);       // brick 4x4x16, 8 waves
+    if (Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);
   }
   if (Q == 1) {
     if (nch % 2 == 0) return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
     return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
   }
-  if (Q == 2) {
-    if (nch % 2 == 0) return launch_cfg2<T, 1, 2, 8, 4, 1, 2, 2, 0>(p, st);
-    return launch_cfg2<T, 1, 2, 8, 4, 1, 2, 1, 0>(p, st);
-  }
+  if (Q == 2) return launch_cfg2<T, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
   if (Q == 4) return launch_cfg2<T, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
 }
