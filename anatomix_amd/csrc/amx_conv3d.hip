@@ -1,21 +1,20 @@
-// anatomix_amd -- implicit-GEMM 3x3x3 reflect-padded convolution for gfx950 (CDNA4).
+// anatomix_amd -- shared pieces of the conv3d path: weight packing (A fragments), BatchNorm folding,
+// 2x2x2 pooling, tile-shape heuristic and the dispatch between the conv kernels.
 //
-// Replaces the nn.Conv3d(k=3, padding='same', padding_mode='reflect') (+ folded eval BatchNorm3d
+// The convolution kernels themselves live in
+//   amx_conv3d_stem.hip    fp32 single-channel stem (27 taps in one MFMA)
+//   amx_conv3d_zmarch.hip  z-marching ring kernel for the narrow HBM-bound layers
+//   amx_conv3d_upcat.hip   merged-tap upsample+concat conv (48 -> 16 at full resolution)
+//   amx_conv3d_v2.hip      generic persistent double-buffered kernel (every other layer)
+// They replace the nn.Conv3d(k=3, padding='same', padding_mode='reflect') (+ folded eval BatchNorm3d
 // + ReLU, + nearest Upsample + torch.cat on the input side) modules that
-// /root/reference/anatomix/model/network.py:309-465 strings together.
-//
-// Formulation (per workgroup = one output brick TZ x TY x TX of one sample, 16*Q output channels):
+// /root/reference/anatomix/model/network.py:309-465 strings together.  Common formulation:
 //   D[cout][voxel] += W[cout][k] * X[k][voxel],   k = (tap, cin)
 //   A operand  = weights (rows = output channels)  -> per-lane accumulators hold 4 consecutive
 //                channels of one voxel, so the epilogue writes 8*Q contiguous bytes per lane.
 //   B operand  = activations: lane (i = lane&15, g = lane>>4) reads ONE 16-byte LDS slot = 8
 //                channels of voxel i at the tap selected by g (see amx_common.h step table).
 //   MFMA       = v_mfma_f32_16x16x32_{f16,bf16}: K = 32 = 2 taps x 16 input channels.
-// LDS image of the input halo: plane-major [8-channel plane][halo voxel] x 16 B, so the 16 lanes
-// of a B-fragment read hit 16 consecutive 16-B slots (ds_read_b128, conflict-free for every tap).
-// Reflect padding, the nearest-x2 upsample of the low-resolution segment and the skip||up
-// channel concat are all resolved in the per-lane global address of the halo gather; none of
-// them is ever materialised in HBM.
 #include <stdio.h>
 #include <stdlib.h>
 
