@@ -83,6 +83,22 @@ def cpu_baseline(size, forwards):
                       f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
 
 
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
+    WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md prescribes; produced by
+    tools/pmc_summary.py).  None when no summary matches this kernel and batch."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_meta", {}).get("batch_per_gpu") == batch and kernel in d:
+            return {"bytes_per_launch": round(d[kernel]["traffic"]), "read": round(d[kernel]["read_corrected"]),
+                    "write": round(d[kernel]["write"]), "source": "profiles/" + os.path.basename(f)}
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -172,7 +188,8 @@ def main():
                     "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
                     "alg_intensity_flop_per_byte": round(flops_per_launch / bytes_per_launch, 1),
                     "share_of_step": round(a["ms"] / reps / total_ms, 3),
-                    "alg_TFLOPs": round(tflops, 1), "alg_GBps": round(gbps, 1), "traffic": None,
+                    "alg_TFLOPs": round(tflops, 1), "alg_GBps": round(gbps, 1),
+                    "traffic": pmc_traffic(dom, B),
                     "per_kernel": {k: {"us_per_step": round(v["ms"] / reps * 1e3, 1), "launches": v["launches"] // reps,
                                        "alg_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else 0.0,
                                        "alg_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}

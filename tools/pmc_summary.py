@@ -1,0 +1,66 @@
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
+/opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes) into per-kernel HBM traffic per launch.
+
+Units/corrections applied (same guide): the counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+the bytes of a wide (16 B/lane) coalesced streaming read -- every read of these kernels is a 16-byte LDS-DMA
+or 16-byte load -- so the read side is doubled; WRITE_SIZE is used as reported (it matches the algorithmic
+output bytes of the store-only stem kernel to 5 digits, which calibrates it for these access patterns).
+
+usage: python tools/pmc_summary.py <fetch_csv> <write_csv> <out_json> [batch]
+"""
+import collections, csv, json, re, sys
+
+
+def friendly(mangled):
+    m = re.match(r"_ZN3amx23conv3d_k3_zmarch_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
+    if m:
+        t, nck, qt, ty, tx, tz, nc, r, o = m.groups()
+        return f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},{16*int(nck)}->{16*int(qt)},{tz}x{ty}x{tx},c{nc}+l{2*int(nck)},r{r},o{o}>"
+    m = re.match(r"_ZN3amx21conv3d_upcat16_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
+    if m:
+        return f"conv3d_upcat16<{'f16' if m.group(1) == 'DF16_' else 'bf16'},2x8x32,c8+l3,r10/6,o{m.group(2)}>"
+    m = re.match(r"_ZN3amx18conv3d_stem_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
+    if m:
+        return f"conv3d_stem<{'f16' if m.group(1) == 'DF16_' else 'bf16'},q{m.group(2)},2x8x32,c8+l1,r10>"
+    m = re.match(r"_ZN3amx19conv3d_k3_v2_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
+    if m:
+        t, wz, wy, wx, nwz, nwy, q, nch, o = m.groups()
+        return (f"conv3d_k3_v2<{'f16' if t == 'DF16_' else 'bf16'},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},"
+                f"w{int(nwz)*int(nwy)},q{q},nch{nch},o{o}>")
+    if "pool2_kernel" in mangled:
+        return "pool2<max>" if "Li0EEE" in mangled else "pool2<avg>"
+    return None
+
+
+def collect(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = friendly(r["Kernel_Name"])
+        if k:
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    return {k: v[1] / v[0] * 1024.0 for k, v in agg.items()}, {k: v[0] for k, v in agg.items()}
+
+
+def main():
+    fetch_csv, write_csv, out = sys.argv[1:4]
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    fetch, nf = collect(fetch_csv, "FETCH_SIZE")
+    write, nw = collect(write_csv, "WRITE_SIZE")
+    res = {"_meta": {"batch_per_gpu": batch, "unit": "bytes per launch",
+                     "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 wide-read under-count), write = WRITE_SIZE x 1024",
+                     "sources": [fetch_csv.split('gpurun_out/')[-1], write_csv.split('gpurun_out/')[-1]]}}
+    for k in sorted(set(fetch) | set(write)):
+        rd, wr = 2.0 * fetch.get(k, 0.0), write.get(k, 0.0)
+        res[k] = {"fetch_size_raw": fetch.get(k, 0.0), "read_corrected": rd, "write": wr, "traffic": rd + wr,
+                  "launches_sampled": [nf.get(k, 0), nw.get(k, 0)]}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        if k != "_meta":
+            print(f"{k:56s} read {v['read_corrected']/1e6:9.1f} MB  write {v['write']/1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
