@@ -315,7 +315,7 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
             const float4 old = *(const float4*)dst;
             o = make_float4(old.x + wg.x * o.x, old.y + wg.y * o.y, old.z + wg.z * o.z, old.w + wg.w * o.w);
           }
-          *(float4*)dst = o;
+          *(float4*)dst = o;     // (a nontemporal store here measured 16 % slower: 282 vs 242 us at batch 4)
         } else {
           float* dst = out32_l + (long long)zo * p.pz + cy * p.py + cx * 16;
           if (p.wmap) {
