@@ -31,6 +31,7 @@ bool conv_upcat16_eligible(const ConvParams& p);
 hipError_t launch_conv_upcat16(const ConvParams& p, int precision, hipStream_t st);
 hipError_t launch_pack_upcat16(const float* w, const float* scale, void* wpk, int precision, hipStream_t st);
 const char* last_conv_upcat_kernel_name();
+bool conv_zmarch_can_pool(const ConvParams& p);
 const char* last_conv_kernel_name();
 }  // namespace amx
 
@@ -218,6 +219,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   std::vector<Tensor> skips;
   Tensor pend_skip;
   bool have_skip = false;
+  Tensor fused_pool;         // pooled tensor written by the preceding conv's epilogue
+  bool have_fused_pool = false;
   size_t conv_i = 0;
 
   for (size_t i = 0; i < h->kinds.size(); ++i) {
@@ -284,6 +287,18 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         r.bytes = in_b + out_b + 2.0 * 27.0 * L.cin * L.cout;
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
+      // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue
+      {
+        size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
+        if (!L.is_final && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
+            cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout / 16) {
+          fused_pool.level = lv + 1; fused_pool.C = L.cout; fused_pool.slot = grab(lv + 1);
+          if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
+          p.out2 = A.slot[lv + 1][fused_pool.slot];
+          p.qx = (long long)L.cout * 2; p.qy = p.qx * (dw / 2); p.qz = p.qy * (dh / 2); p.qn = p.qz * (dd / 2);
+          have_fused_pool = true;
+        }
+      }
       if (p.src0_f32c1) {
         if (L.is_final || L.cout > 32)
           return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
@@ -312,6 +327,14 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           skips.push_back(cur);
           // keep it alive: mark as used by skip (cur release below must not free it)
         }
+    } else if (kind == K_POOL && have_fused_pool) {
+      // already produced by the previous conv's epilogue
+      bool is_skip = false;
+      for (const Tensor& s : skips)
+        if (s.level == cur.level && s.slot == cur.slot) is_skip = true;
+      if (!is_skip) A.used[cur.level][cur.slot] = false;
+      cur = fused_pool;
+      have_fused_pool = false;
     } else if (kind == K_POOL) {
       const int lv = cur.level + 1;
       Tensor out;

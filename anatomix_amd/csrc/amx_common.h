@@ -52,6 +52,8 @@ struct ConvParams {
   float slope;
   int nbz, nby, nbx;           // bricks per axis
   float* stats;                // optional per-(n,c) {sum, sumsq} fp32 accumulators (instance norm)
+  char* out2;                  // optional second output: 2x2x2 MAX-POOLED copy of `out` (16-bit NDHWC, dense), fused
+  long long qn, qz, qy, qx;    //   into the epilogue of the z-marching kernel (nn.MaxPool3d(2), network.py:368)
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
 };
 

@@ -1,21 +1,25 @@
 // anatomix_amd -- conv3d 3x3x3 reflect for the narrow full/half-resolution layers
 // (16 -> 16 @128^3: network.py modules 3, 6, 62, 65; 16 -> 32 and 32 -> 32 @64^3: modules 10, 13, 55
-// of the 6M model): z-marching streaming kernel with producer / consumer wave specialisation.
+// of the 6M model), optionally with the following nn.MaxPool3d(2) fused into the epilogue:
+// z-marching streaming kernel with producer / consumer wave specialisation.
 //
 // Roofline: 216 .. 431 FLOP/B -- these layers sit at or below the ridge point, so
 // the design minimises bytes moved per output voxel and keeps the memory pipeline continuously full:
 //   * a workgroup owns an in-plane tile TY x TX and marches along z through a segment of the
-//     volume.  Input z-planes (with their 1-voxel in-plane halo) live in an LDS RING of R planes;
-//     every input plane is fetched ONCE per workgroup (read amplification (TY+2)(TX+2)/(TY*TX)
-//     instead of the ~2x of a brick with a full 3-D halo);
+//     volume, two output planes per step.  Input z-planes (with their 1-voxel in-plane halo) live in
+//     an LDS RING of R planes; every input plane is fetched ONCE per workgroup (read amplification
+//     (TY+2)(TX+2)/(TY*TX) instead of the ~2x of a brick with a full 3-D halo);
 //   * 2*NCK loader waves (one per 8-channel plane) do nothing but LDS-DMA (global_load_lds_dwordx4, 64
 //     lanes x 16 B, per-lane reflect offsets precomputed once per march): a VMEM instruction blocks
 //     its wave while the memory queue is full, so issuing from the MFMA waves serialised streaming
-//     and math.  Loaders run up to R - (TZ+2) planes ahead with counted waits (never vmcnt(0));
-//   * NC consumer waves only sweep and store.  Each owns ONE 16-channel output tile q and keeps that
-//     tile's packed weights (14*NCK A fragments) and bias in registers for the whole march: the sweep
-//     issues at most one ds_read_b128 (the activation fragment) per MFMA, and fragments of input rows
-//     shared by neighbouring output rows are read once;
+//     and math.  Loaders run up to R - 4 planes ahead with counted waits (never vmcnt(0));
+//   * 8 consumer waves only sweep and store.  Each owns ONE 16-channel output tile q and a 2 (planes) x
+//     2 (rows) x 16 (x) block of voxels per step, and keeps that tile's packed weights (14*NCK A
+//     fragments) and bias in registers for the whole march.  The four input planes and four input rows
+//     the block touches are shared between its four column tiles: 32 ds_read_b128 feed 56 MFMAs;
+//   * the 2x2x2 block is exactly one max-pool window per x pair, so the pooled tensor is produced in
+//     registers (max over the four accumulators, one DPP exchange for the x neighbour) and written
+//     next to the full-resolution output -- the separate pool kernel and its re-read disappear;
 //   * no workgroup barrier in the march: loaders publish "planes landed" and consumers "steps done"
 //     counters in LDS (amx_device.h), so a wave stalled on VMEM issue only delays the waves that
 //     depend on it and the store bursts of different waves de-synchronise.
@@ -30,8 +34,9 @@ namespace amx {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NCK, int QT, int TY, int TX, int TZ, int NC, int R>
+template <int NCK, int QT, int TY, int TX, int R>
 struct ZmCfg {
+  static constexpr int NC = 8, TZ = 2;
   static constexpr int NL = 2 * NCK;                               // loader waves: one per 8-channel plane
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;    // halo voxels of one z-plane
   static constexpr int PPL = ((HVP * 16 + 255) / 256) * 256;       // one 8-channel plane of one z-plane
@@ -40,24 +45,19 @@ struct ZmCfg {
   static constexpr int LDS_BYTES = R * PLSZ + 64;
   static constexpr int XT = TX / 16;
   static constexpr int WPQ = NC / QT;                              // consumer waves per output tile q
-  static constexpr int WPZ = WPQ / TZ;                             // ... per output z-plane
-  static constexpr int ROWS_W = TY / WPZ;                          // y rows per consumer wave
-  static constexpr int CTW = ROWS_W * XT;                          // column tiles per consumer wave
   static constexpr int NDMA = (HVP + 63) / 64;                     // DMA instructions per (z-plane, channel plane)
-  static_assert(NC == 8, "done flags are read as two b128");
-  static_assert(NC % QT == 0 && WPQ % TZ == 0 && TY % WPZ == 0, "tile/wave decomposition");
-  static_assert(R - (TZ + 2) > TZ, "ring must hold more than one step of prefetch");
+  static_assert(WPQ == (TY / 2) * XT, "each consumer wave owns a 2 x 2 x 16 voxel block per step");
+  static_assert(R - 4 > TZ, "ring must hold more than one step of prefetch");
   static_assert(R * NDMA <= 60, "loader wave must not exceed the 6-bit vmcnt range");
   static_assert(NL <= 8 && LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
 };
 
 // One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
-template <typename T, int NCK, int QT, int TY, int TX, int TZ, int NC, int R, int OUTMODE>
-__global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
-  typedef ZmCfg<NCK, QT, TY, TX, TZ, NC, R> C;
+template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE>
+__global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef ZmCfg<NCK, QT, TY, TX, R> C;
   typedef typename Ops<T>::vec8 vec8;
-  constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NDMA = C::NDMA, NL = C::NL;
-  constexpr int RW = C::ROWS_W;
+  constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, NDMA = C::NDMA, NL = C::NL, NC = C::NC, TZ = C::TZ;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
   const int sg = b % nseg;
   const int n = b / nseg;
   const int y0 = by * TY, x0 = bx * TX;
-  const int zs = sg * zseg;
+  const int zs = sg * zseg;                                 // even
   const int ze = (zs + zseg < p.D) ? zs + zseg : p.D;      // output planes [zs, ze)
   const int nplanes = ze - zs + 2;                          // input planes q = 0 .. nplanes-1 <-> z = zs-1+q
   const int nsteps = (ze - zs + TZ - 1) / TZ;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
   const int li = lane & 15, g = lane >> 4, hi = g >> 1;
   const int wq = wave / C::WPQ;                            // output tile (16 channels) of this wave
   const int wr = wave % C::WPQ;
-  const int tz = wr / C::WPZ;
-  const int wrow = (wr % C::WPZ) * RW;
+  const int wrow = (wr / XT) * 2;                          // first of the wave's two rows
+  const int wcx = wr % XT;                                 // the wave's x tile
   // resident weights (A fragments of tile wq) and bias
   vec8 wreg[NCK][kSteps];
 #pragma unroll
@@ -141,21 +141,25 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
   if (p.bias) bias = *(const f32x4*)(p.bias + cb);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  const int lanebase = (g & 1) * PPL + ((wrow * HX) + li) * 16;
+  const int lanebase = (g & 1) * PPL + ((wrow * HX) + wcx * 16 + li) * 16;
   const int base_d1 = lanebase + hi * 16;
   const int base_dx = lanebase + hi * 16 * HX;
   const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
 
   // per-lane output bases (plane z added per step)
-  const int yl = y0 + wrow, xl = x0 + li;
+  const int yl = y0 + wrow, xl = x0 + wcx * 16 + li;
   char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + cb * 2 : nullptr;
   float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)cb * p.pc + (long long)yl * p.py + xl : nullptr;
   // fp32 planar output with 16-byte stores needs x-quads that never straddle a row and aligned planes
   const bool vec_planar = OUTMODE == 1 && !(p.W & 3) && !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) &&
                           !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
   float* out32_q = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(cb + (li & 3)) * p.pc + (long long)yl * p.py +
-                                      x0 + (li & ~3)
+                                      x0 + wcx * 16 + (li & ~3)
                                 : nullptr;
+  // fused 2x2x2 max-pool output (dense 16-bit NDHWC at half resolution); even lanes store
+  char* out2_l = (OUTMODE == 0 && p.out2) ? p.out2 + (long long)n * p.qn + (long long)(yl >> 1) * p.qy +
+                                               (long long)(xl >> 1) * p.qx + cb * 2
+                                          : nullptr;
 
   for (int s = 0; s < nsteps; ++s) {
     {
@@ -174,112 +178,77 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
       asm volatile("" ::: "memory");
     }
 
-    const int zo = zs + s * TZ + tz;                 // this wave's output plane
-    // ring slots of the three input planes zo-1, zo, zo+1  (q = s*TZ + tz + kz)
-    int sl[3];
+    // ring slots of the four input planes zs+2s-1 .. zs+2s+2  (q = 2s + pl)
+    int b1[4], bx3[4];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) sl[kz] = ((s * TZ + tz + kz) % R) * PLSZ;
-    int b1[3], bx3[3];
-#pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      b1[kz] = base_d1 + sl[kz];
-      bx3[kz] = base_dx + sl[kz];
+    for (int pl = 0; pl < 4; ++pl) {
+      const int sl = ((s * TZ + pl) % R) * PLSZ;
+      b1[pl] = base_d1 + sl;
+      bx3[pl] = base_dx + sl;
     }
-    const int bz = lanebase + (hi ? sl[1] : sl[0]);
-    const int b0 = lanebase + sl[2];
-
-    f32x4 acc[CTW];
+    // accumulators: [output plane tz][row cy]
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int c = 0; c < CTW; ++c) acc[c] = bias;
+    for (int tz = 0; tz < 2; ++tz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = bias;
 
     if (!(p.dbg & 2)) {
-      // taps (kz, ky, 0)+(kz, ky, 1): the fragment of input row r serves every (cy, ky) with cy + ky = r, so a
-      // (chunk, plane) batch is RW+2 row fragments per column tile for 3*RW*XT MFMAs.  With one input chunk
-      // the batches are double buffered one batch ahead of their MFMAs (sched_barrier pins the phases);
-      // with two chunks the 28 resident weight fragments leave no registers for the second buffer.
-      constexpr int NB = 3 * NCK;
-      constexpr bool DB = NCK == 1;
-      vec8 F[DB ? 2 : 1][RW + 2][XT];
-      auto load_F = [&](int buf, int idx) {
-        const int k = idx / 3, kz = idx - 3 * k;
 #pragma unroll
-        for (int r = 0; r < RW + 2; ++r)
-#pragma unroll
-          for (int cx = 0; cx < XT; ++cx)
-            F[buf][r][cx] = *(const vec8*)(smem + b1[kz] + k * 2 * PPL + (r * HX + cx * 16) * 16);
-      };
-      auto mma_F = [&](int buf, int idx) {
-        const int k = idx / 3, kz = idx - 3 * k;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < XT; ++cx)
-              acc[cy * XT + cx] = Ops<T>::mfma(wreg[k][kz * 3 + ky], F[buf][cy + ky][cx], acc[cy * XT + cx]);
-      };
-      if (DB) {
-        // one chunk: F(kz=0), F(1) | mma F(0), F(2) | mma F(1), H (steps 9-11) | mma F(2), S (steps 12,13) | mma H, S
-        vec8 H[3][RW][XT], S[2][RW][XT];
-        load_F(0, 0);
-        load_F(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_F(0, 0);
-        load_F(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_F(1, 1);
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-          for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < XT; ++cx) H[kz][cy][cx] = *(const vec8*)(smem + bx3[kz] + 2 * 16 + (cy * HX + cx * 16) * 16);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_F(0, 2);
-#pragma unroll
-        for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-          for (int cx = 0; cx < XT; ++cx) {
-            S[0][cy][cx] = *(const vec8*)(smem + bz + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
-            S[1][cy][cx] = *(const vec8*)(smem + b0 + (2 * HX + 2) * 16 + (cy * HX + cx * 16) * 16);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-          for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < XT; ++cx) acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][9 + kz], H[kz][cy][cx], acc[cy * XT + cx]);
-#pragma unroll
-        for (int cy = 0; cy < RW; ++cy)
-#pragma unroll
-          for (int cx = 0; cx < XT; ++cx) {
-            acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][12], S[0][cy][cx], acc[cy * XT + cx]);
-            acc[cy * XT + cx] = Ops<T>::mfma(wreg[0][13], S[1][cy][cx], acc[cy * XT + cx]);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          load_F(0, i);
-          mma_F(0, i);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < (DB ? 0 : NCK); ++k) {
+      for (int k = 0; k < NCK; ++k) {
         const int koff = k * 2 * PPL;                        // channel planes 2k, 2k+1
-        // taps (kz,0,2)+(kz,1,2), then (0,2,2)+(1,2,2), then (2,2,2)
+        // Per input plane pl: 4 row fragments of taps (kz,ky,0)|(kz,ky,1) and 2 fragments of taps
+        // (kz,0,2)|(kz,1,2); plane pl is tap plane kz = pl - tz of output plane tz.  Batches are double
+        // buffered one plane ahead of their MFMAs (sched_barrier pins the phases).
+        constexpr bool DB = NCK == 1;      // two chunks: 28 resident weight fragments leave no room for a 2nd buffer
+        vec8 F[DB ? 2 : 1][4], H[DB ? 2 : 1][2];
+        auto load_plane = [&](int buf, int pl) {
 #pragma unroll
-        for (int st = 9; st < kSteps; ++st) {
-          const int kz = st < 12 ? st - 9 : 0;
-          const int tapoff = ((st < 12 ? 0 : 2) * HX + 2) * 16;
-          const int bsel = st < 12 ? bx3[kz] : (st == 12 ? bz : b0);
+          for (int r = 0; r < 4; ++r) F[buf][r] = *(const vec8*)(smem + b1[pl] + koff + (r * HX) * 16);
 #pragma unroll
-          for (int cy = 0; cy < RW; ++cy)
+          for (int cy = 0; cy < 2; ++cy) H[buf][cy] = *(const vec8*)(smem + bx3[pl] + koff + (cy * HX + 2) * 16);
+        };
+        auto mma_plane = [&](int buf, int pl) {
 #pragma unroll
-            for (int cx = 0; cx < XT; ++cx) {
-              const vec8 bf = *(const vec8*)(smem + bsel + koff + tapoff + (cy * HX + cx * 16) * 16);
-              acc[cy * XT + cx] = Ops<T>::mfma(wreg[k][st], bf, acc[cy * XT + cx]);
-            }
+          for (int tz = 0; tz < 2; ++tz) {
+            const int kz = pl - tz;
+            if (kz < 0 || kz > 2) continue;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = Ops<T>::mfma(wreg[k][kz * 3 + ky], F[buf][cy + ky], acc[tz][cy]);
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = Ops<T>::mfma(wreg[k][9 + kz], H[buf][cy], acc[tz][cy]);
+          }
+        };
+        if (DB) {
+          load_plane(0, 0);
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            if (pl + 1 < 4) load_plane((pl + 1) & 1, pl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_plane(pl & 1, pl);
+          }
+        } else {
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            load_plane(0, pl);
+            mma_plane(0, pl);
+          }
+        }
+        // taps (0,2,2)|(1,2,2) (low lanes plane tz, high lanes plane tz+1) and (2,2,2) (plane tz+2)
+#pragma unroll
+        for (int tz = 0; tz < 2; ++tz) {
+          const int sl0 = ((s * TZ + tz) % R) * PLSZ, sl1 = ((s * TZ + tz + 1) % R) * PLSZ, sl2 = ((s * TZ + tz + 2) % R) * PLSZ;
+          const int bz = lanebase + (hi ? sl1 : sl0) + koff + (2 * HX + 2) * 16;
+          const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
+            const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
+            acc[tz][cy] = Ops<T>::mfma(wreg[k][12], s0, acc[tz][cy]);
+            acc[tz][cy] = Ops<T>::mfma(wreg[k][13], s1, acc[tz][cy]);
+          }
         }
       }
     }
@@ -287,39 +256,44 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
     flag_store(done + wave, s + 1);
 
     // ---- epilogue: activation + store (never waited for)
-    if (zo < ze && !(p.dbg & 4)) {
+    if (p.dbg & 4) continue;
+    float pooled[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
-      for (int c = 0; c < CTW; ++c) {
-        const int cx = c % XT, cy = c / XT;
-        if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
+    for (int tz = 0; tz < 2; ++tz) {
+      const int zo = zs + s * TZ + tz;
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float f = acc[c][j];
+          float f = acc[tz][cy][j];
           if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
           v[j] = f;
+          pooled[j] = f > pooled[j] ? f : pooled[j];
         }
+        if (zo >= ze) continue;
+        if (!full_xy && !((yl + cy < p.H) & (xl < p.W))) continue;
         if (OUTMODE == 0) {
-          char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
+          char* dst = out_l + (long long)zo * p.oz + cy * p.oy;
           *(uint2*)dst = make_uint2((unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16),
                                     (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16));
         } else if (vec_planar) {
           // 4x4 transpose inside each lane quad (DPP, no LDS): lane (li, g) ends up with channel
           // cb + (li&3) at x = (li&~3) .. +3, i.e. ONE 16-byte store per lane instead of four 4-byte ones.
           quad_transpose4(v, li);
-          float* dst = out32_q + (long long)zo * p.pz + cy * p.py + cx * 16;
+          float* dst = out32_q + (long long)zo * p.pz + cy * p.py;
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (p.wmap) {
-            const float4 wg = *(const float4*)(p.wmap + ((long long)zo * p.H + yl + cy) * p.W + x0 + (li & ~3) + cx * 16);
+            const float4 wg = *(const float4*)(p.wmap + ((long long)zo * p.H + yl + cy) * p.W + x0 + wcx * 16 + (li & ~3));
             const float4 old = *(const float4*)dst;
             o = make_float4(old.x + wg.x * o.x, old.y + wg.y * o.y, old.z + wg.z * o.z, old.w + wg.w * o.w);
           }
           *(float4*)dst = o;     // (a nontemporal store here measured 16 % slower: 282 vs 242 us at batch 4)
         } else {
-          float* dst = out32_l + (long long)zo * p.pz + cy * p.py + cx * 16;
+          float* dst = out32_l + (long long)zo * p.pz + cy * p.py;
           if (p.wmap) {
-            const float wgt = p.wmap[((long long)zo * p.H + yl + cy) * p.W + xl + cx * 16];
+            const float wgt = p.wmap[((long long)zo * p.H + yl + cy) * p.W + xl];
 #pragma unroll
             for (int j = 0; j < 4; ++j) dst[(long long)j * p.pc] += wgt * v[j];
           } else {
@@ -327,6 +301,22 @@ __global__ __launch_bounds__((NC + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(c
             for (int j = 0; j < 4; ++j) dst[(long long)j * p.pc] = v[j];
           }
         }
+      }
+    }
+    if (OUTMODE == 0 && out2_l) {
+      // the wave's 2 x 2 x 16 block is one max-pool window per x pair: exchange with lane ^ 1, even lanes store.
+      // (rounding is monotonic, so pooling the fp32 values equals pooling the stored 16-bit values.)
+      float pm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float o = dpp_quad<0xB1>(pooled[j]);
+        pm[j] = pooled[j] > o ? pooled[j] : o;
+      }
+      const int zp = (zs + s * TZ) >> 1;
+      if (!(li & 1) && zs + s * TZ + 1 < ze && (full_xy || ((yl + 1 < p.H) & (xl + 1 < p.W)))) {
+        char* dst = out2_l + (long long)zp * p.qz;
+        *(uint2*)dst = make_uint2((unsigned)to_bits<T>(pm[0]) | ((unsigned)to_bits<T>(pm[1]) << 16),
+                                  (unsigned)to_bits<T>(pm[2]) | ((unsigned)to_bits<T>(pm[3]) << 16));
       }
     }
   }
@@ -337,11 +327,11 @@ const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
 template <typename T, int NCK, int QT, int TY, int R, int OUTMODE>
 static hipError_t launch_zm(ConvParams p, hipStream_t st) {
-  constexpr int TX = 32, TZ = 2, NC = 8;
-  typedef ZmCfg<NCK, QT, TY, TX, TZ, NC, R> C;
-  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c%d+l%d,r%d,o%d>",
-           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, NC, C::NL, R, OUTMODE);
-  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, TZ, NC, R, OUTMODE>;
+  constexpr int TX = 32, TZ = 2;
+  typedef ZmCfg<NCK, QT, TY, TX, R> C;
+  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c8+l%d,r%d,o%d%s>",
+           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, R, OUTMODE, p.out2 ? ",pool" : "");
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -364,7 +354,7 @@ static hipError_t launch_zm(ConvParams p, hipStream_t st) {
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((NC + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
   return hipGetLastError();
 }
 
@@ -377,6 +367,13 @@ bool conv_zmarch_eligible(const ConvParams& p) {
   if (p.C0 == 16 && p.Cout == 16) return true;
   if (p.out32) return false;                                // planar epilogue only instantiated for 16 -> 16
   return (p.C0 == 16 || p.C0 == 32) && p.Cout == 32;
+}
+
+// The fused max-pool needs even extents (every 2x2x2 window inside one wave's block).
+bool conv_zmarch_can_pool(const ConvParams& p) {
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_POOLFUSE") ? 1 : 0;
+  return !off && conv_zmarch_eligible(p) && !p.out32 && !(p.D & 1) && !(p.H & 1) && !(p.W & 1);
 }
 
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
