@@ -25,7 +25,8 @@ template <int TY, int TX, int TZ, int NC, int R>
 struct StemCfg {
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
   static constexpr int PLSZ = ((HVP * 4 + 255) / 256) * 256;      // one fp32 z-plane with halo
-  static constexpr int LDS_BYTES = R * PLSZ;
+  static constexpr int FLAGOFF = R * PLSZ;                        // ready at +0, done[8] at +32
+  static constexpr int LDS_BYTES = R * PLSZ + 64;
   static constexpr int XT = TX / 16;
   static constexpr int TILES = TZ * TY * XT;
   static constexpr int CTW = TILES / NC;
@@ -63,6 +64,12 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   const int nplanes = ze - zs + 2;
   const int nsteps = (ze - zs + TZ - 1) / TZ;
 
+  // producer/consumer counters in LDS instead of a workgroup barrier per step (amx_device.h)
+  int* ready = (int*)(smem + C::FLAGOFF);
+  int* done = (int*)(smem + C::FLAGOFF + 32);
+  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  __syncthreads();
+
   if (wave >= NC) {
     // ================================ loader wave ================================
     int off[NDMA];
@@ -82,22 +89,21 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
       for (int j = 0; j < NDMA; ++j)
         if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 256), 4, 0, 0);
     };
-    int issued = 0;
-    {
-      const int first = nplanes < R ? nplanes : R;
-      for (; issued < first; ++issued) issue_plane(issued);
-    }
-    for (int s = 0; s < nsteps; ++s) {
-      const int need_hi = s * TZ + TZ + 1;
-      if (issued - 1 - need_hi >= C::AHEAD - TZ) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEAD - TZ) * NDMA) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int next_issue = 0, next_pub = 0;
+    const unsigned a_ready = lds_addr(ready), a_done = lds_addr(done);
+    while (next_pub < nplanes) {
+      if (next_issue < nplanes) {
+        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
+        int lim = R + TZ * md;                              // planes q < TZ*md are dead
+        lim = lim < nplanes ? lim : nplanes;
+        while (next_issue < lim) issue_plane(next_issue++);
       }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int lim = s * TZ + R < nplanes ? s * TZ + R : nplanes;
-      for (; issued < lim; ++issued) issue_plane(issued);
+      if (next_issue == next_pub) {
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      WaitVm<NDMA, R - 1>::run(next_issue - next_pub - 1);
+      flag_store_asm(a_ready, ++next_pub);
     }
     return;
   }
@@ -120,8 +126,12 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 * Q;
 
   for (int s = 0; s < nsteps; ++s) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    {
+      int need = TZ * s + TZ + 2;
+      need = need < nplanes ? need : nplanes;
+      while (flag_load(ready) < need) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    }
     const int zo = zs + s * TZ + tz;
     int sl[3];
 #pragma unroll
@@ -165,6 +175,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
       if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
       else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
+    flag_store(done + wave, s + 1);
   }
 }
 

@@ -45,7 +45,8 @@ struct UpcatCfg {
   static constexpr int LPL = ((LVP * 16 + 255) / 256) * 256;     // one 8-channel plane of a low-res z-plane
   static constexpr int LPSZ = 4 * LPL;                           // 32 channels
   static constexpr int LOFF = R * PLSZ;                          // low-res ring base
-  static constexpr int LDS_BYTES = LOFF + RL * LPSZ;
+  static constexpr int FLAGOFF = LOFF + RL * LPSZ;               // ready[3] at +0, done[8] at +32
+  static constexpr int LDS_BYTES = FLAGOFF + 64;
   static constexpr int NDMA = (HVP + 63) / 64;                   // per (skip z-plane, channel plane)
   static constexpr int NDMAL = 4 * ((LVP + 63) / 64);            // per low-res z-plane
   static constexpr int AHEAD = R - 4;                            // skip planes beyond a step's needs (TZ = 2)
@@ -83,6 +84,13 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
   const int nplanes = ze - zs + 2;                           // skip planes  q  <-> z  = zs - 1 + q
   const int nlow = nsteps + 2;                               // low planes   ql <-> lz = zs/2 - 1 + ql
 
+  // producer/consumer counters in LDS (no workgroup barrier in the march, see amx_device.h):
+  // ready[0], ready[1]: skip planes landed per channel plane; ready[2]: low-res planes landed; done[w]: steps consumed
+  int* ready = (int*)(smem + C::FLAGOFF);
+  int* done = (int*)(smem + C::FLAGOFF + 32);
+  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  __syncthreads();
+
   if (wave >= NC + 2) {
     // ====================== loader: low-res planes (32 channels, replicate-clamped) ======================
     constexpr int NJ = (C::LVP + 63) / 64;
@@ -112,22 +120,21 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
           if (valid[j])
             __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j] + cg * 16), (lptr_t)(dstp + cg * LPL + j * 1024), 16, 0, 0);
     };
-    int issued = 0;
-    {
-      const int first = nlow < RL ? nlow : RL;
-      for (; issued < first; ++issued) issue_plane(issued);
-    }
-    for (int s = 0; s < nsteps; ++s) {
-      const int need_hi = s + 2;
-      if (issued - 1 - need_hi >= C::AHEADL - 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEADL - 1) * C::NDMAL) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int next_issue = 0, next_pub = 0;
+    const unsigned a_ready = lds_addr(ready + 2), a_done = lds_addr(done);
+    while (next_pub < nlow) {
+      if (next_issue < nlow) {
+        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
+        int lim = RL + md;                                    // low planes ql < md are dead
+        lim = lim < nlow ? lim : nlow;
+        while (next_issue < lim) issue_plane(next_issue++);
       }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int lim = s + RL < nlow ? s + RL : nlow;           // low planes ql < s are dead
-      for (; issued < lim; ++issued) issue_plane(issued);
+      if (next_issue == next_pub) {
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      WaitVm<C::NDMAL, RL - 1>::run(next_issue - next_pub - 1);
+      flag_store_asm(a_ready, ++next_pub);
     }
     return;
   }
@@ -152,22 +159,21 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
       for (int j = 0; j < C::NDMA; ++j)
         if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 1024), 16, 0, 0);
     };
-    int issued = 0;
-    {
-      const int first = nplanes < R ? nplanes : R;
-      for (; issued < first; ++issued) issue_plane(issued);
-    }
-    for (int s = 0; s < nsteps; ++s) {
-      const int need_hi = 2 * s + 3;
-      if (issued - 1 - need_hi >= C::AHEAD - 2) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::AHEAD - 2) * C::NDMA) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int next_issue = 0, next_pub = 0;
+    const unsigned a_ready = lds_addr(ready + cp), a_done = lds_addr(done);
+    while (next_pub < nplanes) {
+      if (next_issue < nplanes) {
+        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
+        int lim = R + 2 * md;                                 // skip planes q < 2*md are dead
+        lim = lim < nplanes ? lim : nplanes;
+        while (next_issue < lim) issue_plane(next_issue++);
       }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int lim = 2 * s + R < nplanes ? 2 * s + R : nplanes;
-      for (; issued < lim; ++issued) issue_plane(issued);
+      if (next_issue == next_pub) {
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      WaitVm<C::NDMA, R - 1>::run(next_issue - next_pub - 1);
+      flag_store_asm(a_ready, ++next_pub);
     }
     return;
   }
@@ -200,8 +206,17 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
                                 : nullptr;
 
   for (int s = 0; s < nsteps; ++s) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    {
+      int need = 2 * s + 4, needl = s + 3;                   // skip planes q <= 2s+3 and low planes ql <= s+2
+      need = need < nplanes ? need : nplanes;
+      needl = needl < nlow ? needl : nlow;
+      while (true) {
+        const int r0 = flag_load(ready), r1 = flag_load(ready + 1), r2 = flag_load(ready + 2);
+        if ((r0 < r1 ? r0 : r1) >= need && r2 >= needl) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
     const int zo = zs + 2 * s + pz;
     int sl[3];
 #pragma unroll
@@ -248,6 +263,8 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
         }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
+    flag_store(done + wave, s + 1);
 
     if (zo < ze && !(p.dbg & 4)) {
 #pragma unroll
