@@ -32,6 +32,11 @@ hipError_t launch_conv_upcat16(const ConvParams& p, int precision, hipStream_t s
 hipError_t launch_pack_upcat16(const float* w, const float* scale, void* wpk, int precision, hipStream_t st);
 const char* last_conv_upcat_kernel_name();
 bool conv_zmarch_can_pool(const ConvParams& p);
+size_t instnorm_scratch_bytes(int N, int C);
+hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
+                           float slope, void* scratch, int precision, hipStream_t st);
+hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
+                                      hipStream_t st);
 const char* last_conv_kernel_name();
 }  // namespace amx
 
@@ -65,6 +70,8 @@ struct ConvLayer {
   int cin_pad = 0;
   void* wpk = nullptr;    // packed A fragments
   void* wpk_up = nullptr; // second packing for the 16+32 -> 16 merged-tap kernel (amx_conv3d_upcat.hip)
+  float* in_gamma = nullptr;  // InstanceNorm3d(affine=True) weight / bias of the norm that follows (else null)
+  float* in_beta = nullptr;
   float* scale = nullptr; // folded norm gain (applied to the weights at pack time)
   float* shift = nullptr; // epilogue bias
   bool loaded = false;
@@ -139,7 +146,11 @@ void build_plan(amx_unet* h) {
   if (c.final_act != AMX_ACT_NONE) h->kinds.push_back(K_FINAL_ACT);
 }
 
-int level_channels(const amx_unet* h, int level) { return h->cfg.ngf << level; }
+// widest tensor materialised at a level: its own width, or (trilinear) the upsampled image of the level below it
+int level_channels(const amx_unet* h, int level) {
+  const int own = h->cfg.ngf << level;
+  return (h->cfg.interp == AMX_INTERP_TRILINEAR && level < h->cfg.num_downs) ? 2 * own : own;
+}
 
 struct Profiler {
   std::vector<hipEvent_t> ev;
@@ -189,6 +200,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   const int NL = c.num_downs + 1;
   size_t need = 0;
   for (int l = 0; l < NL; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
+  void* in_scratch = (char*)ws + need;                 // instance-norm partial sums + (a, b) pairs
+  need += align_up(amx::instnorm_scratch_bytes(n, c.ngf << c.num_downs), 256);
   if (ws_bytes < need || ((uintptr_t)ws & 255))
     return fail(AMX_ERR_WORKSPACE, "workspace needs %zu bytes, 256-byte aligned (got %zu)", need, ws_bytes);
 
@@ -221,6 +234,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   bool have_skip = false;
   Tensor fused_pool;         // pooled tensor written by the preceding conv's epilogue
   bool have_fused_pool = false;
+  bool cur_is_full_up = false;   // cur is a materialised (trilinear) upsample at the consumer's resolution
   size_t conv_i = 0;
 
   for (size_t i = 0; i < h->kinds.size(); ++i) {
@@ -238,18 +252,21 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         p.C0 = 16; p.C1 = 0; p.src0_f32c1 = 1;
       } else if (have_cur_up) {
         const Tensor& lo = cur;
-        const long long lx = (long long)lo.C * 2, ly = lx * (dw / 2), lz = ly * (dh / 2);
+        // nearest: `lo` is the half-resolution tensor, read through >> 1; trilinear: already materialised at this level
+        const int lw = cur_is_full_up ? dw : dw / 2, lh = cur_is_full_up ? dh : dh / 2, ld = cur_is_full_up ? dd : dd / 2;
+        const long long lx = (long long)lo.C * 2, ly = lx * lw, lz = ly * lh;
+        p.up_shift = cur_is_full_up ? 0 : 1;
         if (have_skip) {
           const long long sx = (long long)pend_skip.C * 2, sy = sx * dw, sz = sy * dh;
           p.src0 = A.slot[pend_skip.level][pend_skip.slot];
           p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = pend_skip.C;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * (dd / 2); p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
         } else {  // no skip connection: the whole input is the upsampled tensor
           p.src0 = A.slot[lo.level][lo.slot];  // unused segment of zero channels
           p.C0 = 0;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * (dd / 2); p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
         }
       } else {
         const long long sx = (long long)cur.C * 2, sy = sx * dw, sz = sy * dh;
@@ -261,7 +278,10 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
                     L.module_idx, L.cin_pad, p.C0 + p.C1);
       p.wpk = (const char*)L.wpk;
       p.bias = L.shift;
-      p.act = L.has_act ? c.activation : AMX_ACT_NONE;
+      const bool inorm = L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE);
+      // InstanceNorm needs the whole (n, c) plane of RAW conv outputs first: the conv stores un-activated values
+      // and amx::launch_instnorm normalises + activates them in place afterwards
+      p.act = (L.has_act && !inorm) ? c.activation : AMX_ACT_NONE;
       p.slope = c.act_slope;
       Tensor out;
       out.level = lv; out.C = L.cout;
@@ -290,7 +310,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue
       {
         size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
-        if (!L.is_final && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
+        if (!L.is_final && !inorm && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
             cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout / 16) {
           fused_pool.level = lv + 1; fused_pool.C = L.cout; fused_pool.slot = grab(lv + 1);
           if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
@@ -312,11 +332,25 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
         if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_kernel_name());
       }
+      if (inorm) {
+        if (L.is_final) return fail(AMX_ERR_INVALID, "internal: instance norm after the output conv");
+        if (prof) {
+          amx_launch_record r;
+          memset(&r, 0, sizeof r);
+          snprintf(r.kernel, sizeof r.kernel, "instnorm+act");
+          r.module_idx = L.norm_idx; r.cin = r.cout = L.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
+          r.bytes = 2.0 * L.cout * (double)n * dd * dh * dw * 3.0;
+          if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
+        }
+        AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
+                                     L.cout, L.has_act ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st));
+      }
       // inputs are dead once their consumer is enqueued (stream order)
       if (cur.slot >= 0) A.used[cur.level][cur.slot] = false;
       if (have_skip) A.used[pend_skip.level][pend_skip.slot] = false;
       have_skip = false;
       have_cur_up = false;
+      cur_is_full_up = false;
       cur = out;
       // skip to past the fused norm / activation modules
       if (L.norm_idx >= 0) ++i;
@@ -357,8 +391,27 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       if (!is_skip) A.used[cur.level][cur.slot] = false;
       cur = out;
     } else if (kind == K_UP) {
-      if (c.interp != AMX_INTERP_NEAREST)
-        return fail(AMX_ERR_INVALID, "interp='trilinear' is not implemented in the HIP path yet");
+      if (c.interp == AMX_INTERP_TRILINEAR) {
+        // nn.Upsample(2,'trilinear') is materialised (16-bit NDHWC at the finer level); the conv that follows
+        // then reads two full-resolution segments (up_shift = 0)
+        const int lv = cur.level - 1;
+        Tensor up;
+        up.level = lv; up.C = cur.C; up.slot = grab(lv);
+        if (up.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
+        if (prof) {
+          amx_launch_record r;
+          memset(&r, 0, sizeof r);
+          snprintf(r.kernel, sizeof r.kernel, "upsample2<trilinear>");
+          r.module_idx = (int)i; r.cin = r.cout = cur.C; r.n = n; r.d = d >> lv; r.h = hh >> lv; r.w = w >> lv;
+          r.bytes = 2.0 * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 1.125;
+          if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
+        }
+        AMX_HIP(amx::launch_upsample2_trilinear(A.slot[cur.level][cur.slot], A.slot[lv][up.slot], n, d >> cur.level,
+                                                hh >> cur.level, w >> cur.level, cur.C, c.precision, st));
+        A.used[cur.level][cur.slot] = false;
+        cur = up;
+        cur_is_full_up = true;
+      }
       have_cur_up = true;
       if (c.use_skip) {
         pend_skip = skips.back();
@@ -388,8 +441,12 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   if (cfg->input_nc != 1) return fail(AMX_ERR_INVALID, "HIP path supports input_nc == 1 (got %d)", cfg->input_nc);
   if (cfg->output_nc < 16 || cfg->output_nc % 16)
     return fail(AMX_ERR_INVALID, "output_nc must be a multiple of 16 (got %d)", cfg->output_nc);
-  if (cfg->norm != AMX_NORM_NONE && cfg->norm != AMX_NORM_BATCH_EVAL)
-    return fail(AMX_ERR_INVALID, "norm mode %d is not implemented in the HIP path yet (batch/eval and none are)", cfg->norm);
+  if (cfg->norm < AMX_NORM_NONE || cfg->norm > AMX_NORM_INSTANCE_AFFINE)
+    return fail(AMX_ERR_INVALID, "unknown norm mode %d", cfg->norm);
+  if (cfg->interp != AMX_INTERP_NEAREST && cfg->interp != AMX_INTERP_TRILINEAR)
+    return fail(AMX_ERR_INVALID, "unknown interp mode %d", cfg->interp);
+  if ((cfg->ngf << cfg->num_downs) > 2048)
+    return fail(AMX_ERR_INVALID, "widest layer has %d channels; the instance-norm kernels handle <= 2048", cfg->ngf << cfg->num_downs);
   if (cfg->activation < AMX_ACT_NONE || cfg->activation > AMX_ACT_LRELU || cfg->final_act < AMX_ACT_NONE ||
       cfg->final_act > AMX_ACT_LRELU)
     return fail(AMX_ERR_INVALID, "unsupported activation");
@@ -410,6 +467,10 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
+    if (e == hipSuccess && cfg->norm == AMX_NORM_INSTANCE_AFFINE && L.norm_idx >= 0) {
+      e = hipMalloc((void**)&L.in_gamma, L.cout * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void**)&L.in_beta, L.cout * sizeof(float));
+    }
     if (e != hipSuccess) {
       amx_unet_destroy(h);
       return fail(AMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -425,6 +486,8 @@ void amx_unet_destroy(amx_unet_t* h) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);
     if (L.scale) (void)hipFree(L.scale);
+    if (L.in_gamma) (void)hipFree(L.in_gamma);
+    if (L.in_beta) (void)hipFree(L.in_beta);
     if (L.shift) (void)hipFree(L.shift);
   }
   delete h;
@@ -454,6 +517,11 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
     if (bn && (!d_mean || !d_var)) return fail(AMX_ERR_INVALID, "model.%d: BatchNorm running stats required", module_idx);
     AMX_HIP(amx::launch_fold_norm(bn ? d_gamma : nullptr, bn ? d_beta : nullptr, bn ? d_mean : nullptr,
                                   bn ? d_var : nullptr, d_bias, h->cfg.norm_eps, L.cout, L.scale, L.shift, st));
+    if (L.in_gamma) {   // InstanceNorm3d(affine=True): keep its weight / bias for the normalisation pass
+      if (!d_gamma || !d_beta) return fail(AMX_ERR_INVALID, "model.%d: instance_affine needs the norm weight and bias", module_idx);
+      AMX_HIP(hipMemcpyAsync(L.in_gamma, d_gamma, L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+      AMX_HIP(hipMemcpyAsync(L.in_beta, d_beta, L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     if (L.cin == 1 && &L == &h->convs[0]) {   // stem: 27 taps packed into one K = 32 MFMA step
       AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout, h->cfg.precision, st));
     } else {
@@ -471,6 +539,7 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int hh, int w
   if (!h) return 0;
   size_t need = 0;
   for (int l = 0; l <= h->cfg.num_downs; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
+  need += align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs), 256);
   return need;
 }
 
@@ -566,7 +635,7 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
   p.src0 = (const char*)d_x0; p.C0 = c0;
   p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
   if (c1) {
-    p.src1 = (const char*)d_x1; p.C1 = c1;
+    p.src1 = (const char*)d_x1; p.C1 = c1; p.up_shift = 1;
     p.s1x = (long long)c1 * 2; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
   }
   p.wpk = (const char*)d_wpk;
@@ -594,6 +663,24 @@ int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout
               void* stream) {
   if (!d_in || !d_out || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
   AMX_HIP(amx::launch_pool2(d_in, d_out, n, dout, hout, wout, c, avg, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_instance_norm_scratch_bytes(int n, int c) { return amx::instnorm_scratch_bytes(n, c); }
+
+int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, float eps, int n, long long voxels, int c,
+                      int act, float slope, void* d_scratch, int precision, void* stream) {
+  if (!d_x || !d_scratch || c % 8 || c > 2048 || n < 1 || voxels < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  if (!d_gamma != !d_beta) return fail(AMX_ERR_INVALID, "gamma and beta come together");
+  AMX_HIP(amx::launch_instnorm(d_x, d_gamma, d_beta, eps, n, voxels, c, act, slope, d_scratch, precision,
+                               (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c, int precision,
+                            void* stream) {
+  if (!d_in || !d_out || c % 8 || n < 1 || din < 1 || hin < 1 || win < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_upsample2_trilinear(d_in, d_out, n, din, hin, win, c, precision, (hipStream_t)stream));
   return AMX_OK;
 }
 

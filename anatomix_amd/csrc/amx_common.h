@@ -40,6 +40,8 @@ struct ConvParams {
   long long s1n, s1z, s1y, s1x;
   int C0, C1;                  // channels per segment (multiples of 16); Cin = C0 + C1
   int src0_f32c1;              // 1: src0 is a single-channel fp32 volume (network input)
+  int up_shift;                // 1: src1 is HALF resolution and read through nearest x2 (coordinates >> 1);
+                               // 0: src1 is a full-resolution tensor (materialised trilinear upsample)
   const char* wpk;             // packed A fragments [cout_group][chunk][step][q][lane][8]
   const float* bias;           // [Cout] fp32 (folded norm shift / conv bias)
   char* out;                   // 16-bit NDHWC output (OUTMODE 0)

@@ -165,12 +165,12 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
     for (int k = 0; k < NCH; ++k) {
       const int ch = (stage * NCH + k) << 4;                // wave-uniform
       const bool second = ch >= p.C0;
-      const int sh = second ? 1 : 0;
+      const int sh = second ? p.up_shift : 0;
       const char* base = second ? p.src1 + (long long)it.n * p.s1n + (ch - p.C0) * 2
                                 : p.src0 + (long long)it.n * p.s0n + ch * 2;
       const long long sz = second ? p.s1z : p.s0z, sy = second ? p.s1y : p.s0y;
       const int xoff = (gx >> sh) * (int)(second ? p.s1x : p.s0x);
-      if (C::LOWUP && second) {
+      if (C::LOWUP && second && p.up_shift) {
         // low-res halo of the upsampled segment: reflect padding at high resolution == replicate (clamp)
         // at low resolution; brick origins are even.
         const int LD = p.D >> 1, LH = p.H >> 1, LW = p.W >> 1;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
     }
 
     // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
-    const bool up_stage = C::LOWUP && ((cu_stage * NCH) << 4) >= p.C0;
+    const bool up_stage = C::LOWUP && p.up_shift && ((cu_stage * NCH) << 4) >= p.C0;
     if (!(p.dbg & 2) && up_stage) {
       // the stage buffer holds the LOW-RES halo of 16 upsampled channels
       constexpr int LXH = C::LXH;

@@ -1,0 +1,201 @@
+// anatomix_amd -- bandwidth kernels of the InstanceNorm / trilinear variant (`anatomix-dev`:
+// norm='instance', interp='trilinear', pooling='Avg'; anatomix/model/load_from_hf.py:18-24).
+//
+//   nn.InstanceNorm3d(affine=False|True, eps)   network.py:157-163
+//       per (n, c): y = (x - mean) / sqrt(var_biased + eps) [* gamma + beta], followed by the activation.
+//       Two-pass, deterministic: (1) every block reduces a slab of voxels to per-channel shifted sums
+//       S1 = sum(x - K), S2 = sum((x - K)^2) in fp32 (K = the channel's first voxel, which removes the
+//       cancellation of E[x^2] - E[x]^2) and writes them to its own slot; (2) one block per sample
+//       adds the slots in fixed order and emits the affine pair (a, b) with y = a*x + b;
+//       (3) an elementwise pass applies a*x + b and the activation in place.
+//   nn.Upsample(scale_factor=2, mode='trilinear')   network.py:407 (align_corners=False)
+//       per axis out[2i] = .25*in[i-1] + .75*in[i], out[2i+1] = .75*in[i] + .25*in[i+1] with the
+//       neighbour index clamped (PyTorch's source-index clamp puts the whole weight on the edge voxel).
+// All tensors are channels-last 16-bit; one thread moves 8 channels (16 B) of one voxel.
+#include "amx_device.h"
+
+namespace amx {
+
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&f)[8]) {
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)__builtin_bit_cast(T, (unsigned short)(w[e >> 1] >> ((e & 1) * 16)));
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  unsigned o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_bits<T>(f[2 * e]) | ((unsigned)to_bits<T>(f[2 * e + 1]) << 16);
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+constexpr int kInBlocks = 128;   // slabs per sample in the statistics pass
+
+// grid (kInBlocks, N), block 256.  partial[n][blk][c][2]
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ x, float* __restrict__ partial, long long vox,
+                                                      int C) {
+  extern __shared__ float red[];                       // [256/c8n rows][C][2]
+  const int c8n = C >> 3;
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
+  const char* xs = x + (long long)n * vox * C * 2;
+  float K[8];
+  unpack8<T>(*(const uint4*)(xs + c8 * 16), K);       // the channel's first voxel: shift of the sums
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long per = (vox + gridDim.x - 1) / gridDim.x;
+  const long long v0 = (long long)blk * per, v1 = v0 + per < vox ? v0 + per : vox;
+  if (vrow < nrow)
+    for (long long v = v0 + vrow; v < v1; v += nrow) {
+      float f[8];
+      unpack8<T>(*(const uint4*)(xs + (v * C + c8 * 8) * 2), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = f[e] - K[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
+    }
+  // block reduction over the voxel rows (fixed order)
+  if (vrow < nrow)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((vrow * C) + c8 * 8 + e) * 2] = s1[e];
+      red[((vrow * C) + c8 * 8 + e) * 2 + 1] = s2[e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+      a += red[(r * C + c) * 2];
+      b += red[(r * C + c) * 2 + 1];
+    }
+    float* o = partial + (((long long)n * gridDim.x + blk) * C + c) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+// grid N, block 256.  ab[n][c][2] = (a, b) with y = a*x + b
+template <typename T>
+__global__ void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial, const float* gamma,
+                                   const float* beta, float eps, long long vox, int C, int nblk, float* __restrict__ ab) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C + c) * 2);
+    const float K = (float)__builtin_bit_cast(T, kb);
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      const float* q = partial + (((long long)n * nblk + b) * C + c) * 2;
+      s1 += q[0];
+      s2 += q[1];
+    }
+    const double m1 = s1 / (double)vox;
+    double var = s2 / (double)vox - m1 * m1;              // biased variance, shift invariant
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = K + (float)m1;
+    const float g = gamma ? gamma[c] : 1.f;
+    ab[((long long)n * C + c) * 2] = rstd * g;
+    ab[((long long)n * C + c) * 2 + 1] = (beta ? beta[c] : 0.f) - mean * rstd * g;
+  }
+}
+
+template <typename T>
+__global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox, int C, int N, int act,
+                                float slope) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * vox * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    const long long nv = idx / c8n;
+    const int n = nv / vox;
+    float f[8];
+    unpack8<T>(*(const uint4*)(x + idx * 16), f);
+    const float* q = ab + ((long long)n * C + c8 * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = f[e] * q[2 * e] + q[2 * e + 1];
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      f[e] = v;
+    }
+    *(uint4*)(x + idx * 16) = pack8<T>(f);
+  }
+}
+
+// out [N][2D][2H][2W][C] <- in [N][D][H][W][C]
+template <typename T>
+__global__ void upsample2_trilinear_kernel(const char* __restrict__ in, char* __restrict__ out, int N, int D, int H, int W,
+                                           int C) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * D * H * W * 8 * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    long long r = idx / c8n;
+    const int ox = r % (2 * W);
+    r /= 2 * W;
+    const int oy = r % (2 * H);
+    r /= 2 * H;
+    const int oz = r % (2 * D);
+    const int n = r / (2 * D);
+    int i0[3], i1[3];
+    float w1[3];                                           // weight of i1; i0 gets 1 - w1
+    const int o[3] = {oz, oy, ox}, L[3] = {D, H, W};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int i = o[a] >> 1;
+      if (o[a] & 1) { i0[a] = i; i1[a] = i + 1 < L[a] ? i + 1 : L[a] - 1; w1[a] = 0.25f; }
+      else { i0[a] = i > 0 ? i - 1 : 0; i1[a] = i; w1[a] = 0.75f; }
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = (k & 4) ? i1[0] : i0[0], y = (k & 2) ? i1[1] : i0[1], x = (k & 1) ? i1[2] : i0[2];
+      const float wt = ((k & 4) ? w1[0] : 1.f - w1[0]) * ((k & 2) ? w1[1] : 1.f - w1[1]) * ((k & 1) ? w1[2] : 1.f - w1[2]);
+      float f[8];
+      unpack8<T>(*(const uint4*)(in + ((((long long)n * D + z) * H + y) * W + x) * C * 2 + c8 * 16), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wt * f[e];
+    }
+    *(uint4*)(out + idx * 16) = pack8<T>(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- launchers
+size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * kInBlocks * C * 2 + (size_t)N * C * 2) * sizeof(float); }
+
+hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
+                           float slope, void* scratch, int precision, hipStream_t st) {
+  if (C % 8) return hipErrorInvalidValue;
+  float* partial = (float*)scratch;
+  float* ab = partial + (size_t)N * kInBlocks * C * 2;
+  const int c8n = C / 8;
+  if (c8n > 256) return hipErrorInvalidValue;          // C <= 2048
+  const int nrow = 256 / c8n;
+  const size_t lds = (size_t)nrow * C * 2 * sizeof(float);
+  const long long total = (long long)N * vox * c8n;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+#define AMX_IN(T)                                                                                                   \
+  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(kInBlocks, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
+  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
+                     kInBlocks, ab);                                                                                 \
+  hipLaunchKernelGGL(in_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope)
+  if (precision == 0) { AMX_IN(f16); } else { AMX_IN(bf16); }
+#undef AMX_IN
+  return hipGetLastError();
+}
+
+hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
+                                      hipStream_t st) {
+  const long long total = (long long)N * D * H * W * 8 * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(upsample2_trilinear_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
+  else
+    hipLaunchKernelGGL(upsample2_trilinear_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
+  return hipGetLastError();
+}
+
+}  // namespace amx

@@ -182,12 +182,12 @@ class Unet(nn.Module):
             return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
         if c["norm"] == "batch" and self.training:
             return "BatchNorm in train mode (batch statistics) is not implemented in the HIP path yet; call .eval()"
-        if c["norm"] not in ("batch", "none"):
-            return f"norm='{c['norm']}' is not implemented in the HIP path yet"
+        if c["norm"] not in _lib.NORM:
+            return f"norm='{c['norm']}' is not implemented in the HIP path"
         if c["activation"] not in _lib.ACT or c["final_act"] not in _lib.ACT:
             return "activation not implemented in the HIP path"
-        if c["interp"] != "nearest":
-            return f"interp='{c['interp']}' is not implemented in the HIP path yet"
+        if c["interp"] not in _lib.INTERP or c["pooling"] not in _lib.POOL:
+            return f"interp='{c['interp']}' / pooling='{c['pooling']}' is not implemented in the HIP path"
         if c["input_nc"] != 1 or c["ngf"] % 16 or c["output_nc"] % 16:
             return "HIP path needs input_nc == 1 and ngf, output_nc multiples of 16"
         if x.dim() != 5 or x.shape[1] != 1:

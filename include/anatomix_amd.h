@@ -143,6 +143,18 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
 int amx_pool2(const void* d_in, void* d_out, int n, int d_out_, int h_out, int w_out, int c, int avg,
               int precision, void* stream);
 
+/* nn.InstanceNorm3d(c, eps, affine = d_gamma != NULL) followed by the activation, IN PLACE on a 16-bit NDHWC
+ * tensor [n][voxels][c] (network.py:157-163: 'instance' / 'instance_affine'; biased variance over the voxels of
+ * each (n, c) plane).  d_scratch: amx_instance_norm_scratch_bytes(n, c) bytes of fp32 partial sums. */
+size_t amx_instance_norm_scratch_bytes(int n, int c);
+int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, float eps, int n, long long voxels,
+                      int c, int act, float slope, void* d_scratch, int precision, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode='trilinear') (align_corners=False; network.py:407): 16-bit NDHWC
+ * [n][din][hin][win][c] -> [n][2 din][2 hin][2 win][c]. */
+int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
+                            int precision, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

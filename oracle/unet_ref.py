@@ -226,7 +226,7 @@ def fold_conv_params(sd, kwargs, i, plan: Plan, dtype=torch.float64):
 
 
 def forward_lowp(x: torch.Tensor, sd: dict, kwargs: dict, lowp=torch.float16):
-    """BatchNorm-eval / no-norm networks only.  Emulates the HIP path's numerics on CPU: folded
+    """Emulates the HIP path's numerics on CPU (all norm / interp / pooling modes): folded
     weights and every stored activation are rounded to ``lowp`` (fp16 or bf16), products are
     accumulated in fp32, shift + activation are applied in fp32 before the store rounding.  The
     final conv output stays fp32.  Used to separate kernel bugs (must match this to ~1e-4) from
@@ -234,7 +234,7 @@ def forward_lowp(x: torch.Tensor, sd: dict, kwargs: dict, lowp=torch.float16):
     kw = dict(ngf=24, norm="batch", final_act="none", activation="relu", pooling="Max", interp="nearest",
               use_skip_connection=True, norm_eps=1e-5, doubleconv=True)
     kw.update(kwargs)
-    assert kw["norm"] in ("batch", "none") and kw["interp"] == "nearest"
+    inorm = kw["norm"] in ("instance", "instance_affine")
     p = build_plan(**{k: v for k, v in kw.items() if k != "dimension"})
     q = lambda t: t.to(lowp).to(torch.float32)
     feat = q(x.float())
@@ -248,6 +248,8 @@ def forward_lowp(x: torch.Tensor, sd: dict, kwargs: dict, lowp=torch.float16):
             feat = conv3_reflect(feat, q(w.float()), t.float())
             j = i + 1
             if j < n and p.kinds[j] == "norm":
+                if inorm:      # the HIP path stores the raw conv output, then normalises it in place (fp32 math)
+                    feat = norm_apply(q(feat), sd, j, kw["norm"], kw["norm_eps"])
                 j += 1
             if j < n and p.kinds[j] == "act":
                 feat = act_apply(feat, kw["activation"]); j += 1
@@ -263,7 +265,8 @@ def forward_lowp(x: torch.Tensor, sd: dict, kwargs: dict, lowp=torch.float16):
             feat = F.max_pool3d(feat, 2) if kw["pooling"] == "Max" else q(F.avg_pool3d(feat, 2))
             i += 1
         elif kind == "up":
-            feat = F.interpolate(feat, scale_factor=2, mode="nearest")
+            feat = F.interpolate(feat, scale_factor=2, mode="nearest") if kw["interp"] == "nearest" else \
+                q(F.interpolate(feat, scale_factor=2, mode=kw["interp"]))
             i += 1
         else:
             i += 1
