@@ -37,6 +37,10 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
                            float slope, void* scratch, int precision, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
                                       hipStream_t st);
+hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
+                             float slope, int precision, hipStream_t st);
+hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
+                               float* out, int precision, hipStream_t st);
 const char* last_conv_kernel_name();
 }  // namespace amx
 
@@ -74,6 +78,9 @@ struct ConvLayer {
   float* in_beta = nullptr;
   float* scale = nullptr; // folded norm gain (applied to the weights at pack time)
   float* shift = nullptr; // epilogue bias
+  // eval-BatchNorm layers only: UNFOLDED weights + the norm's own shift, for forwards that tap the pre-norm output
+  void* wpk_raw = nullptr;
+  bool raw_has_bias = false;  // conv bias under BatchNorm (the reference never builds that: use_bias == (norm=='instance'))
   bool loaded = false;
 };
 
@@ -84,6 +91,7 @@ struct amx_unet {
   std::vector<int> kinds;
   std::vector<ConvLayer> convs;
   std::vector<int> encoder_idx, decoder_idx;
+  std::vector<int> mod_c, mod_level;  // per module: channels / resolution level of `feat` after it (post-concat for Upsample)
   int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
 };
 
@@ -144,6 +152,25 @@ void build_plan(amx_unet* h) {
   h->kinds.push_back(K_CONV);
   h->convs.push_back(F);
   if (c.final_act != AMX_ACT_NONE) h->kinds.push_back(K_FINAL_ACT);
+  // channels / level of `feat` after every module, as Unet.forward sees it (network.py:479-502)
+  int ch = c.input_nc, lvl = 0;
+  size_t ci = 0;
+  std::vector<int> skip_c;
+  for (size_t i = 0; i < h->kinds.size(); ++i) {
+    switch (h->kinds[i]) {
+      case K_CONV: ch = h->convs[ci].cout; lvl = h->convs[ci].level; ++ci; break;
+      case K_POOL: lvl += 1; break;
+      case K_UP:
+        lvl -= 1;
+        if (c.use_skip) { ch += skip_c.back(); skip_c.pop_back(); }
+        break;
+      default: break;
+    }
+    for (int e : h->encoder_idx)
+      if (e == (int)i && c.use_skip) skip_c.push_back(ch);
+    h->mod_c.push_back(ch);
+    h->mod_level.push_back(lvl);
+  }
 }
 
 // widest tensor materialised at a level: its own width, or (trilinear) the upsampled image of the level below it
@@ -188,11 +215,25 @@ int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
   return AMX_OK;
 }
 
+// Feature taps of Unet.forward(input, layers, encode_only) (network.py:475-529): module ids in ascending order,
+// one fp32 NCDHW device buffer per id; `stop` >= 0 ends the forward after that module (encode_only).
+struct TapReq {
+  const int* modules;
+  int n;
+  float* const* out;
+  int stop;
+};
+
 // One forward.  in_*: fp32 single-channel input view (byte strides); out: fp32 planar output view.
 int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
                 float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
                 const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
-                hipStream_t st, Profiler* prof = nullptr) {
+                hipStream_t st, Profiler* prof = nullptr, const long long* x_offs = nullptr,
+                const long long* y_offs = nullptr, const TapReq* taps = nullptr) {
+  // x_offs / y_offs (host arrays, element offsets, sliding-window mode): sample i reads its window at
+  // x + x_offs[i] and accumulates into y + y_offs[i].  Only the stem and the output conv see the volume, so those
+  // two run once per window (windows overlap: their accumulations must stay ordered on the stream); every layer
+  // in between runs on the whole batch of windows.
   const amx_unet_cfg& c = h->cfg;
   if (int e = check_shape(h, n, d, hh, w)) return e;
   for (const ConvLayer& L : h->convs)
@@ -236,6 +277,18 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   bool have_fused_pool = false;
   bool cur_is_full_up = false;   // cur is a materialised (trilinear) upsample at the consumer's resolution
   size_t conv_i = 0;
+  auto tap_of = [&](int module) -> float* {
+    if (taps)
+      for (int t = 0; t < taps->n; ++t)
+        if (taps->modules[t] == module) return taps->out[t];
+    return nullptr;
+  };
+  const int stop = taps ? taps->stop : -1;
+  // tap = fp32 NCDHW copy of a stored 16-bit tensor
+  auto export_slot = [&](const Tensor& t, float* dst) -> hipError_t {
+    return amx::launch_export_ncdhw(A.slot[t.level][t.slot], t.C, nullptr, 0, 0, n, d >> t.level, hh >> t.level, w >> t.level,
+                                    dst, c.precision, st);
+  };
 
   for (size_t i = 0; i < h->kinds.size(); ++i) {
     const int kind = h->kinds[i];
@@ -281,12 +334,33 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       const bool inorm = L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE);
       // InstanceNorm needs the whole (n, c) plane of RAW conv outputs first: the conv stores un-activated values
       // and amx::launch_instnorm normalises + activates them in place afterwards
-      p.act = (L.has_act && !inorm) ? c.activation : AMX_ACT_NONE;
+      // encode_only whose last layer is this group's conv / norm id: the modules after it never run in the reference,
+      // so the (in-place) activation must not touch the tapped tensor
+      const int idx_act = L.has_act ? L.module_idx + 1 + (L.norm_idx >= 0 ? 1 : 0) : -1;
+      const int stop_at = taps ? taps->stop : -1;
+      const bool act_on = L.has_act && !(stop_at >= L.module_idx && stop_at < idx_act);
+      p.act = (act_on && !inorm) ? c.activation : AMX_ACT_NONE;
       p.slope = c.act_slope;
+      // ---- feature taps inside this conv -> norm -> act group.  The reference's activations are in-place modules
+      // (network.py:188-196), so what the caller holds for a tap at the NORM id (or at the conv id when there is no
+      // norm) is the activated tensor; only a conv followed by a norm yields a distinct, pre-norm tensor.
+      float* tap_conv = tap_of(L.module_idx);
+      float* tap_norm = L.norm_idx >= 0 ? tap_of(L.norm_idx) : nullptr;
+      float* tap_act = idx_act >= 0 ? tap_of(idx_act) : nullptr;
+      // pre-norm tap of a FOLDED eval-BatchNorm layer: run the conv with the unfolded weights, export, apply the norm
+      const bool raw_bn = tap_conv && L.norm_idx >= 0 && !inorm && !L.is_final;
+      if (raw_bn) {
+        if (!L.wpk_raw) return fail(AMX_ERR_INVALID, "internal: model.%d has no unfolded packing", L.module_idx);
+        p.wpk = (const char*)L.wpk_raw;
+        if (L.raw_has_bias)
+          return fail(AMX_ERR_INVALID, "pre-norm tap of model.%d: conv bias under BatchNorm is not supported", L.module_idx);
+        p.bias = nullptr;   // s * conv + L.shift is the whole folded norm (applied by launch_affine_act below)
+        p.act = AMX_ACT_NONE;
+      }
       Tensor out;
       out.level = lv; out.C = L.cout;
       if (L.is_final) {
-        if (c.final_act != AMX_ACT_NONE) p.act = c.final_act;
+        if (c.final_act != AMX_ACT_NONE && stop_at != L.module_idx) p.act = c.final_act;
         p.out32 = y;
         p.pn = ys_n; p.pc = ys_c; p.pz = ys_z; p.py = ys_y;
         p.wmap = wmap;
@@ -310,7 +384,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue
       {
         size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
-        if (!L.is_final && !inorm && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
+        if (!L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
             cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout / 16) {
           fused_pool.level = lv + 1; fused_pool.C = L.cout; fused_pool.slot = grab(lv + 1);
           if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
@@ -319,18 +393,43 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           have_fused_pool = true;
         }
       }
-      if (p.src0_f32c1) {
-        if (L.is_final || L.cout > 32)
-          return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
-        AMX_HIP(amx::launch_conv_stem(p, c.precision, st));
-        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_stem_kernel_name());
-      } else if (L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p)) {
-        p.wpk = (const char*)L.wpk_up;
-        AMX_HIP(amx::launch_conv_upcat16(p, c.precision, st));
-        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_upcat_kernel_name());
+      if (p.src0_f32c1 && (L.is_final || L.cout > 32))
+        return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
+      const bool use_upcat = !p.src0_f32c1 && !raw_bn && L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p);
+      if (use_upcat) p.wpk = (const char*)L.wpk_up;
+      auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
+        if (q.src0_f32c1) return amx::launch_conv_stem(q, c.precision, st);
+        if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
+        return amx::launch_conv(q, c.precision, L.q, st);
+      };
+      if (x_offs && (p.src0_f32c1 || L.is_final)) {
+        for (int wi = 0; wi < n; ++wi) {
+          amx::ConvParams q = p;
+          q.N = 1;
+          if (p.src0_f32c1) {
+            q.src0 = (const char*)(x + x_offs[wi]);
+            q.out = p.out + (long long)wi * p.on;
+            if (p.out2) q.out2 = p.out2 + (long long)wi * p.qn;
+          } else {
+            q.src0 = p.src0 + (long long)wi * p.s0n;
+            if (p.src1) q.src1 = p.src1 + (long long)wi * p.s1n;
+            q.out32 = y + y_offs[wi];
+          }
+          AMX_HIP(launch_one(q));
+        }
       } else {
-        AMX_HIP(amx::launch_conv(p, c.precision, L.q, st));
-        if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_kernel_name());
+        AMX_HIP(launch_one(p));
+      }
+      if (prof)
+        snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s",
+                 p.src0_f32c1 ? amx::last_conv_stem_kernel_name()
+                              : use_upcat ? amx::last_conv_upcat_kernel_name() : amx::last_conv_kernel_name());
+      if (raw_bn) {
+        AMX_HIP(export_slot(out, tap_conv));
+        AMX_HIP(amx::launch_affine_act(A.slot[lv][out.slot], L.scale, L.shift, n, (long long)dd * dh * dw, L.cout,
+                                       act_on ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st));
+      } else if (tap_conv && !L.is_final && inorm) {
+        AMX_HIP(export_slot(out, tap_conv));     // the stored raw convolution output, before the instance norm below
       }
       if (inorm) {
         if (L.is_final) return fail(AMX_ERR_INVALID, "internal: instance norm after the output conv");
@@ -343,7 +442,15 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
-                                     L.cout, L.has_act ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st));
+                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st));
+      }
+      if (L.is_final) {
+        if (tap_conv)   // contiguous [n][Cout][d][h][w] output (taps are only offered by the plain forward)
+          AMX_HIP(hipMemcpyAsync(tap_conv, y, (size_t)n * L.cout * dd * dh * dw * sizeof(float), hipMemcpyDeviceToDevice, st));
+      } else {
+        if (tap_conv && L.norm_idx < 0) AMX_HIP(export_slot(out, tap_conv));   // aliased by the in-place activation
+        if (tap_norm) AMX_HIP(export_slot(out, tap_norm));
+        if (tap_act) AMX_HIP(export_slot(out, tap_act));
       }
       // inputs are dead once their consumer is enqueued (stream order)
       if (cur.slot >= 0) A.used[cur.level][cur.slot] = false;
@@ -361,6 +468,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           skips.push_back(cur);
           // keep it alive: mark as used by skip (cur release below must not free it)
         }
+      if (stop >= L.module_idx && stop <= (int)i) return AMX_OK;   // encode_only: layers[-1] lies in this group
     } else if (kind == K_POOL && have_fused_pool) {
       // already produced by the previous conv's epilogue
       bool is_skip = false;
@@ -369,6 +477,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       if (!is_skip) A.used[cur.level][cur.slot] = false;
       cur = fused_pool;
       have_fused_pool = false;
+      if (float* t = tap_of((int)i)) AMX_HIP(export_slot(cur, t));
+      if (stop == (int)i) return AMX_OK;
     } else if (kind == K_POOL) {
       const int lv = cur.level + 1;
       Tensor out;
@@ -390,6 +500,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         if (s.level == cur.level && s.slot == cur.slot) is_skip = true;
       if (!is_skip) A.used[cur.level][cur.slot] = false;
       cur = out;
+      if (float* t = tap_of((int)i)) AMX_HIP(export_slot(cur, t));
+      if (stop == (int)i) return AMX_OK;
     } else if (kind == K_UP) {
       if (c.interp == AMX_INTERP_TRILINEAR) {
         // nn.Upsample(2,'trilinear') is materialised (16-bit NDHWC at the finer level); the conv that follows
@@ -418,8 +530,17 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         skips.pop_back();
         have_skip = true;
       }
+      if (float* t = tap_of((int)i)) {   // taken after torch.cat((skip, up), 1) -- network.py:500-502
+        const int lv = cur_is_full_up ? cur.level : cur.level - 1;
+        AMX_HIP(amx::launch_export_ncdhw(have_skip ? A.slot[pend_skip.level][pend_skip.slot] : nullptr,
+                                         have_skip ? pend_skip.C : 0, A.slot[cur.level][cur.slot], cur.C,
+                                         cur_is_full_up ? 0 : 1, n, d >> lv, hh >> lv, w >> lv, t, c.precision, st));
+      }
+      if (stop == (int)i) return AMX_OK;
     } else if (kind == K_FINAL_ACT) {
-      // fused into the last conv's epilogue
+      // fused into the last conv's epilogue; the caller's tensor at this id IS the network output
+      if (float* t = tap_of((int)i))
+        AMX_HIP(hipMemcpyAsync(t, y, (size_t)n * c.output_nc * d * hh * w * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
   }
   return AMX_OK;
@@ -465,6 +586,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     hipError_t e = hipMalloc(&L.wpk, wbytes);
     if (e == hipSuccess && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
+    if (e == hipSuccess && cfg->norm == AMX_NORM_BATCH_EVAL && L.norm_idx >= 0) e = hipMalloc(&L.wpk_raw, wbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
     if (e == hipSuccess && cfg->norm == AMX_NORM_INSTANCE_AFFINE && L.norm_idx >= 0) {
@@ -485,6 +607,7 @@ void amx_unet_destroy(amx_unet_t* h) {
   for (ConvLayer& L : h->convs) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);
+    if (L.wpk_raw) (void)hipFree(L.wpk_raw);
     if (L.scale) (void)hipFree(L.scale);
     if (L.in_gamma) (void)hipFree(L.in_gamma);
     if (L.in_beta) (void)hipFree(L.in_beta);
@@ -515,6 +638,7 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
     if (L.module_idx != module_idx) continue;
     const bool bn = L.norm_idx >= 0 && h->cfg.norm == AMX_NORM_BATCH_EVAL;
     if (bn && (!d_mean || !d_var)) return fail(AMX_ERR_INVALID, "model.%d: BatchNorm running stats required", module_idx);
+    L.raw_has_bias = bn && d_bias != nullptr;
     AMX_HIP(amx::launch_fold_norm(bn ? d_gamma : nullptr, bn ? d_beta : nullptr, bn ? d_mean : nullptr,
                                   bn ? d_var : nullptr, d_bias, h->cfg.norm_eps, L.cout, L.scale, L.shift, st));
     if (L.in_gamma) {   // InstanceNorm3d(affine=True): keep its weight / bias for the normalisation pass
@@ -524,7 +648,10 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
     }
     if (L.cin == 1 && &L == &h->convs[0]) {   // stem: 27 taps packed into one K = 32 MFMA step
       AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout, h->cfg.precision, st));
+      if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout, h->cfg.precision, st));
     } else {
+      if (L.wpk_raw)
+        AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, L.wpk_raw, L.cin, L.cin_pad, L.cout, L.q, h->cfg.precision, st));
       AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
                                        h->cfg.precision, st));
       if (L.wpk_up) AMX_HIP(amx::launch_pack_upcat16(d_weight, L.scale, L.wpk_up, h->cfg.precision, st));
@@ -550,6 +677,31 @@ int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, 
   return run_forward(h, d_x, vox * 4, (long long)hh * w * 4, (long long)w * 4, d_y,
                      vox * h->cfg.output_nc, vox, (long long)hh * w, w, nullptr, n, d, hh, w, d_workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+int amx_unet_module_info(const amx_unet_t* h, int module_idx, int* channels, int* level) {
+  if (!h || module_idx < 0 || module_idx >= (int)h->kinds.size()) return fail(AMX_ERR_INVALID, "bad module index %d", module_idx);
+  if (channels) *channels = h->mod_c[module_idx];
+  if (level) *level = h->mod_level[module_idx];
+  return AMX_OK;
+}
+
+int amx_unet_forward_taps(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                          void* d_workspace, size_t workspace_bytes, const int* tap_modules, int n_taps,
+                          float* const* d_tap_out, int stop_module, void* stream) {
+  if (!h || !d_x || !d_y || !d_workspace || n_taps < 0 || (n_taps && (!tap_modules || !d_tap_out)))
+    return fail(AMX_ERR_INVALID, "null argument");
+  const int nmod = (int)h->kinds.size();
+  for (int t = 0; t < n_taps; ++t) {
+    if (tap_modules[t] < 0 || tap_modules[t] >= nmod || !d_tap_out[t] || (t && tap_modules[t] <= tap_modules[t - 1]))
+      return fail(AMX_ERR_INVALID, "tap modules must be strictly ascending ids in [0,%d) with non-null buffers", nmod);
+  }
+  if (stop_module >= nmod) return fail(AMX_ERR_INVALID, "stop_module %d out of range", stop_module);
+  TapReq req{tap_modules, n_taps, d_tap_out, stop_module < 0 ? -1 : stop_module};
+  const long long vox = (long long)d * hh * w;
+  return run_forward(h, d_x, vox * 4, (long long)hh * w * 4, (long long)w * 4, d_y, vox * h->cfg.output_nc, vox,
+                     (long long)hh * w, w, nullptr, n, d, hh, w, d_workspace, workspace_bytes, (hipStream_t)stream,
+                     nullptr, nullptr, nullptr, &req);
 }
 
 int amx_unet_forward_profiled(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
@@ -592,6 +744,24 @@ int amx_unet_forward_window(amx_unet_t* h, const float* d_vol, int vd, int vh, i
   return run_forward(h, d_vol + off, vvox * 4, (long long)vh * vw * 4, (long long)vw * 4, d_acc + off,
                      vvox * h->cfg.output_nc, vvox, (long long)vh * vw, vw, d_wmap, 1, rd, rh, rw,
                      d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int amx_unet_forward_windows(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int n_windows,
+                             const int* offsets_zyx, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !d_vol || !d_acc || !d_wmap || !d_workspace || !offsets_zyx) return fail(AMX_ERR_INVALID, "null argument");
+  if (n_windows < 1 || n_windows > 64) return fail(AMX_ERR_INVALID, "1 <= n_windows <= 64 (got %d)", n_windows);
+  long long offs[64];
+  for (int i = 0; i < n_windows; ++i) {
+    const int oz = offsets_zyx[3 * i], oy = offsets_zyx[3 * i + 1], ox = offsets_zyx[3 * i + 2];
+    if (oz < 0 || oy < 0 || ox < 0 || oz + rd > vd || oy + rh > vh || ox + rw > vw)
+      return fail(AMX_ERR_SHAPE, "window (%d,%d,%d)+(%d,%d,%d) outside volume (%d,%d,%d)", oz, oy, ox, rd, rh, rw, vd, vh, vw);
+    offs[i] = ((long long)oz * vh + oy) * vw + ox;
+  }
+  const long long vvox = (long long)vd * vh * vw;
+  return run_forward(h, d_vol, vvox * 4, (long long)vh * vw * 4, (long long)vw * 4, d_acc, vvox * h->cfg.output_nc, vvox,
+                     (long long)vh * vw, vw, d_wmap, n_windows, rd, rh, rw, d_workspace, workspace_bytes,
+                     (hipStream_t)stream, nullptr, offs, offs);
 }
 
 int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream) {

@@ -30,7 +30,14 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-constexpr int kInBlocks = 128;   // slabs per sample in the statistics pass
+// slabs per sample in the statistics pass: enough blocks to fill the chip on the big planes, >= 8 loads per
+// thread on the small ones, and nblk * C <= 65536 so the partial-sum scratch stays at 512 KiB per sample
+__host__ __device__ inline int in_num_blocks(long long vox, int C) {
+  long long nb = vox * C / (8 * 256 * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb * C > 65536) nb = 65536 / C;
+  return nb < 1 ? 1 : (int)nb;
+}
 
 // grid (kInBlocks, N), block 256.  partial[n][blk][c][2]
 template <typename T>
@@ -77,28 +84,40 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ 
   }
 }
 
-// grid N, block 256.  ab[n][c][2] = (a, b) with y = a*x + b
+// grid (C/8, N), block 256 = 8 channels x 32 partial lanes.  ab[n][c][2] = (a, b) with y = a*x + b.
+// Lane l adds partials l, l+32, ... in order, then the 32 lane sums are added in lane order: fixed order, no atomics.
 template <typename T>
-__global__ void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial, const float* gamma,
-                                   const float* beta, float eps, long long vox, int C, int nblk, float* __restrict__ ab) {
-  const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C + c) * 2);
-    const float K = (float)__builtin_bit_cast(T, kb);
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      const float* q = partial + (((long long)n * nblk + b) * C + c) * 2;
-      s1 += q[0];
-      s2 += q[1];
+__global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
+                                                         const float* gamma, const float* beta, float eps, long long vox,
+                                                         int C, int nblk, float* __restrict__ ab) {
+  __shared__ double red[2][8][32];
+  const int n = blockIdx.y, c = blockIdx.x * 8 + (threadIdx.x & 7), l = threadIdx.x >> 3;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = l; b < nblk; b += 32) {
+    const float* q = partial + (((long long)n * nblk + b) * C + c) * 2;
+    s1 += q[0];
+    s2 += q[1];
+  }
+  red[0][threadIdx.x & 7][l] = s1;
+  red[1][threadIdx.x & 7][l] = s2;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int cc = blockIdx.x * 8 + threadIdx.x;
+    s1 = 0.0; s2 = 0.0;
+    for (int k = 0; k < 32; ++k) {
+      s1 += red[0][threadIdx.x][k];
+      s2 += red[1][threadIdx.x][k];
     }
+    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C + cc) * 2);
+    const float K = (float)__builtin_bit_cast(T, kb);
     const double m1 = s1 / (double)vox;
     double var = s2 / (double)vox - m1 * m1;              // biased variance, shift invariant
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mean = K + (float)m1;
-    const float g = gamma ? gamma[c] : 1.f;
-    ab[((long long)n * C + c) * 2] = rstd * g;
-    ab[((long long)n * C + c) * 2 + 1] = (beta ? beta[c] : 0.f) - mean * rstd * g;
+    const float g = gamma ? gamma[cc] : 1.f;
+    ab[((long long)n * C + cc) * 2] = rstd * g;
+    ab[((long long)n * C + cc) * 2 + 1] = (beta ? beta[cc] : 0.f) - mean * rstd * g;
   }
 }
 
@@ -163,14 +182,69 @@ __global__ void upsample2_trilinear_kernel(const char* __restrict__ in, char* __
   }
 }
 
+// y = scale[c] * x + shift[c], then the activation, in place (eval-mode BatchNorm applied as its own pass: only
+// used when a feature tap asks for the pre-norm convolution output, network.py:475-529).
+template <typename T>
+__global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  long long nvox, int C, int act, float slope) {
+  const int c8n = C >> 3;
+  const long long total = nvox * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    float f[8];
+    unpack8<T>(*(const uint4*)(x + idx * 16), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = f[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      f[e] = v;
+    }
+    *(uint4*)(x + idx * 16) = pack8<T>(f);
+  }
+}
+
+// Feature tap: 16-bit channels-last -> fp32 NCDHW [N][C0+C1][D][H][W], the layout the reference hands to its
+// callers.  Channels [0,C0) come from src0 (full resolution), [C0,C0+C1) from src1, read through >> up_shift
+// (the tap at an nn.Upsample id is taken after torch.cat((skip, up), 1), network.py:500-502).
+// One thread = one voxel x 8 channels; a wavefront writes 64 consecutive floats of each of its 8 planes.
+template <typename T>
+__global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const char* __restrict__ src1, int C1, int up_shift,
+                                    int N, int D, int H, int W, float* __restrict__ out) {
+  const int C = C0 + C1, c8n = C >> 3;
+  const long long vox = (long long)D * H * W;
+  const long long total = (long long)N * c8n * vox;
+  const int lw = W >> up_shift, lh = H >> up_shift, ld = D >> up_shift;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long v = idx % vox;
+    const long long r = idx / vox;
+    const int c8 = r % c8n, n = r / c8n;
+    const int c = c8 * 8;
+    const char* sp;
+    if (c < C0) {
+      sp = src0 + (((long long)n * vox + v) * C0 + c) * 2;
+    } else {
+      const int x = v % W, y = (v / W) % H, z = v / ((long long)W * H);
+      const long long lv = (((long long)n * ld + (z >> up_shift)) * lh + (y >> up_shift)) * lw + (x >> up_shift);
+      sp = src1 + (lv * C1 + (c - C0)) * 2;
+    }
+    float f[8];
+    unpack8<T>(*(const uint4*)sp, f);
+    float* o = out + ((long long)n * C + c) * vox + v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e * vox] = f[e];
+  }
+}
+
 // ------------------------------------------------------------------------------------------- launchers
-size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * kInBlocks * C * 2 + (size_t)N * C * 2) * sizeof(float); }
+size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * 65536 * 2 + (size_t)N * C * 2) * sizeof(float); }
 
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st) {
   if (C % 8) return hipErrorInvalidValue;
   float* partial = (float*)scratch;
-  float* ab = partial + (size_t)N * kInBlocks * C * 2;
+  float* ab = partial + (size_t)N * 65536 * 2;
+  const int nblk = in_num_blocks(vox, C);
   const int c8n = C / 8;
   if (c8n > 256) return hipErrorInvalidValue;          // C <= 2048
   const int nrow = 256 / c8n;
@@ -178,9 +252,9 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   const long long total = (long long)N * vox * c8n;
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define AMX_IN(T)                                                                                                   \
-  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(kInBlocks, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
-  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
-                     kInBlocks, ab);                                                                                 \
+  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
+  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
+                     nblk, ab);                                                                                 \
   hipLaunchKernelGGL(in_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope)
   if (precision == 0) { AMX_IN(f16); } else { AMX_IN(bf16); }
 #undef AMX_IN
@@ -195,6 +269,32 @@ hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, i
     hipLaunchKernelGGL(upsample2_trilinear_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
   else
     hipLaunchKernelGGL(upsample2_trilinear_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
+                             float slope, int precision, hipStream_t st) {
+  if (C % 8) return hipErrorInvalidValue;
+  const long long total = (long long)N * vox * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope);
+  else
+    hipLaunchKernelGGL(affine_act_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope);
+  return hipGetLastError();
+}
+
+hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
+                               float* out, int precision, hipStream_t st) {
+  if (C0 % 8 || C1 % 8 || C0 + C1 < 8) return hipErrorInvalidValue;
+  const long long total = (long long)N * ((C0 + C1) / 8) * D * H * W;
+  const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(export_ncdhw_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1,
+                       up_shift, N, D, H, W, out);
+  else
+    hipLaunchKernelGGL(export_ncdhw_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1,
+                       up_shift, N, D, H, W, out);
   return hipGetLastError();
 }
 

@@ -174,8 +174,6 @@ class Unet(nn.Module):
         c = self._cfg
         if not x.is_cuda:
             return "input is not on a GPU device"
-        if len(layers) > 0:
-            return "feature taps (`layers`) are not implemented in the HIP path yet"
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return "autograd is enabled (wrap inference in torch.no_grad()); backward kernels are not implemented yet"
         if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
@@ -269,6 +267,38 @@ class Unet(nn.Module):
                                             need, stream))
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
+    def forward_hip_taps(self, x, layers, encode_only=False):
+        """Unet.forward(input, layers, encode_only) (network.py:475-529) on the HIP kernels.  Features are fp32 NCDHW
+        tensors collected in traversal order; with ``encode_only`` the forward stops after module ``layers[-1]``."""
+        device = x.device
+        lib = self._ensure_handle(device)
+        nmod = len(self.model)
+        stop = layers[-1] if (encode_only and 0 <= layers[-1] < nmod) else -1
+        want = sorted({int(l) for l in layers if 0 <= int(l) < nmod and (stop < 0 or int(l) <= stop)})
+        with torch.cuda.device(device):
+            if self._weights_dirty:
+                self._upload_weights(lib, device)
+            xin = x.detach()
+            if xin.dtype != torch.float32 or not xin.is_contiguous():
+                xin = xin.float().contiguous()
+            n, _, d, h, w = xin.shape
+            ws, need = self._get_workspace(lib, n, d, h, w, device)
+            y = torch.empty((n, self._cfg["output_nc"], d, h, w), dtype=torch.float32, device=device)
+            feats = []
+            ch, lv = ctypes.c_int(), ctypes.c_int()
+            for m in want:
+                _lib.check(lib.amx_unet_module_info(self._handle, m, ctypes.byref(ch), ctypes.byref(lv)))
+                feats.append(torch.empty((n, ch.value, d >> lv.value, h >> lv.value, w >> lv.value), dtype=torch.float32,
+                                         device=device))
+            mods = (ctypes.c_int * max(len(want), 1))(*want)
+            outs = (ctypes.c_void_p * max(len(want), 1))(*[f.data_ptr() for f in feats])
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.amx_unet_forward_taps(self._handle, _lib.ptr(xin), _lib.ptr(y), n, d, h, w, _lib.ptr(ws), need,
+                                                 mods, len(want), outs, stop, stream))
+        if x.dtype != torch.float32:
+            y, feats = y.to(x.dtype), [f.to(x.dtype) for f in feats]
+        return feats if stop >= 0 else (y, feats)
+
     def profile_forward(self, x):
         """One forward with a hipEvent around every launch (amx_unet_forward_profiled).  Returns
         (output, [dict(kernel, module_idx, cin, cout, n, d, h, w, ms, flops, bytes), ...])."""
@@ -328,6 +358,10 @@ class Unet(nn.Module):
         ``layers``; ``feats`` alone with ``encode_only``."""
         reason = self.hip_unsupported_reason(input, layers)
         if reason is None:
+            if len(layers) > 0:
+                if verbose:
+                    print("anatomix_amd.Unet: verbose per-layer shapes are only printed on the stock torch path")
+                return self.forward_hip_taps(input, list(layers), encode_only)
             return self.forward_hip(input)
         if not self.allow_torch_path:
             raise RuntimeError(

@@ -158,8 +158,12 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     return acc
 
 
+FUSED_WINDOW_BATCH = 4     # windows per amx_unet_forward_windows call (fills the chip on the deep levels)
+
+
 def _run_fused(inputs, roi, starts, wmap, model, cnt):
-    """One amx_unet_forward_window + one amx_sw_count per window, all on the current stream."""
+    """amx_unet_forward_windows on groups of FUSED_WINDOW_BATCH windows + one amx_sw_count per window, all on
+    the current stream (overlapping windows accumulate in issue order)."""
     lib = _lib.load()
     dev = inputs.device
     B = inputs.shape[0]
@@ -173,14 +177,18 @@ def _run_fused(inputs, roi, starts, wmap, model, cnt):
         model._ensure_handle(dev)
         if model._weights_dirty:
             model._upload_weights(lib, dev)
-        ws, need = model._get_workspace(lib, 1, roi[0], roi[1], roi[2], dev)
+        k = max(1, min(FUSED_WINDOW_BATCH, len(starts)))
+        ws, need = model._get_workspace(lib, k, roi[0], roi[1], roi[2], dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         wm = wmap.contiguous()
-        for (z, y, xx) in starts:
+        for g0 in range(0, len(starts), k):
+            grp = starts[g0:g0 + k]
+            offs = (ctypes.c_int * (3 * len(grp)))(*[v for s3 in grp for v in s3])
             for b in range(B):
-                _lib.check(lib.amx_unet_forward_window(model._handle, _lib.ptr(x[b]), size[0], size[1], size[2], z, y,
-                                                       xx, roi[0], roi[1], roi[2], _lib.ptr(wm), _lib.ptr(acc[b]),
-                                                       _lib.ptr(ws), need, st))
-            _lib.check(lib.amx_sw_count(_lib.ptr(cnt), size[0], size[1], size[2], z, y, xx, roi[0], roi[1], roi[2],
-                                        _lib.ptr(wm), st))
+                _lib.check(lib.amx_unet_forward_windows(model._handle, _lib.ptr(x[b]), size[0], size[1], size[2], len(grp),
+                                                        offs, roi[0], roi[1], roi[2], _lib.ptr(wm), _lib.ptr(acc[b]),
+                                                        _lib.ptr(ws), need, st))
+            for (z, y, xx) in grp:
+                _lib.check(lib.amx_sw_count(_lib.ptr(cnt), size[0], size[1], size[2], z, y, xx, roi[0], roi[1], roi[2],
+                                            _lib.ptr(wm), st))
     return acc

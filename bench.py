@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_VOLUME_6M = 346.986381312
+GFLOP_PER_VOLUME_DEV = 1418.75         # SURVEY.md section 8(d), anatomix-dev
 
 
 def parse():
@@ -40,14 +41,19 @@ def parse():
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
+    ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev"],
+                    help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M)")
+    ap.add_argument("--sw-volume", type=int, default=0,
+                    help="BASELINE configs[1] end to end: a step = sliding-window extraction (roi 128, overlap 0.8, "
+                         "gaussian) over one 1x1xS^3 volume, windows dealt to the ranks, one all_reduce")
     return ap.parse_args()
 
 
-def cpu_baseline(size, forwards):
+def cpu_baseline(size, forwards, variant="anatomix"):
     """oracle (CPU restatement) on one [1,1,S,S,S] volume, all host threads, fp32 eval."""
     import torch
     from oracle import unet_ref as R
-    kw = R.VARIANTS["anatomix"]
+    kw = R.VARIANTS[variant]
     sd = R.synthetic_state_dict(kw, 0)
     x = R.synthetic_input(100, 1, (size,) * 3)
     try:
@@ -120,7 +126,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    kw = R.VARIANTS["anatomix"]
+    kw = R.VARIANTS[args.variant]
     sys.stdout.flush()
     devnull = open(os.devnull, "w")
     so, sys.stdout = sys.stdout, devnull             # the constructor prints two lines (reference parity)
@@ -138,16 +144,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step = lambda: model(x)
+    units_per_step = world * B          # 128^3 volumes all ranks process per step
+    if args.sw_volume:
+        from anatomix_amd.registration.sliding_window import sliding_window_inference, window_starts
+        V = args.sw_volume
+        vol = R.synthetic_input(101, 1, (V, V, V)).to(dev)          # every rank holds the volume
+        group = dist.group.WORLD if world > 1 else None
+        step = lambda: sliding_window_inference(vol, (S, S, S), 2, model, overlap=0.8, mode="gaussian",
+                                                sigma_scale=0.25, group=group)
+        units_per_step = len(window_starts((V, V, V), (S, S, S), 0.8))
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            y = model(x)
+            y = step()
         barrier()
         t0 = time.perf_counter()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         for _ in range(args.steps):
-            y = model(x)
-        e1.record()
+            y = step()
         barrier()
         elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -155,7 +169,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    value = units_per_step * args.steps / elapsed
     assert torch.isfinite(y).all()
 
     result = None
@@ -194,22 +208,32 @@ def main():
                                        "alg_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else 0.0,
                                        "alg_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
-        gflop_vol = GFLOP_PER_VOLUME_6M * (S / 128.0) ** 3
+        gflop_vol = (GFLOP_PER_VOLUME_6M if args.variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
+        name = "anatomix 6M UNet (ngf=16,num_downs=4)" if args.variant == "anatomix" else \
+            "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)"
+        if args.sw_volume:
+            workload = (f"{name}: sliding-window feature extraction of one 1x{args.sw_volume}^3 volume = {units_per_step} windows "
+                        f"of {S}^3 per step (overlap 0.8, gaussian 0.25), fused gaussian accumulate (BASELINE configs[1])")
+            par = f"windows dealt to {world} rank(s), one all_reduce(SUM) of the accumulators" if world > 1 else "1 GPU"
+        else:
+            workload = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
+                        "sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, 16-bit channels-last "
+                        "activations, fp32 accumulate")
+            par = f"replicas x{world} (no data-path collective)"
         result = {
-            "metric": "128^3 volumes/sec feature-extraction (6M UNet)", "value": round(value, 2), "unit": "volumes/s",
+            "metric": "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if args.variant == "anatomix" else "94M dev UNet"),
+            "value": round(value, 2), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic (uniform [0,1) volumes, seeded random weights of the anatomix 6M architecture)",
-            "config": {"workload": f"anatomix 6M UNet (ngf=16,num_downs=4) forward on sw_batch={B} windows of "
-                                   f"1x{S}^3 (the predictor call of sliding_window_inference, BASELINE configs[1]); "
-                                   "fp32 NCDHW in/out, 16-bit channels-last activations, fp32 accumulate",
-                       "batch_per_gpu": B, "window": S, "parallelism": f"replicas x{world} (no data-path collective)"},
+            "higher_is_better": True, "scaling": "strong" if args.sw_volume else "weak", "vs_baseline": None,
+            "dtype": args.precision,
+            "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {args.variant} architecture)",
+            "config": {"workload": workload, "batch_per_gpu": 1 if args.sw_volume else B, "window": S, "parallelism": par},
             "end_to_end_TFLOPs": round(value * gflop_vol / 1e3, 1),
             "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(S, args.cpu_forwards)
+            result["cpu_baseline"] = cpu_baseline(S, args.cpu_forwards, args.variant)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -104,6 +104,24 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int w_h, int 
 int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
                      void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Channels and resolution level (spatial size = input size >> level) of `feat` after Unet.model[module_idx]
+ * as Unet.forward's `layers` branch sees it: for an nn.Upsample id that is AFTER torch.cat((skip, up), 1)
+ * (network.py:500-502). */
+int amx_unet_module_info(const amx_unet_t* h, int module_idx, int* channels, int* level);
+
+/* Unet.forward(input, layers, encode_only) (network.py:475-529), eval mode.  tap_modules: HOST array of n_taps
+ * module ids, strictly ascending (the reference collects in traversal order whatever the order of `layers`);
+ * d_tap_out: HOST array of n_taps device buffers, fp32 NCDHW [n][channels][d>>level][h>>level][w>>level] per
+ * amx_unet_module_info.  stop_module >= 0 reproduces encode_only: the forward ends after that module (d_y is
+ * then left untouched unless the network got that far), modules after it do not run -- in particular an in-place
+ * activation that would otherwise overwrite the tapped tensor.  Tap semantics follow the reference exactly:
+ *   conv id followed by a norm ........ the pre-norm convolution output;
+ *   norm id followed by an activation . the ACTIVATED tensor (nn.ReLU(inplace=True) aliases it, network.py:188-196);
+ *   activation / pool id .............. that module's output;   upsample id: the concatenated tensor. */
+int amx_unet_forward_taps(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
+                          void* d_workspace, size_t workspace_bytes, const int* tap_modules, int n_taps,
+                          float* const* d_tap_out, int stop_module, void* stream);
+
 /* Same forward, with a hipEvent recorded on `stream` around every launch; synchronises the
  * stream before returning and fills up to max_records records (profiling aid for bench.py's
  * roofline figures -- not used in the timed region). */
@@ -119,6 +137,15 @@ int amx_unet_forward_profiled(amx_unet_t* h, const float* d_x, float* d_y, int n
 int amx_unet_forward_window(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int oz, int oy,
                             int ox, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
                             void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* n_windows sliding-window steps in one call (the reference hands sw_batch_size windows to the predictor at a
+ * time, convex_adam_utils.py:205; any batching gives the same result because every norm mode is per sample or
+ * uses running statistics).  offsets_zyx: HOST array [n_windows][3] of window corners.  The stem and the output
+ * convolution run once per window in the given order (so overlapping accumulations are ordered on the stream);
+ * all layers between them run on the whole batch.  Workspace: amx_unet_workspace_bytes(h, n_windows, rd, rh, rw). */
+int amx_unet_forward_windows(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int n_windows,
+                             const int* offsets_zyx, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Final step of sliding_window_inference: d_acc[c][v] /= d_cnt[v] in place. */
 int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream);

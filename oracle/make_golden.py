@@ -71,6 +71,38 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "unet_forward_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) / 1e6, "MB")
+    taps_of_every_module_kind()
+
+
+# One tap per module kind (network.py:475-529).  Two reference behaviours these pin down:
+#   * a tap at an Upsample id is taken AFTER the concat with the skip (network.py:500-502 precede 504-516);
+#   * the activation modules are built with inplace=True (network.py:188-196), so a tap at a NORM id aliases
+#     the tensor the next ReLU overwrites: the caller sees post-activation values there.
+KIND_TAPS = {"anatomix": (32, [0, 1, 2, 8, 9, 36, 37, 39, 58, 59, 64, 65]),
+             "anatomix-dev": (64, [0, 1, 2, 9, 43, 44, 45, 79])}
+
+
+def taps_of_every_module_kind():
+    out = {}
+    for variant, (size, taps) in KIND_TAPS.items():
+        kw = R.VARIANTS[variant]
+        m = RefUnet(**kw).eval()
+        m.load_state_dict(R.synthetic_state_dict(kw, 0), strict=True)
+        x = R.synthetic_input(100, 1, (size,) * 3)
+        with torch.no_grad():
+            y, feats = m(x, taps, False)
+            enc = m(x, taps[:4], True)
+        assert len(enc) == 4 and all(torch.equal(a, b) for a, b in zip(enc, feats))
+        tag = f"{variant}|s0|{size}"
+        out[tag + "|taps"] = np.array(taps)
+        for t, f in zip(taps, feats):
+            i2, v2 = probes(f, np.random.RandomState(3000 + t))
+            out[tag + f"|tap{t}|idx"], out[tag + f"|tap{t}|val"] = i2, v2
+            out[tag + f"|tap{t}|shape"] = np.array(f.shape)
+            out[tag + f"|tap{t}|stats"] = np.array([f.double().mean().item(), f.double().norm().item(), f.min().item()])
+    path = os.path.join(ROOT, "tests", "golden", "unet_taps_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) / 1e6, "MB")
 
 
 if __name__ == "__main__":

@@ -149,17 +149,19 @@ def norm_apply(x, sd, i, norm, eps):
 
 
 def act_apply(x, activation):
-    """get_actvn_layer -- network.py:171-204 (relu, lrelu slope 0.3)."""
+    """get_actvn_layer -- network.py:171-204 (relu, lrelu slope 0.3).  relu / lrelu / selu are built with
+    inplace=True there (188-196): they OVERWRITE their input, so a feature tap taken at the preceding norm (or, with
+    norm='none', conv) module aliases the activated values.  The in-place functional forms keep that behaviour."""
     if activation == "relu":
-        return F.relu(x)
+        return F.relu_(x)
     if activation == "lrelu":
-        return F.leaky_relu(x, 0.3)
+        return F.leaky_relu_(x, 0.3)
     if activation == "tanh":
         return torch.tanh(x)
     if activation == "elu":
         return F.elu(x)
     if activation == "selu":
-        return F.selu(x)
+        return F.selu(x, inplace=True)
     raise ValueError(activation)
 
 
