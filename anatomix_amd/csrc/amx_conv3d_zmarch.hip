@@ -52,12 +52,33 @@ struct ZmCfg {
   static_assert(NL <= 8 && LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
 };
 
+// Output staging of the storer waves (NS = 2): one step of the tile (2 planes x TY x TX voxels) in LDS.
+//   OUTMODE 0: [tz][y][x][Cout] 16-bit, exactly the global row layout (a row of TX voxels = TX * CB bytes);
+//   OUTMODE 1: [c][tz][y][x] fp32 with the channel stride padded to 2112 B (conflict-free b128 writes).
+template <int QT, int TY, int TX, int OUTMODE>
+struct ZmStage {
+  static constexpr int CB = 32 * QT;                                // bytes of one voxel (16-bit, Cout channels)
+  static constexpr int CS = 2 * TY * TX * 4 + 64;                   // fp32 planar: bytes of one channel
+  static constexpr int BYTES = OUTMODE == 0 ? 2 * TY * TX * CB : 16 * QT * CS;
+  static constexpr int NB = OUTMODE == 0 ? 2 : 1;                   // staging tiles (the 32 KiB fp32 tile fits once)
+  static constexpr int TOTAL = NB * BYTES;
+};
+
 // One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
-template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE>
-__global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+// NS = 2 adds two STORER waves: the MFMA waves leave each step's outputs in an LDS staging tile and the storers
+// copy it out (storer w owns output plane w of every step).  A wave that issues global stores stalls while the
+// memory queue is full; with the stores on the MFMA waves, math and write-out serialised (16 -> 16 @128^3, batch
+// 4: 91 us without the epilogue, 100 us without the math, 130 us together; fp32 planar output 93 / 165 / 247 us).
+// Requires full tiles and 16-byte aligned dense outputs (conv_zmarch_can_stage), else NS = 0.
+template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS>
+__global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
   typedef ZmCfg<NCK, QT, TY, TX, R> C;
+  typedef ZmStage<QT, TY, TX, OUTMODE> SG;
   typedef typename Ops<T>::vec8 vec8;
   constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, NDMA = C::NDMA, NL = C::NL, NC = C::NC, TZ = C::TZ;
+  constexpr int STAGEOFF = C::FLAGOFF + 128;                        // flags: ready +0, done +32, staged +64, stored +96
+  static_assert(NS == 0 || NS == 2, "one storer wave per output plane of a step");
+  static_assert(NS == 0 || STAGEOFF + SG::TOTAL <= 160 * 1024, "ring + staging tile must fit the LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -82,8 +103,61 @@ __global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(co
 
   int* ready = (int*)(smem + C::FLAGOFF);
   int* done = (int*)(smem + C::FLAGOFF + 32);
-  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  int* staged = (int*)(smem + C::FLAGOFF + 64);              // per consumer wave: steps whose outputs are in the staging tile
+  int* stored = (int*)(smem + C::FLAGOFF + 96);              // per storer wave: steps it has read out of the staging tile
+  if (tid < (NS ? 32 : 16)) ((int*)(smem + C::FLAGOFF))[tid] = 0;
   __syncthreads();
+
+  if (NS && wave >= NC + NL) {
+    // =========================== storer wave: output plane w of every step ===========================
+    const int w = wave - NC - NL;
+    const unsigned a_staged = lds_addr(staged), a_stored = lds_addr(stored + w);
+    if constexpr (OUTMODE == 0) {
+      constexpr int NR = TY * QT;                            // 1 KiB pieces of this plane's TY rows
+      const char* sbase = smem + STAGEOFF + w * TY * TX * SG::CB + lane * 16;
+      char* gbase = p.out + (long long)n * p.on + (long long)y0 * p.oy + (long long)x0 * p.ox + lane * 16;
+      for (int s = 0; s < nsteps; ++s) {
+        while (__builtin_amdgcn_readfirstlane(flag_min8_asm(a_staged)) < s + 1) __builtin_amdgcn_s_sleep(1);
+        uint4 v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = *(const uint4*)(sbase + (s % SG::NB) * SG::BYTES + r * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flag_store_asm(a_stored, s + 1);
+        const int zo = zs + s * TZ + w;
+        if (zo >= ze || (p.dbg & 4)) continue;
+        char* dst = gbase + (long long)zo * p.oz;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) *(uint4*)(dst + (long long)(r / QT) * p.oy + (r % QT) * 1024) = v[r];
+      }
+    } else {
+      constexpr int NCH = 16 * QT;
+      const int y = lane >> 3, xq = lane & 7;                // one instruction = 8 rows x 128 B of one channel plane
+      const char* sbase = smem + STAGEOFF + (w * TY + y) * (TX * 4) + xq * 16;
+      float* gbase = p.out32 + (long long)n * p.pn + (long long)(y0 + y) * p.py + x0 + xq * 4;
+      for (int s = 0; s < nsteps; ++s) {
+        while (__builtin_amdgcn_readfirstlane(flag_min8_asm(a_staged)) < s + 1) __builtin_amdgcn_s_sleep(1);
+        float4 v[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = *(const float4*)(sbase + c * SG::CS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flag_store_asm(a_stored, s + 1);
+        const int zo = zs + s * TZ + w;
+        if (zo >= ze || (p.dbg & 4)) continue;
+        float* dst = gbase + (long long)zo * p.pz;
+        if (p.wmap) {   // sliding-window accumulate: acc += wmap * feature
+          const float4 wg = *(const float4*)(p.wmap + ((long long)zo * p.H + y0 + y) * p.W + x0 + xq * 4);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const float4 old = *(const float4*)(dst + (long long)c * p.pc);
+            v[c] = make_float4(old.x + wg.x * v[c].x, old.y + wg.y * v[c].y, old.z + wg.z * v[c].z, old.w + wg.w * v[c].w);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *(float4*)(dst + (long long)c * p.pc) = v[c];
+      }
+    }
+    return;
+  }
 
   if (wave >= NC) {
     // =========================== loader wave: channel plane cp = wave - NC ===========================
@@ -256,7 +330,15 @@ __global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(co
     flag_store(done + wave, s + 1);
 
     // ---- epilogue: activation + store (never waited for)
-    if (p.dbg & 4) continue;
+    if (p.dbg & 4) {
+      if (NS) flag_store(staged + wave, s + 1);
+      continue;
+    }
+    if constexpr (NS > 0) {   // the staging tile still holds step s-1 until both storers have read it into registers
+      if (s >= SG::NB)
+        while (flag_load(stored) < s + 1 - SG::NB || flag_load(stored + 1) < s + 1 - SG::NB) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    }
     float pooled[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int tz = 0; tz < 2; ++tz) {
@@ -271,6 +353,18 @@ __global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(co
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
           v[j] = f;
           pooled[j] = f > pooled[j] ? f : pooled[j];
+        }
+        if constexpr (NS > 0) {
+          if (OUTMODE == 0) {
+            char* dst = smem + STAGEOFF + (s % SG::NB) * SG::BYTES + (((tz * TY + wrow + cy) * TX) + wcx * 16 + li) * SG::CB + cb * 2;
+            *(uint2*)dst = make_uint2((unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16),
+                                      (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16));
+          } else {
+            quad_transpose4(v, li);          // lane: channel cb + (li&3), x = (li&~3) .. +3
+            char* dst = smem + STAGEOFF + (cb + (li & 3)) * SG::CS + ((tz * TY + wrow + cy) * TX + wcx * 16 + (li & ~3)) * 4;
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          }
+          continue;
         }
         if (zo >= ze) continue;
         if (!full_xy && !((yl + cy < p.H) & (xl < p.W))) continue;
@@ -303,6 +397,10 @@ __global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(co
         }
       }
     }
+    if constexpr (NS > 0) {
+      asm volatile("" ::: "memory");                        // LDS is in-order: the flag lands after the staged data
+      flag_store(staged + wave, s + 1);
+    }
     if (OUTMODE == 0 && out2_l) {
       // the wave's 2 x 2 x 16 block is one max-pool window per x pair: exchange with lane ^ 1, even lanes store.
       // (rounding is monotonic, so pooling the fp32 values equals pooling the stored 16-bit values.)
@@ -325,16 +423,17 @@ __global__ __launch_bounds__((8 + 2 * NCK) * 64) void conv3d_k3_zmarch_kernel(co
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int NCK, int QT, int TY, int R, int OUTMODE>
-static hipError_t launch_zm(ConvParams p, hipStream_t st) {
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS>
+static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   constexpr int TX = 32, TZ = 2;
   typedef ZmCfg<NCK, QT, TY, TX, R> C;
-  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c8+l%d,r%d,o%d%s>",
-           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, R, OUTMODE, p.out2 ? ",pool" : "");
-  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE>;
+  constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
+  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
+           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE, p.out2 ? ",pool" : "");
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -354,8 +453,30 @@ static hipError_t launch_zm(ConvParams p, hipStream_t st) {
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + C::NL + NS) * 64), LDS, st, p, zseg, nseg);
   return hipGetLastError();
+}
+
+// Storer waves need full tiles and dense, 16-byte aligned outputs (whole rows are copied as 16-byte pieces).
+template <int QT, int TY, int OUTMODE>
+static bool zm_can_stage(const ConvParams& p) {
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_STORERS") ? 1 : 0;
+  if (off || p.H % TY || p.W % 32) return false;
+  if (OUTMODE == 0)
+    return p.ox == 32 * QT && !((size_t)p.out & 15) && !(p.oy & 15) && !(p.oz & 15) && !(p.on & 15);
+  return !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) && !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
+}
+
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE>
+static hipError_t launch_zm(const ConvParams& p, hipStream_t st) {
+  // 12 waves = 3 per SIMD keep the 170-VGPR budget of the MFMA waves; the 32 -> 32 kernel already has 4 loaders
+  // Measured (batch 4, 128^3, 16 -> 16): fp32 planar output 253 -> 177 us with storers (whole 128-byte lines, eight
+  // rows per store instruction, instead of 64-byte pieces from the MFMA lanes); 16-bit NDHWC output 130 -> 155 us
+  // (its direct stores are already 512-byte runs; the staging round trip only adds LDS traffic) -- so planar only.
+  if constexpr (NCK == 1 && OUTMODE == 1)
+    if (zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
+  return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 0>(p, st);
 }
 
 // Eligibility: one full-resolution input segment of 16 or 32 channels, 16 or 32 output channels
