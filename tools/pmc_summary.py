@@ -12,10 +12,11 @@ import collections, csv, json, re, sys
 
 
 def friendly(mangled):
-    m = re.match(r"_ZN3amx23conv3d_k3_zmarch_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
-    if m:
-        t, nck, qt, ty, tx, tz, nc, r, o = m.groups()
-        return f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},{16*int(nck)}->{16*int(qt)},{tz}x{ty}x{tx},c{nc}+l{2*int(nck)},r{r},o{o}>"
+    m = re.match(r"_ZN3amx23conv3d_k3_zmarch_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
+    if m:   # <T, NCK, QT, TY, TX, R, OUTMODE, NS>; same text as the launcher prints (minus the run-time ",pool" tag)
+        t, nck, qt, ty, tx, r, o, ns = m.groups()
+        return (f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},{16*int(nck)}->{16*int(qt)},2x{ty}x{tx},"
+                f"c8+l{2*int(nck)}+s{ns},r{r},o{o}>")
     m = re.match(r"_ZN3amx21conv3d_upcat16_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
     if m:
         return f"conv3d_upcat16<{'f16' if m.group(1) == 'DF16_' else 'bf16'},2x8x32,c8+l3,r10/6,o{m.group(2)}>"
