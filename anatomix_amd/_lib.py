@@ -62,6 +62,8 @@ SYMBOLS = {
     "amx_instance_norm_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_instance_norm": (_I, [_P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _I, _P]),
     "amx_upsample2_trilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "amx_supcon_scratch_bytes": (C.c_size_t, [_I, _I]),
+    "amx_supcon_loss": (_I, [_P, _P, _I, _I, C.c_float, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

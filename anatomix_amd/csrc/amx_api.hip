@@ -42,6 +42,9 @@ hipError_t launch_affine_act(void* x, const float* scale, const float* shift, in
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
                                float* out, int precision, hipStream_t st);
 const char* last_conv_kernel_name();
+size_t supcon_scratch_bytes(int N, int C);
+hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
+                         int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st);
 }  // namespace amx
 
 namespace {
@@ -833,6 +836,20 @@ int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout
               void* stream) {
   if (!d_in || !d_out || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
   AMX_HIP(amx::launch_pool2(d_in, d_out, n, dout, hout, wout, c, avg, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_supcon_scratch_bytes(int n, int c) { return amx::supcon_scratch_bytes(n, c); }
+
+int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, float temperature, int weigh_rarity,
+                    int balance_denominator, int sqrt_mode, float* d_loss, float* d_grad, void* d_scratch,
+                    size_t scratch_bytes, void* stream) {
+  if (!d_feat || !d_labels || !d_loss || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
+  if (n < 2 || n > 16384 || c < 1 || !(temperature > 0.f)) return fail(AMX_ERR_INVALID, "bad sizes (n=%d c=%d T=%g)", n, c, temperature);
+  if (scratch_bytes < amx::supcon_scratch_bytes(n, c))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx::supcon_scratch_bytes(n, c), scratch_bytes);
+  AMX_HIP(amx::launch_supcon(d_feat, d_labels, n, c, temperature, weigh_rarity, balance_denominator, sqrt_mode, d_loss,
+                             d_grad, d_scratch, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -1,0 +1,14 @@
+"""MI355X-side mirror of the reference's contrastive-pretraining pieces (reference: pretraining/models/).
+
+  SupPatchNCELoss ... pretraining/models/supcl_model.py:16-226     (HIP forward+backward kernel, amx_supcon_loss)
+  PatchSampleF ...... pretraining/models/pretraining_networks.py:264-519
+  contrastive_step .. the per-batch body of SupCLModel.optimize_parameters / forward / calculate_NCE_loss
+                      (supcl_model.py:603-661, 723-843) without the option parsing / logging around it.
+The UNet's backward is not a HIP kernel yet: the step runs the network through
+torch autograd on the stock modules (``Unet.allow_torch_path``), the loss through the HIP kernel.
+"""
+from .supcon import SupPatchNCELoss
+from .patch_sample import PatchSampleF
+from .step import contrastive_step
+
+__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step"]

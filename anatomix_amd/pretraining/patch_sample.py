@@ -1,0 +1,93 @@
+"""PatchSampleF with the reference's constructor and call contract (pretraining_networks.py:264-519)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..model.network import get_actvn_layer, get_norm_layer
+
+
+class PatchSampleF(nn.Module):
+    """Samples ``num_patches`` voxel coordinates per feature map (the SAME coordinates for every view in the batch),
+    gathers ``feat[:, :, x, y, z]`` -> ``[views * P, C]`` and projects it with a lazily created per-layer MLP
+    ``mlp_k`` (Linear(C, nc, no bias) - norm - act [- Linear - norm - act] - Linear - norm(affine=False)).
+
+    Differences from the reference, both deliberate: tensors stay on the device of ``feats`` (the reference
+    hard-codes ``.cuda()``, pretraining_networks.py:400,405), and the given-``patch_ids`` branch returns the given
+    coordinates (the reference leaves ``coords`` unbound there, :432-447,499)."""
+
+    def __init__(self, use_mlp=False, init_type="normal", init_gain=0.02, nc=256, gpu_ids=[], n_mlps=2, activation="relu",
+                 norm="batch", norm_eps=1e-5):
+        super().__init__()
+        self.use_mlp = use_mlp
+        print("Use MLP: {}".format(use_mlp))
+        self.nc = nc
+        self.mlp_init = False
+        self.init_type, self.init_gain, self.gpu_ids = init_type, init_gain, gpu_ids
+        self.n_mlps, self.activation, self.normtype, self.norm_eps = n_mlps, activation, norm, norm_eps
+
+    def create_mlp(self, feats):
+        for mlp_id, feat in enumerate(feats):
+            cin = feat.shape[1]
+            norm = get_norm_layer(1, self.normtype, eps=self.norm_eps)
+            act = get_actvn_layer(self.activation)
+            if self.n_mlps == 2:
+                layers = [nn.Linear(cin, self.nc, bias=False), norm(self.nc), act,
+                          nn.Linear(self.nc, self.nc, bias=False), norm(self.nc, affine=False)]
+            elif self.n_mlps == 3:
+                layers = [nn.Linear(cin, self.nc, bias=False), norm(self.nc), act,
+                          nn.Linear(self.nc, self.nc, bias=False), norm(self.nc), act,
+                          nn.Linear(self.nc, self.nc, bias=False), norm(self.nc, affine=False)]
+            else:
+                raise NotImplementedError
+            mlp = nn.Sequential(*layers).to(feat.device)
+            setattr(self, "mlp_%d" % mlp_id, mlp)
+            print("mlp_%d created, input nc %d" % (mlp_id, cin))
+        self._init_weights()
+        self.mlp_init = True
+
+    def _init_weights(self):
+        """init_net -> init_weights (pretraining_networks.py:666-715): Linear / Conv weights by ``init_type``; the
+        BatchNorm1d layers are NOT matched by its class-name test (only 'BatchNorm3d' is) and keep gamma=1, beta=0."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                if self.init_type == "normal":
+                    nn.init.normal_(m.weight, 0.0, self.init_gain)
+                elif self.init_type == "xavier":
+                    nn.init.xavier_normal_(m.weight, gain=self.init_gain)
+                elif self.init_type == "kaiming":
+                    nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in")
+                elif self.init_type == "orthogonal":
+                    nn.init.orthogonal_(m.weight, gain=self.init_gain)
+                else:
+                    raise NotImplementedError("initialization method [%s] is not implemented" % self.init_type)
+
+    def forward(self, feats, num_patches=64, patch_ids=None, mask=None, verbose=False):
+        return_ids, return_feats = [], []
+        ndims = feats[0].dim() - 2
+        if ndims not in (2, 3):
+            raise NotImplementedError
+        if self.use_mlp and not self.mlp_init:
+            self.create_mlp(feats)
+        for k, feat in enumerate(feats):
+            if num_patches > 0:
+                if patch_ids is not None:
+                    coords = patch_ids[k].to(feat.device)
+                else:
+                    if mask is not None:
+                        m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
+                        fg = torch.where(m > 0)[2:]
+                    else:       # every voxel of the grid, in C order (what torch.where of an all-ones mask enumerates)
+                        fg = torch.unravel_index(torch.arange(feat[0, 0].numel(), device=feat.device), feat.shape[2:])
+                    perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
+                    coords = torch.stack([f[perm] for f in fg], dim=1)
+                idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
+                x_sample = feat[idx]                                   # [views, C, P]
+            else:
+                x_sample, coords = feat.flatten(2), []
+            nviews, nc, nsample = x_sample.size()
+            x_sample = x_sample.permute(0, 2, 1).flatten(0, 1)         # [views * P, C]
+            return_ids.append(coords)
+            if self.use_mlp:
+                x_sample = getattr(self, "mlp_%d" % k)(x_sample).view(nviews, nsample, -1)
+            return_feats.append(x_sample)
+        return return_feats, return_ids

@@ -1,0 +1,101 @@
+"""SupPatchNCELoss with the reference's constructor and call contract (supcl_model.py:16-226)."""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+
+class _SupConHip(torch.autograd.Function):
+    """loss, d loss / d features from ONE amx_supcon_loss call (forward and backward are fused in the library)."""
+
+    @staticmethod
+    def forward(ctx, feat2d, labels, temperature, rarity, balance, sqrt_mode):
+        lib = _lib.load()
+        dev = feat2d.device
+        x = feat2d.detach().float().contiguous()
+        n, c = x.shape
+        need_grad = feat2d.requires_grad
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(x) if need_grad else None
+        with torch.cuda.device(dev):
+            nbytes = lib.amx_supcon_scratch_bytes(n, c)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.amx_supcon_loss(_lib.ptr(x), _lib.ptr(labels), n, c, float(temperature), int(rarity), int(balance),
+                                           int(sqrt_mode), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(scratch), nbytes, st))
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = feat2d.dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).to(ctx.in_dtype), None, None, None, None, None
+
+
+class SupPatchNCELoss(nn.Module):
+    """``SupPatchNCELoss(opt)``; ``opt`` carries nce_T, weigh_rarity, balance_denominator, weighting_mode
+    (supcl_model.py:49-58).  ``forward(features [views,P,C], labels_seg [1,1,H,W,D], labels_coords [P,3], coords_range)``
+    returns the scalar loss.  CUDA features run on the HIP kernel; CPU features raise unless ``allow_torch_path``."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.mask_dtype = torch.bool
+        self.temperature = opt.nce_T
+        self.weigh_rarity = getattr(opt, "weigh_rarity", False)
+        self.balance_denominator = getattr(opt, "balance_denominator", False)
+        self.weighting_mode = getattr(opt, "weighting_mode", "raw")
+        self.allow_torch_path = os.environ.get("AMX_ALLOW_TORCH_PATH", "0") == "1"
+
+    @staticmethod
+    def gather_labels(labels_seg, labels_coords, coords_range):
+        """supcl_model.py:100-123: nearest-resize the segmentation to the feature map, gather at the coordinates."""
+        n = len(coords_range)
+        if n not in (2, 3):
+            raise NotImplementedError
+        seg = F.interpolate(labels_seg, size=tuple(int(v) for v in coords_range), mode="nearest").squeeze(1)
+        if n == 3:
+            return seg[:, labels_coords[:, 0], labels_coords[:, 1], labels_coords[:, 2]]
+        return seg[:, labels_coords[:, 0], labels_coords[:, 1]]
+
+    def forward(self, features, labels_seg, labels_coords, coords_range, debug=False):
+        labels = self.gather_labels(labels_seg, labels_coords, coords_range)        # [bs = 1, P]
+        ntps, num_patches, nc = features.size()
+        if labels.shape[0] != 1:
+            raise NotImplementedError("one segmentation shared by the views (the reference's eq(labels, labels.T) needs bs == 1)")
+        if features.is_cuda:
+            # class ids as int32, tiled over the views in (view, patch) order = features.view(ntps * P, nc)
+            lab = labels[0].to(device=features.device).round().to(torch.int32).repeat(ntps).contiguous()
+            return _SupConHip.apply(features.reshape(ntps * num_patches, nc), lab, self.temperature, self.weigh_rarity,
+                                    self.balance_denominator, self.weighting_mode == "sqrt")
+        if not self.allow_torch_path:
+            raise RuntimeError("anatomix_amd.SupPatchNCELoss: features are not on a GPU; set allow_torch_path = True "
+                               "(or AMX_ALLOW_TORCH_PATH=1) to evaluate the loss with stock torch ops")
+        return self._forward_torch(features, labels)
+
+    def _forward_torch(self, features, labels):
+        ntps, p, nc = features.size()
+        x = F.normalize(features.view(ntps * p, nc), dim=-1, eps=1e-8)
+        logits = x @ x.t() / self.temperature
+        logits = logits - logits.max(dim=1, keepdim=True).values.detach()
+        same = torch.eq(labels, labels.T).float().repeat(ntps, ntps)
+        counts = same.sum(1)
+        off = 1.0 - torch.eye(ntps * p, dtype=same.dtype, device=same.device)
+        pos = same * off
+        if self.balance_denominator:
+            npc = counts.unsqueeze(0) - same
+            if self.weighting_mode == "sqrt":
+                npc = npc.sqrt()
+            log_prob = logits - torch.logsumexp(logits + torch.log(off / npc), dim=1, keepdim=True)
+        else:
+            log_prob = logits - torch.log((torch.exp(logits) * off).sum(1, keepdim=True))
+        loss = -(pos * log_prob).sum(1) / pos.sum(1)
+        if self.weigh_rarity:
+            w = 1.0 / (counts.sqrt() if self.weighting_mode == "sqrt" else counts)
+            return (w * loss).sum() / w.sum()
+        return loss.view(ntps, p).mean()

@@ -182,6 +182,17 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
 int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
                             int precision, void* stream);
 
+/* SupPatchNCELoss.forward + its backward (pretraining/models/supcl_model.py:73-226) for one nce layer.
+ * d_feat: fp32 [n][c], n = views * patches anchors in (view, patch) order (features.view(ntps * num_patches, nc),
+ * supcl_model.py:134); d_labels: int32 [n], the segmentation class of every anchor (the label gather of :100-112,
+ * tiled over the views); flags = opt.weigh_rarity / opt.balance_denominator / (opt.weighting_mode == 'sqrt');
+ * d_loss: 1 float; d_grad: fp32 [n][c] = d loss / d feat, or NULL for the forward only.
+ * d_scratch: amx_supcon_scratch_bytes(n, c) bytes.  Deterministic (fixed-order reductions). */
+size_t amx_supcon_scratch_bytes(int n, int c);
+int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, float temperature, int weigh_rarity,
+                    int balance_denominator, int sqrt_mode, float* d_loss, float* d_grad, void* d_scratch,
+                    size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
