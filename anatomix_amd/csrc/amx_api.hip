@@ -42,6 +42,19 @@ hipError_t launch_affine_act(void* x, const float* scale, const float* shift, in
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
                                float* out, int precision, hipStream_t st);
 const char* last_conv_kernel_name();
+size_t train_scratch_bytes(int C);
+hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, const float* beta, float eps, long long rows, int C,
+                                   int act, float slope, void* scratch, float* save_mean, float* save_rstd, float* running_mean,
+                                   float* running_var, float momentum, int precision, hipStream_t st);
+hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                  const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
+                                  int C, int act, float slope, void* scratch, int precision, hipStream_t st);
+hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
+                           hipStream_t st);
+hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
+                                     int accumulate, int precision, hipStream_t st);
+size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad);
+hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, void* scratch, int precision, hipStream_t st);
 size_t supcon_scratch_bytes(int N, int C);
 hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
                          int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st);
@@ -836,6 +849,71 @@ int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout
               void* stream) {
   if (!d_in || !d_out || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
   AMX_HIP(amx::launch_pool2(d_in, d_out, n, dout, hout, wout, c, avg, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+// ---------------------------------------------------------------- training-path operators
+size_t amx_train_scratch_bytes(int c) { return amx::train_scratch_bytes(c); }
+
+int amx_bn_train_forward(const void* d_x, void* d_y, const float* d_gamma, const float* d_beta, float eps, int n,
+                         long long voxels, int c, int act, float slope, void* d_scratch, float* d_save_mean,
+                         float* d_save_rstd, float* d_running_mean, float* d_running_var, float momentum, int precision,
+                         void* stream) {
+  if (!d_x || !d_y || !d_scratch || n < 1 || voxels < 1 || c % 8 || c > 2048) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_bn_train_forward(d_x, d_y, d_gamma, d_beta, eps, (long long)n * voxels, c, act, slope, d_scratch, d_save_mean,
+                                       d_save_rstd, d_running_mean, d_running_var, momentum, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_bn_act_backward(const void* d_dy, const void* d_y, const void* d_x, const float* d_mean, const float* d_rstd,
+                        const float* d_gamma, float* d_dgamma, float* d_dbeta, void* d_dx_framed, int n, int d, int hh, int w,
+                        int c, int act, float slope, void* d_scratch, int precision, void* stream) {
+  if (!d_dy || !d_y || !d_dx_framed || !d_scratch || c % 8 || c > 2048) return fail(AMX_ERR_INVALID, "bad argument");
+  if (d_mean && (!d_x || !d_rstd || !d_dgamma || !d_dbeta)) return fail(AMX_ERR_INVALID, "norm backward needs x, rstd, dgamma, dbeta");
+  AMX_HIP(amx::launch_bn_act_backward(d_dy, d_y, d_x ? d_x : d_y, d_mean, d_rstd, d_gamma, d_dgamma, d_dbeta, d_dx_framed, n, d, hh,
+                                      w, c, act, slope, d_scratch, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_pad_fold(const void* d_g_framed, void* d_din, int n, int d, int hh, int w, int c, int accumulate, int precision,
+                 void* stream) {
+  if (!d_g_framed || !d_din || c % 8 || d < 2 || hh < 2 || w < 2) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_pad_fold(d_g_framed, d_din, n, d, hh, w, c, accumulate, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_pool2_max_backward(const void* d_dp, const void* d_in, void* d_din, int n, int dout, int hout, int wout, int c,
+                           int accumulate, int precision, void* stream) {
+  if (!d_dp || !d_in || !d_din || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_pool2_max_backward(d_dp, d_in, d_din, n, dout, hout, wout, c, accumulate, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_conv3d_wgrad_scratch_bytes(int n, int d, int hh, int w, int cout, int cin_pad) {
+  return amx::wgrad_scratch_bytes(n, d, hh, w, cout, cin_pad);
+}
+
+int amx_conv3d_wgrad(const void* d_dy, long long dy_sn, long long dy_sz, long long dy_sy, long long dy_sx, const void* d_x0,
+                     int c0, const void* d_x1, int c1, int cin_real, int cout, int n, int d, int hh, int w, float* d_dw,
+                     int accumulate, void* d_scratch, size_t scratch_bytes, int precision, void* stream) {
+  if (!d_dy || !d_x0 || !d_dw || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
+  if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16 || cin_real < 1 || cin_real > c0 + c1)
+    return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
+  if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
+  if (d < 2 || hh < 2 || w < 2 || w > 160) return fail(AMX_ERR_SHAPE, "wgrad supports 2 <= w <= 160 (got %d)", w);
+  if (scratch_bytes < amx::wgrad_scratch_bytes(n, d, hh, w, cout, c0 + c1))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes", amx::wgrad_scratch_bytes(n, d, hh, w, cout, c0 + c1));
+  amx::WgradParams p;
+  memset(&p, 0, sizeof p);
+  p.dy = (const char*)d_dy; p.yn = dy_sn; p.yz = dy_sz; p.yy = dy_sy; p.yx = dy_sx;
+  p.src0 = (const char*)d_x0; p.C0 = c0;
+  p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
+  if (c1) {
+    p.src1 = (const char*)d_x1; p.C1 = c1; p.up_shift = 1;
+    p.s1x = (long long)c1 * 2; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
+  }
+  p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
+  AMX_HIP(amx::launch_wgrad(p, cin_real, d_dw, accumulate, d_scratch, precision, (hipStream_t)stream));
   return AMX_OK;
 }
 

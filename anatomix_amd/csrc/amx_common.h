@@ -59,4 +59,18 @@ struct ConvParams {
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
 };
 
+// Weight-gradient launch (amx_wgrad.hip).
+struct WgradParams {
+  const char* dy;                       // 16-bit [N][D][H][W][Cout] through byte strides (may be a framed view)
+  long long yn, yz, yy, yx;
+  const char* src0;                     // full-resolution input segment, C0 channels
+  long long s0n, s0z, s0y, s0x;
+  const char* src1;                     // second segment, C1 channels, read through >> up_shift
+  long long s1n, s1z, s1y, s1x;
+  int C0, C1, up_shift;
+  int N, D, H, W, Cout;
+  float* partial;                       // [nchunk][npairs][27][16][16]
+  int nchunk, items_per_chunk, nitems, nyt;
+};
+
 }  // namespace amx

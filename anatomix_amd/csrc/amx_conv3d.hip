@@ -129,8 +129,9 @@ const char* last_conv_kernel_name() { return g_kernel_name; }
 int conv_pick_q(int Cout, int W) {
   if (Cout == 16) return 1;
   if (Cout == 32) return 2;
-  if (W >= 32) return 4;      // Cout >= 64 at 32^3 and larger
-  return 2;                   // 16^3 and below: more cout groups to fill the chip, still two tiles per weight read
+  int q = W >= 32 ? 4 : 2;    // Cout >= 64 at 32^3 and larger: 4; 16^3 and below: more cout groups to fill the chip
+  while (Cout % (16 * q)) q >>= 1;   // 48 / 96 / 192 output channels (data gradients of the concat convs): 1 / 2 / 4
+  return q;
 }
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);

@@ -1,0 +1,396 @@
+// anatomix_amd -- bandwidth kernels of the TRAINING path (contrastive step, pretraining/models/supcl_model.py:603-661:
+// the UNet runs in train mode, BatchNorm3d uses batch statistics over the two views, everything is differentiated).
+// All tensors are dense 16-bit channels-last [N][voxels][C]; statistics and gradients of parameters are fp32;
+// every reduction is two-stage with a fixed order (slab partials, then one thread per channel) -- no atomics.
+//
+//   bn_train_forward  : nn.BatchNorm3d(train) + activation                           network.py:148-152, 171-196
+//                       y = act(gamma (x - mean) rstd + beta); saves mean / rstd; updates the running statistics
+//                       (momentum 0.1, UNBIASED variance into running_var, as torch does)
+//   bn_act_backward   : adjoint of the above: dz = dy * act'(y); dbeta = sum dz; dgamma = sum dz xhat;
+//                       dx = gamma rstd (dz - dbeta / M - xhat dgamma / M), written into the interior of a zero-FRAMED
+//                       buffer [N][D+4][H+4][W+4][C] -- the input layout of the data-gradient convolution below
+//   pad_fold          : adjoint of the reflect padding of nn.Conv3d(padding='same', padding_mode='reflect'): the
+//                       data gradient is first computed on the padded domain [-1, D] as a plain 3x3x3 correlation
+//                       of the framed output gradient with the flipped, transposed weights (the forward kernel on a
+//                       (D+4)^3 volume: its reflect gather only ever touches the zero frame there), then the border
+//                       planes are folded back: dIn[1] += g[-1], dIn[D-2] += g[D] per axis
+//   pool2_max_backward: adjoint of nn.MaxPool3d(2): the gradient goes to the FIRST maximum of each window in (z,y,x)
+//                       order (torch's tie rule)
+#include "amx_device.h"
+
+namespace amx {
+
+template <typename T>
+__device__ __forceinline__ void t_unpack8(const uint4& raw, float (&f)[8]) {
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)__builtin_bit_cast(T, (unsigned short)(w[e >> 1] >> ((e & 1) * 16)));
+}
+template <typename T>
+__device__ __forceinline__ uint4 t_pack8(const float (&f)[8]) {
+  unsigned o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)to_bits<T>(f[2 * e]) | ((unsigned)to_bits<T>(f[2 * e + 1]) << 16);
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__host__ __device__ inline int tr_num_blocks(long long rows, int C) {   // slabs of the statistics passes
+  long long nb = rows * C / (8 * 256 * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb * C > 65536) nb = 65536 / C;
+  return nb < 1 ? 1 : (int)nb;
+}
+
+// ---------------------------------------------------------------- forward statistics
+// grid nblk, block 256: partial[blk][c] = (count, sum(x - K_blk), sum (x - K_blk)^2) with K_blk = the slab's first row
+// (shifted sums: no E[x^2] - E[x]^2 cancellation); rows = N * voxels.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const char* __restrict__ x, float* __restrict__ partial, long long rows,
+                                                      int C) {
+  extern __shared__ float red[];                       // [nrow][C][2]
+  const int c8n = C >> 3;
+  const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long v0 = (long long)blockIdx.x * per, v1 = v0 + per < rows ? v0 + per : rows;
+  float K[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (v0 < rows) t_unpack8<T>(*(const uint4*)(x + (v0 * C + c8 * 8) * 2), K);
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (vrow < nrow)
+    for (long long v = v0 + vrow; v < v1; v += nrow) {
+      float f[8];
+      t_unpack8<T>(*(const uint4*)(x + (v * C + c8 * 8) * 2), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = f[e] - K[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
+    }
+  if (vrow < nrow)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((vrow * C) + c8 * 8 + e) * 2] = s1[e];
+      red[((vrow * C) + c8 * 8 + e) * 2 + 1] = s2[e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+      a += red[(r * C + c) * 2];
+      b += red[(r * C + c) * 2 + 1];
+    }
+    float* o = partial + ((long long)blockIdx.x * C + c) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+// grid C/64, block 64: merge the slabs (Chan's parallel variance, fp64, slab order) -> mean, rstd, (a, b), running stats
+template <typename T>
+__global__ void bn_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial, const float* gamma,
+                                   const float* beta, float eps, long long rows, int C, int nblk, float* __restrict__ ab,
+                                   float* save_mean, float* save_rstd, float* running_mean, float* running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long long per = (rows + nblk - 1) / nblk;
+  double cnt = 0.0, mean = 0.0, m2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    const long long v0 = (long long)b * per, v1 = v0 + per < rows ? v0 + per : rows;
+    if (v0 >= rows) break;
+    const double nb = (double)(v1 - v0);
+    const float K = (float)__builtin_bit_cast(T, *(const unsigned short*)(x + (v0 * C + c) * 2));
+    const double s1 = partial[((long long)b * C + c) * 2], s2 = partial[((long long)b * C + c) * 2 + 1];
+    const double mb = (double)K + s1 / nb, m2b = s2 - s1 * s1 / nb;
+    const double delta = mb - mean, tot = cnt + nb;
+    mean += delta * nb / tot;
+    m2 += m2b + delta * delta * cnt * nb / tot;
+    cnt = tot;
+  }
+  double var = m2 / cnt;
+  var = var < 0.0 ? 0.0 : var;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  ab[2 * c] = rstd * g;
+  ab[2 * c + 1] = (beta ? beta[c] : 0.f) - (float)mean * rstd * g;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_rstd) save_rstd[c] = rstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(cnt > 1.0 ? m2 / (cnt - 1.0) : var);
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const char* __restrict__ x, char* __restrict__ y, const float* __restrict__ ab, long long rows,
+                                int C, int act, float slope) {
+  const int c8n = C >> 3;
+  const long long total = rows * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    float f[8];
+    t_unpack8<T>(*(const uint4*)(x + idx * 16), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = f[e] * ab[2 * (c8 * 8 + e)] + ab[2 * (c8 * 8 + e) + 1];
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      f[e] = v;
+    }
+    *(uint4*)(y + idx * 16) = t_pack8<T>(f);
+  }
+}
+
+// ---------------------------------------------------------------- backward of norm + activation
+// partial[blk][c] = (sum dz, sum dz * xhat)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restrict__ dy, const char* __restrict__ y,
+                                                          const char* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ partial,
+                                                          long long rows, int C, int act, float slope) {
+  extern __shared__ float red[];
+  const int c8n = C >> 3;
+  const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long v0 = (long long)blockIdx.x * per, v1 = v0 + per < rows ? v0 + per : rows;
+  float mu[8], rs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean ? mean[c8 * 8 + e] : 0.f;
+    rs[e] = rstd ? rstd[c8 * 8 + e] : 1.f;
+  }
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (vrow < nrow)
+    for (long long v = v0 + vrow; v < v1; v += nrow) {
+      float g[8], yy[8], xx[8];
+      const long long o = (v * C + c8 * 8) * 2;
+      t_unpack8<T>(*(const uint4*)(dy + o), g);
+      t_unpack8<T>(*(const uint4*)(y + o), yy);
+      t_unpack8<T>(*(const uint4*)(x + o), xx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dz = g[e];
+        if (act == ACT_RELU) dz = yy[e] > 0.f ? dz : 0.f;
+        else if (act == ACT_LRELU) dz = yy[e] > 0.f ? dz : dz * slope;
+        s1[e] += dz;
+        s2[e] += dz * (xx[e] - mu[e]) * rs[e];
+      }
+    }
+  if (vrow < nrow)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((vrow * C) + c8 * 8 + e) * 2] = s1[e];
+      red[((vrow * C) + c8 * 8 + e) * 2 + 1] = s2[e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+      a += red[(r * C + c) * 2];
+      b += red[(r * C + c) * 2 + 1];
+    }
+    float* o = partial + ((long long)blockIdx.x * C + c) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int C, int nblk, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    a += partial[((long long)k * C + c) * 2];
+    b += partial[((long long)k * C + c) * 2 + 1];
+  }
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+}
+
+// dx into the interior of the framed buffer [N][D+4][H+4][W+4][C]
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ y, const char* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, char* __restrict__ dxf,
+                                    int N, int D, int H, int W, int C, int act, float slope) {
+  const int c8n = C >> 3;
+  const long long vox = (long long)D * H * W, rows = (long long)N * vox, total = rows * c8n;
+  const float invM = 1.f / (float)rows;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    const long long v = idx / c8n;
+    const int n = v / vox;
+    long long r = v - (long long)n * vox;
+    const int xx0 = r % W;
+    r /= W;
+    const int yy0 = r % H, zz0 = r / H;
+    float g[8], yy[8], xx[8];
+    t_unpack8<T>(*(const uint4*)(dy + idx * 16), g);
+    t_unpack8<T>(*(const uint4*)(y + idx * 16), yy);
+    t_unpack8<T>(*(const uint4*)(x + idx * 16), xx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      float dz = g[e];
+      if (act == ACT_RELU) dz = yy[e] > 0.f ? dz : 0.f;
+      else if (act == ACT_LRELU) dz = yy[e] > 0.f ? dz : dz * slope;
+      if (mean) {
+        const float xh = (xx[e] - mean[c]) * rstd[c];
+        dz = (gamma ? gamma[c] : 1.f) * rstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+      }
+      g[e] = dz;
+    }
+    const long long fo = ((((long long)n * (D + 4) + zz0 + 2) * (H + 4) + yy0 + 2) * (W + 4) + xx0 + 2) * C + c8 * 8;
+    *(uint4*)(dxf + fo * 2) = t_pack8<T>(g);
+  }
+}
+
+// ---------------------------------------------------------------- reflect-padding adjoint
+template <typename T>
+__global__ void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ din, int N, int D, int H, int W, int C,
+                                int accumulate) {
+  const int c8n = C >> 3;
+  const long long vox = (long long)D * H * W, total = (long long)N * vox * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    const long long v = idx / c8n;
+    const int n = v / vox;
+    long long r = v - (long long)n * vox;
+    const int x = r % W;
+    r /= W;
+    const int y = r % H, z = r / H;
+    // framed coordinate e = padded coordinate j + 2; voxel i collects j = i, j = -1 (if i == 1), j = L (if i == L-2)
+    int ez[3], ey[3], ex[3], nz = 0, ny = 0, nx = 0;
+    ez[nz++] = z + 2; if (z == 1) ez[nz++] = 1; if (z == D - 2) ez[nz++] = D + 2;
+    ey[ny++] = y + 2; if (y == 1) ey[ny++] = 1; if (y == H - 2) ey[ny++] = H + 2;
+    ex[nx++] = x + 2; if (x == 1) ex[nx++] = 1; if (x == W - 2) ex[nx++] = W + 2;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) t_unpack8<T>(*(const uint4*)(din + idx * 16), acc);
+    for (int a = 0; a < nz; ++a)
+      for (int b = 0; b < ny; ++b)
+        for (int c = 0; c < nx; ++c) {
+          float f[8];
+          const long long o = ((((long long)n * (D + 4) + ez[a]) * (H + 4) + ey[b]) * (W + 4) + ex[c]) * C + c8 * 8;
+          t_unpack8<T>(*(const uint4*)(gf + o * 2), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+    *(uint4*)(din + idx * 16) = t_pack8<T>(acc);
+  }
+}
+
+// ---------------------------------------------------------------- max-pool adjoint
+// one thread = one pooled voxel x 8 channels; writes all 8 children of the window (dp at the first maximum, else 0)
+template <typename T>
+__global__ void pool2_max_bwd_kernel(const char* __restrict__ dp, const char* __restrict__ in, char* __restrict__ din, int N,
+                                     int Do, int Ho, int Wo, int C, int accumulate) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * Do * Ho * Wo * c8n;
+  const int H = 2 * Ho, W = 2 * Wo, D = 2 * Do;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    long long r = idx / c8n;
+    const int xo = r % Wo;
+    r /= Wo;
+    const int yo = r % Ho;
+    r /= Ho;
+    const int zo = r % Do, n = r / Do;
+    float g[8];
+    t_unpack8<T>(*(const uint4*)(dp + idx * 16), g);
+    float best[8];
+    int arg[8];
+    float val[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long o = ((((long long)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1)) * C + c8 * 8;
+      t_unpack8<T>(*(const uint4*)(in + o * 2), val[k]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = val[0][e];
+      arg[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (val[k][e] > best[e]) { best[e] = val[k][e]; arg[e] = k; }    // strict >: the first maximum wins
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long o = ((((long long)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1)) * C + c8 * 8;
+      float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (accumulate) t_unpack8<T>(*(const uint4*)(din + o * 2), out);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] += arg[e] == k ? g[e] : 0.f;
+      *(uint4*)(din + o * 2) = t_pack8<T>(out);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- launchers
+size_t train_scratch_bytes(int C) { return ((size_t)65536 * 2 + (size_t)C * 2) * sizeof(float); }
+
+static int grid_for(long long total) { return (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256); }
+
+hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, const float* beta, float eps, long long rows, int C,
+                                   int act, float slope, void* scratch, float* save_mean, float* save_rstd, float* running_mean,
+                                   float* running_var, float momentum, int precision, hipStream_t st) {
+  if (C % 8 || C > 2048 || rows < 1) return hipErrorInvalidValue;
+  float* partial = (float*)scratch;
+  float* ab = partial + (size_t)65536 * 2;
+  const int nblk = tr_num_blocks(rows, C), c8n = C / 8, nrow = 256 / c8n;
+  const size_t lds = (size_t)nrow * C * 2 * sizeof(float);
+  const int blocks = grid_for(rows * c8n);
+#define AMX_BN(T)                                                                                                        \
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)x, partial, rows, C);              \
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 63) / 64), dim3(64), 0, st, (const char*)x, partial, gamma, beta, eps, \
+                     rows, C, nblk, ab, save_mean, save_rstd, running_mean, running_var, momentum);                      \
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope)
+  if (precision == 0) { AMX_BN(f16); } else { AMX_BN(bf16); }
+#undef AMX_BN
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                  const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
+                                  int C, int act, float slope, void* scratch, int precision, hipStream_t st) {
+  if (C % 8 || C > 2048) return hipErrorInvalidValue;
+  const long long rows = (long long)N * D * H * W;
+  float* partial = (float*)scratch;
+  const int nblk = tr_num_blocks(rows, C), c8n = C / 8, nrow = 256 / c8n;
+  const size_t lds = (size_t)nrow * C * 2 * sizeof(float);
+  const int blocks = grid_for(rows * c8n);
+#define AMX_BNB(T)                                                                                                       \
+  if (mean) {                                                                                                            \
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)dy, (const char*)y,          \
+                       (const char*)x, mean, rstd, partial, rows, C, act, slope);                                        \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, C, nblk, dgamma, dbeta);    \
+  }                                                                                                                      \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)dy, (const char*)y,            \
+                     (const char*)x, mean, rstd, gamma, dgamma, dbeta, (char*)dx_framed, N, D, H, W, C, act, slope)
+  if (precision == 0) { AMX_BNB(f16); } else { AMX_BNB(bf16); }
+#undef AMX_BNB
+  return hipGetLastError();
+}
+
+hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
+                           hipStream_t st) {
+  if (C % 8 || D < 2 || H < 2 || W < 2) return hipErrorInvalidValue;
+  const int blocks = grid_for((long long)N * D * H * W * (C / 8));
+  if (precision == 0)
+    hipLaunchKernelGGL(pad_fold_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)g_framed, (char*)din, N, D, H, W, C, accumulate);
+  else
+    hipLaunchKernelGGL(pad_fold_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)g_framed, (char*)din, N, D, H, W, C, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
+                                     int accumulate, int precision, hipStream_t st) {
+  if (C % 8) return hipErrorInvalidValue;
+  const int blocks = grid_for((long long)N * Do * Ho * Wo * (C / 8));
+  if (precision == 0)
+    hipLaunchKernelGGL(pool2_max_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)dp, (const char*)in, (char*)din, N,
+                       Do, Ho, Wo, C, accumulate);
+  else
+    hipLaunchKernelGGL(pool2_max_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)dp, (const char*)in, (char*)din, N,
+                       Do, Ho, Wo, C, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace amx

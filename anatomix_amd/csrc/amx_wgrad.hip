@@ -1,0 +1,211 @@
+// anatomix_amd -- weight gradient of nn.Conv3d(k3, stride 1, padding='same', padding_mode='reflect')
+// (the wgrad half of the backward of anatomix/model/network.py:310-461, needed by the contrastive step,
+// pretraining/models/supcl_model.py:603-661).
+//
+//   dW[co][ci][kz][ky][kx] = sum over (n, z, y, x) of  dY[n][z][y][x][co] * In[n][r(z+kz-1)][r(y+ky-1)][r(x+kx-1)][ci]
+//   (r = reflect; In may be the concatenation of a full-resolution segment and a nearest-upsampled half-resolution
+//    segment, exactly as the forward kernels read it).
+//
+// A GEMM whose reduction index is the VOXEL: D[co][ci] += A[co][k] B[k][ci] per tap with k = 32 consecutive x of
+// one row, v_mfma_f32_16x16x32.  Activations are channels-last, so the 8 consecutive k a lane needs are 8 different
+// voxels: fragments are gathered from an LDS tile with 16-bit reads.  Two tricks keep that affordable:
+//   * the three x taps of one (kz, ky) read overlapping windows x-1 .. x+8: 10 values are gathered once and the kx = 1
+//     fragment is formed with four v_alignbit (34 % of the reads of three separate gathers);
+//   * one 32-byte pad slot after every 8 voxels of an LDS row shifts the four k-groups of a fragment onto different
+//     banks (8 voxels x 32 B = 256 B would otherwise alias them).
+// Work decomposition: grid (co-tile x ci-tile pairs, spatial chunks).  A workgroup walks its chunk of (n, z, 4-row)
+// items, staging per item the dY rows and the 3 x 6 halo rows of In (reflect / upsample resolved at staging);
+// its 8 waves split the item's K-blocks, keep 27 accumulators each for the whole chunk, and are summed through LDS
+// at the end.  Partials [chunk][pair][27][16][16] fp32 are then added in chunk order by wgrad_reduce_kernel:
+// deterministic, no atomics.
+#include "amx_device.h"
+
+namespace amx {
+
+constexpr int WG_TY = 4;
+
+__device__ __forceinline__ int padx(int x) { return x + (x >> 3); }
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, int Wp) {
+  typedef typename Ops<T>::vec8 vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PW = padx(Wp) + 1, PWH = padx(Wp + 2) + 2;              // padded row lengths (voxel slots) of dY / In rows
+  char* dys = smem;                                                 // [WG_TY][PW][32 B]
+  char* ins = smem + (size_t)WG_TY * PW * 32;                       // [3][WG_TY + 2][PWH][32 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+
+  const int ncit = (p.C0 + p.C1) / 16;
+  const int pair = blockIdx.x, cot = pair / ncit, cit = pair % ncit;
+  const int chunk = blockIdx.y;
+  const bool seg1 = cit * 16 >= p.C0;
+  const int ci0 = seg1 ? cit * 16 - p.C0 : cit * 16;
+  const int sh = seg1 ? p.up_shift : 0;
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nxb = Wp / 32;
+  const int item0 = chunk * p.items_per_chunk;
+  const int item1 = item0 + p.items_per_chunk < p.nitems ? item0 + p.items_per_chunk : p.nitems;
+  for (int item = item0; item < item1; ++item) {
+    int r = item;
+    const int yt = r % p.nyt;
+    r /= p.nyt;
+    const int z = r % p.D, n = r / p.D;
+    const int y0 = yt * WG_TY;
+    __syncthreads();                                                // previous item's fragments are consumed
+    // ---- stage dY rows: [row][x < Wp], zero beyond W and beyond H
+    for (int t = tid; t < WG_TY * Wp * 2; t += 512) {
+      const int half = t & 1, x = (t >> 1) % Wp, row = (t >> 1) / Wp;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (x < p.W && y0 + row < p.H)
+        v = *(const uint4*)(p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + row) * p.yy + (long long)x * p.yx +
+                            cot * 32 + half * 16);
+      *(uint4*)(dys + ((size_t)row * PW + padx(x)) * 32 + half * 16) = v;
+    }
+    // ---- stage In halo rows: [kz][row y0-1 .. y0+TY][xh = x + 1 in 0 .. Wp + 1], reflect resolved here, zero beyond W + 1
+    for (int t = tid; t < 3 * (WG_TY + 2) * (Wp + 2) * 2; t += 512) {
+      const int half = t & 1;
+      int q = t >> 1;
+      const int xh = q % (Wp + 2);
+      q /= Wp + 2;
+      const int hr = q % (WG_TY + 2), kz = q / (WG_TY + 2);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (xh <= p.W + 1) {
+        const int zz = reflect_clamp(z + kz - 1, p.D) >> sh, yy = reflect_clamp(y0 + hr - 1, p.H) >> sh,
+                  xx = reflect_clamp(xh - 1, p.W) >> sh;
+        const char* src = seg1 ? p.src1 + (long long)n * p.s1n + (long long)zz * p.s1z + (long long)yy * p.s1y + (long long)xx * p.s1x
+                               : p.src0 + (long long)n * p.s0n + (long long)zz * p.s0z + (long long)yy * p.s0y + (long long)xx * p.s0x;
+        v = *(const uint4*)(src + ci0 * 2 + half * 16);
+      }
+      *(uint4*)(ins + (((size_t)kz * (WG_TY + 2) + hr) * PWH + padx(xh)) * 32 + half * 16) = v;
+    }
+    __syncthreads();
+    // ---- K-blocks of this item: (row, xb) -> 32 voxels
+    for (int kb = wave; kb < WG_TY * nxb; kb += 8) {
+      const int row = kb / nxb, xb = kb % nxb;
+      const int X0 = xb * 32 + kg * 8;                             // multiple of 8
+      const unsigned short* ap = (const unsigned short*)(dys + ((size_t)row * PW + padx(X0)) * 32) + m;
+      unsigned a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = (unsigned)ap[(2 * j) * 16] | ((unsigned)ap[(2 * j + 1) * 16] << 16);
+      const vec8 af = __builtin_bit_cast(vec8, a);
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned short* bp =
+              (const unsigned short*)(ins + (((size_t)kz * (WG_TY + 2) + row + ky) * PWH + padx(X0)) * 32) + m;
+          // window of 10 halo voxels X0 .. X0 + 9 (= x - 1 .. x + 8); slot of element i: i + (i >> 3)
+          unsigned pk[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const int e0 = 2 * i, e1 = 2 * i + 1;
+            pk[i] = (unsigned)bp[(e0 + (e0 >> 3)) * 16] | ((unsigned)bp[(e1 + (e1 >> 3)) * 16] << 16);
+          }
+          unsigned b0[4] = {pk[0], pk[1], pk[2], pk[3]};                                   // kx = 0: x - 1 ..
+          unsigned b2[4] = {pk[1], pk[2], pk[3], pk[4]};                                   // kx = 2: x + 1 ..
+          unsigned b1[4];                                                                  // kx = 1: x ..
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b1[i] = __builtin_amdgcn_alignbit(pk[i + 1], pk[i], 16);
+          const int t0 = (kz * 3 + ky) * 3;
+          acc[t0] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b0), acc[t0]);
+          acc[t0 + 1] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+          acc[t0 + 2] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+        }
+    }
+  }
+  // ---- sum the 8 waves through LDS (3 rounds), wave 0 writes the partial
+  float* red = (float*)smem;                                        // [4 waves][27][64][4] floats = 108 KiB
+  for (int half = 4; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (wave >= half && wave < 2 * half)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) *(f32x4*)(red + (((size_t)(wave - half) * 27 + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave < half)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const f32x4 o = *(const f32x4*)(red + (((size_t)wave * 27 + t) * 64 + lane) * 4);
+        acc[t] = acc[t] + o;
+      }
+  }
+  if (wave == 0) {
+    float* out = p.partial + ((size_t)chunk * gridDim.x + pair) * 27 * 256;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[t * 256 + (kg * 4 + j) * 16 + m] = acc[t][j];      // [tap][co][ci]
+  }
+}
+
+// dW[co][ci][tap] (+)= sum over chunks, in chunk order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout, int Cin, int CinPad,
+                                    int nchunk, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Cin * 27) return;
+  const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / (27 * Cin);
+  const int ncit = CinPad / 16, npairs = (Cout / 16) * ncit;
+  const int pair = (co / 16) * ncit + ci / 16;
+  float s = accumulate ? dw[idx] : 0.f;
+  for (int c = 0; c < nchunk; ++c) s += partial[(((size_t)c * npairs + pair) * 27 + tap) * 256 + (co % 16) * 16 + ci % 16];
+  dw[idx] = s;
+}
+
+static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* nitems, int* nchunk, int* ipc, int* nyt) {
+  *nyt = (H + WG_TY - 1) / WG_TY;
+  *nitems = N * D * *nyt;
+  const int npairs = (Cout / 16) * (CinPad / 16);
+  int nc = (1024 + npairs - 1) / npairs;
+  if (nc > *nitems) nc = *nitems;
+  if (nc < 1) nc = 1;
+  *ipc = (*nitems + nc - 1) / nc;
+  *nchunk = (*nitems + *ipc - 1) / *ipc;
+}
+
+size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad) {
+  int nitems, nchunk, ipc, nyt;
+  wgrad_plan(N, D, H, W, Cout, CinPad, &nitems, &nchunk, &ipc, &nyt);
+  return (size_t)nchunk * (Cout / 16) * (CinPad / 16) * 27 * 256 * sizeof(float);
+}
+
+hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, void* scratch, int precision, hipStream_t st) {
+  const int CinPad = p.C0 + p.C1;
+  int nitems, nchunk, ipc, nyt;
+  wgrad_plan(p.N, p.D, p.H, p.W, p.Cout, CinPad, &nitems, &nchunk, &ipc, &nyt);
+  p.partial = (float*)scratch;
+  p.nchunk = nchunk; p.items_per_chunk = ipc; p.nitems = nitems; p.nyt = nyt;
+  const int Wp = (p.W + 31) / 32 * 32;
+  const int PW = Wp + (Wp >> 3) + 1, PWH = (Wp + 2) + ((Wp + 2) >> 3) + 2;
+  size_t lds = ((size_t)WG_TY * PW + (size_t)3 * (WG_TY + 2) * PWH) * 32;
+  const size_t red = (size_t)4 * 27 * 64 * 4 * sizeof(float);
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;              // W <= ~160
+  const int npairs = (p.Cout / 16) * (CinPad / 16);
+  if (precision == 0) {
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      done = true;
+    }
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<f16>, dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);
+  } else {
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      done = true;
+    }
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16>, dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);
+  }
+  const int total = p.Cout * CinReal * 27;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)scratch, dw, p.Cout, CinReal,
+                     CinPad, nchunk, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace amx

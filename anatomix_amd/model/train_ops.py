@@ -1,0 +1,151 @@
+"""Thin torch-tensor wrappers over the training-path entry points of libanatomix_amd.so.
+
+Every function takes / returns CUDA tensors in the library's layout -- activations and gradients dense 16-bit
+channels-last ``[N, D, H, W, C]`` (``torch.float16`` or ``torch.bfloat16``), parameters and their gradients fp32 -- and
+enqueues on the current stream.  No arithmetic happens in Python; torch only owns the memory.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_PREC = {torch.float16: 0, torch.bfloat16: 1}
+ACT = _lib.ACT
+
+
+def _st(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _scratch(lib, dev, c):
+    return torch.empty(lib.amx_train_scratch_bytes(int(c)), dtype=torch.uint8, device=dev)
+
+
+def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None):
+    """nn.Conv3d(k3, reflect 'same') on cat(x0, nearest_up2(x1)); weight fp32 [Cout, Cin, 3, 3, 3] (Cin may be smaller than
+    the padded channel count of x0 when x1 is None: the stem).  Returns 16-bit NDHWC, or fp32 NCDHW when ``out32``."""
+    lib = _lib.load()
+    dev = x0.device
+    n, d, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    wt = weight.detach().float()
+    if cin < c0 + c1:                                  # zero-pad the input channels of the weights
+        wt = torch.cat((wt, wt.new_zeros(cout, c0 + c1 - cin, 3, 3, 3)), dim=1)
+    wt = wt.reshape(cout, c0 + c1, 27).contiguous()
+    with torch.cuda.device(dev):
+        wpk = torch.empty(lib.amx_conv3d_packed_bytes(c0 + c1, cout), dtype=torch.uint8, device=dev)
+        if out32:
+            out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=dev)
+            o16, o32 = None, out
+        else:
+            out = torch.empty((n, d, h, w, cout), dtype=x0.dtype, device=dev)
+            o16, o32 = out, None
+        _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(wt), None, _lib.ptr(shift), cout, n, d,
+                                             h, w, ACT[act], slope, _PREC[x0.dtype], _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32),
+                                             _st(dev)))
+    return out
+
+
+def bn_train_forward(x, gamma, beta, eps, act="relu", slope=0.3, running_mean=None, running_var=None, momentum=0.1):
+    """BatchNorm3d(train) + activation.  Returns (y, save_mean, save_rstd)."""
+    lib = _lib.load()
+    dev = x.device
+    n, c = x.shape[0], x.shape[-1]
+    vox = x[0, ..., 0].numel()
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    rstd = torch.empty(c, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        sc = _scratch(lib, dev, c)
+        _lib.check(lib.amx_bn_train_forward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), float(eps), n, vox, c,
+                                            ACT[act], slope, _lib.ptr(sc), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(running_mean),
+                                            _lib.ptr(running_var), float(momentum), _PREC[x.dtype], _st(dev)))
+    return y, mean, rstd
+
+
+def new_framed(n, d, h, w, c, dtype, device):
+    """Zero-framed gradient buffer [N, D+4, H+4, W+4, C] (frame stays zero; the interior is overwritten by every use)."""
+    return torch.zeros((n, d + 4, h + 4, w + 4, c), dtype=dtype, device=device)
+
+
+def interior(framed):
+    return framed[:, 2:-2, 2:-2, 2:-2, :]
+
+
+def bn_act_backward(dy, y, x, mean, rstd, gamma, act="relu", slope=0.3, framed=None):
+    """Adjoint of bn_train_forward (mean=None: of the bare activation).  Returns (dx_framed, dgamma, dbeta)."""
+    lib = _lib.load()
+    dev = dy.device
+    n, d, h, w, c = dy.shape
+    if framed is None:
+        framed = new_framed(n, d, h, w, c, dy.dtype, dev)
+    dgamma = dbeta = None
+    if mean is not None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        sc = _scratch(lib, dev, c)
+        _lib.check(lib.amx_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                                           _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(framed), n, d, h, w, c, ACT[act], slope,
+                                           _lib.ptr(sc), _PREC[dy.dtype], _st(dev)))
+    return framed, dgamma, dbeta
+
+
+def conv_dgrad(dx_framed, weight, cin_keep=None, accumulate_into=None):
+    """Data gradient of Conv3d(k3, reflect): the forward kernel on the framed output gradient with the flipped, transposed
+    weights, then the reflect-padding adjoint.  weight fp32 [Cout, Cin, 3,3,3]; returns 16-bit [N, D, H, W, Cin_pad16]."""
+    lib = _lib.load()
+    dev = dx_framed.device
+    n, df, hf, wf, cout = dx_framed.shape
+    cin = weight.shape[1]
+    cin_pad = (cin + 15) // 16 * 16
+    wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1)          # [Cin, Cout, 3,3,3]
+    if cin_pad != cin:
+        wt = torch.cat((wt, wt.new_zeros(cin_pad - cin, cout, 3, 3, 3)), dim=0)
+    g = conv_forward(dx_framed, None, wt.contiguous())                    # [N, D+4, H+4, W+4, Cin_pad]
+    d, h, w = df - 4, hf - 4, wf - 4
+    din = accumulate_into if accumulate_into is not None else torch.empty((n, d, h, w, cin_pad), dtype=dx_framed.dtype, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.amx_pad_fold(_lib.ptr(g), _lib.ptr(din), n, d, h, w, cin_pad, int(accumulate_into is not None),
+                                    _PREC[dx_framed.dtype], _st(dev)))
+    return din
+
+
+def conv_wgrad(dx_framed, x0, x1, cin_real, cout):
+    """Weight gradient: fp32 [Cout, cin_real, 3, 3, 3]."""
+    lib = _lib.load()
+    dev = x0.device
+    n, d, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    dw = torch.empty((cout, cin_real, 3, 3, 3), dtype=torch.float32, device=dev)
+    view = interior(dx_framed)
+    es = dx_framed.element_size()
+    sn, sz, sy, sx, _ = [s * es for s in view.stride()]
+    with torch.cuda.device(dev):
+        nbytes = lib.amx_conv3d_wgrad_scratch_bytes(n, d, h, w, cout, c0 + c1)
+        sc = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.amx_conv3d_wgrad(ctypes.c_void_p(view.data_ptr()), sn, sz, sy, sx, _lib.ptr(x0), c0, _lib.ptr(x1), c1,
+                                        cin_real, cout, n, d, h, w, _lib.ptr(dw), 0, _lib.ptr(sc), nbytes, _PREC[x0.dtype],
+                                        _st(dev)))
+    return dw
+
+
+def pool2_max(x):
+    lib = _lib.load()
+    n, d, h, w, c = x.shape
+    out = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.amx_pool2(_lib.ptr(x), _lib.ptr(out), n, d // 2, h // 2, w // 2, c, 0, _PREC[x.dtype], _st(x.device)))
+    return out
+
+
+def pool2_max_backward(dp, inp, accumulate_into=None):
+    lib = _lib.load()
+    n, do, ho, wo, c = dp.shape
+    din = accumulate_into if accumulate_into is not None else torch.empty_like(inp)
+    with torch.cuda.device(dp.device):
+        _lib.check(lib.amx_pool2_max_backward(_lib.ptr(dp), _lib.ptr(inp), _lib.ptr(din), n, do, ho, wo, c,
+                                              int(accumulate_into is not None), _PREC[dp.dtype], _st(dp.device)))
+    return din

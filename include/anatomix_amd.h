@@ -182,6 +182,47 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
 int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
                             int precision, void* stream);
 
+/* ---- Training-path operators (the UNet inside the contrastive step, pretraining/models/supcl_model.py:603-661, runs in
+ * train mode and is differentiated).  All activations / gradients: dense 16-bit channels-last [n][d][h][w][c];
+ * parameter gradients and statistics fp32.  d_scratch: amx_train_scratch_bytes(c) bytes. */
+size_t amx_train_scratch_bytes(int c);
+
+/* nn.BatchNorm3d in TRAIN mode + activation (network.py:148-152,171-196): y = act(gamma (x - mean) rstd + beta) with the
+ * biased batch variance over n * voxels rows; saves mean / rstd (each [c], may be NULL), updates the running statistics
+ * (running_var with the unbiased variance; pointers may be NULL).  d_y may equal d_x. */
+int amx_bn_train_forward(const void* d_x, void* d_y, const float* d_gamma, const float* d_beta, float eps, int n,
+                         long long voxels, int c, int act, float slope, void* d_scratch, float* d_save_mean,
+                         float* d_save_rstd, float* d_running_mean, float* d_running_var, float momentum, int precision,
+                         void* stream);
+
+/* Adjoint of the above (and of a bare activation when d_mean == NULL): dz = dy * act'(y); dbeta = sum dz;
+ * dgamma = sum dz * xhat; dx = gamma rstd (dz - dbeta / M - xhat dgamma / M), written into the INTERIOR of the zero-framed
+ * buffer d_dx_framed [n][d+4][h+4][w+4][c] (the caller zeroes the frame once), the input of the data-gradient conv. */
+int amx_bn_act_backward(const void* d_dy, const void* d_y, const void* d_x, const float* d_mean, const float* d_rstd,
+                        const float* d_gamma, float* d_dgamma, float* d_dbeta, void* d_dx_framed, int n, int d, int hh, int w,
+                        int c, int act, float slope, void* d_scratch, int precision, void* stream);
+
+/* Adjoint of the reflect padding of nn.Conv3d(padding='same', padding_mode='reflect') (network.py:310-318).  The data
+ * gradient of the conv is amx_conv3d_k3_reflect run on the framed (d+4)(h+4)(w+4) output gradient with the weights
+ * flipped along the three taps and transposed (cin <-> cout); this folds the result [n][d+4][h+4][w+4][c] back onto
+ * [n][d][h][w][c]: voxel i collects padded positions i, -1 (if i == 1) and L (if i == L-2) per axis. */
+int amx_pad_fold(const void* d_g_framed, void* d_din, int n, int d, int hh, int w, int c, int accumulate, int precision,
+                 void* stream);
+
+/* Adjoint of nn.MaxPool3d(2) (network.py:297,368): d_dp [n][dout][hout][wout][c] is routed to the FIRST maximum of each
+ * 2x2x2 window of d_in [n][2 dout][2 hout][2 wout][c] (z, y, x order: torch's tie rule). */
+int amx_pool2_max_backward(const void* d_dp, const void* d_in, void* d_din, int n, int dout, int hout, int wout, int c,
+                           int accumulate, int precision, void* stream);
+
+/* Weight gradient of nn.Conv3d(k3, reflect): d_dw fp32 [cout][cin_real][3][3][3] (+)= sum over voxels of dy (x) input.
+ * d_dy: 16-bit [n][d][h][w][cout] through BYTE strides (so the interior of a framed buffer can be passed);
+ * input = cat(d_x0 [c0 ch, full resolution], nearest-upsampled d_x1 [c1 ch, half resolution]) as in the forward;
+ * cin_real <= c0 + c1 trims zero-padded input channels (the stem: 1 real channel padded to 16). */
+size_t amx_conv3d_wgrad_scratch_bytes(int n, int d, int hh, int w, int cout, int cin_pad);
+int amx_conv3d_wgrad(const void* d_dy, long long dy_sn, long long dy_sz, long long dy_sy, long long dy_sx, const void* d_x0,
+                     int c0, const void* d_x1, int c1, int cin_real, int cout, int n, int d, int hh, int w, float* d_dw,
+                     int accumulate, void* d_scratch, size_t scratch_bytes, int precision, void* stream);
+
 /* SupPatchNCELoss.forward + its backward (pretraining/models/supcl_model.py:73-226) for one nce layer.
  * d_feat: fp32 [n][c], n = views * patches anchors in (view, patch) order (features.view(ntps * num_patches, nc),
  * supcl_model.py:134); d_labels: int32 [n], the segmentation class of every anchor (the label gather of :100-112,

@@ -1,0 +1,139 @@
+"""GPU parity of the training-path operators (C ABI through anatomix_amd.model.train_ops) against torch autograd on CPU
+(float64 on the SAME rounded operands)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import rel_l2
+from anatomix_amd.model import train_ops as T
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+ULP = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}
+
+
+def cl(x, dt, device):            # NCDHW float -> NDHWC 16-bit on the device
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(dt).to(device)
+
+
+def ncdhw(x):                     # NDHWC device tensor -> NCDHW double on the host
+    return x.detach().cpu().double().permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 12, 16), (2, 32, 16, 16, 16), (1, 256, 2, 2, 2), (3, 64, 5, 6, 7)])
+def test_bn_train_forward_and_backward(device, prec, shape):
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(1)
+    n, c = shape[0], shape[1]
+    x = (torch.randn(shape, generator=g) * (0.2 + torch.rand(c, generator=g))[None, :, None, None, None]
+         + 2.0 * torch.randn(c, generator=g)[None, :, None, None, None])
+    gamma, beta = 0.5 + torch.rand(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    rm0, rv0 = torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)
+    dy = torch.randn(shape, generator=g)
+    xq = x.to(dt)
+    rm, rv = rm0.clone().to(device), rv0.clone().to(device)
+    y, mean, rstd = T.bn_train_forward(cl(x, dt, device), gamma.to(device), beta.to(device), 1e-5, "relu", running_mean=rm,
+                                       running_var=rv)
+    # reference: double, on the rounded input
+    xr = xq.double().requires_grad_(True)
+    rmr, rvr = rm0.double().clone(), rv0.double().clone()
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5))
+    assert rel_l2(ncdhw(y), yr.detach()) < ULP[prec]
+    torch.testing.assert_close(mean.cpu().double(), xq.double().mean((0, 2, 3, 4)), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rm.cpu().double(), rmr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rv.cpu().double(), rvr, rtol=1e-4, atol=1e-5)
+    # backward with the kernel's own stored (rounded) y as the activation mask, as the step does
+    dyq = dy.to(dt)
+    yr.backward(dyq.double())
+    framed, dgamma, dbeta = T.bn_act_backward(cl(dy, dt, device), y, cl(x, dt, device), mean, rstd, gamma.to(device), "relu")
+    assert framed.shape == (n, shape[2] + 4, shape[3] + 4, shape[4] + 4, c)
+    dx = ncdhw(T.interior(framed))
+    assert rel_l2(dx, xr.grad) < 4 * ULP[prec], rel_l2(dx, xr.grad)
+    fz = framed.clone()
+    T.interior(fz).zero_()
+    assert not fz.any()                                            # the frame stays zero
+    torch.testing.assert_close(dgamma.cpu().double(), gr.grad, rtol=2e-3, atol=2e-3 * gr.grad.abs().max().item())
+    torch.testing.assert_close(dbeta.cpu().double(), br.grad, rtol=2e-3, atol=2e-3 * br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,size", [(16, 16, (8, 16, 32)), (32, 16, (6, 10, 12)), (64, 128, (4, 4, 4)), (1, 16, (8, 8, 40)),
+                                            (16, 32, (2, 2, 2)), (128, 64, (8, 8, 8))])
+def test_conv_dgrad_and_wgrad(device, prec, cin, cout, size):
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(2)
+    n = 2
+    cin_pad = (cin + 15) // 16 * 16
+    x = torch.randn(n, cin, *size, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    dy = torch.randn(n, cout, *size, generator=g)
+    xq, dyq, wq = x.to(dt).double().requires_grad_(True), dy.to(dt).double(), w.to(dt).double().requires_grad_(True)
+    yr = F.conv3d(F.pad(xq, (1,) * 6, mode="reflect"), wq)
+    yr.backward(dyq)
+    # device side
+    xd = torch.zeros((n, *size, cin_pad), dtype=dt, device=device)
+    xd[..., :cin] = cl(x, dt, device)
+    framed = T.new_framed(n, *size, cout, dt, device)
+    T.interior(framed).copy_(cl(dy, dt, device))
+    # forward sanity (same entry point the step uses)
+    y = T.conv_forward(xd, None, w.to(device))
+    assert rel_l2(ncdhw(y), yr.detach()) < 2 * ULP[prec]
+    din = T.conv_dgrad(framed, w.to(device))
+    assert din.shape[-1] == cin_pad
+    assert rel_l2(ncdhw(din)[:, :cin], xq.grad) < 2 * ULP[prec], rel_l2(ncdhw(din)[:, :cin], xq.grad)
+    if cin_pad != cin:
+        assert not din[..., cin:].any()
+    dw = T.conv_wgrad(framed, xd, None, cin, cout)
+    assert dw.shape == (cout, cin, 3, 3, 3)
+    assert rel_l2(dw.cpu().double(), wq.grad) < 1e-5, rel_l2(dw.cpu().double(), wq.grad)      # fp32 accumulate of exact products
+
+
+@pytest.mark.parametrize("prec", ["bf16"])
+@pytest.mark.parametrize("c0,c1,cout,size", [(16, 32, 16, (8, 8, 32)), (32, 64, 32, (4, 8, 12)), (128, 256, 128, (4, 4, 4))])
+def test_wgrad_and_dgrad_of_upsample_concat_conv(device, prec, c0, c1, cout, size):
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(3)
+    n = 2
+    lo = tuple(s // 2 for s in size)
+    skip, low = torch.randn(n, c0, *size, generator=g), torch.randn(n, c1, *lo, generator=g)
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, generator=g) / (27 * (c0 + c1)) ** 0.5
+    dy = torch.randn(n, cout, *size, generator=g)
+    sq, lq = skip.to(dt).double().requires_grad_(True), low.to(dt).double().requires_grad_(True)
+    wq = w.to(dt).double().requires_grad_(True)
+    cat = torch.cat((sq, F.interpolate(lq, scale_factor=2, mode="nearest")), 1)
+    yr = F.conv3d(F.pad(cat, (1,) * 6, mode="reflect"), wq)
+    yr.backward(dy.to(dt).double())
+    framed = T.new_framed(n, *size, cout, dt, device)
+    T.interior(framed).copy_(cl(dy, dt, device))
+    sd, ld = cl(skip, dt, device), cl(low, dt, device)
+    y = T.conv_forward(sd, ld, w.to(device))
+    assert rel_l2(ncdhw(y), yr.detach()) < 2 * ULP[prec]
+    dw = T.conv_wgrad(framed, sd, ld, c0 + c1, cout)
+    assert rel_l2(dw.cpu().double(), wq.grad) < 1e-5
+    dcat = ncdhw(T.conv_dgrad(framed, w.to(device)))
+    assert rel_l2(dcat[:, :c0], sq.grad) < 2 * ULP[prec]
+    # adjoint of the nearest upsample = sum over the 8 children (host arithmetic in the test; the step uses torch ops too)
+    dl = dcat[:, c0:].reshape(n, c1, lo[0], 2, lo[1], 2, lo[2], 2).sum((3, 5, 7))
+    assert rel_l2(dl, lq.grad) < 2 * ULP[prec]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_pool2_max_backward_first_max_tie_rule(device, prec):
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 16, 8, 8, 8, generator=g).relu()            # many exact ties at 0
+    x[0, :, :2, :2, :2] = 1.5                                       # and a non-zero tie
+    dp = torch.randn(2, 16, 4, 4, 4, generator=g)
+    xq = x.to(dt).double().requires_grad_(True)
+    F.max_pool3d(xq, 2).backward(dp.to(dt).double())
+    xd = cl(x, dt, device)
+    p = T.pool2_max(xd)
+    assert torch.equal(ncdhw(p), F.max_pool3d(x.to(dt).double(), 2))
+    din = T.pool2_max_backward(cl(dp, dt, device), xd)
+    assert torch.equal(ncdhw(din), xq.grad)
+    acc = torch.ones_like(xd)
+    T.pool2_max_backward(cl(dp, dt, device), xd, accumulate_into=acc)
+    assert rel_l2(ncdhw(acc), xq.grad + 1.0) < ULP[prec]
