@@ -356,6 +356,11 @@ class Unet(nn.Module):
     def forward(self, input, layers=[], encode_only=False, verbose=False):
         """Same call contract as network.py:467: tensor without ``layers``; ``(out, feats)`` with
         ``layers``; ``feats`` alone with ``encode_only``."""
+        if input.is_cuda and self.training and self._cfg["norm"] == "batch" and not encode_only:
+            # train-mode BatchNorm (batch statistics) and/or autograd: the differentiable HIP path (model/train.py)
+            from . import train
+            if train.unsupported_reason(self, input, list(layers)) is None:
+                return train.forward_train(self, input, list(layers))
         reason = self.hip_unsupported_reason(input, layers)
         if reason is None:
             if len(layers) > 0:

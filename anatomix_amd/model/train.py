@@ -1,0 +1,222 @@
+"""Differentiable train-mode forward of ``Unet`` on the HIP kernels (the UNet inside the reference's contrastive
+step, pretraining/models/supcl_model.py:603-661, 735-742: ``netG(reals, nce_layers, False)`` with BatchNorm in train
+mode, then ``loss.backward()``).
+
+One ``torch.autograd.Function`` covers the whole network: the forward runs conv -> train-mode BatchNorm -> activation
+blocks, max-pools and the upsample + concat convs through the library's single-operator entry points
+(``anatomix_amd.model.train_ops``), keeps what the adjoint needs (raw conv outputs, activations, batch statistics) in
+16-bit channels-last tensors, and the backward walks the blocks in reverse: activation/BatchNorm adjoint -> weight
+gradient (MFMA kernel) -> data gradient (forward kernel on the zero-framed gradient with flipped weights + reflect fold)
+-> max-pool / upsample / concat adjoints.  Storage precision is ``model.precision`` ("bf16" mirrors the reference's
+bf16 autocast); parameter gradients and BatchNorm statistics are fp32.
+
+Supported configuration (what the reference trains): norm='batch', activation relu/lrelu, pooling='Max',
+interp='nearest', doubleconv either, skip connections either; feature taps at conv / norm / activation ids and at the
+output conv.  Everything else raises (the caller can still opt into the stock-module path).
+"""
+import torch
+import torch.nn as nn
+
+from . import train_ops as T
+
+_DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def unsupported_reason(model, x, layers):
+    c = model._cfg
+    if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
+        return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
+    if c["norm"] != "batch" or c["activation"] not in ("relu", "lrelu") or c["final_act"] != "none":
+        return "the HIP training path covers norm='batch', activation relu/lrelu, final_act='none'"
+    if c["pooling"] != "Max" or c["interp"] != "nearest":
+        return "the HIP training path covers pooling='Max', interp='nearest'"
+    if c["input_nc"] != 1 or c["ngf"] % 16 or c["output_nc"] % 16 or c["output_nc"] > 32:
+        return "the HIP training path needs input_nc == 1, ngf a multiple of 16, output_nc in {16, 32}"
+    if x.dim() != 5 or x.shape[1] != 1 or not x.is_cuda:
+        return "expected a CUDA input of shape [N, 1, D, H, W]"
+    m = 1 << c["num_downs"]
+    if any(s % m or (s >> c["num_downs"]) < 2 for s in x.shape[2:]) or x.shape[4] < 32 or x.shape[4] > 156:
+        return "spatial dims must be divisible by 2^num_downs, >= 2 at the bottleneck, 32 <= W <= 156"
+    kinds = _module_kinds(model)
+    for l in layers:
+        if not (0 <= l < len(kinds)) or kinds[l] not in ("conv", "norm", "act"):
+            return "feature taps are implemented at conv / norm / activation ids"
+    return None
+
+
+def _module_kinds(model):
+    kinds = []
+    for mod in model.model:
+        if isinstance(mod, nn.Conv3d):
+            kinds.append("conv")
+        elif isinstance(mod, nn.BatchNorm3d):
+            kinds.append("norm")
+        elif isinstance(mod, (nn.ReLU, nn.LeakyReLU)):
+            kinds.append("act")
+        elif isinstance(mod, nn.MaxPool3d):
+            kinds.append("pool")
+        elif isinstance(mod, nn.Upsample):
+            kinds.append("up")
+        else:
+            kinds.append("other")
+    return kinds
+
+
+def _to_cl(t, dt):            # fp32 NCDHW -> 16-bit NDHWC
+    return t.permute(0, 2, 3, 4, 1).to(dt).contiguous()
+
+
+def _to_ncdhw(t):             # 16-bit NDHWC -> fp32 NCDHW
+    return t.permute(0, 4, 1, 2, 3).float().contiguous()
+
+
+class _UnetTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, layers, *params):
+        dt = _DT[model.precision]
+        act = model._cfg["activation"]
+        kinds = _module_kinds(model)
+        mods = list(model.model)
+        dev = x.device
+        n, _, d, h, w = x.shape
+        xin = torch.zeros((n, d, h, w, 16), dtype=dt, device=dev)        # the single input channel, padded to one MFMA chunk
+        xin[..., 0] = x.detach()[:, 0].to(dt)
+        tensors = {"x": xin}
+        blocks, ops, skips = [], [], []
+        cur, pending_low = "x", None
+        taps = {}
+        i = 0
+        while i < len(mods):
+            k = kinds[i]
+            if k == "conv":
+                conv = mods[i]
+                has_bn = i + 1 < len(mods) and kinds[i + 1] == "norm"
+                has_act = i + 1 + int(has_bn) < len(mods) and kinds[i + 1 + int(has_bn)] == "act"
+                in0, in1 = (skips.pop(), pending_low) if (pending_low is not None and model.use_skip_connection) else (cur, None)
+                if pending_low is not None and not model.use_skip_connection:
+                    raise NotImplementedError("upsample without skip connection in the HIP training path")
+                pending_low = None
+                blk = dict(idx=i, conv=conv, in0=in0, in1=in1, cin=conv.in_channels, cout=conv.out_channels, name=f"y{i}",
+                           alias_ids=[i + 1 + a for a in range(int(has_bn) + int(has_act))])
+                if has_bn:
+                    bn = mods[i + 1]
+                    X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight)
+                    Y, mean, rstd = T.bn_train_forward(X, bn.weight.detach(), bn.bias.detach(), bn.eps, act if has_act else "none", 0.3,
+                                                       bn.running_mean, bn.running_var,
+                                                       0.1 if bn.momentum is None else bn.momentum)
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked += 1
+                    blk.update(bn=bn, X=X, Y=Y, mean=mean, rstd=rstd, act=act if has_act else "none")
+                    tensors[blk["name"]] = Y
+                    if i in layers:
+                        taps[i] = _to_ncdhw(X)                           # pre-norm conv output
+                    for j in blk["alias_ids"]:
+                        if j in layers:
+                            taps[j] = _to_ncdhw(Y)                       # in-place activation aliases the norm output
+                    i += 1 + int(has_act)
+                else:                                                    # the bare output conv
+                    out = T.conv_forward(tensors[in0], None, conv.weight, out32=True)
+                    blk.update(bn=None, final=True)
+                    tensors[blk["name"]] = out
+                blocks.append(blk)
+                ops.append(("conv", blk))
+                cur = blk["name"]
+                if model.use_skip_connection and i in model.encoder_idx:
+                    skips.append(cur)
+            elif k == "pool":
+                dst = f"p{i}"
+                tensors[dst] = T.pool2_max(tensors[cur])
+                ops.append(("pool", cur, dst))
+                cur = dst
+            elif k == "up":
+                pending_low = cur
+            else:
+                raise NotImplementedError(f"module {i} ({type(mods[i]).__name__}) in the HIP training path")
+            i += 1
+        ctx.model, ctx.tensors, ctx.ops, ctx.layers, ctx.dt = model, tensors, ops, sorted(taps), dt
+        ctx.param_ids = [id(p) for p in model.parameters()]
+        ctx.final_idx = blocks[-1]["idx"]
+        out = tensors[blocks[-1]["name"]]
+        return (out,) + tuple(taps[l] for l in sorted(taps))
+
+    @staticmethod
+    def backward(ctx, dout, *dtaps):
+        model, tensors, dt = ctx.model, ctx.tensors, ctx.dt
+        dtap = {l: g for l, g in zip(ctx.layers, dtaps) if g is not None}
+        grads, pgrads, frames = {}, {}, {}
+
+        def add_grad(name, g):
+            grads[name] = g if name not in grads else grads[name] + g
+
+        def frame(shape, c):
+            key = (tuple(shape), c)
+            if key not in frames:
+                frames[key] = T.new_framed(shape[0], shape[1], shape[2], shape[3], c, dt, tensors["x"].device)
+            return frames[key]
+
+        for op in reversed(ctx.ops):
+            if op[0] == "pool":
+                _, src, dst = op
+                if dst not in grads:
+                    continue
+                dp = grads.pop(dst)
+                if src in grads:
+                    T.pool2_max_backward(dp, tensors[src], accumulate_into=grads[src])
+                else:
+                    grads[src] = T.pool2_max_backward(dp, tensors[src])
+                continue
+            blk = op[1]
+            conv, idx = blk["conv"], blk["idx"]
+            x0 = tensors[blk["in0"]]
+            x1 = None if blk["in1"] is None else tensors[blk["in1"]]
+            n, d, h, w, c0 = x0.shape
+            if blk.get("final"):
+                g = dout
+                if g is None:
+                    continue
+                fr = frame((n, d, h, w), blk["cout"])
+                T.interior(fr).copy_(g.permute(0, 2, 3, 4, 1))
+            else:
+                name = blk["name"]
+                dy = grads.pop(name, None)
+                bn = blk["bn"]
+                for j in blk["alias_ids"]:                              # taps that alias the activated output
+                    if j in dtap:
+                        gj = _to_cl(dtap.pop(j), dt)
+                        dy = gj if dy is None else dy + gj
+                if dy is None and idx not in dtap:
+                    continue                                            # nothing downstream of this block was used
+                fr = frame((n, d, h, w), blk["cout"])
+                if dy is not None:
+                    _, dgamma, dbeta = T.bn_act_backward(dy, blk["Y"], blk["X"], blk["mean"], blk["rstd"], bn.weight.detach(),
+                                                         blk["act"], 0.3, framed=fr)
+                    pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgamma, dbeta
+                else:
+                    T.interior(fr).zero_()
+                if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
+                    T.interior(fr).add_(dtap.pop(idx).permute(0, 2, 3, 4, 1).to(dt))
+            pgrads[id(conv.weight)] = T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"])
+            if blk["in0"] == "x":
+                continue                                                # the network input needs no gradient
+            dcat = T.conv_dgrad(fr, conv.weight)
+            if x1 is None:
+                add_grad(blk["in0"], dcat[..., : x0.shape[-1]] if dcat.shape[-1] != x0.shape[-1] else dcat)
+            else:
+                c1 = x1.shape[-1]
+                add_grad(blk["in0"], dcat[..., :c0].contiguous())
+                up = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1)
+                add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))   # adjoint of the nearest x2 upsample
+        return (None, None, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
+
+
+def forward_train(model, x, layers):
+    """(out, feats) like Unet.forward(input, layers) -- or out alone when ``layers`` is empty -- differentiable."""
+    layers = [int(l) for l in layers]
+    final_idx = max(i for i, m in enumerate(model.model) if isinstance(m, nn.Conv3d))
+    want = sorted({l for l in layers if l != final_idx})
+    res = _UnetTrainFn.apply(model, x, tuple(want), *list(model.parameters()))
+    out, taps = res[0], dict(zip(want, res[1:]))
+    if not layers:
+        return out
+    feats = [out if l == final_idx else taps[l] for l in sorted(set(layers))]
+    return out, feats

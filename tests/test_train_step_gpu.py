@@ -1,0 +1,134 @@
+"""GPU: the differentiable train-mode forward of Unet on the HIP kernels (anatomix_amd/model/train.py) against the stock
+torch modules (fp32 autograd on the same device) and against the step record captured from the reference."""
+import copy
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from _util import rel_l2
+import anatomix_amd
+from anatomix_amd.pretraining import PatchSampleF, SupPatchNCELoss, contrastive_step
+from oracle import pretrain_inputs as PI
+from oracle import unet_ref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "pretrain_golden.npz"))
+KW = R.VARIANTS["anatomix"]
+
+
+def _pair(device, precision="bf16"):
+    """The same network twice: `hip` runs the HIP training path, `ref` the stock modules (fp32)."""
+    hip = anatomix_amd.Unet(**KW)
+    hip.load_state_dict(R.synthetic_state_dict(KW, 3, gain=2 ** 0.5), strict=True)
+    hip.precision = precision
+    ref = copy.deepcopy(hip)
+    ref.allow_torch_path, ref._warned = True, True
+    return hip.to(device).train(), ref.to(device).train()
+
+
+def _ref_forward(ref, x, layers):
+    return ref._forward_torch(x, layers, False, False)
+
+
+def _pair_kw(device, kw, precision, seed=3, gain=1.0):
+    hip = anatomix_amd.Unet(**kw)
+    hip.load_state_dict(R.synthetic_state_dict(kw, seed, gain=gain), strict=True)
+    hip.precision = precision
+    ref = copy.deepcopy(hip)
+    ref.allow_torch_path, ref._warned = True, True
+    return hip.to(device).train(), ref.to(device).train()
+
+
+def _compare(hip, ref, x, layers, device, loss_scale=1.0):
+    out_h, feats_h = hip(x, layers)
+    out_r, feats_r = _ref_forward(ref, x, layers)
+    errs = {"out": rel_l2(out_h.detach().cpu(), out_r.detach().cpu())}
+    for l, a, b in zip(sorted(layers), feats_h, feats_r):
+        assert a.shape == b.shape, l
+        errs[f"tap{l}"] = rel_l2(a.detach().cpu(), b.detach().cpu())
+    g = torch.Generator().manual_seed(5)
+    cots = [torch.randn(f.shape, generator=g).to(device) / f[0].numel() ** 0.5 for f in feats_r]
+    loss_h = sum((f * c).sum() for f, c in zip(feats_h, cots)) + 0.1 * out_h.square().mean()
+    loss_r = sum((f * c).sum() for f, c in zip(feats_r, cots)) + 0.1 * out_r.square().mean()
+    (loss_h * loss_scale).backward()       # f16 gradients need the usual loss scaling (the reference runs a GradScaler)
+    loss_r.backward()
+    for ph in hip.parameters():
+        ph.grad /= loss_scale
+    gerrs, cos = {}, {}
+    for (name, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
+        assert ph.grad is not None and ph.grad.shape == pr.grad.shape, name
+        gerrs[name] = rel_l2(ph.grad.cpu(), pr.grad.cpu())
+        a, b = ph.grad.double().flatten().cpu(), pr.grad.double().flatten().cpu()
+        cos[name] = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+    return errs, gerrs, cos
+
+
+@pytest.mark.parametrize("kw,layers", [
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=1, ngf=16), [0, 3, 5, 10, 13, 17, 20]),
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16, doubleconv=False, activation="lrelu"), [0, 3, 7, 11, 15, 19]),
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=32), [3, 13, 20, 27, 34]),
+])
+def test_shallow_networks_forward_and_gradients_match_stock_modules(device, kw, layers):
+    """Short networks keep the rounding amplification of train-mode BatchNorm small, so f16 storage must agree with the
+    fp32 stock modules tightly: this is the bug-catching end-to-end check (a mis-routed gradient is an O(1) error)."""
+    hip, ref = _pair_kw(device, kw, "f16")
+    x = R.synthetic_input(11, 2, (32, 32, 64)).to(device)
+    errs, gerrs, cos = _compare(hip, ref, x, layers, device, loss_scale=4096.0)
+    print("fwd", {k: f"{v:.2e}" for k, v in errs.items()})
+    print("grad worst", max(gerrs.values()), "min cos", min(cos.values()))
+    assert max(errs.values()) < 1e-2, errs
+    # The activations of the two runs differ by ~2e-3, which flips the ReLU mask of the voxels whose pre-activation lies
+    # within that distance of zero: a fraction f ~ 2e-3 of the mask, i.e. a sqrt(2f) ~ 5e-2 relative change of the
+    # gradient that is a property of comparing two nearby forwards, not of the backward kernels (those are exact to
+    # rounding: tests/test_train_ops_gpu.py).  The LAST layers, upstream of no mask, must agree tightly.
+    last = [k for k in gerrs if k.startswith(f"model.{len(hip.model) - 1}.")]
+    assert all(gerrs[k] < 2e-3 for k in last), {k: gerrs[k] for k in last}
+    assert max(gerrs.values()) < 0.2 and min(cos.values()) > 0.98, (max(gerrs.values()), min(cos.values()))
+    for i, m in enumerate(hip.model):
+        if isinstance(m, torch.nn.BatchNorm3d):
+            torch.testing.assert_close(m.running_mean, ref.model[i].running_mean, rtol=2e-3, atol=2e-4)
+            torch.testing.assert_close(m.running_var, ref.model[i].running_var, rtol=5e-3, atol=2e-4)
+            assert int(m.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("precision,fwd_tol,cos_min", [("f16", 8e-2, 0.75), ("bf16", 0.5, 0.0)])
+def test_full_6m_network_train_step_sanity(device, precision, fwd_tol, cos_min):
+    """20 train-mode conv+BatchNorm layers on random weights amplify storage rounding by ~1.28x per layer (measured:
+    f16 3e-4 -> 4e-2, bf16 3e-3 -> 0.27 at the output; the reference's own bf16 autocast sits at the bf16 level).
+    The full network is therefore checked loosely here and through its losses / gradient norms below."""
+    hip, ref = _pair(device, precision)
+    A, B, _ = PI.step_inputs(64)
+    x = torch.cat((A, B)).to(device)
+    errs, gerrs, cos = _compare(hip, ref, x, [0, 7, 27, 31, 38, 45, 52, 65], device, loss_scale=4096.0 if precision == "f16" else 1.0)
+    print(precision, "fwd", {k: f"{v:.2e}" for k, v in errs.items()})
+    print(precision, "grad worst", max(gerrs.values()), "min cos", min(cos.values()))
+    assert errs["tap0"] < (1e-3 if precision == "f16" else 6e-3)
+    assert max(errs.values()) < fwd_tol, errs
+    assert min(cos.values()) > cos_min, {k: v for k, v in cos.items() if v < 0.99}
+
+
+def test_contrastive_step_fully_on_hip_matches_reference_record(device):
+    """netG forward + backward on the HIP kernels (bf16 storage, as the reference's bf16 autocast), losses on the HIP kernel."""
+    hip, _ = _pair(device, "bf16")
+    A, B, seg = [t.to(device) for t in PI.step_inputs(64)]
+    ids = [torch.from_numpy(GOLD[f"step|ids|{k}"].astype(np.int64)).to(device) for k in range(6)]
+    netF = PatchSampleF(use_mlp=True, nc=PI.NETF_NC, n_mlps=3)
+    chans = [128, 256, 128, 64, 32, 16]
+    netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=device) for c in chans])
+    netF.load_state_dict(PI.mlp_state_dict(chans, seed=9), strict=True)
+    netF = netF.to(device).train()
+    opt = Namespace(nce_T=PI.NCE_T, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    crits = [SupPatchNCELoss(opt) for _ in PI.NCE_LAYERS]
+    opt_G = torch.optim.AdamW(hip.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    opt_F = torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    rec = contrastive_step(hip, netF, crits, A, B, seg, PI.NCE_LAYERS, num_patches=PI.NUM_PATCHES, sample_ids=ids,
+                           optimizers=(opt_G, opt_F))
+    got = np.array(list(rec["per_layer"].values()))
+    print("per-layer", got, "ref", GOLD["step|per_layer"], "gG", rec["grad_norm_G"], float(GOLD["step|grad_norm_G"]))
+    np.testing.assert_allclose(got, GOLD["step|per_layer"], rtol=2e-2)
+    assert abs(rec["loss"] - float(GOLD["step|total"])) < 1e-2 * rec["loss"]
+    assert abs(rec["grad_norm_G"] - float(GOLD["step|grad_norm_G"])) < 0.3 * rec["grad_norm_G"]
+    assert abs(rec["grad_norm_F"] - float(GOLD["step|grad_norm_F"])) < 0.3 * rec["grad_norm_F"]
