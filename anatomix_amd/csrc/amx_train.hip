@@ -85,25 +85,43 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* __restrict__ 
   }
 }
 
-// grid C/64, block 64: merge the slabs (Chan's parallel variance, fp64, slab order) -> mean, rstd, (a, b), running stats
+// grid C/8, block 256 = 8 channels x 32 lanes: lane l merges slabs l, l+32, ... (Chan's parallel variance, fp64, in
+// order), then the 32 lane results are merged in lane order -> mean, rstd, (a, b), running statistics.  Fixed tree.
 template <typename T>
-__global__ void bn_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial, const float* gamma,
-                                   const float* beta, float eps, long long rows, int C, int nblk, float* __restrict__ ab,
-                                   float* save_mean, float* save_rstd, float* running_mean, float* running_var, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
+                                                         const float* gamma, const float* beta, float eps, long long rows, int C,
+                                                         int nblk, float* __restrict__ ab, float* save_mean, float* save_rstd,
+                                                         float* running_mean, float* running_var, float momentum) {
+  __shared__ double sh[3][8][32];
+  const int cl = threadIdx.x & 7, l = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   const long long per = (rows + nblk - 1) / nblk;
   double cnt = 0.0, mean = 0.0, m2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    const long long v0 = (long long)b * per, v1 = v0 + per < rows ? v0 + per : rows;
-    if (v0 >= rows) break;
-    const double nb = (double)(v1 - v0);
-    const float K = (float)__builtin_bit_cast(T, *(const unsigned short*)(x + (v0 * C + c) * 2));
-    const double s1 = partial[((long long)b * C + c) * 2], s2 = partial[((long long)b * C + c) * 2 + 1];
-    const double mb = (double)K + s1 / nb, m2b = s2 - s1 * s1 / nb;
-    const double delta = mb - mean, tot = cnt + nb;
+  if (c < C)
+    for (int b = l; b < nblk; b += 32) {
+      const long long v0 = (long long)b * per, v1 = v0 + per < rows ? v0 + per : rows;
+      if (v0 >= rows) break;
+      const double nb = (double)(v1 - v0);
+      const float K = (float)__builtin_bit_cast(T, *(const unsigned short*)(x + (v0 * C + c) * 2));
+      const double s1 = partial[((long long)b * C + c) * 2], s2 = partial[((long long)b * C + c) * 2 + 1];
+      const double mb = (double)K + s1 / nb, m2b = s2 - s1 * s1 / nb;
+      const double delta = mb - mean, tot = cnt + nb;
+      mean += delta * nb / tot;
+      m2 += m2b + delta * delta * cnt * nb / tot;
+      cnt = tot;
+    }
+  sh[0][cl][l] = cnt;
+  sh[1][cl][l] = mean;
+  sh[2][cl][l] = m2;
+  __syncthreads();
+  if (threadIdx.x >= 8 || c >= C) return;
+  cnt = 0.0; mean = 0.0; m2 = 0.0;
+  for (int k = 0; k < 32; ++k) {
+    const double nb = sh[0][cl][k];
+    if (nb == 0.0) continue;
+    const double delta = sh[1][cl][k] - mean, tot = cnt + nb;
     mean += delta * nb / tot;
-    m2 += m2b + delta * delta * cnt * nb / tot;
+    m2 += sh[2][cl][k] + delta * delta * cnt * nb / tot;
     cnt = tot;
   }
   double var = m2 / cnt;
@@ -192,14 +210,25 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restric
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int C, int nblk, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int C, int nblk,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 7, l = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblk; ++k) {
-    a += partial[((long long)k * C + c) * 2];
-    b += partial[((long long)k * C + c) * 2 + 1];
+  if (c < C)
+    for (int k = l; k < nblk; k += 32) {
+      a += partial[((long long)k * C + c) * 2];
+      b += partial[((long long)k * C + c) * 2 + 1];
+    }
+  sh[0][cl][l] = a;
+  sh[1][cl][l] = b;
+  __syncthreads();
+  if (threadIdx.x >= 8 || c >= C) return;
+  a = 0.0; b = 0.0;
+  for (int k = 0; k < 32; ++k) {
+    a += sh[0][cl][k];
+    b += sh[1][cl][k];
   }
   dbeta[c] = (float)a;
   dgamma[c] = (float)b;
@@ -339,7 +368,7 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
   const int blocks = grid_for(rows * c8n);
 #define AMX_BN(T)                                                                                                        \
   hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)x, partial, rows, C);              \
-  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 63) / 64), dim3(64), 0, st, (const char*)x, partial, gamma, beta, eps, \
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 7) / 8), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, \
                      rows, C, nblk, ab, save_mean, save_rstd, running_mean, running_var, momentum);                      \
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope)
   if (precision == 0) { AMX_BN(f16); } else { AMX_BN(bf16); }
@@ -360,7 +389,7 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
   if (mean) {                                                                                                            \
     hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)dy, (const char*)y,          \
                        (const char*)x, mean, rstd, partial, rows, C, act, slope);                                        \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, C, nblk, dgamma, dbeta);    \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, C, nblk, dgamma, dbeta);    \
   }                                                                                                                      \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)dy, (const char*)y,            \
                      (const char*)x, mean, rstd, gamma, dgamma, dbeta, (char*)dx_framed, N, D, H, W, C, act, slope)

@@ -142,17 +142,32 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
   }
 }
 
-// dW[co][ci][tap] (+)= sum over chunks, in chunk order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout, int Cin, int CinPad,
-                                    int nchunk, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Cout * Cin * 27) return;
-  const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / (27 * Cin);
+// dW[co][ci][tap] (+)= sum over chunks.  A block owns 8 consecutive elements of the partial layout
+// [pair][tap][co16][ci16] (32 contiguous bytes per chunk); its 32 lanes per element add chunks l, l+32, ... in order and the
+// 32 lane sums are added in lane order: a fixed summation tree, independent of the launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
+                                                          int Cin, int CinPad, int nchunk, int accumulate) {
+  __shared__ float red[8][33];
   const int ncit = CinPad / 16, npairs = (Cout / 16) * ncit;
-  const int pair = (co / 16) * ncit + ci / 16;
-  float s = accumulate ? dw[idx] : 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partial[(((size_t)c * npairs + pair) * 27 + tap) * 256 + (co % 16) * 16 + ci % 16];
-  dw[idx] = s;
+  const long long E = (long long)npairs * 27 * 256;
+  const int el = threadIdx.x & 7, l = threadIdx.x >> 3;
+  const long long e = (long long)blockIdx.x * 8 + el;
+  float s = 0.f;
+  if (e < E)
+    for (int c = l; c < nchunk; c += 32) s += partial[(size_t)c * E + e];
+  red[el][l] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && (long long)blockIdx.x * 8 + threadIdx.x < E) {
+    const long long ee = (long long)blockIdx.x * 8 + threadIdx.x;
+    float t = 0.f;
+    for (int k = 0; k < 32; ++k) t += red[threadIdx.x][k];
+    const int ci16 = ee % 16, co16 = (ee / 16) % 16, tap = (ee / 256) % 27, pair = ee / (256 * 27);
+    const int co = (pair / ncit) * 16 + co16, ci = (pair % ncit) * 16 + ci16;
+    if (ci < Cin) {
+      float* o = dw + ((long long)co * Cin + ci) * 27 + tap;
+      *o = accumulate ? *o + t : t;
+    }
+  }
 }
 
 static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* nitems, int* nchunk, int* ipc, int* nyt) {
@@ -202,9 +217,9 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
     }
     hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16>, dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);
   }
-  const int total = p.Cout * CinReal * 27;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)scratch, dw, p.Cout, CinReal,
-                     CinPad, nchunk, accumulate);
+  const long long E = (long long)npairs * 27 * 256;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 7) / 8)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
+                     CinReal, CinPad, nchunk, accumulate);
   return hipGetLastError();
 }
 

@@ -7,13 +7,14 @@ import torch.nn as nn
 
 
 def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights=None, num_patches=512,
-                     lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1):
+                     lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1, grad_sync=None):
     """Two aligned views through the shared network with feature taps, same-coordinate patch sampling, per-layer
     SupPatchNCELoss, weighted sum, backward and (optionally) the optimizer steps.
 
     netG: Unet (train mode: BatchNorm batch statistics over the two views, supcl_model.py:735-742);
     netF: PatchSampleF; criterions: one SupPatchNCELoss per nce layer; nce_weights default 1/len (supcl_model.py:388-393);
-    optimizers: (opt_G, opt_F) or None (gradients only); sample_ids: captured coordinates per layer or None (randperm).
+    optimizers: (opt_G, opt_F) or None (gradients only); sample_ids: captured coordinates per layer or None (randperm);
+    grad_sync: callable run between backward and the optimizer steps (data parallel: the gradient all-reduce).
     Returns an OrderedDict(loss, per_layer, grad_norm_G, grad_norm_F, sample_ids, out).
     """
     if nce_weights is None:
@@ -28,6 +29,8 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
         total = total + loss.mean() * w * lambda_nce
         per_layer[str(layer)] = float(loss.mean().item())
     (total / grad_accum_iters).backward()
+    if grad_sync is not None:
+        grad_sync()
     # clip_grad_norm_(max_norm=inf) only measures (supcl_model.py:635-655)
     gG = nn.utils.clip_grad_norm_(netG.parameters(), max_norm=float("inf"), norm_type=2).item()
     gF = nn.utils.clip_grad_norm_(netF.parameters(), max_norm=float("inf"), norm_type=2).item()

@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
     ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev"],
                     help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M)")
+    ap.add_argument("--workload", default="forward", choices=["forward", "step"],
+                    help="step = BASELINE configs[2]: one contrastive pretraining step per rank (two views of one 128^3 "
+                         "volume through the 6M UNet with taps, patch sampling + MLPs, six SupCon losses, backward, "
+                         "gradient all-reduce over the ranks, AdamW); value = 128^3 volumes/s through the whole step")
     ap.add_argument("--sw-volume", type=int, default=0,
                     help="BASELINE configs[1] end to end: a step = sliding-window extraction (roi 128, overlap 0.8, "
                          "gaussian) over one 1x1xS^3 volume, windows dealt to the ranks, one all_reduce")
@@ -105,6 +109,73 @@ def pmc_traffic(kernel, batch):
     return None
 
 
+def forward_roofline(torch, model, x, B):
+    # ---- roofline of the dominant kernel: hipEvents around every launch (not the timed region)
+    with torch.no_grad():
+        agg = {}
+        reps = 5
+        for _ in range(reps):
+            _, recs = model.profile_forward(x)
+            for r in recs:
+                a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    a = agg[dom]
+    avg_ms = a["ms"] / a["launches"]
+    flops_per_launch = a["flops"] / a["launches"]
+    bytes_per_launch = a["bytes"] / a["launches"]
+    tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    total_ms = sum(v["ms"] for v in agg.values()) / reps
+    # the kernel's own roofline: algorithmic intensity against the ridge point of the two peaks
+    hbm_bound = flops_per_launch / bytes_per_launch < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+                "achieved": round(gbps if hbm_bound else tflops, 2),
+                "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(gbps / HBM_PEAK_GBS if hbm_bound else tflops / MFMA_PEAK_TFLOPS, 4),
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["launches"] // reps,
+                "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
+                "alg_intensity_flop_per_byte": round(flops_per_launch / bytes_per_launch, 1),
+                "share_of_step": round(a["ms"] / reps / total_ms, 3),
+                "alg_TFLOPs": round(tflops, 1), "alg_GBps": round(gbps, 1),
+                "traffic": pmc_traffic(dom, B),
+                "per_kernel": {k: {"us_per_step": round(v["ms"] / reps * 1e3, 1), "launches": v["launches"] // reps,
+                                   "alg_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else 0.0,
+                                   "alg_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
+    return roofline
+
+
+def step_roofline(torch, dev, S):
+    """The step's dominant kernel is the MFMA weight-gradient kernel; its largest launch (48 -> 16 channels at S^3, the
+    upsample+concat conv, 25 % of the network's FLOPs) is timed alone with events on the launch stream."""
+    from anatomix_amd.model import train_ops as T
+    dt = torch.bfloat16
+    n = 2
+    x0 = torch.randn(n, S, S, S, 16, device=dev).to(dt)
+    x1 = torch.randn(n, S // 2, S // 2, S // 2, 32, device=dev).to(dt)
+    fr = T.new_framed(n, S, S, S, 16, dt, dev)
+    T.interior(fr).copy_(torch.randn(n, S, S, S, 16, device=dev))
+    for _ in range(3):
+        T.conv_wgrad(fr, x0, x1, 48, 16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        T.conv_wgrad(fr, x0, x1, 48, 16)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * 27 * 48 * 16 * n * S ** 3
+    bytes_ = 2.0 * n * S ** 3 * (16 + 16) + 2.0 * n * (S // 2) ** 3 * 32 + 4.0 * 27 * 48 * 16
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv3d_wgrad<bf16> + wgrad_reduce, 16||up32 -> 16 @%d^3 x %d views" % (S, n),
+            "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
+            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
+
+
 def main():
     args = parse()
     import torch
@@ -146,6 +217,42 @@ def main():
 
     step = lambda: model(x)
     units_per_step = world * B          # 128^3 volumes all ranks process per step
+    grad_ctx = torch.no_grad()
+    if args.workload == "step":
+        from argparse import Namespace
+        from anatomix_amd.pretraining import PatchSampleF, SupPatchNCELoss, contrastive_step
+        from oracle import pretrain_inputs as PI      # synthetic two-view inputs only
+        model.precision = "bf16"                      # the reference trains under bf16 autocast
+        model.train()
+        so, sys.stdout = sys.stdout, devnull
+        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+        netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+        sys.stdout = so
+        netF = netF.to(dev).train()
+        nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+        crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+        opts = (torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5),
+                torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5))
+        vA, vB, seg = [t.to(dev) for t in PI.step_inputs(S)]
+        vA = (vA + 0.01 * rank).clamp(0, 1)           # a different pair per rank
+
+        def grad_sync():                              # plain data parallel: average the gradients over the ranks (RCCL)
+            if world == 1:
+                return
+            for net in (model, netF):
+                gs = [p.grad for p in net.parameters() if p.grad is not None]
+                flat = torch.cat([g.reshape(-1) for g in gs])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat /= world
+                o = 0
+                for g in gs:
+                    g.copy_(flat[o:o + g.numel()].view_as(g))
+                    o += g.numel()
+
+        step = lambda: contrastive_step(model, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts,
+                                        grad_sync=grad_sync)["out"]
+        units_per_step = world * 2
+        grad_ctx = torch.enable_grad()
     if args.sw_volume:
         from anatomix_amd.registration.sliding_window import sliding_window_inference, window_starts
         V = args.sw_volume
@@ -155,7 +262,7 @@ def main():
                                                 sigma_scale=0.25, group=group)
         units_per_step = len(window_starts((V, V, V), (S, S, S), 0.8))
 
-    with torch.no_grad():
+    with grad_ctx:
         for _ in range(args.warmup):
             y = step()
         barrier()
@@ -174,40 +281,10 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: hipEvents around every launch (not the timed region)
-        with torch.no_grad():
-            agg = {}
-            reps = 5
-            for _ in range(reps):
-                _, recs = model.profile_forward(x)
-                for r in recs:
-                    a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                    a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        a = agg[dom]
-        avg_ms = a["ms"] / a["launches"]
-        flops_per_launch = a["flops"] / a["launches"]
-        bytes_per_launch = a["bytes"] / a["launches"]
-        tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        total_ms = sum(v["ms"] for v in agg.values()) / reps
-        # the kernel's own roofline: algorithmic intensity against the ridge point of the two peaks
-        hbm_bound = flops_per_launch / bytes_per_launch < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
-                    "achieved": round(gbps if hbm_bound else tflops, 2),
-                    "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(gbps / HBM_PEAK_GBS if hbm_bound else tflops / MFMA_PEAK_TFLOPS, 4),
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a["launches"] // reps,
-                    "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
-                    "alg_intensity_flop_per_byte": round(flops_per_launch / bytes_per_launch, 1),
-                    "share_of_step": round(a["ms"] / reps / total_ms, 3),
-                    "alg_TFLOPs": round(tflops, 1), "alg_GBps": round(gbps, 1),
-                    "traffic": pmc_traffic(dom, B),
-                    "per_kernel": {k: {"us_per_step": round(v["ms"] / reps * 1e3, 1), "launches": v["launches"] // reps,
-                                       "alg_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else 0.0,
-                                       "alg_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
-                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
+        if args.workload == "step":
+            roofline = step_roofline(torch, dev, S)
+        else:
+            roofline = forward_roofline(torch, model, x, B)
         gflop_vol = (GFLOP_PER_VOLUME_6M if args.variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
         name = "anatomix 6M UNet (ngf=16,num_downs=4)" if args.variant == "anatomix" else \
             "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)"
@@ -215,24 +292,31 @@ def main():
             workload = (f"{name}: sliding-window feature extraction of one 1x{args.sw_volume}^3 volume = {units_per_step} windows "
                         f"of {S}^3 per step (overlap 0.8, gaussian 0.25), fused gaussian accumulate (BASELINE configs[1])")
             par = f"windows dealt to {world} rank(s), one all_reduce(SUM) of the accumulators" if world > 1 else "1 GPU"
+        elif args.workload == "step":
+            workload = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
+                        "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; AdamW), bf16 "
+                        "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels (BASELINE configs[2])")
+            par = f"data parallel x{world}: one pair per rank, gradients averaged with one all_reduce per network"
+            gflop_vol *= 3.0      # forward + data gradient + weight gradient
         else:
             workload = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
                         "sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, 16-bit channels-last "
                         "activations, fp32 accumulate")
             par = f"replicas x{world} (no data-path collective)"
         result = {
-            "metric": "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if args.variant == "anatomix" else "94M dev UNet"),
+            "metric": ("128^3 volumes/sec through the contrastive pretraining step (6M UNet)" if args.workload == "step" else
+                       "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if args.variant == "anatomix" else "94M dev UNet")),
             "value": round(value, 2), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong" if args.sw_volume else "weak", "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": "bf16" if args.workload == "step" else args.precision,
             "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {args.variant} architecture)",
-            "config": {"workload": workload, "batch_per_gpu": 1 if args.sw_volume else B, "window": S, "parallelism": par},
+            "config": {"workload": workload, "batch_per_gpu": 1 if args.sw_volume else (2 if args.workload == "step" else B), "window": S, "parallelism": par},
             "end_to_end_TFLOPs": round(value * gflop_vol / 1e3, 1),
             "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "step":
             result["cpu_baseline"] = cpu_baseline(S, args.cpu_forwards, args.variant)
     if world > 1:
         dist.barrier()
