@@ -132,3 +132,27 @@ def test_contrastive_step_fully_on_hip_matches_reference_record(device):
     assert abs(rec["loss"] - float(GOLD["step|total"])) < 1e-2 * rec["loss"]
     assert abs(rec["grad_norm_G"] - float(GOLD["step|grad_norm_G"])) < 0.3 * rec["grad_norm_G"]
     assert abs(rec["grad_norm_F"] - float(GOLD["step|grad_norm_F"])) < 0.3 * rec["grad_norm_F"]
+
+
+def test_segmentation_finetuning_composition_trains(device):
+    """The finetuning caller (anatomix/segmentation/segmentation_utils.py:93-116): nn.Sequential(Unet, 1x1x1 conv head),
+    .train(), cross-entropy, optimizer steps -- runs on the HIP training path without opting into the stock modules and
+    the loss goes down."""
+    torch.manual_seed(0)
+    net = anatomix_amd.Unet(**KW)
+    net.load_state_dict(R.synthetic_state_dict(KW, 1, gain=2 ** 0.5), strict=True)
+    net.precision = "bf16"
+    head = torch.nn.Conv3d(16, 4, kernel_size=1)                      # monai's UnetOutBlock(3, feat, n_classes + 1) is this conv
+    model = torch.nn.Sequential(net, head).to(device).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    x = R.synthetic_input(3, 2, (32, 32, 64)).to(device)
+    target = (x[:, 0] * 3.999).long().clamp(0, 3)                     # a learnable voxel-wise labelling of the input
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(x), target)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(p.grad is not None for p in net.parameters())
+    assert all(b < a for a, b in zip(losses, losses[1:])) and losses[-1] < 0.9 * losses[0], losses
