@@ -353,7 +353,8 @@ class Unet(nn.Module):
                     return feats
         return (feat, feats) if want else feat
 
-    def forward(self, input, layers=[], encode_only=False, verbose=False):
+    @torch.compiler.disable      # the reference wraps the module in torch.compile (README.md:64, train.py:223): the HIP
+    def forward(self, input, layers=[], encode_only=False, verbose=False):   # path is opaque to Dynamo -> clean graph break
         """Same call contract as network.py:467: tensor without ``layers``; ``(out, feats)`` with
         ``layers``; ``feats`` alone with ``encode_only``."""
         if input.is_cuda and self.training and self._cfg["norm"] == "batch" and not encode_only:

@@ -63,6 +63,7 @@ class SupPatchNCELoss(nn.Module):
             return seg[:, labels_coords[:, 0], labels_coords[:, 1], labels_coords[:, 2]]
         return seg[:, labels_coords[:, 0], labels_coords[:, 1]]
 
+    @torch.compiler.disable      # the reference compiles its criterion (supcl_model.py:477-489); the kernel call is opaque
     def forward(self, features, labels_seg, labels_coords, coords_range, debug=False):
         labels = self.gather_labels(labels_seg, labels_coords, coords_range)        # [bs = 1, P]
         ntps, num_patches, nc = features.size()

@@ -110,3 +110,16 @@ def test_weights_repacked_after_load_state_dict(device):
         ref1 = R.forward_lowp(x, sd1, KW, torch.float16)
     assert not torch.allclose(y0, y1)
     assert rel_l2(y1, ref1) < 1e-3
+
+
+def test_torch_compile_graph_breaks_cleanly(device):
+    """The reference wraps the module in torch.compile (README.md:64, pretraining/trainers/train.py:223)."""
+    m, _ = _model(device, 0, 1.0)
+    x = R.synthetic_input(100, 1, (32, 32, 32)).to(device)
+    with torch.no_grad():
+        y0 = m(x)
+        y1 = torch.compile(m)(x)
+        seq = torch.nn.Sequential(m, torch.nn.Conv3d(16, 3, 1).to(device))
+        a, b = seq(x), torch.compile(seq)(x)
+    assert torch.equal(y0, y1)
+    assert torch.allclose(a, b, atol=1e-5)
