@@ -145,6 +145,14 @@ class Unet(nn.Module):
     def _mark_dirty(self):
         self._weights_dirty = True
 
+    def _param_signature(self):
+        """In-place updates (optimizer steps, nn.init.*, net.apply(init_func) as pretraining_networks.py:687-715 does) bump
+        every tensor's version counter: comparing them per call catches changes no hook sees."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _weights_stale(self):
+        return self._weights_dirty or getattr(self, "_uploaded_sig", None) != self._param_signature()
+
     def refresh_weights(self):
         """Call after mutating parameters in place (e.g. a manual ``param.data.copy_``)."""
         self._mark_dirty()
@@ -240,6 +248,7 @@ class Unet(nn.Module):
             _lib.check(lib.amx_unet_load_conv(self._handle, mi.value, _lib.ptr(w), _lib.ptr(b), _lib.ptr(g),
                                               _lib.ptr(be), _lib.ptr(mu), _lib.ptr(var), stream))
         self._weights_dirty = False
+        self._uploaded_sig = self._param_signature()
 
     def _get_workspace(self, lib, n, d, h, w, device):
         need = lib.amx_unet_workspace_bytes(self._handle, n, d, h, w)
@@ -254,7 +263,7 @@ class Unet(nn.Module):
         device = x.device
         lib = self._ensure_handle(device)
         with torch.cuda.device(device):
-            if self._weights_dirty:
+            if self._weights_stale():
                 self._upload_weights(lib, device)
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
@@ -276,7 +285,7 @@ class Unet(nn.Module):
         stop = layers[-1] if (encode_only and 0 <= layers[-1] < nmod) else -1
         want = sorted({int(l) for l in layers if 0 <= int(l) < nmod and (stop < 0 or int(l) <= stop)})
         with torch.cuda.device(device):
-            if self._weights_dirty:
+            if self._weights_stale():
                 self._upload_weights(lib, device)
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
@@ -308,7 +317,7 @@ class Unet(nn.Module):
         device = x.device
         lib = self._ensure_handle(device)
         with torch.cuda.device(device):
-            if self._weights_dirty:
+            if self._weights_stale():
                 self._upload_weights(lib, device)
             xin = x.detach().float().contiguous()
             n, _, d, h, w = xin.shape

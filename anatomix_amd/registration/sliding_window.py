@@ -175,7 +175,7 @@ def _run_fused(inputs, roi, starts, wmap, model, cnt):
     acc = torch.zeros((B, cout) + size, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         model._ensure_handle(dev)
-        if model._weights_dirty:
+        if model._weights_stale():
             model._upload_weights(lib, dev)
         k = max(1, min(FUSED_WINDOW_BATCH, len(starts)))
         ws, need = model._get_workspace(lib, k, roi[0], roi[1], roi[2], dev)

@@ -123,3 +123,20 @@ def test_torch_compile_graph_breaks_cleanly(device):
         a, b = seq(x), torch.compile(seq)(x)
     assert torch.equal(y0, y1)
     assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_in_place_parameter_updates_are_picked_up(device):
+    """optimizer.step() / nn.init.* / net.apply(init) change parameters in place without any module hook firing."""
+    m, sd = _model(device, 0, 1.0)
+    x = R.synthetic_input(9, 1, (32, 32, 32))
+    with torch.no_grad():
+        y0 = m(x.to(device)).cpu()
+        m.model[65].weight.mul_(2.0)                       # in place, no hook
+        m.model[1].running_var.add_(0.5)                   # a buffer, too
+        y1 = m(x.to(device)).cpu()
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2["model.65.weight"] = sd2["model.65.weight"] * 2.0
+        sd2["model.1.running_var"] = sd2["model.1.running_var"] + 0.5
+        ref = R.forward(x, sd2, KW)
+    assert not torch.allclose(y0, y1)
+    assert rel_l2(y1, ref) < 1e-3
