@@ -187,7 +187,7 @@ class Unet(nn.Module):
         if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
             return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
         if c["norm"] == "batch" and self.training:
-            return "BatchNorm in train mode (batch statistics) is not implemented in the HIP path yet; call .eval()"
+            return "train-mode BatchNorm with encode_only is not implemented in the HIP path; call .eval()"
         if c["norm"] not in _lib.NORM:
             return f"norm='{c['norm']}' is not implemented in the HIP path"
         if c["activation"] not in _lib.ACT or c["final_act"] not in _lib.ACT:
@@ -366,12 +366,16 @@ class Unet(nn.Module):
     def forward(self, input, layers=[], encode_only=False, verbose=False):   # path is opaque to Dynamo -> clean graph break
         """Same call contract as network.py:467: tensor without ``layers``; ``(out, feats)`` with
         ``layers``; ``feats`` alone with ``encode_only``."""
+        train_reason = None
         if input.is_cuda and self.training and self._cfg["norm"] == "batch" and not encode_only:
             # train-mode BatchNorm (batch statistics) and/or autograd: the differentiable HIP path (model/train.py)
             from . import train
-            if train.unsupported_reason(self, input, list(layers)) is None:
+            train_reason = train.unsupported_reason(self, input, list(layers))
+            if train_reason is None:
                 return train.forward_train(self, input, list(layers))
         reason = self.hip_unsupported_reason(input, layers)
+        if reason is not None and train_reason is not None:
+            reason = train_reason
         if reason is None:
             if len(layers) > 0:
                 if verbose:
