@@ -29,7 +29,7 @@ namespace amx {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
 struct Conv2Cfg {
   static constexpr int NW = NWZ * NWY;
   static constexpr int TZ = WZ * NWZ, TY = WY * NWY, TX = WX;
@@ -40,7 +40,8 @@ struct Conv2Cfg {
   static constexpr int WOFF = NCH * HALO;
   static constexpr int BIASOFF = WOFF + NCH * WSUB;   // 16*Q fp32 (256 B reserved)
   static constexpr int BUF = BIASOFF + 256;           // one pipeline buffer
-  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int FLAGOFF = NBUF * BUF;           // loader-wave mode: ready[NLW] at +0, done[8] at +32
+  static constexpr int LDS_BYTES = NBUF * BUF + (NLW ? 64 : 0);
   static constexpr int LX = WX >= 16 ? 16 : 8;
   static constexpr int LY = 16 / LX;
   static constexpr int XT = WX / LX;
@@ -60,7 +61,8 @@ struct Conv2Cfg {
   static constexpr int NINST = (NROW + RR - 1) / RR;
   static_assert(HX <= 64, "halo row must fit one wave");
   static_assert(WY % LY == 0 && WX % LX == 0, "wave sub-brick must tile into 16-voxel columns");
-  static_assert(LDS_BYTES <= 160 * 1024, "two pipeline buffers must fit the 160 KiB LDS");
+  static_assert(LDS_BYTES <= 160 * 1024, "the pipeline buffers must fit the 160 KiB LDS");
+  static_assert(NLW == 0 ? NBUF == 2 : (NBUF >= 2 && NLW <= 4 && NWZ * NWY <= 8), "pipeline shape");
 };
 
 struct ItemCoord {   // all members wave-uniform
@@ -79,9 +81,13 @@ __device__ __forceinline__ void advance_item(ItemCoord& c, const ConvParams& p) 
   ++c.cg;
 }
 
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
-__global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvParams p) {
-  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
+// NLW > 0: LOADER-WAVE mode.  NLW extra waves issue every LDS-DMA of the (item, stage) sequence into a ring of NBUF
+// buffers and the MFMA waves only multiply and store; the two sides meet through LDS counters (no workgroup barrier).
+// Reason (cycle trace of 128 -> 128 @16^3, batch 4): per stage a MFMA wave spent ~2050 cycles ISSUING its share of the
+// next stage's DMA (a VMEM instruction blocks its wave while the memory queue is full) next to ~2250 cycles of MFMAs.
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW, int NBUF>
+__global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(const ConvParams p) {
+  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
   typedef typename Ops<T>::vec8 vec8;
   constexpr int HY = C::HY, HX = C::HX, PLANE = C::PLANE, HALO = C::HALO, NW = C::NW;
   constexpr int WOFF = C::WOFF, CTW = C::CTW, LX = C::LX, LY = C::LY, XT = C::XT, YT = C::YT;
@@ -105,7 +111,11 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
   const int nstage = nchunk / NCH;
   const int T_total = (it1 - it0) * nstage;
   if (T_total <= 0) return;
-  const bool resident = nstage == 1 && ncg == 1;     // weights + bias loaded once per workgroup
+  const bool resident = NLW == 0 && nstage == 1 && ncg == 1;     // weights + bias loaded once per workgroup
+  // DMA work is split over the issuing waves: all NW waves (classic) or the NLW loader waves
+  const int iw = NLW ? wave - NW : wave;
+  constexpr int INW = NLW ? NLW : NW;
+  int dma_count = 0;                                   // DMA instructions this wave issued in the current issue() call
 
   // ---- lane-constant LDS read bases (relative to the pipeline buffer)
   const int wz = wave / NWY, wy = wave % NWY;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
         const int dl2 = lane / C::LXH, hx2 = lane - dl2 * C::LXH;
         int gx2 = (x0 >> 1) - 1 + hx2;
         gx2 = gx2 < 0 ? 0 : (gx2 >= LW ? LW - 1 : gx2);
-        for (int j = wave; j < C::NINSTL; j += NW) {
+        for (int j = iw; j < C::NINSTL; j += INW) {
           const int r = j * C::RRL + dl2;
           const int lz = r / C::LYH, ly = r - lz * C::LYH;
           int gz = (z0 >> 1) - 1 + lz, gy = (y0 >> 1) - 1 + ly;
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
           gy = gy < 0 ? 0 : (gy >= LH ? LH - 1 : gy);
           const char* src = base + gz * sz + gy * sy + gx2 * (int)p.s1x;
           char* dst = buf + k * HALO + j * (C::RRL * C::LXH * 16);   // uniform
+          dma_count += 2;
           if (dl2 < C::RRL && r < C::NROWL) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
@@ -192,25 +203,27 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
         }
       } else if (C::RR == 1) {
         // one halo row per instruction: (z, y) addressing stays on the scalar unit
-        for (int j = wave; j < C::NROW; j += NW) {
+        for (int j = iw; j < C::NROW; j += INW) {
           const int hz = j / HY, hy = j - hz * HY;
           const int gz = reflect_clamp(z0 + hz - 1, p.D) >> sh;
           const int gy = reflect_clamp(y0 + hy - 1, p.H) >> sh;
           const char* row = base + gz * sz + gy * sy;         // uniform
           char* dst = buf + k * HALO + j * (HX * 16);          // uniform LDS row base
+          dma_count += 2;
           if (dma_lane) {
             __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff), (lptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
           }
         }
       } else {
-        for (int j = wave; j < C::NINST; j += NW) {
+        for (int j = iw; j < C::NINST; j += INW) {
           const int r = j * C::RR + dl;
           const int hz = r / HY, hy = r - hz * HY;
           const int gz = reflect_clamp(z0 + hz - 1, p.D) >> sh;
           const int gy = reflect_clamp(y0 + hy - 1, p.H) >> sh;
           const char* src = base + gz * sz + gy * sy + xoff;
           char* dst = buf + k * HALO + j * (C::RR * HX * 16);   // uniform
+          dma_count += 2;
           if (dma_lane && r < C::NROW) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
@@ -222,10 +235,13 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
       // packed weights of these sub-chunks: linear copy, 1 KiB per instruction
       const char* ws = p.wpk + ((long long)it.cg * nchunk + (long long)stage * NCH) * C::WSUB;
       constexpr int NWI = NCH * C::WSUB / 1024;
-      for (int j = wave; j < NWI; j += NW)
+      for (int j = iw; j < NWI; j += INW) {
+        ++dma_count;
         __builtin_amdgcn_global_load_lds((gptr_t)(ws + j * 1024 + lane * 16), (lptr_t)(buf + WOFF + j * 1024), 16,
                                          0, 0);
-      if (wave == NW - 1 && stage == 0 && p.bias) {     // bias rides with the item's first stage
+      }
+      if (iw == INW - 1 && stage == 0 && p.bias) {     // bias rides with the item's first stage
+        ++dma_count;
         if (lane < 4 * Q)
           __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.bias + (it.cg * 16 * Q) * 4 + lane * 16),
                                            (lptr_t)(buf + C::BIASOFF), 16, 0, 0);
@@ -238,6 +254,31 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
       advance_item(nx, p);
     }
   };
+
+  int* ready = (int*)(smem + C::FLAGOFF);
+  int* done = (int*)(smem + C::FLAGOFF + 32);
+  if (NLW) {
+    if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = (tid >= 8 + NW) ? 0x7fffffff : 0;   // absent MFMA waves: "done"
+    __syncthreads();
+    if (wave >= NW) {
+      // ================================ loader wave ================================
+      const unsigned a_ready = lds_addr(ready + iw), a_done = lds_addr(done);
+      for (int t = 0; t < T_total; ++t) {
+        if (t >= NBUF)                                    // buffer t % NBUF is free once every MFMA wave finished step t - NBUF
+          while (__builtin_amdgcn_readfirstlane(flag_min8_asm(a_done)) < t - NBUF + 1) __builtin_amdgcn_s_sleep(1);
+        dma_count = 0;
+        issue(nx, nx_stage, t % NBUF, true);
+        step_next();
+        if (t > 0) {                                      // step t-1 has landed once only step t's DMA is still in flight
+          wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(dma_count));
+          flag_store_asm(a_ready, t);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flag_store_asm(a_ready, T_total);
+      return;
+    }
+  }
 
   // ---- deferred store of a finished item's packed outputs
   unsigned pend[CTW][NPEND];
@@ -296,17 +337,33 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
   } while (0)
 
   AMX_STAMP();
-  issue(nx, nx_stage, 0, true);
-  step_next();
+  if (!NLW) {
+    issue(nx, nx_stage, 0, true);
+    step_next();
+  }
   AMX_STAMP();
   for (int t = 0; t < T_total; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(t) pieces (and older stores) are done
-    AMX_STAMP();
-    __syncthreads();                                   // every wave's DMA(t) landed; buffer (t+1)&1 is free
-    AMX_STAMP();
-    if (t + 1 < T_total && !(p.dbg & 1)) {
-      issue(nx, nx_stage, (t + 1) & 1, !resident);
-      step_next();
+    if (NLW) {
+      while (true) {                                   // every loader's share of step t has landed
+        int m = flag_load(ready);
+#pragma unroll
+        for (int i = 1; i < (NLW ? NLW : 1); ++i) {
+          const int r = flag_load(ready + i);
+          m = r < m ? r : m;
+        }
+        if (m >= t + 1) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(t) pieces (and older stores) are done
+      AMX_STAMP();
+      __syncthreads();                                   // every wave's DMA(t) landed; buffer (t+1)&1 is free
+      AMX_STAMP();
+      if (t + 1 < T_total && !(p.dbg & 1)) {
+        issue(nx, nx_stage, (t + 1) & 1, !resident);
+        step_next();
+      }
     }
     AMX_STAMP();
     if (pending) {                                     // previous item's outputs drain under this sweep
@@ -314,7 +371,7 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
       pending = false;
     }
     AMX_STAMP();
-    const char* buf = smem + (t & 1) * C::BUF;
+    const char* buf = smem + (t % NBUF) * C::BUF;
     const char* wbuf = resident ? smem : buf;          // resident weights/bias live in buffer 0
     if (cu_stage == 0) {
       // accumulators start from the bias (folded norm shift): lane holds channels cb .. cb+4Q-1
@@ -374,6 +431,10 @@ __global__ __launch_bounds__(NWZ* NWY * 64) void conv3d_k3_v2_kernel(const ConvP
       }
     }
     AMX_STAMP();
+    if (NLW) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this stage has returned: the buffer may be refilled
+      flag_store(done + wave, t + 1);
+    }
     if (++cu_stage < nstage) continue;
     cu_stage = 0;
 
@@ -414,12 +475,16 @@ const char* last_conv_v2_kernel_name() { return g_kernel_name2; }
 
 static int g_num_cus = 0;
 
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
 static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
-  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C;
-  snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
-           __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
-  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>;
+  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
+  if (NLW)
+    snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d+l%d,b%d,q%d,nch%d,o%d>",
+             __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, NLW, NBUF, Q, NCH, OUTMODE);
+  else
+    snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
+             __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
+  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -451,7 +516,7 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
     (void)hipMemsetAsync(trace_buf, 0, 1024 * 128 * 8, st);
     p.stats = (float*)trace_buf;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NW * 64), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((C::NW + NLW) * 64), C::LDS_BYTES, st, p);
   if (dbg & 8) {
     static int printed = 0;
     (void)hipStreamSynchronize(st);
@@ -470,27 +535,42 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Loader-wave mode (4 loader waves, ring of 3 buffers) where three stage buffers fit the LDS -- the deep, small levels,
+// whose stages are short: 128 -> 128 @16^3 32 -> 27 us, 384 -> 128 @16^3 66 -> 52 us, 256 -> 256 @8^3 36 -> 30 us at batch 4.
+// With only two buffers the loaders cannot run ahead and the classic barrier pipeline is faster (96 -> 32 @64^3: 202 vs 223 us).
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
+  static int classic = -1;
+  if (classic < 0) classic = getenv("AMX_V2_CLASSIC") ? 1 : 0;
+  typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C0;
+  constexpr bool can = 3 * C0::BUF + 64 <= 160 * 1024 && NWZ * NWY <= 8;
+  if constexpr (can) {
+    if (!classic) return launch_cfg2<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, 4, 3>(p, st);
+  }
+  return launch_cfg2<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>(p, st);
+}
+
 template <typename T, int OUTMODE>
 static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   const int nch = (p.C0 + p.C1) / 16;
   if (p.W >= 32) {
-    if (Q == 1) return launch_cfg2<T, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
-    if (Q == 2) return launch_cfg2<T, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
-    if (OUTMODE == 0 && Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
+    if (Q == 1) return launch_pick<T, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
+    if (Q == 2) return launch_pick<T, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
+    if (OUTMODE == 0 && Q == 4) return launch_pick<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
     return hipErrorInvalidValue;
   }
   if (OUTMODE == 1) return hipErrorInvalidValue;
   if (p.W >= 16) {
-    if (Q == 1) return launch_cfg2<T, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
-    if (Q == 2) return launch_cfg2<T, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);       // brick 4x4x16, 8 waves
-    if (Q == 4) return launch_cfg2<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);
+    if (Q == 1) return launch_pick<T, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
+    if (Q == 2) return launch_pick<T, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);       // brick 4x4x16, 8 waves
+    if (Q == 4) return launch_pick<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);
   }
   if (Q == 1) {
-    if (nch % 2 == 0) return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
-    return launch_cfg2<T, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
+    if (nch % 2 == 0) return launch_pick<T, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
+    return launch_pick<T, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
   }
-  if (Q == 2) return launch_cfg2<T, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
-  if (Q == 4) return launch_cfg2<T, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
+  if (Q == 2) return launch_pick<T, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
+  if (Q == 4) return launch_pick<T, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
 }
 

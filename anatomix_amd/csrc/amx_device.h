@@ -109,4 +109,22 @@ struct WaitVm<PER, -1> {
   static __device__ __forceinline__ void run(int) {}
 };
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n.  The field is 6 bits: n > 63 waits for <= 63 outstanding, which is
+// stricter than asked (vector memory operations of one wave complete in order), hence still correct.
+template <int I>
+struct WaitVmDyn {
+  static __device__ __forceinline__ void run(int n) {
+    if (n >= I) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(I) : "memory");
+    } else {
+      WaitVmDyn<I - 1>::run(n);
+    }
+  }
+};
+template <>
+struct WaitVmDyn<0> {
+  static __device__ __forceinline__ void run(int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) { WaitVmDyn<63>::run(n); }
+
 }  // namespace amx
