@@ -34,8 +34,8 @@ GFLOP_PER_VOLUME_DEV = 1418.75         # SURVEY.md section 8(d), anatomix-dev
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="128^3 windows per step per GPU (sliding-window batch)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
