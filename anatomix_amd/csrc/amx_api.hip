@@ -375,8 +375,13 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       }
       Tensor out;
       out.level = lv; out.C = L.cout;
-      if (L.is_final) {
-        if (c.final_act != AMX_ACT_NONE && stop_at != L.module_idx) p.act = c.final_act;
+      // the fp32 planar epilogues need W >= 32 and <= 32 output channels; outside that the output conv stores 16-bit
+      // channels-last like any other layer and one export pass produces the fp32 NCDHW tensor
+      const bool final_via_export = L.is_final && (dw < 32 || L.cout > 32);
+      if (final_via_export && (wmap || x_offs))
+        return fail(AMX_ERR_SHAPE, "sliding-window accumulation needs roi width >= 32 and output_nc <= 32");
+      if (L.is_final && c.final_act != AMX_ACT_NONE && stop_at != L.module_idx) p.act = c.final_act;
+      if (L.is_final && !final_via_export) {
         p.out32 = y;
         p.pn = ys_n; p.pc = ys_c; p.pz = ys_z; p.py = ys_y;
         p.wmap = wmap;
@@ -460,6 +465,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
                                      L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st));
       }
+      if (final_via_export)
+        AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st));
       if (L.is_final) {
         if (tap_conv)   // contiguous [n][Cout][d][h][w] output (taps are only offered by the plain forward)
           AMX_HIP(hipMemcpyAsync(tap_conv, y, (size_t)n * L.cout * dd * dh * dw * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -140,3 +140,21 @@ def test_in_place_parameter_updates_are_picked_up(device):
         ref = R.forward(x, sd2, KW)
     assert not torch.allclose(y0, y1)
     assert rel_l2(y1, ref) < 1e-3
+
+
+@pytest.mark.parametrize("kw,size", [
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16), (8, 12, 16)),     # W < 32: output through the export pass
+    (dict(dimension=3, input_nc=1, output_nc=64, num_downs=1, ngf=16), (32, 32, 32)),    # more than 32 output channels
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=3, ngf=16, doubleconv=False), (16, 16, 24)),
+])
+def test_small_volumes_and_wide_outputs(device, kw, size):
+    m = anatomix_amd.Unet(**kw)
+    sd = R.synthetic_state_dict(kw, 4)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    x = R.synthetic_input(21, 2, size)
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+        ref = R.forward(x, sd, kw)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 1.5e-3, rel_l2(y, ref)
