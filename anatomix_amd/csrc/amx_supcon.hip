@@ -64,12 +64,20 @@ __global__ __launch_bounds__(256) void sc_gemm_sym_kernel(const float* __restric
   const int i0 = blockIdx.y * BM, c0 = blockIdx.x * BM;
   float acc[4][4] = {};
   for (int k0 = 0; k0 < N; k0 += BK) {
+    // two coalesced passes over the A tile: G[i][k] (k fastest) and G[k][i] (i fastest) -- a single pass with one of the
+    // two index orders reads the other operand with stride N (147 us instead of ~30 for N = 1024)
     for (int t = threadIdx.x; t < BM * BK; t += 256) {
       const int m = t / BK, kk = t % BK;
       const int i = i0 + m, k = k0 + kk;
-      As[kk][m] = (i < N && k < N) ? G[(long long)i * N + k] + G[(long long)k * N + i] : 0.f;
+      As[kk][m] = (i < N && k < N) ? G[(long long)i * N + k] : 0.f;
       const int cc = t % BM, kk2 = t / BM;                 // X tile: row k0 + kk2, columns c0 + cc (coalesced)
       Bs[kk2][cc] = (k0 + kk2 < N && c0 + cc < Cc) ? X[(long long)(k0 + kk2) * Cc + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < BM * BK; t += 256) {
+      const int m = t % BM, kk = t / BM;
+      const int i = i0 + m, k = k0 + kk;
+      if (i < N && k < N) As[kk][m] += G[(long long)k * N + i];
     }
     __syncthreads();
 #pragma unroll

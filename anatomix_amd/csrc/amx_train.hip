@@ -240,21 +240,22 @@ __global__ void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __r
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, char* __restrict__ dxf,
                                     int N, int D, int H, int W, int C, int act, float slope) {
-  const int c8n = C >> 3;
-  const long long vox = (long long)D * H * W, rows = (long long)N * vox, total = rows * c8n;
+  const unsigned c8n = C >> 3;
+  const unsigned vox = (unsigned)D * H * W;                  // launcher guarantees N * vox * c8n < 2^31: 32-bit index math
+  const unsigned rows = (unsigned)N * vox, total = rows * c8n;
   const float invM = 1.f / (float)rows;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c8 = idx % c8n;
-    const long long v = idx / c8n;
-    const int n = v / vox;
-    long long r = v - (long long)n * vox;
-    const int xx0 = r % W;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const unsigned c8 = idx % c8n;
+    const unsigned v = idx / c8n;
+    const unsigned n = v / vox;
+    unsigned r = v - n * vox;
+    const unsigned xx0 = r % W;
     r /= W;
-    const int yy0 = r % H, zz0 = r / H;
+    const unsigned yy0 = r % H, zz0 = r / H;
     float g[8], yy[8], xx[8];
-    t_unpack8<T>(*(const uint4*)(dy + idx * 16), g);
-    t_unpack8<T>(*(const uint4*)(y + idx * 16), yy);
-    t_unpack8<T>(*(const uint4*)(x + idx * 16), xx);
+    t_unpack8<T>(*(const uint4*)(dy + (size_t)idx * 16), g);
+    t_unpack8<T>(*(const uint4*)(y + (size_t)idx * 16), yy);
+    t_unpack8<T>(*(const uint4*)(x + (size_t)idx * 16), xx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = c8 * 8 + e;
@@ -276,13 +277,13 @@ __global__ void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __r
 template <typename T>
 __global__ void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ din, int N, int D, int H, int W, int C,
                                 int accumulate) {
-  const int c8n = C >> 3;
-  const long long vox = (long long)D * H * W, total = (long long)N * vox * c8n;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c8 = idx % c8n;
-    const long long v = idx / c8n;
+  const unsigned c8n = C >> 3;
+  const unsigned vox = (unsigned)D * H * W, total = (unsigned)N * vox * c8n;   // < 2^31 (launcher)
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const unsigned c8 = idx % c8n;
+    const unsigned v = idx / c8n;
     const int n = v / vox;
-    long long r = v - (long long)n * vox;
+    unsigned r = v - (unsigned)n * vox;
     const int x = r % W;
     r /= W;
     const int y = r % H, z = r / H;
@@ -292,7 +293,7 @@ __global__ void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ 
     ey[ny++] = y + 2; if (y == 1) ey[ny++] = 1; if (y == H - 2) ey[ny++] = H + 2;
     ex[nx++] = x + 2; if (x == 1) ex[nx++] = 1; if (x == W - 2) ex[nx++] = W + 2;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (accumulate) t_unpack8<T>(*(const uint4*)(din + idx * 16), acc);
+    if (accumulate) t_unpack8<T>(*(const uint4*)(din + (size_t)idx * 16), acc);
     for (int a = 0; a < nz; ++a)
       for (int b = 0; b < ny; ++b)
         for (int c = 0; c < nx; ++c) {
@@ -302,7 +303,7 @@ __global__ void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[e] += f[e];
         }
-    *(uint4*)(din + idx * 16) = t_pack8<T>(acc);
+    *(uint4*)(din + (size_t)idx * 16) = t_pack8<T>(acc);
   }
 }
 
@@ -379,7 +380,7 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
 hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                                   const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
                                   int C, int act, float slope, void* scratch, int precision, hipStream_t st) {
-  if (C % 8 || C > 2048) return hipErrorInvalidValue;
+  if (C % 8 || C > 2048 || (long long)N * D * H * W * (C / 8) >= (1ll << 31)) return hipErrorInvalidValue;
   const long long rows = (long long)N * D * H * W;
   float* partial = (float*)scratch;
   const int nblk = tr_num_blocks(rows, C), c8n = C / 8, nrow = 256 / c8n;
@@ -400,7 +401,7 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
 
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
                            hipStream_t st) {
-  if (C % 8 || D < 2 || H < 2 || W < 2) return hipErrorInvalidValue;
+  if (C % 8 || D < 2 || H < 2 || W < 2 || (long long)N * D * H * W * (C / 8) >= (1ll << 31)) return hipErrorInvalidValue;
   const int blocks = grid_for((long long)N * D * H * W * (C / 8));
   if (precision == 0)
     hipLaunchKernelGGL(pad_fold_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)g_framed, (char*)din, N, D, H, W, C, accumulate);

@@ -23,20 +23,25 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
     out, feat_kq = netG(reals, list(nce_layers), False)
     pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False)
     total = 0.0
-    per_layer = OrderedDict()
+    layer_losses = []
     for f_kq, sid, crit, layer, w, feat in zip(pooled, ids, criterions, nce_layers, nce_weights, feat_kq):
         loss = crit(f_kq, seg_A, sid, feat.size()[2:])
         total = total + loss.mean() * w * lambda_nce
-        per_layer[str(layer)] = float(loss.mean().item())
+        layer_losses.append(loss.detach().mean())
     (total / grad_accum_iters).backward()
     if grad_sync is not None:
         grad_sync()
     # clip_grad_norm_(max_norm=inf) only measures (supcl_model.py:635-655)
-    gG = nn.utils.clip_grad_norm_(netG.parameters(), max_norm=float("inf"), norm_type=2).item()
-    gF = nn.utils.clip_grad_norm_(netF.parameters(), max_norm=float("inf"), norm_type=2).item()
+    gG = nn.utils.clip_grad_norm_(netG.parameters(), max_norm=float("inf"), norm_type=2)
+    gF = nn.utils.clip_grad_norm_(netF.parameters(), max_norm=float("inf"), norm_type=2)
     if optimizers is not None:
         for opt in optimizers:
             opt.step()
         for opt in optimizers:
             opt.zero_grad()
-    return OrderedDict(loss=float(total.item()), per_layer=per_layer, grad_norm_G=gG, grad_norm_F=gF, sample_ids=ids, out=out)
+    # ONE host synchronisation per step, after everything is enqueued (the reference reads every scalar with .item() as it
+    # goes, supcl_model.py:841; that only paces the host, the values are the same)
+    scalars = torch.stack([total.detach(), gG.detach(), gF.detach()] + layer_losses).tolist()
+    per_layer = OrderedDict((str(layer), v) for layer, v in zip(nce_layers, scalars[3:]))
+    return OrderedDict(loss=scalars[0], per_layer=per_layer, grad_norm_G=scalars[1], grad_norm_F=scalars[2], sample_ids=ids,
+                       out=out)
