@@ -58,6 +58,7 @@ SYMBOLS = {
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
     "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_conv3d_k3_reflect_ex": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "amx_pool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_instance_norm_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_instance_norm": (_I, [_P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _I, _P]),

@@ -13,7 +13,7 @@
 namespace amx {
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st);
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st);
+                               int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0);
 hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
                             const float* conv_bias, float eps, int C, float* scale, float* shift,
                             hipStream_t st);
@@ -809,10 +809,10 @@ size_t amx_conv3d_packed_bytes(int cin, int cout) {
   return bytes;
 }
 
-int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
-                          const float* d_scale, const float* d_shift, int cout, int n, int d, int hh, int w,
-                          int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
-                          void* stream) {
+static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
+                         int cin_real, int cout_real, const float* d_scale, const float* d_shift, int cout, int n, int d,
+                         int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
+                         void* stream) {
   if (!d_x0 || !d_weight || !d_wpk || (!d_out16 == !d_out32)) return fail(AMX_ERR_INVALID, "bad pointer arguments");
   if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16)
     return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
@@ -821,7 +821,9 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
   hipStream_t st = (hipStream_t)stream;
   const int q = amx::conv_pick_q(cout, w);
   if (d_out32 && (q > 2 || w < 32)) return fail(AMX_ERR_INVALID, "fp32 planar output needs cout <= 32 and w >= 32");
-  AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, c0 + c1, c0 + c1, cout, q, precision, st));
+  if (cin_real < 1 || cin_real > c0 + c1 || cout_real < 1 || cout_real > cout || (weight_mode != 0 && weight_mode != 1))
+    return fail(AMX_ERR_INVALID, "bad weight description (mode %d, cin_real %d, cout_real %d)", weight_mode, cin_real, cout_real);
+  AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, cin_real, c0 + c1, cout, q, precision, st, weight_mode, cout_real));
   amx::ConvParams p;
   memset(&p, 0, sizeof p);
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
@@ -841,7 +843,7 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
     p.out32 = d_out32;
     p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
   }
-  if (c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
+  if (weight_mode == 0 && cin_real == 48 && c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
     char* up = (char*)d_wpk + ((size_t)cout * (c0 + c1) * 28 * 2 + 255) / 256 * 256;
     AMX_HIP(amx::launch_pack_upcat16(d_weight, d_scale, up, precision, st));
     p.wpk = up;
@@ -850,6 +852,22 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
   }
   AMX_HIP(amx::launch_conv(p, precision, q, st));
   return AMX_OK;
+}
+
+int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
+                          const float* d_scale, const float* d_shift, int cout, int n, int d, int hh, int w,
+                          int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
+                          void* stream) {
+  return conv3d_single(d_x0, c0, d_x1, c1, d_weight, 0, c0 + c1, cout, d_scale, d_shift, cout, n, d, hh, w, act, slope,
+                       precision, d_wpk, d_out16, d_out32, stream);
+}
+
+int amx_conv3d_k3_reflect_ex(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
+                             int cin_real, int cout_real, const float* d_scale, const float* d_shift, int cout, int n,
+                             int d, int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
+                             float* d_out32, void* stream) {
+  return conv3d_single(d_x0, c0, d_x1, c1, d_weight, weight_mode, cin_real, cout_real, d_scale, d_shift, cout, n, d, hh, w,
+                       act, slope, precision, d_wpk, d_out16, d_out32, stream);
 }
 
 int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout, int c, int avg, int precision,

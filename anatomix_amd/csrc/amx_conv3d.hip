@@ -30,7 +30,7 @@ namespace amx {
 // -------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q) {
+                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal) {
   const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8;
   const int nchunk = CinPad / 16;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -50,7 +50,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     const int cin = chunk * 16 + (g & 1) * 8 + e;
     float v = 0.f;
     if (tap >= 0 && cin < CinReal) {
-      v = w[((long long)cout * CinReal + cin) * 27 + tap];
+      if (mode == 0) {
+        v = w[((long long)cout * CinReal + cin) * 27 + tap];
+      } else if (cout < CoutReal) {
+        // data-gradient weights straight from the forward tensor w[CinReal][CoutReal][27]: taps flipped, channels transposed
+        v = w[((long long)cin * CoutReal + cout) * 27 + (26 - tap)];
+      }
       if (scale) v *= scale[cout];
     }
     wpk[idx] = (T)v;
@@ -155,15 +160,15 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 }
 
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st) {
+                               int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal) {
   const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (precision == 0)
     hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk,
-                       CinReal, CinPad, Cout, Q);
+                       CinReal, CinPad, Cout, Q, mode, CoutReal);
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale,
-                       (bf16*)wpk, CinReal, CinPad, Cout, Q);
+                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal);
   return hipGetLastError();
 }
 

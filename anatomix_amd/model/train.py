@@ -154,7 +154,7 @@ class _UnetTrainFn(torch.autograd.Function):
         def frame(shape, c):
             key = (tuple(shape), c)
             if key not in frames:
-                frames[key] = T.new_framed(shape[0], shape[1], shape[2], shape[3], c, dt, tensors["x"].device)
+                frames[key] = T.shared_framed(shape[0], shape[1], shape[2], shape[3], c, dt, tensors["x"].device)
             return frames[key]
 
         for op in reversed(ctx.ops):

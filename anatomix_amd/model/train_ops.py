@@ -18,33 +18,55 @@ def _st(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+_CACHE = {}
+
+
+def _cached(key, make):
+    """Per-process scratch buffers reused across calls (same stream order => no hazards): packed-weight scratch, the
+    statistics scratch of the norm kernels and the zero-framed gradient buffers."""
+    t = _CACHE.get(key)
+    if t is None:
+        t = _CACHE[key] = make()
+    return t
+
+
 def _scratch(lib, dev, c):
-    return torch.empty(lib.amx_train_scratch_bytes(int(c)), dtype=torch.uint8, device=dev)
+    nbytes = lib.amx_train_scratch_bytes(2048)
+    return _cached(("train_scratch", dev), lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
 
-def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None):
-    """nn.Conv3d(k3, reflect 'same') on cat(x0, nearest_up2(x1)); weight fp32 [Cout, Cin, 3, 3, 3] (Cin may be smaller than
-    the padded channel count of x0 when x1 is None: the stem).  Returns 16-bit NDHWC, or fp32 NCDHW when ``out32``."""
+def _as_weight(weight):
+    w = weight.detach()
+    return w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().contiguous()
+
+
+def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None, weight_mode=0):
+    """nn.Conv3d(k3, reflect 'same') on cat(x0, nearest_up2(x1)).  weight_mode 0: weight fp32 [Cout, Cin, 3, 3, 3] with Cin <=
+    channels of the inputs (the stem's single channel sits in a 16-channel tensor); weight_mode 1: the data-gradient
+    convolution of the conv whose FORWARD weight is ``weight`` [Cin_of_x0, Cout_result, 3,3,3] (flip + transpose happen in
+    the library's packer).  Returns 16-bit NDHWC, or fp32 NCDHW when ``out32``."""
     lib = _lib.load()
     dev = x0.device
     n, d, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[-1]
-    cout, cin = weight.shape[0], weight.shape[1]
-    wt = weight.detach().float()
-    if cin < c0 + c1:                                  # zero-pad the input channels of the weights
-        wt = torch.cat((wt, wt.new_zeros(cout, c0 + c1 - cin, 3, 3, 3)), dim=1)
-    wt = wt.reshape(cout, c0 + c1, 27).contiguous()
+    wt = _as_weight(weight)
+    if weight_mode == 0:
+        cout_real, cin_real = wt.shape[0], wt.shape[1]
+    else:
+        cin_real, cout_real = wt.shape[0], wt.shape[1]
+    cout = (cout_real + 15) // 16 * 16
     with torch.cuda.device(dev):
-        wpk = torch.empty(lib.amx_conv3d_packed_bytes(c0 + c1, cout), dtype=torch.uint8, device=dev)
+        nb = lib.amx_conv3d_packed_bytes(c0 + c1, cout)
+        wpk = _cached(("wpk", dev, nb), lambda: torch.empty(nb, dtype=torch.uint8, device=dev))
         if out32:
             out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=dev)
             o16, o32 = None, out
         else:
             out = torch.empty((n, d, h, w, cout), dtype=x0.dtype, device=dev)
             o16, o32 = out, None
-        _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(wt), None, _lib.ptr(shift), cout, n, d,
-                                             h, w, ACT[act], slope, _PREC[x0.dtype], _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32),
-                                             _st(dev)))
+        _lib.check(lib.amx_conv3d_k3_reflect_ex(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(wt), weight_mode, cin_real, cout_real,
+                                                None, _lib.ptr(shift), cout, n, d, h, w, ACT[act], slope, _PREC[x0.dtype],
+                                                _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), _st(dev)))
     return out
 
 
@@ -68,6 +90,12 @@ def bn_train_forward(x, gamma, beta, eps, act="relu", slope=0.3, running_mean=No
 def new_framed(n, d, h, w, c, dtype, device):
     """Zero-framed gradient buffer [N, D+4, H+4, W+4, C] (frame stays zero; the interior is overwritten by every use)."""
     return torch.zeros((n, d + 4, h + 4, w + 4, c), dtype=dtype, device=device)
+
+
+def shared_framed(n, d, h, w, c, dtype, device):
+    """The framed buffer of this shape shared by all uses in the process: every user overwrites the whole interior and
+    nobody writes the frame, so one buffer per shape serves every layer and every step."""
+    return _cached(("frame", device, n, d, h, w, c, dtype), lambda: new_framed(n, d, h, w, c, dtype, device))
 
 
 def interior(framed):
@@ -95,16 +123,13 @@ def bn_act_backward(dy, y, x, mean, rstd, gamma, act="relu", slope=0.3, framed=N
 
 def conv_dgrad(dx_framed, weight, cin_keep=None, accumulate_into=None):
     """Data gradient of Conv3d(k3, reflect): the forward kernel on the framed output gradient with the flipped, transposed
-    weights, then the reflect-padding adjoint.  weight fp32 [Cout, Cin, 3,3,3]; returns 16-bit [N, D, H, W, Cin_pad16]."""
+    weights (packed straight from the forward tensor), then the reflect-padding adjoint.  weight fp32 [Cout, Cin, 3,3,3];
+    returns 16-bit [N, D, H, W, Cin_pad16]."""
     lib = _lib.load()
     dev = dx_framed.device
     n, df, hf, wf, cout = dx_framed.shape
-    cin = weight.shape[1]
-    cin_pad = (cin + 15) // 16 * 16
-    wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1)          # [Cin, Cout, 3,3,3]
-    if cin_pad != cin:
-        wt = torch.cat((wt, wt.new_zeros(cin_pad - cin, cout, 3, 3, 3)), dim=0)
-    g = conv_forward(dx_framed, None, wt.contiguous())                    # [N, D+4, H+4, W+4, Cin_pad]
+    g = conv_forward(dx_framed, None, weight, weight_mode=1)             # [N, D+4, H+4, W+4, Cin_pad]
+    cin_pad = g.shape[-1]
     d, h, w = df - 4, hf - 4, wf - 4
     din = accumulate_into if accumulate_into is not None else torch.empty((n, d, h, w, cin_pad), dtype=dx_framed.dtype, device=dev)
     with torch.cuda.device(dev):
@@ -125,7 +150,7 @@ def conv_wgrad(dx_framed, x0, x1, cin_real, cout):
     sn, sz, sy, sx, _ = [s * es for s in view.stride()]
     with torch.cuda.device(dev):
         nbytes = lib.amx_conv3d_wgrad_scratch_bytes(n, d, h, w, cout, c0 + c1)
-        sc = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sc = _cached(("wgrad", dev, nbytes), lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
         _lib.check(lib.amx_conv3d_wgrad(ctypes.c_void_p(view.data_ptr()), sn, sz, sy, sx, _lib.ptr(x0), c0, _lib.ptr(x1), c1,
                                         cin_real, cout, n, d, h, w, _lib.ptr(dw), 0, _lib.ptr(sc), nbytes, _PREC[x0.dtype],
                                         _st(dev)))

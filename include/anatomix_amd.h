@@ -166,6 +166,17 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
                           int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
                           float* d_out32, void* stream);
 
+/* The same convolution with a described weight tensor, so that callers need no host-side reshuffling:
+ *   weight_mode 0: d_weight fp32 [cout_real][cin_real][27]; input channels cin_real .. c0+c1-1 and output channels
+ *                  cout_real .. cout-1 are zero padding (the stem: one real input channel in a 16-channel tensor);
+ *   weight_mode 1: DATA-GRADIENT weights taken from the forward tensor d_weight fp32 [cin_real][cout_real][27]
+ *                  (= the forward conv's [Cout][Cin][27]): taps flipped, channels transposed -- run on the zero-framed
+ *                  output gradient and followed by amx_pad_fold it is the adjoint of the forward conv. */
+int amx_conv3d_k3_reflect_ex(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
+                             int cin_real, int cout_real, const float* d_scale, const float* d_shift, int cout, int n,
+                             int d, int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
+                             float* d_out32, void* stream);
+
 /* nn.MaxPool3d(2) / nn.AvgPool3d(2) on a 16-bit NDHWC tensor (network.py:297,368). */
 int amx_pool2(const void* d_in, void* d_out, int n, int d_out_, int h_out, int w_out, int c, int avg,
               int precision, void* stream);
