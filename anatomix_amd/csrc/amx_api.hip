@@ -925,7 +925,7 @@ int amx_conv3d_wgrad(const void* d_dy, long long dy_sn, long long dy_sz, long lo
   if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16 || cin_real < 1 || cin_real > c0 + c1)
     return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
   if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
-  if (d < 2 || hh < 2 || w < 2 || w > 160) return fail(AMX_ERR_SHAPE, "wgrad supports 2 <= w <= 160 (got %d)", w);
+  if (d < 2 || hh < 2 || w < 2 || w > 128) return fail(AMX_ERR_SHAPE, "wgrad supports 2 <= w <= 128 (got %d)", w);
   if (scratch_bytes < amx::wgrad_scratch_bytes(n, d, hh, w, cout, c0 + c1))
     return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes", amx::wgrad_scratch_bytes(n, d, hh, w, cout, c0 + c1));
   amx::WgradParams p;

@@ -7,39 +7,43 @@
 //    segment, exactly as the forward kernels read it).
 //
 // A GEMM whose reduction index is the VOXEL: D[co][ci] += A[co][k] B[k][ci] per tap with k = 32 consecutive x of
-// one row, v_mfma_f32_16x16x32.  Activations are channels-last, so the 8 consecutive k a lane needs are 8 different
-// voxels: fragments are gathered from an LDS tile with 16-bit reads.  Two tricks keep that affordable:
-//   * the three x taps of one (kz, ky) read overlapping windows x-1 .. x+8: 10 values are gathered once and the kx = 1
-//     fragment is formed with four v_alignbit (34 % of the reads of three separate gathers);
-//   * one 32-byte pad slot after every 8 voxels of an LDS row shifts the four k-groups of a fragment onto different
-//     banks (8 voxels x 32 B = 256 B would otherwise alias them).
+// one row, v_mfma_f32_16x16x32.  A lane of an MFMA operand holds 8 consecutive k of ONE channel, but the tensors are
+// channels-last; the tiles are therefore TRANSPOSED when they are staged into LDS ([row][channel][x], two voxels per
+// 32-bit write), after which
+//   * an A fragment (dY) is one ds_read_b128;
+//   * the three x taps of one (kz, ky) come from TWO ds_read_b128 of the halo row (x-1+0 .. +15 in halo coordinates):
+//     kx = 0 is the first block itself, kx = 2 is a register renaming, kx = 1 four v_alignbit;
+//   * a row stride of 136 halves (272 B = 256 + 16) puts the 16 channel rows of a fragment read on 16 different
+//     16-byte bank groups: conflict-free.
+// (First version: channels-last tiles and 16-bit gathers, 98 LDS reads + ~140 VALU per 27 MFMAs -- LDS/VALU bound.)
+// Reflect padding and the nearest upsample of the concat convs are resolved when the tile is staged.
 // Work decomposition: grid (co-tile x ci-tile pairs, spatial chunks).  A workgroup walks its chunk of (n, 4-row tile, z)
-// items (z fastest), staging per item the dY rows and the 3 x 6 halo rows of In (reflect / upsample resolved at staging);
-// its 8 waves split the item's K-blocks, keep 27 accumulators each for the whole chunk, and are summed through LDS
-// at the end.  Partials [chunk][pair][27][16][16] fp32 are then added in chunk order by wgrad_reduce_kernel:
-// deterministic, no atomics.
+// items (z fastest): the 3 input z-planes of an item live in a ring of 4 LDS slots (slot = plane & 3), so a step stages
+// ONE new plane (+ the next dY rows), and those global loads are issued into registers BEFORE the item's MFMA sweep and
+// written to LDS after it (software prefetch; one barrier per item).  Its 8 waves split the item's K-blocks, keep 27
+// accumulators each for the whole chunk, and are summed through LDS at the end.  Partials [chunk][pair][27][16][16]
+// fp32 are then added by wgrad_reduce_kernel with a fixed summation tree: deterministic, no atomics.
 #include "amx_device.h"
 
 namespace amx {
 
 constexpr int WG_TY = 4;
+constexpr int WG_RS = 136;            // LDS row stride in halves: >= W + 8 for W <= 128, and 2 * RS = 16 (mod 256)
 
-__device__ __forceinline__ int padx(int x) { return x + (x >> 3); }
+struct WgUnit {                       // staging unit: two adjacent voxels x 8 channels
+  uint4 a, b;
+};
 
-// RING: the chunk's items march along z at a fixed (n, row tile); the 3 input z-planes of an item live in a ring of 4
-// LDS slots (slot = plane & 3), so a step stages ONE new plane (+ the next dY rows) instead of three, and those global
-// loads are issued into registers BEFORE the item's MFMA sweep and written to LDS after it (software prefetch; one
-// barrier per item).  Needs 4 planes + 2 dY buffers in LDS (W <= 128); otherwise every item is staged cold.
 template <typename T, bool RING>
 __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, int Wp) {
   typedef typename Ops<T>::vec8 vec8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NDB = RING ? 2 : 1;
-  constexpr int NPL = 4, NDY = 2;                                   // prefetch registers per thread (Wp <= 128 when RING)
-  const int PW = padx(Wp) + 1, PWH = padx(Wp + 2) + 2;              // padded row lengths (voxel slots) of dY / In rows
-  const int dy_bytes = WG_TY * PW * 32, plane_bytes = (WG_TY + 2) * PWH * 32;
-  char* dys = smem;                                                 // [NDB][WG_TY][PW][32 B]
-  char* ins = smem + (size_t)NDB * dy_bytes;                        // [RING ? 4 : 3][WG_TY + 2][PWH][32 B]
+  constexpr int RS = WG_RS;
+  constexpr int DY_BYTES = WG_TY * 16 * RS * 2, PLANE_BYTES = (WG_TY + 2) * 16 * RS * 2;
+  constexpr int NPL = 2, NDY = 1;                                   // prefetch units per thread (Wp <= 128)
+  char* dys = smem;                                                 // [NDB][WG_TY][16 co][RS]
+  char* ins = smem + NDB * DY_BYTES;                                // [RING ? 4 : 3][WG_TY + 2][16 ci][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, kg = lane >> 4;
 
@@ -50,33 +54,46 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
   const int ci0 = seg1 ? cit * 16 - p.C0 : cit * 16;
   const int sh = seg1 ? p.up_shift : 0;
 
-  // one 16-byte piece of the dY tile / of one halo plane, by flat index t (rows beyond the volume and x >= W: zero)
-  auto load_dy = [&](int t, int n, int z, int y0) -> uint4 {
-    const int half = t & 1, x = (t >> 1) % Wp, row = (t >> 1) / Wp;
-    if (row < WG_TY && x < p.W && y0 + row < p.H)
-      return *(const uint4*)(p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + row) * p.yy + (long long)x * p.yx +
-                             cot * 32 + half * 16);
-    return make_uint4(0, 0, 0, 0);
-  };
-  auto store_dy = [&](int t, int buf, uint4 v) {
-    const int half = t & 1, x = (t >> 1) % Wp, row = (t >> 1) / Wp;
-    if (row < WG_TY) *(uint4*)(dys + (size_t)buf * dy_bytes + ((size_t)row * PW + padx(x)) * 32 + half * 16) = v;
-  };
-  auto load_pl = [&](int t, int n, int zz, int y0) -> uint4 {       // zz: full-resolution plane index (already reflected)
-    const int half = t & 1, xh = (t >> 1) % (Wp + 2), hr = (t >> 1) / (Wp + 2);
-    if (hr < WG_TY + 2 && xh <= p.W + 1) {
-      const int z2 = zz >> sh, yy = reflect_clamp(y0 + hr - 1, p.H) >> sh, xx = reflect_clamp(xh - 1, p.W) >> sh;
-      const char* src = seg1 ? p.src1 + (long long)n * p.s1n + (long long)z2 * p.s1z + (long long)yy * p.s1y + (long long)xx * p.s1x
-                             : p.src0 + (long long)n * p.s0n + (long long)z2 * p.s0z + (long long)yy * p.s0y + (long long)xx * p.s0x;
-      return *(const uint4*)(src + ci0 * 2 + half * 16);
+  // two 16-byte global loads per unit, eight 32-bit LDS writes (transposed: channel rows, x along the row)
+  const int hwp = Wp / 2, hwh = (Wp + 2) / 2;
+  const int ndy = WG_TY * hwp * 2, npl = (WG_TY + 2) * hwh * 2;
+  auto load_dy = [&](int u, int n, int z, int y0) -> WgUnit {
+    const int half = u & 1, xp = (u >> 1) % hwp, row = (u >> 1) / hwp, x = 2 * xp;
+    WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (u < ndy && y0 + row < p.H) {
+      const char* b = p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + row) * p.yy + cot * 32 + half * 16;
+      if (x < p.W) r.a = *(const uint4*)(b + (long long)x * p.yx);
+      if (x + 1 < p.W) r.b = *(const uint4*)(b + (long long)(x + 1) * p.yx);
     }
-    return make_uint4(0, 0, 0, 0);
+    return r;
   };
-  auto store_pl = [&](int t, int slot, uint4 v) {
-    const int half = t & 1, xh = (t >> 1) % (Wp + 2), hr = (t >> 1) / (Wp + 2);
-    if (hr < WG_TY + 2) *(uint4*)(ins + (size_t)slot * plane_bytes + ((size_t)hr * PWH + padx(xh)) * 32 + half * 16) = v;
+  auto load_pl = [&](int u, int n, int zz, int y0) -> WgUnit {      // zz: full-resolution plane index (already reflected)
+    const int half = u & 1, xp = (u >> 1) % hwh, hr = (u >> 1) / hwh, xh = 2 * xp;
+    WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (u < npl) {
+      const int z2 = zz >> sh, yy = reflect_clamp(y0 + hr - 1, p.H) >> sh;
+      const char* b = seg1 ? p.src1 + (long long)n * p.s1n + (long long)z2 * p.s1z + (long long)yy * p.s1y + ci0 * 2 + half * 16
+                           : p.src0 + (long long)n * p.s0n + (long long)z2 * p.s0z + (long long)yy * p.s0y + ci0 * 2 + half * 16;
+      const long long sx = seg1 ? p.s1x : p.s0x;
+      if (xh <= p.W + 1) r.a = *(const uint4*)(b + (long long)(reflect_clamp(xh - 1, p.W) >> sh) * sx);
+      if (xh + 1 <= p.W + 1) r.b = *(const uint4*)(b + (long long)(reflect_clamp(xh, p.W) >> sh) * sx);
+    }
+    return r;
   };
-  const int ndy = WG_TY * Wp * 2, npl = (WG_TY + 2) * (Wp + 2) * 2;
+  auto store_unit = [&](char* base, int rowc, int x, int half, const WgUnit& v) {   // rowc = tile row; x even
+    const unsigned a[4] = {v.a.x, v.a.y, v.a.z, v.a.w}, b[4] = {v.b.x, v.b.y, v.b.z, v.b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (b[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+      *(unsigned*)(base + ((size_t)(rowc * 16 + half * 8 + e) * RS + x) * 2) = lo | (hi << 16);
+    }
+  };
+  auto store_dy = [&](int u, int buf, const WgUnit& v) {
+    if (u < ndy) store_unit(dys + (size_t)buf * DY_BYTES, (u >> 1) / hwp, 2 * ((u >> 1) % hwp), u & 1, v);
+  };
+  auto store_pl = [&](int u, int slot, const WgUnit& v) {
+    if (u < npl) store_unit(ins + (size_t)slot * PLANE_BYTES, (u >> 1) / hwh, 2 * ((u >> 1) % hwh), u & 1, v);
+  };
 
   f32x4 acc[27];
 #pragma unroll
@@ -97,54 +114,42 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
     const bool cold = !RING || item == item0 || z == 0;
     if (cold) {
       __syncthreads();                                              // previous item's fragments are consumed
-      for (int t = tid; t < ndy; t += 512) store_dy(t, db, load_dy(t, n, z, y0));
+      for (int u = tid; u < ndy; u += 512) store_dy(u, db, load_dy(u, n, z, y0));
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
         if (RING && kz == 2 && slot[2] == slot[0]) continue;        // z = 0 or D-1: the reflected plane is already staged
         const int zz = reflect_clamp(z + kz - 1, p.D);
-        for (int t = tid; t < npl; t += 512) store_pl(t, slot[kz], load_pl(t, n, zz, y0));
+        for (int u = tid; u < npl; u += 512) store_pl(u, slot[kz], load_pl(u, n, zz, y0));
       }
       __syncthreads();
     }
     // ---- prefetch the next item's new data into registers (RING, next item = z + 1 of the same tile)
     const bool has_next = RING && item + 1 < item1 && z + 1 < p.D;
     const bool next_plane = has_next && z + 2 < p.D;
-    uint4 rdy[NDY], rpl[NPL];
+    WgUnit rdy[NDY], rpl[NPL];
     if (has_next) {
 #pragma unroll
-      for (int k = 0; k < NDY; ++k) rdy[k] = tid + k * 512 < ndy ? load_dy(tid + k * 512, n, z + 1, y0) : make_uint4(0, 0, 0, 0);
+      for (int k = 0; k < NDY; ++k) rdy[k] = load_dy(tid + k * 512, n, z + 1, y0);
       if (next_plane)
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) rpl[k] = tid + k * 512 < npl ? load_pl(tid + k * 512, n, z + 2, y0) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < NPL; ++k) rpl[k] = load_pl(tid + k * 512, n, z + 2, y0);
     }
     // ---- K-blocks of this item: (row, xb) -> 32 voxels
-    const char* dyb = dys + (size_t)db * dy_bytes;
+    const char* dyb = dys + (size_t)db * DY_BYTES;
     for (int kb = wave; kb < WG_TY * nxb; kb += 8) {
       const int row = kb / nxb, xb = kb % nxb;
-      const int X0 = xb * 32 + kg * 8;                             // multiple of 8
-      const unsigned short* ap = (const unsigned short*)(dyb + ((size_t)row * PW + padx(X0)) * 32) + m;
-      unsigned a[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = (unsigned)ap[(2 * j) * 16] | ((unsigned)ap[(2 * j + 1) * 16] << 16);
-      const vec8 af = __builtin_bit_cast(vec8, a);
+      const int X0 = xb * 32 + kg * 8;                             // multiple of 8 halves = 16 bytes
+      const vec8 af = *(const vec8*)(dyb + ((size_t)(row * 16 + m) * RS + X0) * 2);
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const unsigned short* bp =
-              (const unsigned short*)(ins + (size_t)slot[kz] * plane_bytes + ((size_t)(row + ky) * PWH + padx(X0)) * 32) + m;
-          // window of 10 halo voxels X0 .. X0 + 9 (= x - 1 .. x + 8); slot of element i: i + (i >> 3)
-          unsigned pk[5];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            const int e0 = 2 * i, e1 = 2 * i + 1;
-            pk[i] = (unsigned)bp[(e0 + (e0 >> 3)) * 16] | ((unsigned)bp[(e1 + (e1 >> 3)) * 16] << 16);
-          }
-          unsigned b0[4] = {pk[0], pk[1], pk[2], pk[3]};                                   // kx = 0: x - 1 ..
-          unsigned b2[4] = {pk[1], pk[2], pk[3], pk[4]};                                   // kx = 2: x + 1 ..
-          unsigned b1[4];                                                                  // kx = 1: x ..
-#pragma unroll
-          for (int i = 0; i < 4; ++i) b1[i] = __builtin_amdgcn_alignbit(pk[i + 1], pk[i], 16);
+          const char* bp = ins + (size_t)slot[kz] * PLANE_BYTES + ((size_t)((row + ky) * 16 + m) * RS + X0) * 2;
+          const uint4 B0 = *(const uint4*)bp, B1 = *(const uint4*)(bp + 16);   // halo x = X0 .. X0 + 15  (= x - 1 ..)
+          const unsigned b0[4] = {B0.x, B0.y, B0.z, B0.w};                       // kx = 0
+          const unsigned b1[4] = {__builtin_amdgcn_alignbit(B0.y, B0.x, 16), __builtin_amdgcn_alignbit(B0.z, B0.y, 16),
+                                  __builtin_amdgcn_alignbit(B0.w, B0.z, 16), __builtin_amdgcn_alignbit(B1.x, B0.w, 16)};   // kx = 1
+          const unsigned b2[4] = {B0.y, B0.z, B0.w, B1.x};                       // kx = 2
           const int t0 = (kz * 3 + ky) * 3;
           acc[t0] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b0), acc[t0]);
           acc[t0 + 1] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
@@ -155,12 +160,10 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
       // slot (z + 2) & 3 and the other dY buffer are not read by this item, and the item that read them last ended with
       // the barrier below
 #pragma unroll
-      for (int k = 0; k < NDY; ++k)
-        if (tid + k * 512 < ndy) store_dy(tid + k * 512, db ^ 1, rdy[k]);
+      for (int k = 0; k < NDY; ++k) store_dy(tid + k * 512, db ^ 1, rdy[k]);
       if (next_plane)
 #pragma unroll
-        for (int k = 0; k < NPL; ++k)
-          if (tid + k * 512 < npl) store_pl(tid + k * 512, (z + 2) & 3, rpl[k]);
+        for (int k = 0; k < NPL; ++k) store_pl(tid + k * 512, (z + 2) & 3, rpl[k]);
       db ^= 1;
       __syncthreads();
     }
@@ -241,14 +244,12 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
   p.partial = (float*)scratch;
   p.nchunk = nchunk; p.items_per_chunk = ipc; p.nitems = nitems; p.nyt = nyt;
   const int Wp = (p.W + 31) / 32 * 32;
-  const int PW = Wp + (Wp >> 3) + 1, PWH = (Wp + 2) + ((Wp + 2) >> 3) + 2;
+  if (Wp > 128) return hipErrorInvalidValue;                       // WG_RS covers W <= 128
+  const size_t dyb = (size_t)WG_TY * 16 * WG_RS * 2, plb = (size_t)(WG_TY + 2) * 16 * WG_RS * 2;
   const size_t red = (size_t)4 * 27 * 64 * 4 * sizeof(float);
-  const size_t lds_ring = ((size_t)2 * WG_TY * PW + (size_t)4 * (WG_TY + 2) * PWH) * 32;
-  const size_t lds_cold = ((size_t)WG_TY * PW + (size_t)3 * (WG_TY + 2) * PWH) * 32;
-  const bool ring = Wp <= 128 && lds_ring <= 160 * 1024 && p.D >= 3;
-  size_t lds = ring ? lds_ring : lds_cold;
+  const bool ring = p.D >= 3;
+  size_t lds = ring ? 2 * dyb + 4 * plb : dyb + 3 * plb;
   if (lds < red) lds = red;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;              // W <= ~160
   const int npairs = (p.Cout / 16) * (CinPad / 16);
 #define AMX_WG(T, R)                                                                                                         \
   {                                                                                                                          \

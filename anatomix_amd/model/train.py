@@ -35,8 +35,8 @@ def unsupported_reason(model, x, layers):
     if x.dim() != 5 or x.shape[1] != 1 or not x.is_cuda:
         return "expected a CUDA input of shape [N, 1, D, H, W]"
     m = 1 << c["num_downs"]
-    if any(s % m or (s >> c["num_downs"]) < 2 for s in x.shape[2:]) or x.shape[4] < 32 or x.shape[4] > 156:
-        return "spatial dims must be divisible by 2^num_downs, >= 2 at the bottleneck, 32 <= W <= 156"
+    if any(s % m or (s >> c["num_downs"]) < 2 for s in x.shape[2:]) or x.shape[4] < 32 or x.shape[4] > 128:
+        return "spatial dims must be divisible by 2^num_downs, >= 2 at the bottleneck, 32 <= W <= 128"
     if any(isinstance(mod, nn.BatchNorm3d) and not mod.training for mod in model.model):
         # the reference can freeze the statistics of single layers (pretraining/models/base_model.py:175-184)
         return "BatchNorm layers switched to eval inside a train-mode network are not implemented in the HIP training path"
