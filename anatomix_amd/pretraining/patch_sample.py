@@ -76,10 +76,19 @@ class PatchSampleF(nn.Module):
                     if mask is not None:
                         m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
                         fg = torch.where(m > 0)[2:]
-                    else:       # every voxel of the grid, in C order (what torch.where of an all-ones mask enumerates)
-                        fg = torch.unravel_index(torch.arange(feat[0, 0].numel(), device=feat.device), feat.shape[2:])
-                    perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
-                    coords = torch.stack([f[perm] for f in fg], dim=1)
+                        perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
+                        coords = torch.stack([f[perm] for f in fg], dim=1)
+                    else:
+                        # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
+                        # unravelling of k, computed arithmetically (no host round trip: the step can be graph-captured)
+                        nvox = feat[0, 0].numel()
+                        flat = torch.randperm(nvox, device=feat.device)[: int(min(num_patches, nvox))]
+                        dims = list(feat.shape[2:])
+                        cs = []
+                        for a in range(ndims - 1, -1, -1):
+                            cs.append(flat % dims[a])
+                            flat = torch.div(flat, dims[a], rounding_mode="floor")
+                        coords = torch.stack(cs[::-1], dim=1)
                 idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
                 x_sample = feat[idx]                                   # [views, C, P]
             else:
