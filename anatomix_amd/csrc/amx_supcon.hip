@@ -56,28 +56,34 @@ __global__ __launch_bounds__(256) void sc_gemm_nt_kernel(const float* __restrict
     }
 }
 
-// D[i][c] = scale * sum_k (G[i][k] + G[k][i]) * X[k][c]   (G: N x N, X: N x Cc)
+// D[z][i][c] = scale * sum over the z-th quarter of k of (G[i][k] + G[k][i]) * X[k][c]   (G: N x N, X: N x Cc).
+// The output is only N x Cc (1024 x 256 = 64 tiles): the reduction is split four ways over blockIdx.z so that 256
+// workgroups run; sc_dnorm_kernel adds the four partials in order.
+constexpr int SC_KSPLIT = 4;
 __global__ __launch_bounds__(256) void sc_gemm_sym_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                          float* __restrict__ Dm, int N, int Cc, float scale) {
   __shared__ float As[BK][BM + 4], Bs[BK][BM + 4];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int i0 = blockIdx.y * BM, c0 = blockIdx.x * BM;
+  const int kper = ((N + SC_KSPLIT - 1) / SC_KSPLIT + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.z * kper, kend = kbeg + kper < N ? kbeg + kper : N;
+  Dm += (size_t)blockIdx.z * N * Cc;
   float acc[4][4] = {};
-  for (int k0 = 0; k0 < N; k0 += BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     // two coalesced passes over the A tile: G[i][k] (k fastest) and G[k][i] (i fastest) -- a single pass with one of the
     // two index orders reads the other operand with stride N (147 us instead of ~30 for N = 1024)
     for (int t = threadIdx.x; t < BM * BK; t += 256) {
       const int m = t / BK, kk = t % BK;
       const int i = i0 + m, k = k0 + kk;
-      As[kk][m] = (i < N && k < N) ? G[(long long)i * N + k] : 0.f;
+      As[kk][m] = (i < N && k < kend) ? G[(long long)i * N + k] : 0.f;
       const int cc = t % BM, kk2 = t / BM;                 // X tile: row k0 + kk2, columns c0 + cc (coalesced)
-      Bs[kk2][cc] = (k0 + kk2 < N && c0 + cc < Cc) ? X[(long long)(k0 + kk2) * Cc + c0 + cc] : 0.f;
+      Bs[kk2][cc] = (k0 + kk2 < kend && c0 + cc < Cc) ? X[(long long)(k0 + kk2) * Cc + c0 + cc] : 0.f;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < BM * BK; t += 256) {
       const int m = t % BM, kk = t / BM;
       const int i = i0 + m, k = k0 + kk;
-      if (i < N && k < N) As[kk][m] += G[(long long)k * N + i];
+      if (i < N && k < kend) As[kk][m] += G[(long long)k * N + i];
     }
     __syncthreads();
 #pragma unroll
@@ -229,29 +235,35 @@ __global__ __launch_bounds__(256) void sc_reduce_kernel(const float* __restrict_
 // one block per row: dx = (dxn - xn (xn . dxn)) * inv   (the clamp max(|x|, eps) is inactive for any non-degenerate row;
 // for |x| < eps PyTorch's normalize has zero gradient through the clamp: dx = dxn / eps)
 __global__ __launch_bounds__(256) void sc_dnorm_kernel(const float* __restrict__ xn, const float* __restrict__ dxn,
-                                                      const float* __restrict__ inv, float* __restrict__ dx, int C) {
+                                                      const float* __restrict__ inv, float* __restrict__ dx, int C, int N) {
   __shared__ float red[4];
   const int i = blockIdx.x;
+  auto dval = [&](int c) {                                 // the four k-quarters of sc_gemm_sym_kernel, in order
+    float d = 0.f;
+#pragma unroll
+    for (int z = 0; z < SC_KSPLIT; ++z) d += dxn[((size_t)z * N + i) * C + c];
+    return d;
+  };
   float s = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) s += xn[(long long)i * C + c] * dxn[(long long)i * C + c];
+  for (int c = threadIdx.x; c < C; c += 256) s += xn[(long long)i * C + c] * dval(c);
   s = block_sum(s, red);
   const float r = inv[i];
   const bool clamped = r >= 0.99e8f;
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float d = dxn[(long long)i * C + c];
+    const float d = dval(c);
     dx[(long long)i * C + c] = clamped ? d * r : (d - xn[(long long)i * C + c] * s) * r;
   }
 }
 
 size_t supcon_scratch_bytes(int N, int C) {
-  return ((size_t)2 * N * C + (size_t)N * N + (size_t)4 * N + 64) * sizeof(float);
+  return ((size_t)(1 + SC_KSPLIT) * N * C + (size_t)N * N + (size_t)4 * N + 64) * sizeof(float);
 }
 
 hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
                          int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st) {
   float* xn = (float*)scratch;
   float* dxn = xn + (size_t)N * C;
-  float* S = dxn + (size_t)N * C;
+  float* S = dxn + (size_t)SC_KSPLIT * N * C;
   float* inv = S + (size_t)N * N;
   float* cnt = inv + N;
   float* rowloss = cnt + N;
@@ -265,9 +277,9 @@ hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, flo
   hipLaunchKernelGGL(sc_rows_kernel, dim3(N), blk, 0, st, S, labels, cnt, wsum, rowloss, N, rarity, balance, sqrt_mode);
   hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), blk, 0, st, rowloss, loss, N);
   if (grad) {
-    hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM), blk, 0, st, S, xn, dxn, N, C,
+    hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM, SC_KSPLIT), blk, 0, st, S, xn, dxn, N, C,
                        1.f / temperature);
-    hipLaunchKernelGGL(sc_dnorm_kernel, dim3(N), blk, 0, st, xn, dxn, inv, grad, C);
+    hipLaunchKernelGGL(sc_dnorm_kernel, dim3(N), blk, 0, st, xn, dxn, inv, grad, C, N);
   }
   return hipGetLastError();
 }

@@ -234,76 +234,81 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   dgamma[c] = (float)b;
 }
 
-// dx into the interior of the framed buffer [N][D+4][H+4][W+4][C]
+// dx into the interior of the framed buffer [N][D+4][H+4][W+4][C].  One block per (n, z, y) row: the row decomposition
+// is scalar, the per-channel coefficients dx = a dz + b x + k (a = gamma rstd, b = -gamma rstd^2 dgamma / M,
+// k = -a dbeta / M - b mean) are formed once per block in LDS, a thread only splits its index into (x, 8-channel group).
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ y, const char* __restrict__ x,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, char* __restrict__ dxf,
-                                    int N, int D, int H, int W, int C, int act, float slope) {
-  const unsigned c8n = C >> 3;
-  const unsigned vox = (unsigned)D * H * W;                  // launcher guarantees N * vox * c8n < 2^31: 32-bit index math
-  const unsigned rows = (unsigned)N * vox, total = rows * c8n;
-  const float invM = 1.f / (float)rows;
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const unsigned c8 = idx % c8n;
-    const unsigned v = idx / c8n;
-    const unsigned n = v / vox;
-    unsigned r = v - n * vox;
-    const unsigned xx0 = r % W;
-    r /= W;
-    const unsigned yy0 = r % H, zz0 = r / H;
-    float g[8], yy[8], xx[8];
-    t_unpack8<T>(*(const uint4*)(dy + (size_t)idx * 16), g);
-    t_unpack8<T>(*(const uint4*)(y + (size_t)idx * 16), yy);
-    t_unpack8<T>(*(const uint4*)(x + (size_t)idx * 16), xx);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ y,
+                                                          const char* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                          char* __restrict__ dxf, int N, int D, int H, int W, int C, int act,
+                                                          float slope) {
+  extern __shared__ float coef[];                            // [C][3]
+  const float invM = 1.f / ((float)N * D * H * W);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 1.f, b = 0.f, k = 0.f;
+    if (mean) {
+      a = (gamma ? gamma[c] : 1.f) * rstd[c];
+      b = -a * rstd[c] * dgamma[c] * invM;
+      k = -a * dbeta[c] * invM - b * mean[c];
+    }
+    coef[3 * c] = a; coef[3 * c + 1] = b; coef[3 * c + 2] = k;
+  }
+  __syncthreads();
+  const int row = blockIdx.x;                                // (n * D + z) * H + y
+  const int yy0 = row % H, zz0 = (row / H) % D, n = row / (H * D);
+  const int c8n = C >> 3, per_row = W * c8n;
+  const size_t in_off = (size_t)row * W * C * 2;
+  const size_t out_off = ((((size_t)n * (D + 4) + zz0 + 2) * (H + 4) + yy0 + 2) * (W + 4) + 2) * C * 2;
+  for (int i = threadIdx.x; i < per_row; i += 256) {
+    const int c8 = i % c8n;
+    float g[8], yv[8], xv[8];
+    t_unpack8<T>(*(const uint4*)(dy + in_off + (size_t)i * 16), g);
+    t_unpack8<T>(*(const uint4*)(y + in_off + (size_t)i * 16), yv);
+    if (mean) t_unpack8<T>(*(const uint4*)(x + in_off + (size_t)i * 16), xv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c8 * 8 + e;
       float dz = g[e];
-      if (act == ACT_RELU) dz = yy[e] > 0.f ? dz : 0.f;
-      else if (act == ACT_LRELU) dz = yy[e] > 0.f ? dz : dz * slope;
-      if (mean) {
-        const float xh = (xx[e] - mean[c]) * rstd[c];
-        dz = (gamma ? gamma[c] : 1.f) * rstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
-      }
-      g[e] = dz;
+      if (act == ACT_RELU) dz = yv[e] > 0.f ? dz : 0.f;
+      else if (act == ACT_LRELU) dz = yv[e] > 0.f ? dz : dz * slope;
+      const float* q = coef + 3 * (c8 * 8 + e);
+      g[e] = mean ? q[0] * dz + q[1] * xv[e] + q[2] : dz;
     }
-    const long long fo = ((((long long)n * (D + 4) + zz0 + 2) * (H + 4) + yy0 + 2) * (W + 4) + xx0 + 2) * C + c8 * 8;
-    *(uint4*)(dxf + fo * 2) = t_pack8<T>(g);
+    *(uint4*)(dxf + out_off + (size_t)i * 16) = t_pack8<T>(g);     // i = x * c8n + c8: the row is contiguous in the frame too
   }
 }
 
 // ---------------------------------------------------------------- reflect-padding adjoint
+// one block per output row (n, z, y): the z / y source lists are scalar, only the x list depends on the thread
 template <typename T>
-__global__ void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ din, int N, int D, int H, int W, int C,
-                                int accumulate) {
-  const unsigned c8n = C >> 3;
-  const unsigned vox = (unsigned)D * H * W, total = (unsigned)N * vox * c8n;   // < 2^31 (launcher)
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const unsigned c8 = idx % c8n;
-    const unsigned v = idx / c8n;
-    const int n = v / vox;
-    unsigned r = v - (unsigned)n * vox;
-    const int x = r % W;
-    r /= W;
-    const int y = r % H, z = r / H;
-    // framed coordinate e = padded coordinate j + 2; voxel i collects j = i, j = -1 (if i == 1), j = L (if i == L-2)
-    int ez[3], ey[3], ex[3], nz = 0, ny = 0, nx = 0;
-    ez[nz++] = z + 2; if (z == 1) ez[nz++] = 1; if (z == D - 2) ez[nz++] = D + 2;
-    ey[ny++] = y + 2; if (y == 1) ey[ny++] = 1; if (y == H - 2) ey[ny++] = H + 2;
+__global__ __launch_bounds__(256) void pad_fold_kernel(const char* __restrict__ gf, char* __restrict__ din, int N, int D, int H,
+                                                      int W, int C, int accumulate) {
+  const int row = blockIdx.x;
+  const int y = row % H, z = (row / H) % D, n = row / (H * D);
+  // framed coordinate e = padded coordinate j + 2; voxel i collects j = i, j = -1 (if i == 1), j = L (if i == L-2)
+  int ez[3], ey[3], nz = 0, ny = 0;
+  ez[nz++] = z + 2; if (z == 1) ez[nz++] = 1; if (z == D - 2) ez[nz++] = D + 2;
+  ey[ny++] = y + 2; if (y == 1) ey[ny++] = 1; if (y == H - 2) ey[ny++] = H + 2;
+  const int c8n = C >> 3, per_row = W * c8n;
+  char* orow = din + (size_t)row * W * C * 2;
+  for (int i = threadIdx.x; i < per_row; i += 256) {
+    const int c8 = i % c8n, x = i / c8n;
+    int ex[3], nx = 0;
     ex[nx++] = x + 2; if (x == 1) ex[nx++] = 1; if (x == W - 2) ex[nx++] = W + 2;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (accumulate) t_unpack8<T>(*(const uint4*)(din + (size_t)idx * 16), acc);
+    if (accumulate) t_unpack8<T>(*(const uint4*)(orow + (size_t)i * 16), acc);
     for (int a = 0; a < nz; ++a)
-      for (int b = 0; b < ny; ++b)
+      for (int b = 0; b < ny; ++b) {
+        const char* frow = gf + ((((size_t)n * (D + 4) + ez[a]) * (H + 4) + ey[b]) * (W + 4)) * C * 2 + c8 * 16;
         for (int c = 0; c < nx; ++c) {
           float f[8];
-          const long long o = ((((long long)n * (D + 4) + ez[a]) * (H + 4) + ey[b]) * (W + 4) + ex[c]) * C + c8 * 8;
-          t_unpack8<T>(*(const uint4*)(gf + o * 2), f);
+          t_unpack8<T>(*(const uint4*)(frow + (size_t)ex[c] * C * 2), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[e] += f[e];
         }
-    *(uint4*)(din + (size_t)idx * 16) = t_pack8<T>(acc);
+      }
+    *(uint4*)(orow + (size_t)i * 16) = t_pack8<T>(acc);
   }
 }
 
@@ -385,15 +390,15 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
   float* partial = (float*)scratch;
   const int nblk = tr_num_blocks(rows, C), c8n = C / 8, nrow = 256 / c8n;
   const size_t lds = (size_t)nrow * C * 2 * sizeof(float);
-  const int blocks = grid_for(rows * c8n);
 #define AMX_BNB(T)                                                                                                       \
   if (mean) {                                                                                                            \
     hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)dy, (const char*)y,          \
                        (const char*)x, mean, rstd, partial, rows, C, act, slope);                                        \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, C, nblk, dgamma, dbeta);    \
   }                                                                                                                      \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)dy, (const char*)y,            \
-                     (const char*)x, mean, rstd, gamma, dgamma, dbeta, (char*)dx_framed, N, D, H, W, C, act, slope)
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)(N * D * H)), dim3(256), (size_t)C * 3 * sizeof(float), st,  \
+                     (const char*)dy, (const char*)y, (const char*)x, mean, rstd, gamma, dgamma, dbeta, (char*)dx_framed, N, D, H, \
+                     W, C, act, slope)
   if (precision == 0) { AMX_BNB(f16); } else { AMX_BNB(bf16); }
 #undef AMX_BNB
   return hipGetLastError();
@@ -402,7 +407,7 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
                            hipStream_t st) {
   if (C % 8 || D < 2 || H < 2 || W < 2 || (long long)N * D * H * W * (C / 8) >= (1ll << 31)) return hipErrorInvalidValue;
-  const int blocks = grid_for((long long)N * D * H * W * (C / 8));
+  const unsigned blocks = (unsigned)(N * D * H);
   if (precision == 0)
     hipLaunchKernelGGL(pad_fold_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)g_framed, (char*)din, N, D, H, W, C, accumulate);
   else
