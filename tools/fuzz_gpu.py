@@ -1,0 +1,84 @@
+"""Randomised parity sweep on the GPU: single convs (amx_conv3d_k3_reflect) and whole networks against the CPU references.
+usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+import sys, os, time, random, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import anatomix_amd
+from _util import run_conv, ref_conv, ref_conv_upcat_merged, rel_l2
+from oracle import unet_ref as R
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+nconv = nnet = nfail = 0
+devnull = open(os.devnull, "w")
+while time.time() < t_end:
+    try:
+        if rng.random() < 0.6:
+            prec = rng.choice(["f16", "bf16"])
+            up = rng.random() < 0.35
+            c0 = rng.choice([16, 32, 48, 64, 128]); c1 = rng.choice([16, 32, 64, 128]) if up else 0
+            cout = rng.choice([16, 32, 48, 64, 96, 128])
+            if up:
+                size = tuple(2 * rng.randint(1, m) for m in (6, 8, 20))
+            else:
+                size = tuple(rng.randint(2, m) for m in (12, 16, 40))
+            n = rng.randint(1, 3)
+            act = rng.choice([0, 1, 2])
+            g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+            x0 = torch.randn(n, c0, *size, generator=g)
+            x1 = torch.randn(n, c1, *[s // 2 for s in size], generator=g) if up else None
+            w = torch.randn(cout, c0 + c1, 3, 3, 3, generator=g) / (27 * (c0 + c1)) ** 0.5
+            scale = (0.5 + torch.rand(cout, generator=g)) if rng.random() < 0.5 else None
+            shift = torch.randn(cout, generator=g) * 0.1 if rng.random() < 0.7 else None
+            planar = (cout <= 32 and size[2] >= 32 and rng.random() < 0.3)
+            y = run_conv(dev, x0, x1, w, scale, shift, act, prec, planar=planar)
+            merged = up and c0 == 16 and c1 == 32 and cout == 16 and size[2] >= 32 and size[1] >= 8 and size[0] >= 4
+            r = (ref_conv_upcat_merged if merged else ref_conv)(x0, x1, w, scale, shift, act, prec)
+            tol = (2.0 ** -11 if prec == "f16" else 2.0 ** -8) * (0.02 if planar else 1.0) + 2e-6
+            e = rel_l2(y, r)
+            nconv += 1
+            if not (e < tol) or torch.isnan(y).any():
+                nfail += 1
+                print("CONV FAIL", dict(prec=prec, c0=c0, c1=c1, cout=cout, size=size, n=n, act=act, planar=planar, scale=scale is not None), "rel_l2", e)
+        else:
+            nd = rng.randint(1, 3)
+            kw = dict(dimension=3, input_nc=1, output_nc=rng.choice([16, 32]), num_downs=nd, ngf=rng.choice([16, 32]),
+                      norm=rng.choice(["batch", "batch", "instance", "instance_affine", "none"]), activation=rng.choice(["relu", "lrelu"]),
+                      pooling=rng.choice(["Max", "Avg"]), interp=rng.choice(["nearest", "trilinear"]),
+                      doubleconv=rng.random() < 0.8, use_skip_connection=rng.random() < 0.85)
+            if kw["norm"] != "batch":
+                kw["norm_eps"] = 1e-2
+            mul = 1 << nd
+            size = tuple(mul * rng.randint(2 if a < 2 else max(2, 32 // mul), 6 if a < 2 else max(3, 64 // mul)) for a in range(3))
+            so, sys.stdout = sys.stdout, devnull
+            m = anatomix_amd.Unet(**kw)
+            sys.stdout = so
+            sd = R.synthetic_state_dict(kw, rng.randint(0, 99))
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).eval()
+            x = R.synthetic_input(rng.randint(0, 999), rng.randint(1, 2), size)
+            nmod = len(m.model)
+            layers = sorted(rng.sample(range(nmod), rng.randint(0, 4)))
+            with torch.no_grad():
+                if layers:
+                    y, feats = m(x.to(dev), layers)
+                    ry, rfeats = R.forward(x, sd, kw, layers=layers)
+                else:
+                    y, feats, rfeats = m(x.to(dev)), [], []
+                    ry = R.forward(x, sd, kw)
+                rl = R.forward_lowp(x, sd, kw, torch.float16)
+            e_ref, e_emu = rel_l2(y.cpu(), ry), rel_l2(rl, ry)
+            nnet += 1
+            ok = e_ref < max(2.5 * e_emu, 2e-3) and all(a.shape == b.shape for a, b in zip(feats, rfeats))
+            for l, a, b in zip(layers, feats, rfeats):
+                ok = ok and rel_l2(a.cpu(), b) < max(4 * e_emu, 4e-3)
+            if not ok:
+                nfail += 1
+                print("NET FAIL", kw, size, layers, "e_ref", e_ref, "e_emul", e_emu, [rel_l2(a.cpu(), b) for a, b in zip(feats, rfeats)])
+    except Exception as ex:
+        nfail += 1
+        print("EXCEPTION", type(ex).__name__, str(ex)[:300])
+        traceback.print_exc(limit=2)
+print(f"fuzz: {nconv} convs, {nnet} networks, {nfail} failures in {budget:.0f} s")
