@@ -11,11 +11,62 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-nconv = nnet = nfail = 0
+nconv = nnet = nbwd = nfail = 0
+import torch.nn.functional as F
+from anatomix_amd.model import train_ops as T
+
+
+def cl(x, dt):
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(dt).to(dev)
+
+
+def ncdhw(x):
+    return x.detach().cpu().double().permute(0, 4, 1, 2, 3).contiguous()
 devnull = open(os.devnull, "w")
 while time.time() < t_end:
     try:
-        if rng.random() < 0.6:
+        pick = rng.random()
+        if pick < 0.2:
+            # ---- conv backward: weight gradient + data gradient against torch autograd (double, rounded operands)
+            dt = rng.choice([torch.bfloat16, torch.float16])
+            up = rng.random() < 0.4
+            c0 = rng.choice([16, 32, 64]); c1 = rng.choice([16, 32, 64]) if up else 0
+            cin = 1 if (not up and rng.random() < 0.15) else c0 + c1
+            cout = rng.choice([16, 32, 64])
+            size = tuple(2 * rng.randint(1, m) for m in (5, 7, 30)) if up else tuple(rng.randint(2, m) for m in (9, 13, 70))
+            n = rng.randint(1, 2)
+            g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+            if cin == 1:
+                c0 = 16
+            x0 = torch.randn(n, c0 if cin != 1 else 1, *size, generator=g)
+            x1 = torch.randn(n, c1, *[s // 2 for s in size], generator=g) if up else None
+            w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+            dy = torch.randn(n, cout, *size, generator=g)
+            xq = x0.to(dt).double().requires_grad_(True)
+            lq = x1.to(dt).double().requires_grad_(True) if up else None
+            wq = w.to(dt).double().requires_grad_(True)
+            inp = torch.cat((xq, F.interpolate(lq, scale_factor=2, mode="nearest")), 1) if up else xq
+            F.conv3d(F.pad(inp, (1,) * 6, mode="reflect"), wq).backward(dy.to(dt).double())
+            xd = torch.zeros((n, *size, c0), dtype=dt, device=dev)
+            xd[..., : x0.shape[1]] = cl(x0, dt)
+            ld = cl(x1, dt) if up else None
+            fr = T.new_framed(n, *size, cout, dt, dev)
+            T.interior(fr).copy_(cl(dy, dt))
+            dw = T.conv_wgrad(fr, xd, ld, cin, cout)
+            din = ncdhw(T.conv_dgrad(fr, w.to(dev)))
+            ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+            e_w = rel_l2(dw.cpu().double(), wq.grad)
+            e_x = rel_l2(din[:, : x0.shape[1]], xq.grad)
+            ok = e_w < 2e-5 and e_x < 2 * ulp
+            if up:
+                lo = [s // 2 for s in size]
+                dl = din[:, c0:].reshape(n, c1, lo[0], 2, lo[1], 2, lo[2], 2).sum((3, 5, 7))
+                ok = ok and rel_l2(dl, lq.grad) < 2 * ulp
+            nbwd += 1
+            if not ok:
+                nfail += 1
+                print("BWD FAIL", dict(dt=str(dt), c0=c0, c1=c1, cin=cin, cout=cout, size=size, n=n), "e_w", e_w, "e_x", e_x)
+        elif pick < 0.65:
             prec = rng.choice(["f16", "bf16"])
             up = rng.random() < 0.35
             c0 = rng.choice([16, 32, 48, 64, 128]); c1 = rng.choice([16, 32, 64, 128]) if up else 0
@@ -81,4 +132,4 @@ while time.time() < t_end:
         nfail += 1
         print("EXCEPTION", type(ex).__name__, str(ex)[:300])
         traceback.print_exc(limit=2)
-print(f"fuzz: {nconv} convs, {nnet} networks, {nfail} failures in {budget:.0f} s")
+print(f"fuzz: {nconv} convs, {nbwd} conv backwards, {nnet} networks, {nfail} failures in {budget:.0f} s")
