@@ -58,6 +58,15 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
 size_t supcon_scratch_bytes(int N, int C);
 hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
                          int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st);
+size_t mindssc_scratch_bytes(int H, int W, int D);
+hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int dilation, float* out, void* scratch,
+                          hipStream_t st);
+hipError_t launch_pool_cat(const float* a, int ca, float sa, const float* b, int cb, float sb, int H, int W, int D, int g,
+                           float* out, hipStream_t st);
+hipError_t launch_box_filter(const float* in, float* out, int C, int H, int W, int D, int k, hipStream_t st);
+size_t correlate_scratch_bytes(int h, int w, int d, int disp_hw);
+hipError_t launch_correlate(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, float* ssd,
+                            long long* argmin, void* scratch, hipStream_t st);
 }  // namespace amx
 
 namespace {
@@ -971,6 +980,48 @@ int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int h
                             void* stream) {
   if (!d_in || !d_out || c % 8 || n < 1 || din < 1 || hin < 1 || win < 1) return fail(AMX_ERR_INVALID, "bad argument");
   AMX_HIP(amx::launch_upsample2_trilinear(d_in, d_out, n, din, hin, win, c, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_mindssc_scratch_bytes(int H, int W, int D) { return amx::mindssc_scratch_bytes(H, W, D); }
+
+int amx_mindssc(const float* d_img, int H, int W, int D, int radius, int dilation, float* d_out, void* d_scratch,
+                size_t scratch_bytes, void* stream) {
+  if (!d_img || !d_out || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
+  if (H < 1 || W < 1 || D < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  if (radius < 1 || radius > 2 || dilation < 1) return fail(AMX_ERR_INVALID, "radius in {1, 2}, dilation >= 1 (got %d, %d)", radius, dilation);
+  if (scratch_bytes < amx::mindssc_scratch_bytes(H, W, D))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx::mindssc_scratch_bytes(H, W, D), scratch_bytes);
+  AMX_HIP(amx::launch_mindssc(d_img, H, W, D, radius, dilation, d_out, d_scratch, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_avg_pool3d_cat(const float* d_a, int ca, float scale_a, const float* d_b, int cb, float scale_b, int H, int W, int D,
+                       int g, float* d_out, void* stream) {
+  if (!d_out || (ca > 0 && !d_a) || (cb > 0 && !d_b) || ca < 0 || cb < 0 || ca + cb < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  if (g < 1 || H < g || W < g || D < g) return fail(AMX_ERR_SHAPE, "pool size %d does not fit (%d,%d,%d)", g, H, W, D);
+  AMX_HIP(amx::launch_pool_cat(d_a, ca, scale_a, d_b, cb, scale_b, H, W, D, g, d_out, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_box_filter3d(const float* d_in, float* d_out, int c, int H, int W, int D, int k, void* stream) {
+  if (!d_in || !d_out || d_in == d_out || c < 1 || c > 65535) return fail(AMX_ERR_INVALID, "bad argument");
+  if (H < 1 || W < 1 || D < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  if (k < 3 || k > 9 || !(k & 1)) return fail(AMX_ERR_INVALID, "kernel size must be odd in [3, 9] (got %d)", k);
+  AMX_HIP(amx::launch_box_filter(d_in, d_out, c, H, W, D, k, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_correlate_scratch_bytes(int h, int w, int d, int disp_hw) { return amx::correlate_scratch_bytes(h, w, d, disp_hw); }
+
+int amx_correlate_ssd(const float* d_fix, const float* d_mov, int c, int h, int w, int d, int disp_hw, float* d_ssd,
+                      long long* d_argmin, void* d_scratch, size_t scratch_bytes, void* stream) {
+  if (!d_fix || !d_mov || !d_ssd || !d_scratch || c < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  if (h < 1 || w < 1 || d < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  if (disp_hw < 1 || disp_hw > 3) return fail(AMX_ERR_INVALID, "disp_hw in {1, 2, 3} (got %d)", disp_hw);
+  if (scratch_bytes < amx::correlate_scratch_bytes(h, w, d, disp_hw))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx::correlate_scratch_bytes(h, w, d, disp_hw), scratch_bytes);
+  AMX_HIP(amx::launch_correlate(d_fix, d_mov, c, h, w, d, disp_hw, d_ssd, d_argmin, d_scratch, (hipStream_t)stream));
   return AMX_OK;
 }
 

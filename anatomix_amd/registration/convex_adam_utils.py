@@ -1,14 +1,18 @@
-"""Feature-extraction front end of the registration pipeline with the surface of
-``anatomix.registration.convex_adam_utils`` (reference lines 16-78, 134-221): model loading,
-min-max normalisation and the sliding-window feature extraction of the fixed / moving volumes.
-The rest of that reference module (MIND-SSC, correlation volume, coupled-convex solver, Jacobian
-utilities) is downstream of the UNet path and out of scope here.
+"""Feature side of the registration pipeline with the surface of ``anatomix.registration.convex_adam_utils``:
+model loading, min-max normalisation and sliding-window feature extraction (reference lines 16-78, 134-221), and the
+feature post-processing that runs on the extracted tensors before the convex optimisation -- ``MINDSSC`` (:311-406),
+``apply_avg_pool3d`` (:105-131) and the SSD correlation volume ``correlate`` (:409-491) -- on the HIP kernels of
+``csrc/amx_regfeat.hip``.  The solver itself (coupled_convex, inverse_consistency, the Adam instance optimisation,
+Jacobian utilities) is downstream of the feature path and not part of this package.
 """
 from __future__ import annotations
+
+import ctypes
 
 import numpy as np
 import torch
 
+from .. import _lib
 from ..model.load_from_hf import ANATOMIX_VARIANTS, _load_handling_compile
 from ..model.network import Unet
 from .sliding_window import sliding_window_inference
@@ -54,3 +58,88 @@ def extract_features(img_fixed, img_moving, model, fixminclip=None, fixmaxclip=N
             outs.append(sliding_window_inference(im, (128, 128, 128), 2, model, overlap=0.8, mode="gaussian",
                                                  sigma_scale=0.25, group=group))
     return outs[0], outs[1]
+
+
+# ---- feature post-processing on the HIP kernels (fp32, batch 1, like the reference's tensors) -------------------------
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _f32c(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the registration feature kernels run on the GPU (got a {t.device} tensor); there is no CPU path")
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def MINDSSC(img, radius=2, dilation=2):
+    """convex_adam_utils.py:311-406.  img [1, 1, H, W, D] -> MIND-SSC descriptor [1, 12, H, W, D] (fp32).  Unlike the
+    reference there is no host synchronisation: the global mean used for the variance clamp (:389-393) stays on the GPU."""
+    if img.dim() != 5 or img.shape[0] != 1 or img.shape[1] != 1:
+        raise ValueError(f"MINDSSC expects [1, 1, H, W, D] (got {tuple(img.shape)})")
+    lib = _lib.load()
+    x = _f32c(img, "MINDSSC")
+    _, _, h, w, d = x.shape
+    out = torch.empty((1, 12, h, w, d), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nb = lib.amx_mindssc_scratch_bytes(h, w, d)
+        sc = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.amx_mindssc(_lib.ptr(x), h, w, d, int(radius), int(dilation), _lib.ptr(out), _lib.ptr(sc), nb,
+                                   _stream(x.device)))
+    return out
+
+
+def apply_avg_pool3d(disp_hr, kernel_size, num_repeats):
+    """convex_adam_utils.py:105-131: ``num_repeats`` x F.avg_pool3d(kernel_size, padding=kernel_size // 2, stride=1).
+    disp_hr [1, C, H, W, D] (forward only: the instance optimisation's autograd use of this function is outside the
+    feature path)."""
+    if disp_hr.dim() != 5 or disp_hr.shape[0] != 1:
+        raise ValueError(f"apply_avg_pool3d expects [1, C, H, W, D] (got {tuple(disp_hr.shape)})")
+    if disp_hr.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("apply_avg_pool3d on the HIP kernels is forward-only")
+    lib = _lib.load()
+    x = _f32c(disp_hr, "apply_avg_pool3d")
+    _, c, h, w, d = x.shape
+    with torch.cuda.device(x.device):
+        for _ in range(int(num_repeats)):
+            y = torch.empty_like(x)
+            _lib.check(lib.amx_box_filter3d(_lib.ptr(x), _lib.ptr(y), c, h, w, d, int(kernel_size), _stream(x.device)))
+            x = y
+    return x
+
+
+def smooth_merged_features(mind, pred, grid_sp, downscale_feat_scalar=0.1):
+    """``F.avg_pool3d(cat([mind, pred * downscale_feat_scalar], 1), grid_sp, stride=grid_sp)`` in one pass
+    (run_convex_adam_with_network_feats.py:164-205 + instance_optimization.py:111-117) without materialising the scaled
+    copy and the 28-channel concat at full resolution.  mind [1, 12, H, W, D] or None, pred [1, C, H, W, D]."""
+    lib = _lib.load()
+    b = _f32c(pred, "smooth_merged_features")
+    a = None if mind is None else _f32c(mind, "smooth_merged_features")
+    _, cb, h, w, d = b.shape
+    ca = 0 if a is None else a.shape[1]
+    g = int(grid_sp)
+    out = torch.empty((1, ca + cb, h // g, w // g, d // g), dtype=torch.float32, device=b.device)
+    with torch.cuda.device(b.device):
+        _lib.check(lib.amx_avg_pool3d_cat(_lib.ptr(a), ca, 1.0, _lib.ptr(b), cb, float(downscale_feat_scalar), h, w, d, g,
+                                          _lib.ptr(out), _stream(b.device)))
+    return out
+
+
+def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12):
+    """convex_adam_utils.py:409-491.  mind_fix, mind_mov [1, ch, H/grid_sp, W/grid_sp, D/grid_sp] ->
+    (ssd [(2 disp_hw + 1)^3, h, w, d], ssd_argmin int64 [h, w, d])."""
+    lib = _lib.load()
+    f = _f32c(mind_fix, "correlate")
+    m = _f32c(mind_mov, "correlate")
+    h, w, d = int(shape[0]) // grid_sp, int(shape[1]) // grid_sp, int(shape[2]) // grid_sp
+    if tuple(f.shape) != (1, ch, h, w, d) or tuple(m.shape) != tuple(f.shape):
+        raise ValueError(f"correlate: features {tuple(f.shape)} / {tuple(m.shape)} do not match (1, {ch}, {h}, {w}, {d})")
+    k = 2 * int(disp_hw) + 1
+    ssd = torch.empty((k ** 3, h, w, d), dtype=torch.float32, device=f.device)
+    amin = torch.empty((h, w, d), dtype=torch.int64, device=f.device)
+    with torch.cuda.device(f.device):
+        nb = lib.amx_correlate_scratch_bytes(h, w, d, int(disp_hw))
+        sc = torch.empty(nb, dtype=torch.uint8, device=f.device)
+        _lib.check(lib.amx_correlate_ssd(_lib.ptr(f), _lib.ptr(m), ch, h, w, d, int(disp_hw), _lib.ptr(ssd), _lib.ptr(amin),
+                                         _lib.ptr(sc), nb, _stream(f.device)))
+    return ssd, amin

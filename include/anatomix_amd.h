@@ -245,6 +245,36 @@ int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, floa
                     int balance_denominator, int sqrt_mode, float* d_loss, float* d_grad, void* d_scratch,
                     size_t scratch_bytes, void* stream);
 
+/* ---- registration feature post-processing (what the reference does to the extracted features before the convex
+ * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */
+
+/* MINDSSC(img, radius, dilation) (anatomix/registration/convex_adam_utils.py:311-406): d_img fp32 [H][W][D] ->
+ * d_out fp32 [12][H][W][D], channels in the reference's final (permuted) order.  radius in {1, 2}, dilation >= 1.
+ * d_scratch: amx_mindssc_scratch_bytes(H, W, D).  The global mean the descriptor variance is clamped against
+ * (`mind_var.mean().item()`, :389-393) stays on the device: no host synchronisation. */
+size_t amx_mindssc_scratch_bytes(int H, int W, int D);
+int amx_mindssc(const float* d_img, int H, int W, int D, int radius, int dilation, float* d_out, void* d_scratch,
+                size_t scratch_bytes, void* stream);
+
+/* F.avg_pool3d(cat(scale_a * a, scale_b * b), g, stride=g) in one pass: the `pred * downscale_feat_scalar`,
+ * merge_features' concat (instance_optimization.py:111-117) and the grid_sp pooling of
+ * run_convex_adam_with_network_feats.py:164-205.  d_a fp32 [ca][H][W][D] (may be NULL with ca == 0), d_b [cb][H][W][D];
+ * d_out [ca + cb][H/g][W/g][D/g] (floor division like avg_pool3d). */
+int amx_avg_pool3d_cat(const float* d_a, int ca, float scale_a, const float* d_b, int cb, float scale_b, int H, int W, int D,
+                       int g, float* d_out, void* stream);
+
+/* One pass of apply_avg_pool3d (convex_adam_utils.py:105-131): F.avg_pool3d(x, k, padding=k/2, stride=1), zero padding
+ * counted in the divisor.  d_in, d_out fp32 [c][H][W][D], distinct buffers; k odd, 3 <= k <= 9. */
+int amx_box_filter3d(const float* d_in, float* d_out, int c, int H, int W, int D, int k, void* stream);
+
+/* correlate(mind_fix, mind_mov, disp_hw, ...) (convex_adam_utils.py:409-491): d_fix, d_mov fp32 [c][h][w][d] (the pooled
+ * features) -> d_ssd fp32 [(2 disp_hw + 1)^3][h][w][d] (twice box-filtered sum of squared differences, displacement
+ * index (dx * k + dy) * k + dz as the reference's view/transpose/reshape leaves it) and d_argmin int64 [h][w][d]
+ * (nullable).  disp_hw in {1, 2, 3}.  d_scratch: amx_correlate_scratch_bytes(h, w, d, disp_hw). */
+size_t amx_correlate_scratch_bytes(int h, int w, int d, int disp_hw);
+int amx_correlate_ssd(const float* d_fix, const float* d_mov, int c, int h, int w, int d, int disp_hw, float* d_ssd,
+                      long long* d_argmin, void* d_scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
