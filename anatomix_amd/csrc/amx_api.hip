@@ -989,7 +989,8 @@ int amx_mindssc(const float* d_img, int H, int W, int D, int radius, int dilatio
                 size_t scratch_bytes, void* stream) {
   if (!d_img || !d_out || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
   if (H < 1 || W < 1 || D < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
-  if (radius < 1 || radius > 2 || dilation < 1) return fail(AMX_ERR_INVALID, "radius in {1, 2}, dilation >= 1 (got %d, %d)", radius, dilation);
+  if (radius < 1 || radius > 2 || dilation < 1 || dilation > 4)
+    return fail(AMX_ERR_INVALID, "radius in {1, 2}, dilation in [1, 4] (got %d, %d)", radius, dilation);
   if (scratch_bytes < amx::mindssc_scratch_bytes(H, W, D))
     return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx::mindssc_scratch_bytes(H, W, D), scratch_bytes);
   AMX_HIP(amx::launch_mindssc(d_img, H, W, D, radius, dilation, d_out, d_scratch, (hipStream_t)stream));

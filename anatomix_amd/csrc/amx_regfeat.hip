@@ -20,61 +20,72 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > h
 
 // One 8 x 8 x 16 brick per block, 4 voxels per thread.  Per pair c: the squared difference field on the brick + R halo
 // goes to LDS (sampled with replication at the volume border, twice: once for the dilated samples, once for the box
-// filter -- exactly the two ReplicationPad3d of the reference), then every thread box-sums its voxels.  The 12 sums wait
-// in LDS; the epilogue subtracts the per-voxel minimum, writes the unnormalised descriptor and reduces the
+// filter -- exactly the two ReplicationPad3d of the reference), then every thread box-sums its voxels.  The 12 sums stay
+// in registers; the epilogue subtracts the per-voxel minimum, writes the unnormalised descriptor and reduces the
 // per-voxel channel mean for the global mean the reference clamps against.
 template <int R>
-__global__ __launch_bounds__(256) void mind_ssd_kernel(const float* __restrict__ img, int H, int W, int D, MindPairs mp,
+__global__ __launch_bounds__(256) void mind_ssd_kernel(const float* __restrict__ img, int H, int W, int D, int dil, MindPairs mp,
                                                        float* __restrict__ out, double* __restrict__ partials) {
   constexpr int TZ = 8, TY = 8, TX = 16, HZ = TZ + 2 * R, HY = TY + 2 * R, HX = TX + 2 * R, HXP = HX + 1;
   constexpr int K = 2 * R + 1;
-  __shared__ float d2[HZ * HY * HXP];
+  extern __shared__ float lds[];
+  // image brick with an (R + dil) halo, holding I(clamp(coordinate)): one global load + clamp per point, once
+  const int G = R + dil, IZ = TZ + 2 * G, IY = TY + 2 * G, IX = TX + 2 * G, IXP = IX | 1;
+  float* it = lds;                                   // [IZ][IY][IXP]
+  float* d2 = it + IZ * IY * IXP;                    // [HZ][HY][HXP]
   __shared__ double red[256];
   const int bx = blockIdx.x * TX, by = blockIdx.y * TY, bz = blockIdx.z * TZ;
-  const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) & 7, tz = threadIdx.x >> 7;
-  __shared__ float ssd[12][4 * 256];   // [pair][voxel of the brick]: LDS rather than a dynamically indexed register array
-#pragma unroll 1
+  const int tx = threadIdx.x & 15, ty = (threadIdx.x >> 4) & 7, tz = (threadIdx.x >> 7) * 4;   // 4 consecutive z per thread
+  for (int t = threadIdx.x; t < IZ * IY * IX; t += 256) {
+    const int ix = t % IX, iy = (t / IX) % IY, iz = t / (IX * IY);
+    it[(iz * IY + iy) * IXP + ix] =
+        img[((long long)clampi(bz + iz - G, H - 1) * W + clampi(by + iy - G, W - 1)) * D + clampi(bx + ix - G, D - 1)];
+  }
+  __syncthreads();
+  float ssd[12][4];                                  // box sums of this thread's voxels (c is unrolled: static indices)
+#pragma unroll
   for (int c = 0; c < 12; ++c) {
+    const int oa = (mp.a[c][0] * IY + mp.a[c][1]) * IXP + mp.a[c][2], ob = (mp.b[c][0] * IY + mp.b[c][1]) * IXP + mp.b[c][2];
+#pragma unroll 1
     for (int t = threadIdx.x; t < HZ * HY * HX; t += 256) {
       const int hx = t % HX, hy = (t / HX) % HY, hz = t / (HX * HY);
-      const int z = clampi(bz + hz - R, H - 1), y = clampi(by + hy - R, W - 1), x = clampi(bx + hx - R, D - 1);
-      const float va = img[((long long)clampi(z + mp.a[c][0], H - 1) * W + clampi(y + mp.a[c][1], W - 1)) * D + clampi(x + mp.a[c][2], D - 1)];
-      const float vb = img[((long long)clampi(z + mp.b[c][0], H - 1) * W + clampi(y + mp.b[c][1], W - 1)) * D + clampi(x + mp.b[c][2], D - 1)];
-      const float df = va - vb;
+      // the box filter replicates the DIFFERENCE field at the volume border: evaluate it at the clamped position
+      const int z = clampi(bz + hz - R, H - 1) - bz + G, y = clampi(by + hy - R, W - 1) - by + G, x = clampi(bx + hx - R, D - 1) - bx + G;
+      const int base = (z * IY + y) * IXP + x;
+      const float df = it[base + oa] - it[base + ob];
       d2[(hz * HY + hy) * HXP + hx] = df * df;
     }
     __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int v = 0; v < 4; ++v) {
-      const int lz = tz + 2 * v;
-      float s = 0.f;
-#pragma unroll 1
-      for (int kz = 0; kz < K; ++kz)
+    for (int hz = 0; hz < 4 + 2 * R; ++hz) {          // K x K plane sums, each shared by the K outputs it belongs to
+      float ps = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky)
+      for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) s += d2[((lz + kz) * HY + ty + ky) * HXP + tx + kx];
-      ssd[c][v * 256 + threadIdx.x] = s / (float)(K * K * K);
+        for (int kx = 0; kx < K; ++kx) ps += d2[((tz + hz) * HY + ty + ky) * HXP + tx + kx];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (hz >= o && hz < o + K) acc[o] += ps;
     }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) ssd[c][o] = acc[o] / (float)(K * K * K);
     __syncthreads();
   }
   const long long plane = (long long)H * W * D;
   double vsum = 0.0;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    const int z = bz + tz + 2 * v, y = by + ty, x = bx + tx;
+    const int z = bz + tz + v, y = by + ty, x = bx + tx;
     if (z >= H || y >= W || x >= D) continue;
-    float sv[12];
+    float mn = ssd[0][v];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) sv[c] = ssd[c][v * 256 + threadIdx.x];
-    float mn = sv[0];
-#pragma unroll
-    for (int c = 1; c < 12; ++c) mn = fminf(mn, sv[c]);
+    for (int c = 1; c < 12; ++c) mn = fminf(mn, ssd[c][v]);
     float sum = 0.f;
     const long long o = ((long long)z * W + y) * D + x;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
-      const float m = sv[c] - mn;
+      const float m = ssd[c][v] - mn;
       sum += m;
       out[(long long)mp.slot[c] * plane + o] = m;
     }
@@ -143,29 +154,43 @@ __global__ __launch_bounds__(256) void pool_cat_kernel(const float* __restrict__
   }
 }
 
-// avg_pool3d(k, stride 1, padding k/2), zero padding counted in the divisor
+// avg_pool3d(k, stride 1, padding k/2), zero padding counted in the divisor.  4 x 8 x 64 outputs per block from an LDS
+// brick with an r halo (zeros outside the volume); each thread owns two (y, x) columns and walks z with k x k plane sums
+// shared by the k outputs they contribute to.
 __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
                                                          int W, int D, int k) {
+  constexpr int TZ = 4, TY = 8, TX = 64;
+  extern __shared__ float lds[];
+  const int r = k / 2, HZ = TZ + 2 * r, HY = TY + 2 * r, HX = TX + 2 * r, HXP = HX | 1;
   const long long plane = (long long)H * W * D;
-  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (o >= plane) return;
-  const int x = (int)(o % D), y = (int)((o / D) % W), z = (int)(o / ((long long)D * W));
+  const int nbx = (D + TX - 1) / TX, nby = (W + TY - 1) / TY;
+  const int bx = (blockIdx.x % nbx) * TX, by = ((blockIdx.x / nbx) % nby) * TY, bz = (blockIdx.x / (nbx * nby)) * TZ;
   const float* src = in + (long long)blockIdx.y * plane;
-  const int r = k / 2;
-  float s = 0.f;
-  for (int kz = -r; kz <= r; ++kz) {
-    const int zz = z + kz;
-    if (zz < 0 || zz >= H) continue;
-    for (int ky = -r; ky <= r; ++ky) {
-      const int yy = y + ky;
-      if (yy < 0 || yy >= W) continue;
-      for (int kx = -r; kx <= r; ++kx) {
-        const int xx = x + kx;
-        if (xx >= 0 && xx < D) s += src[((long long)zz * W + yy) * D + xx];
-      }
-    }
+  for (int t = threadIdx.x; t < HZ * HY * HX; t += 256) {
+    const int hx = t % HX, hy = (t / HX) % HY, hz = t / (HX * HY);
+    const int z = bz + hz - r, y = by + hy - r, x = bx + hx - r;
+    lds[(hz * HY + hy) * HXP + hx] = (z >= 0 && z < H && y >= 0 && y < W && x >= 0 && x < D) ? src[((long long)z * W + y) * D + x] : 0.f;
   }
-  out[(long long)blockIdx.y * plane + o] = s / (float)(k * k * k);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+  const float div = (float)(k * k * k);
+  for (int yy = 0; yy < 2; ++yy) {
+    const int ty = ty0 + 4 * yy;
+    float acc[TZ] = {0.f, 0.f, 0.f, 0.f};
+    for (int hz = 0; hz < HZ; ++hz) {
+      float ps = 0.f;
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) ps += lds[(hz * HY + ty + ky) * HXP + tx + kx];
+#pragma unroll
+      for (int o = 0; o < TZ; ++o)
+        if (hz >= o && hz < o + k) acc[o] += ps;
+    }
+    const int y = by + ty, x = bx + tx;
+    if (y < W && x < D)
+#pragma unroll
+      for (int o = 0; o < TZ; ++o)
+        if (bz + o < H) out[(long long)blockIdx.y * plane + ((long long)(bz + o) * W + y) * D + x] = acc[o] / div;
+  }
 }
 
 // raw SSD: blockIdx.y = dz.  ssd[(dx*K + dy)*K + dz][p] = sum_c (fix[c][p] - mov0[c][p + (dz,dy,dx) - hw])^2, mov zero outside
@@ -260,8 +285,13 @@ hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int
   const int nb = grid.x * grid.y * grid.z;
   double* partials = (double*)scratch;
   float* gm = (float*)((char*)scratch + (size_t)nb * sizeof(double));
-  if (radius == 1) mind_ssd_kernel<1><<<grid, 256, 0, st>>>(img, H, W, D, mp, out, partials);
-  else mind_ssd_kernel<2><<<grid, 256, 0, st>>>(img, H, W, D, mp, out, partials);
+  const int G = radius + dilation, HR = 2 * radius;
+  const size_t lds = ((size_t)(8 + 2 * G) * (8 + 2 * G) * ((16 + 2 * G) | 1) + (size_t)(8 + HR) * (8 + HR) * (16 + HR + 1)) * 4;
+  if (lds > 150 * 1024) return hipErrorInvalidValue;   // dilation too large for the LDS brick (checked by the caller)
+  auto kern = radius == 1 ? mind_ssd_kernel<1> : mind_ssd_kernel<2>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  kern<<<grid, 256, lds, st>>>(img, H, W, D, dilation, mp, out, partials);
   const long long plane = (long long)H * W * D;
   mind_mean_kernel<<<1, 256, 0, st>>>(partials, nb, 1.0 / (double)plane, gm);
   mind_finish_kernel<<<cdiv_i(plane, 256), 256, 0, st>>>(out, plane, mp, gm);
@@ -275,9 +305,14 @@ hipError_t launch_pool_cat(const float* a, int ca, float sa, const float* b, int
   return hipGetLastError();
 }
 
+static inline dim3 box_grid(int C, int H, int W, int D) { return dim3(cdiv_i(D, 64) * cdiv_i(W, 8) * cdiv_i(H, 4), C); }
+static inline size_t box_lds(int k) {
+  const int r = k / 2;
+  return (size_t)(4 + 2 * r) * (8 + 2 * r) * ((64 + 2 * r) | 1) * 4;
+}
+
 hipError_t launch_box_filter(const float* in, float* out, int C, int H, int W, int D, int k, hipStream_t st) {
-  const long long plane = (long long)H * W * D;
-  box_filter_kernel<<<dim3(cdiv_i(plane, 256), C), 256, 0, st>>>(in, out, H, W, D, k);
+  box_filter_kernel<<<box_grid(C, H, W, D), 256, box_lds(k), st>>>(in, out, H, W, D, k);
   return hipGetLastError();
 }
 
@@ -295,8 +330,8 @@ hipError_t launch_correlate(const float* fix, const float* mov, int C, int h, in
   if (disp_hw == 1) ssd_raw_kernel<3><<<grid, 256, 0, st>>>(fix, mov, C, h, w, d, ssd);
   else if (disp_hw == 2) ssd_raw_kernel<5><<<grid, 256, 0, st>>>(fix, mov, C, h, w, d, ssd);
   else ssd_raw_kernel<7><<<grid, 256, 0, st>>>(fix, mov, C, h, w, d, ssd);
-  box_filter_kernel<<<dim3(cdiv_i(plane, 256), n), 256, 0, st>>>(ssd, tmp, h, w, d, 3);
-  box_filter_kernel<<<dim3(cdiv_i(plane, 256), n), 256, 0, st>>>(tmp, ssd, h, w, d, 3);
+  box_filter_kernel<<<box_grid(n, h, w, d), 256, box_lds(3), st>>>(ssd, tmp, h, w, d, 3);
+  box_filter_kernel<<<box_grid(n, h, w, d), 256, box_lds(3), st>>>(tmp, ssd, h, w, d, 3);
   if (argmin) argmin_kernel<<<cdiv_i(plane, 256), 256, 0, st>>>(ssd, n, plane, argmin);
   return hipGetLastError();
 }

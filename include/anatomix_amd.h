@@ -249,7 +249,7 @@ int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, floa
  * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */
 
 /* MINDSSC(img, radius, dilation) (anatomix/registration/convex_adam_utils.py:311-406): d_img fp32 [H][W][D] ->
- * d_out fp32 [12][H][W][D], channels in the reference's final (permuted) order.  radius in {1, 2}, dilation >= 1.
+ * d_out fp32 [12][H][W][D], channels in the reference's final (permuted) order.  radius in {1, 2}, dilation in [1, 4].
  * d_scratch: amx_mindssc_scratch_bytes(H, W, D).  The global mean the descriptor variance is clamped against
  * (`mind_var.mean().item()`, :389-393) stays on the device: no host synchronisation. */
 size_t amx_mindssc_scratch_bytes(int H, int W, int D);

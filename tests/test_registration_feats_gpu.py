@@ -67,7 +67,8 @@ def test_ragged_sizes_against_oracle():
         img = rs.rand(*shape).astype(np.float32)
         for radius, dil in ((1, 2), (2, 2), (1, 1), (2, 3)):
             got = MINDSSC(cu(img)[None, None], radius, dil)[0].cpu().numpy()
-            assert np.abs(got - RR.mindssc(img, radius, dil)).max() < 1e-5, (shape, radius, dil)
+            # white noise: ssd - min(ssd) cancels most of the 125-term box sums, whose summation order differs
+            assert np.abs(got - RR.mindssc(img, radius, dil)).max() < 5e-5, (shape, radius, dil)
     feats = rs.randn(5, 13, 10, 21).astype(np.float32)
     for g in (1, 2, 3):
         got = smooth_merged_features(None, cu(feats)[None], g, 0.1)[0].cpu().numpy()
