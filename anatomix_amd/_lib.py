@@ -74,6 +74,9 @@ SYMBOLS = {
                               _I, _P, _I, _P, C.c_size_t, _I, _P]),
     "amx_supcon_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_supcon_loss": (_I, [_P, _P, _I, _I, C.c_float, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
+    "amx_mlp_head_forward": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, C.c_float, _P, _P, _P, _P, _P]),
+    "amx_mlp_head_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
+    "amx_mlp_head_backward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "amx_mindssc_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_mindssc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "amx_avg_pool3d_cat": (_I, [_P, _I, C.c_float, _P, _I, C.c_float, _I, _I, _I, _I, _P, _P]),

@@ -58,6 +58,14 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
 size_t supcon_scratch_bytes(int N, int C);
 hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
                          int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st);
+hipError_t launch_mlp_layer_forward(const float* x, int n, int k, const float* w, int m, const float* gamma, const float* beta,
+                                    float eps, int act, float slope, float* z, float* y, float* mean, float* rstd, float* rmean,
+                                    float* rvar, float momentum, hipStream_t st);
+hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                                     const float* gamma, int act, float slope, const float* x, const float* w, int n, int k,
+                                     int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
+                                     hipStream_t st);
+size_t mlp_backward_scratch_floats(int n, int cin, int width);
 size_t mindssc_scratch_bytes(int H, int W, int D);
 hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int dilation, float* out, void* scratch,
                           hipStream_t st);
@@ -1023,6 +1031,58 @@ int amx_correlate_ssd(const float* d_fix, const float* d_mov, int c, int h, int 
   if (scratch_bytes < amx::correlate_scratch_bytes(h, w, d, disp_hw))
     return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx::correlate_scratch_bytes(h, w, d, disp_hw), scratch_bytes);
   AMX_HIP(amx::launch_correlate(d_fix, d_mov, c, h, w, d, disp_hw, d_ssd, d_argmin, d_scratch, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+static int mlp_check(int n, int cin, int width, int n_layers) {
+  if (n < 1 || n > 2048) return fail(AMX_ERR_SHAPE, "mlp head: 1 <= n <= 2048 rows (got %d)", n);
+  if (cin < 4 || cin % 4 || width < 8 || width % 8) return fail(AMX_ERR_SHAPE, "mlp head: cin %% 4 == 0 and width %% 8 == 0 (got %d, %d)", cin, width);
+  if (cin > 4096 || width > 4096) return fail(AMX_ERR_SHAPE, "mlp head: at most 4096 features per layer (got %d, %d)", cin, width);
+  if (n_layers < 1 || n_layers > 8) return fail(AMX_ERR_INVALID, "mlp head: 1 <= n_layers <= 8 (got %d)", n_layers);
+  return AMX_OK;
+}
+
+int amx_mlp_head_forward(const float* d_x, int n, int cin, int width, int n_layers, const float* const* w,
+                         const float* const* gamma, const float* const* beta, float* const* running_mean,
+                         float* const* running_var, float eps, float momentum, int act, float slope, float* d_z, float* d_y,
+                         float* d_mean, float* d_rstd, void* stream) {
+  if (!d_x || !w || !gamma || !beta || !running_mean || !running_var || !d_z || !d_y || !d_mean || !d_rstd)
+    return fail(AMX_ERR_INVALID, "null argument");
+  if (int rc = mlp_check(n, cin, width, n_layers)) return rc;
+  if (act != AMX_ACT_NONE && act != AMX_ACT_RELU && act != AMX_ACT_LRELU) return fail(AMX_ERR_INVALID, "unsupported activation");
+  const size_t plane = (size_t)n * width;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!w[l] || (!gamma[l] != !beta[l]) || (!running_mean[l] != !running_var[l])) return fail(AMX_ERR_INVALID, "layer %d: bad parameter pointers", l);
+    AMX_HIP(amx::launch_mlp_layer_forward(l ? d_y + (l - 1) * plane : d_x, n, l ? width : cin, w[l], width, gamma[l], beta[l], eps,
+                                          l + 1 < n_layers ? act : AMX_ACT_NONE, slope, d_z + l * plane, d_y + l * plane,
+                                          d_mean + (size_t)l * width, d_rstd + (size_t)l * width, running_mean[l], running_var[l],
+                                          momentum, (hipStream_t)stream));
+  }
+  return AMX_OK;
+}
+
+size_t amx_mlp_head_scratch_bytes(int n, int cin, int width) { return amx::mlp_backward_scratch_floats(n, cin, width) * sizeof(float); }
+
+int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, int width, int n_layers,
+                          const float* const* w, const float* const* gamma, int act, float slope, const float* d_z,
+                          const float* d_y, const float* d_mean, const float* d_rstd, float* const* dw, float* const* dgamma,
+                          float* const* dbeta, float* d_dx, void* d_scratch, size_t scratch_bytes, void* stream) {
+  if (!d_dy || !d_x || !w || !gamma || !d_z || !d_y || !d_mean || !d_rstd || !dw || !dgamma || !dbeta || !d_scratch)
+    return fail(AMX_ERR_INVALID, "null argument");
+  if (int rc = mlp_check(n, cin, width, n_layers)) return rc;
+  if (scratch_bytes < amx_mlp_head_scratch_bytes(n, cin, width))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", amx_mlp_head_scratch_bytes(n, cin, width), scratch_bytes);
+  const size_t plane = (size_t)n * width;
+  float* dz = (float*)d_scratch;
+  float* dprev = dz + plane;
+  for (int l = n_layers - 1; l >= 0; --l) {
+    if (!w[l] || !dw[l] || (gamma[l] && (!dgamma[l] || !dbeta[l]))) return fail(AMX_ERR_INVALID, "layer %d: bad parameter pointers", l);
+    AMX_HIP(amx::launch_mlp_layer_backward(l + 1 < n_layers ? dprev : d_dy, d_y + l * plane, d_z + l * plane,
+                                           d_mean + (size_t)l * width, d_rstd + (size_t)l * width, gamma[l],
+                                           l + 1 < n_layers ? act : AMX_ACT_NONE, slope, l ? d_y + (l - 1) * plane : d_x, w[l], n,
+                                           l ? width : cin, width, dz, gamma[l] ? dgamma[l] : nullptr, gamma[l] ? dbeta[l] : nullptr,
+                                           dw[l], l ? dprev : d_dx, dprev + plane, (hipStream_t)stream));
+  }
   return AMX_OK;
 }
 

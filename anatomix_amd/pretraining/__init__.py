@@ -1,11 +1,11 @@
 """MI355X-side mirror of the reference's contrastive-pretraining pieces (reference: pretraining/models/).
 
   SupPatchNCELoss ... pretraining/models/supcl_model.py:16-226     (HIP forward+backward kernel, amx_supcon_loss)
-  PatchSampleF ...... pretraining/models/pretraining_networks.py:264-519
+  PatchSampleF ...... pretraining/models/pretraining_networks.py:264-519  (projection heads: HIP forward + backward,
+                      amx_mlp_head_forward / _backward)
   contrastive_step .. the per-batch body of SupCLModel.optimize_parameters / forward / calculate_NCE_loss
                       (supcl_model.py:603-661, 723-843) without the option parsing / logging around it.
-The UNet's backward is not a HIP kernel yet: the step runs the network through
-torch autograd on the stock modules (``Unet.allow_torch_path``), the loss through the HIP kernel.
+The UNet inside the step runs forward and backward on the HIP kernels (anatomix_amd.model.train).
 """
 from .supcon import SupPatchNCELoss
 from .patch_sample import PatchSampleF

@@ -4,6 +4,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..model.network import get_actvn_layer, get_norm_layer
+from . import mlp_head
 
 
 class PatchSampleF(nn.Module):
@@ -97,6 +98,12 @@ class PatchSampleF(nn.Module):
             x_sample = x_sample.permute(0, 2, 1).flatten(0, 1)         # [views * P, C]
             return_ids.append(coords)
             if self.use_mlp:
-                x_sample = getattr(self, "mlp_%d" % k)(x_sample).view(nviews, nsample, -1)
+                mlp = getattr(self, "mlp_%d" % k)
+                # train-mode heads of the structure the reference builds run on the HIP kernels (one call per head and
+                # direction); anything else -- eval mode, CPU tensors, exotic shapes -- goes through the stock modules
+                if x_sample.is_cuda and mlp_head.unsupported_reason(mlp, x_sample) is None:
+                    x_sample = mlp_head.run_head(mlp, x_sample).view(nviews, nsample, -1)
+                else:
+                    x_sample = mlp(x_sample).view(nviews, nsample, -1)
             return_feats.append(x_sample)
         return return_feats, return_ids

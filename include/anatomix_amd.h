@@ -245,6 +245,29 @@ int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, floa
                     int balance_denominator, int sqrt_mode, float* d_loss, float* d_grad, void* d_scratch,
                     size_t scratch_bytes, void* stream);
 
+/* Projection head of PatchSampleF (pretraining/models/pretraining_networks.py:338-350, applied at :505-511) in train
+ * mode: n_layers x [Linear(bias=False) -> BatchNorm1d(batch statistics) -> activation], no activation after the last
+ * layer, affine parameters optional per layer.  All device tensors fp32, row-major:
+ *   d_x [n][cin] the sampled features; w[l] [width][cin or width]; gamma[l] / beta[l] [width] or NULL (affine=False);
+ *   running_mean[l] / running_var[l] [width] updated in place like nn.BatchNorm1d (momentum, unbiased variance) or NULL;
+ *   d_z, d_y [n_layers][n][width]: pre-norm and post-activation outputs of every layer (kept for the backward;
+ *   the head's output is d_y + (n_layers - 1) * n * width); d_mean, d_rstd [n_layers][width] the batch statistics.
+ * w, gamma, beta, running_mean, running_var are HOST arrays of n_layers device pointers.
+ * Limits: 1 <= n <= 2048, cin % 4 == 0, width % 8 == 0, 1 <= n_layers <= 8.  Two kernels per layer. */
+int amx_mlp_head_forward(const float* d_x, int n, int cin, int width, int n_layers, const float* const* w,
+                         const float* const* gamma, const float* const* beta, float* const* running_mean,
+                         float* const* running_var, float eps, float momentum, int act, float slope, float* d_z, float* d_y,
+                         float* d_mean, float* d_rstd, void* stream);
+
+/* Backward of amx_mlp_head_forward: d_dy [n][width] = d loss / d head output.  Writes dw[l] (shape of w[l]), dgamma[l] /
+ * dbeta[l] (where gamma[l] is not NULL) and d_dx [n][cin] (nullable).  d_scratch: amx_mlp_head_scratch_bytes(n, cin, width).
+ * Four small kernels per layer; deterministic (fixed-order reductions). */
+size_t amx_mlp_head_scratch_bytes(int n, int cin, int width);
+int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, int width, int n_layers,
+                          const float* const* w, const float* const* gamma, int act, float slope, const float* d_z,
+                          const float* d_y, const float* d_mean, const float* d_rstd, float* const* dw, float* const* dgamma,
+                          float* const* dbeta, float* d_dx, void* d_scratch, size_t scratch_bytes, void* stream);
+
 /* ---- registration feature post-processing (what the reference does to the extracted features before the convex
  * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */
 

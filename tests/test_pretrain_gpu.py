@@ -89,3 +89,86 @@ def test_contrastive_step_on_gpu_matches_reference_record(device):
     assert abs(rec["grad_norm_F"] - float(GOLD["step|grad_norm_F"])) < 2e-2 * rec["grad_norm_F"]
     assert not torch.equal(w0, netG.model[0].weight.detach())          # AdamW stepped
     assert all(p.grad is None or not p.grad.any() for p in netG.parameters())   # and zero_grad ran
+
+
+# ---- projection head on the HIP kernels (csrc/amx_mlp.hip) -------------------------------------------------------------
+
+def _head(cin, width, n_mlps, act, seed):
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    A = (lambda: nn.ReLU(inplace=True)) if act == "relu" else (lambda: nn.LeakyReLU(0.3, inplace=True))
+    mods = [nn.Linear(cin, width, bias=False), nn.BatchNorm1d(width), A()]
+    for _ in range(n_mlps - 2):
+        mods += [nn.Linear(width, width, bias=False), nn.BatchNorm1d(width), A()]
+    mods += [nn.Linear(width, width, bias=False), nn.BatchNorm1d(width, affine=False)]
+    m = nn.Sequential(*mods)
+    for mod in m:
+        if isinstance(mod, nn.BatchNorm1d) and mod.weight is not None:
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    return m
+
+
+@pytest.mark.parametrize("n,cin,width,n_mlps,act", [(1024, 16, 256, 3, "relu"), (1024, 256, 256, 3, "relu"),
+                                                    (128, 128, 256, 2, "relu"), (1000, 64, 128, 3, "lrelu"),
+                                                    (2048, 32, 64, 2, "lrelu"), (7, 4, 8, 3, "relu")])
+def test_mlp_head_matches_float64_modules(n, cin, width, n_mlps, act):
+    import copy
+    from anatomix_amd.pretraining import mlp_head
+    dev = torch.device("cuda:0")
+    ref = _head(cin, width, n_mlps, act, seed=n + cin).double().train()
+    hip = copy.deepcopy(ref).float().to(dev).train()
+    torch.manual_seed(1)
+    x64 = torch.randn(n, cin, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(n, width, dtype=torch.float64)
+    y64 = ref(x64)
+    (y64 * gy).sum().backward()
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    assert mlp_head.unsupported_reason(hip, x) is None
+    y = mlp_head.run_head(hip, x)
+    (y * gy.float().to(dev)).sum().backward()
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+    assert rel(y, y64.detach()) < 2e-5
+    assert rel(x.grad, x64.grad) < 2e-4
+    for (name, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 2e-4, name
+    for (name, b), (_, c) in zip(hip.named_buffers(), ref.named_buffers()):
+        if "num_batches" in name:
+            assert int(b) == int(c) == 1
+        else:
+            assert rel(b, c) < 1e-5, name
+
+
+def test_mlp_head_is_deterministic_and_used_by_the_sampler():
+    from anatomix_amd.pretraining import PatchSampleF, mlp_head
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+    feats = [torch.randn(2, c, s, s, s, device=dev, requires_grad=True) for c, s in ((128, 8), (16, 32))]
+    netF.create_mlp(feats)
+    netF = netF.to(dev).train()
+    calls = []
+    orig = mlp_head.run_head
+    mlp_head.run_head = lambda m, x: calls.append(x.shape) or orig(m, x)
+    try:
+        out, ids = netF(feats, 512, None, None)
+        out2, _ = netF([f.detach() for f in feats], 512, ids, None)
+    finally:
+        mlp_head.run_head = orig
+    assert len(calls) == 4 and out[0].shape == (2, 512, 256)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))            # same ids, same batch -> bit-identical
+    sum(o.square().mean() for o in out).backward()
+    assert all(f.grad is not None and torch.isfinite(f.grad).all() for f in feats)
+    assert all(p.grad is not None for p in netF.parameters())
+    netF.eval()                                                          # eval mode: running statistics, stock modules
+    calls.clear()
+    mlp_head.run_head = lambda m, x: calls.append(x.shape) or orig(m, x)
+    try:
+        with torch.no_grad():
+            netF([f.detach() for f in feats], 512, ids, None)
+    finally:
+        mlp_head.run_head = orig
+    assert not calls
