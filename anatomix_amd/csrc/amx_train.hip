@@ -85,45 +85,70 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* __restrict__ 
   }
 }
 
-// grid C/8, block 256 = 8 channels x 32 lanes: lane l merges slabs l, l+32, ... (Chan's parallel variance, fp64, in
-// order), then the 32 lane results are merged in lane order -> mean, rstd, (a, b), running statistics.  Fixed tree.
+// grid C/2, block 256 = 2 channels x 128 lanes: two fp64 passes over the slab sums (mean, then centred second moment),
+// lane l takes slabs l, l+128, ..., the 128 lane results are added in lane order -> mean, rstd, (a, b), running statistics.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
                                                          const float* gamma, const float* beta, float eps, long long rows, int C,
                                                          int nblk, float* __restrict__ ab, float* save_mean, float* save_rstd,
                                                          float* running_mean, float* running_var, float momentum) {
-  __shared__ double sh[3][8][32];
-  const int cl = threadIdx.x & 7, l = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  constexpr int FC = 2, FL = 128;                  // channels per block x lanes per channel
+  __shared__ double sh[2][FC][FL];
+  __shared__ double smean[FC];
+  const int cl = threadIdx.x % FC, l = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + cl;
   const long long per = (rows + nblk - 1) / nblk;
-  double cnt = 0.0, mean = 0.0, m2 = 0.0;
+  const double inv_per = 1.0 / (double)per;
+  // Slab b holds sums shifted by its own first element K_b: mean_b = K_b + s1 / n_b, M2_b = s2 - s1^2 / n_b.
+  // Pass 1: total mean = sum n_b mean_b / N.  Pass 2: M2 = sum M2_b + n_b (mean_b - mean)^2.  Plain fp64 sums in a fixed
+  // order (lane l takes slabs l, l + 128, ...; the 128 lane sums are added in lane order) -- no division per slab, and
+  // few enough slabs per lane that the scattered K_b loads do not serialise.
+  double sn = 0.0, sm = 0.0;
   if (c < C)
-    for (int b = l; b < nblk; b += 32) {
+    for (int b = l; b < nblk; b += FL) {
       const long long v0 = (long long)b * per, v1 = v0 + per < rows ? v0 + per : rows;
       if (v0 >= rows) break;
       const double nb = (double)(v1 - v0);
       const float K = (float)__builtin_bit_cast(T, *(const unsigned short*)(x + (v0 * C + c) * 2));
-      const double s1 = partial[((long long)b * C + c) * 2], s2 = partial[((long long)b * C + c) * 2 + 1];
-      const double mb = (double)K + s1 / nb, m2b = s2 - s1 * s1 / nb;
-      const double delta = mb - mean, tot = cnt + nb;
-      mean += delta * nb / tot;
-      m2 += m2b + delta * delta * cnt * nb / tot;
-      cnt = tot;
+      const double s1 = partial[((long long)b * C + c) * 2];
+      sn += nb;
+      sm += nb * (double)K + s1;
     }
-  sh[0][cl][l] = cnt;
-  sh[1][cl][l] = mean;
-  sh[2][cl][l] = m2;
+  sh[0][cl][l] = sn;
+  sh[1][cl][l] = sm;
   __syncthreads();
-  if (threadIdx.x >= 8 || c >= C) return;
-  cnt = 0.0; mean = 0.0; m2 = 0.0;
-  for (int k = 0; k < 32; ++k) {
-    const double nb = sh[0][cl][k];
-    if (nb == 0.0) continue;
-    const double delta = sh[1][cl][k] - mean, tot = cnt + nb;
-    mean += delta * nb / tot;
-    m2 += sh[2][cl][k] + delta * delta * cnt * nb / tot;
-    cnt = tot;
+  if (threadIdx.x < FC) {
+    double tn = 0.0, tm = 0.0;
+    for (int k = 0; k < FL; ++k) {
+      tn += sh[0][cl][k];
+      tm += sh[1][cl][k];
+    }
+    smean[cl] = tn > 0.0 ? tm / tn : 0.0;
   }
+  __syncthreads();
+  const double mean_all = smean[cl];
+  double m2 = 0.0;
+  if (c < C)
+    for (int b = l; b < nblk; b += FL) {
+      const long long v0 = (long long)b * per, v1 = v0 + per < rows ? v0 + per : rows;
+      if (v0 >= rows) break;
+      const double nb = (double)(v1 - v0), inb = (v1 - v0) == per ? inv_per : 1.0 / nb;
+      const float K = (float)__builtin_bit_cast(T, *(const unsigned short*)(x + (v0 * C + c) * 2));
+      const double s1 = partial[((long long)b * C + c) * 2], s2 = partial[((long long)b * C + c) * 2 + 1];
+      const double dm = (double)K + s1 * inb - mean_all;
+      m2 += (s2 - s1 * s1 * inb) + nb * dm * dm;
+    }
+  __syncthreads();
+  sh[1][cl][l] = m2;
+  __syncthreads();
+  if (threadIdx.x >= FC || c >= C) return;
+  double cnt = 0.0;
+  m2 = 0.0;
+  for (int k = 0; k < FL; ++k) {
+    cnt += sh[0][cl][k];
+    m2 += sh[1][cl][k];
+  }
+  const double mean = mean_all;
   double var = m2 / cnt;
   var = var < 0.0 ? 0.0 : var;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -374,7 +399,7 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
   const int blocks = grid_for(rows * c8n);
 #define AMX_BN(T)                                                                                                        \
   hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)x, partial, rows, C);              \
-  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 7) / 8), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, \
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 1) / 2), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, \
                      rows, C, nblk, ab, save_mean, save_rstd, running_mean, running_var, momentum);                      \
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope)
   if (precision == 0) { AMX_BN(f16); } else { AMX_BN(bf16); }

@@ -193,24 +193,31 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
 }
 
 // dW[co][ci][tap] (+)= sum over chunks.  A block owns 8 consecutive elements of the partial layout
-// [pair][tap][co16][ci16] (32 contiguous bytes per chunk); its 32 lanes per element add chunks l, l+32, ... in order and the
-// 32 lane sums are added in lane order: a fixed summation tree, independent of the launch.
+// [pair][tap][co16][ci16] (64 contiguous bytes per chunk); its 16 lanes per element add chunks l, l+16, ... in order and the
+// 16 lane sums are added in lane order: a fixed summation tree, independent of the launch.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
                                                           int Cin, int CinPad, int nchunk, int accumulate) {
-  __shared__ float red[8][33];
+  __shared__ float red[16][17];
   const int ncit = CinPad / 16, npairs = (Cout / 16) * ncit;
   const long long E = (long long)npairs * 27 * 256;
-  const int el = threadIdx.x & 7, l = threadIdx.x >> 3;
-  const long long e = (long long)blockIdx.x * 8 + el;
+  const int el = threadIdx.x & 15, l = threadIdx.x >> 4;     // 16 consecutive elements (one 64-byte segment) x 16 chunk lanes
+  const long long e = (long long)blockIdx.x * 16 + el;
   float s = 0.f;
-  if (e < E)
-    for (int c = l; c < nchunk; c += 32) s += partial[(size_t)c * E + e];
+  if (e < E) {
+    int c = l;
+    for (; c + 48 < nchunk; c += 64) {                        // four independent loads in flight, added in chunk order
+      const float v0 = partial[(size_t)c * E + e], v1 = partial[(size_t)(c + 16) * E + e];
+      const float v2 = partial[(size_t)(c + 32) * E + e], v3 = partial[(size_t)(c + 48) * E + e];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; c < nchunk; c += 16) s += partial[(size_t)c * E + e];
+  }
   red[el][l] = s;
   __syncthreads();
-  if (threadIdx.x < 8 && (long long)blockIdx.x * 8 + threadIdx.x < E) {
-    const long long ee = (long long)blockIdx.x * 8 + threadIdx.x;
+  if (threadIdx.x < 16 && (long long)blockIdx.x * 16 + threadIdx.x < E) {
+    const long long ee = (long long)blockIdx.x * 16 + threadIdx.x;
     float t = 0.f;
-    for (int k = 0; k < 32; ++k) t += red[threadIdx.x][k];
+    for (int k = 0; k < 16; ++k) t += red[threadIdx.x][k];
     const int ci16 = ee % 16, co16 = (ee / 16) % 16, tap = (ee / 256) % 27, pair = ee / (256 * 27);
     const int co = (pair / ncit) * 16 + co16, ci = (pair % ncit) * 16 + ci16;
     if (ci < Cin) {
@@ -269,7 +276,7 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
   }
 #undef AMX_WG
   const long long E = (long long)npairs * 27 * 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 7) / 8)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 15) / 16)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
                      CinReal, CinPad, nchunk, accumulate);
   return hipGetLastError();
 }
