@@ -77,6 +77,7 @@ SYMBOLS = {
     "amx_mlp_head_forward": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, C.c_float, _P, _P, _P, _P, _P]),
     "amx_mlp_head_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_mlp_head_backward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "amx_sample_coords": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "amx_mindssc_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_mindssc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "amx_avg_pool3d_cat": (_I, [_P, _I, C.c_float, _P, _I, C.c_float, _I, _I, _I, _I, _P, _P]),

@@ -66,6 +66,7 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
+hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
 size_t mindssc_scratch_bytes(int H, int W, int D);
 hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int dilation, float* out, void* scratch,
                           hipStream_t st);
@@ -1083,6 +1084,14 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
                                            l ? width : cin, width, dz, gamma[l] ? dgamma[l] : nullptr, gamma[l] ? dbeta[l] : nullptr,
                                            dw[l], l ? dprev : d_dx, dprev + plane, (hipStream_t)stream));
   }
+  return AMX_OK;
+}
+
+int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, int d1, int d2, long long* d_coords, void* stream) {
+  if (!d_draws || !d_coords) return fail(AMX_ERR_INVALID, "null argument");
+  if (num < 1 || n_draws < num || n_draws > 4096) return fail(AMX_ERR_INVALID, "1 <= num <= n_draws <= 4096 (got %d, %d)", num, n_draws);
+  if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  AMX_HIP(amx::launch_sample_coords(d_draws, n_draws, num, d0, d1, d2, d_coords, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -62,6 +62,21 @@ class PatchSampleF(nn.Module):
                 else:
                     raise NotImplementedError("initialization method [%s] is not implemented" % self.init_type)
 
+    @staticmethod
+    def _sample_distinct(device, nvox, num, dims):
+        """``randperm(nvox)[:num]`` without sorting every voxel: 2 * num draws with replacement from torch's generator, then
+        the first ``num`` distinct ones in draw order (same distribution) unravelled by one HIP kernel (amx_sample_coords)."""
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        draws = torch.randint(nvox, (2 * num,), device=device, dtype=torch.int64)
+        d = [1] * (3 - len(dims)) + [int(v) for v in dims]
+        coords = torch.empty((num, 3), dtype=torch.int64, device=device)
+        with torch.cuda.device(device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.amx_sample_coords(_lib.ptr(draws), 2 * num, num, d[0], d[1], d[2], _lib.ptr(coords), st))
+        return coords[:, 3 - len(dims):]
+
     def forward(self, feats, num_patches=64, patch_ids=None, mask=None, verbose=False):
         return_ids, return_feats = [], []
         ndims = feats[0].dim() - 2
@@ -81,15 +96,19 @@ class PatchSampleF(nn.Module):
                         coords = torch.stack([f[perm] for f in fg], dim=1)
                     else:
                         # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
-                        # unravelling of k, computed arithmetically (no host round trip: the step can be graph-captured)
+                        # unravelling of k (no host round trip anywhere on this path)
                         nvox = feat[0, 0].numel()
-                        flat = torch.randperm(nvox, device=feat.device)[: int(min(num_patches, nvox))]
                         dims = list(feat.shape[2:])
-                        cs = []
-                        for a in range(ndims - 1, -1, -1):
-                            cs.append(flat % dims[a])
-                            flat = torch.div(flat, dims[a], rounding_mode="floor")
-                        coords = torch.stack(cs[::-1], dim=1)
+                        num = int(min(num_patches, nvox))
+                        if feat.is_cuda and nvox >= 8 * num and 2 * num <= 4096:
+                            coords = self._sample_distinct(feat.device, nvox, num, dims)
+                        else:
+                            flat = torch.randperm(nvox, device=feat.device)[:num]
+                            cs = []
+                            for a in range(ndims - 1, -1, -1):
+                                cs.append(flat % dims[a])
+                                flat = torch.div(flat, dims[a], rounding_mode="floor")
+                            coords = torch.stack(cs[::-1], dim=1)
                 idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
                 x_sample = feat[idx]                                   # [views, C, P]
             else:

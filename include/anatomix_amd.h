@@ -268,6 +268,12 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
                           const float* d_y, const float* d_mean, const float* d_rstd, float* const* dw, float* const* dgamma,
                           float* const* dbeta, float* d_dx, void* d_scratch, size_t scratch_bytes, void* stream);
 
+/* Patch coordinates of PatchSampleF's no-mask branch (pretraining_networks.py:443-470: `randperm(n_voxels)[:num]`, then the
+ * flat ids unravelled): d_draws int64 [n_draws], values in [0, d0*d1*d2) drawn WITH replacement by the caller's generator;
+ * d_coords int64 [num][3] receives the C-order coordinates of the first `num` distinct draws in draw order -- the same
+ * distribution as a random permutation's head, without sorting every voxel.  num <= n_draws <= 4096.  One launch. */
+int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, int d1, int d2, long long* d_coords, void* stream);
+
 /* ---- registration feature post-processing (what the reference does to the extracted features before the convex
  * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */
 

@@ -172,3 +172,40 @@ def test_mlp_head_is_deterministic_and_used_by_the_sampler():
     finally:
         mlp_head.run_head = orig
     assert not calls
+
+
+def test_distinct_coordinate_sampler():
+    """amx_sample_coords behind PatchSampleF's no-mask branch: distinct in-range coordinates, reproducible from torch's
+    generator, uniform over the grid, and robust when the draws collide a lot."""
+    from anatomix_amd.pretraining import PatchSampleF
+    dev = torch.device("cuda:0")
+    for dims, num in (((128, 128, 128), 512), ((16, 16, 16), 512), ((20, 12, 18), 300), ((64, 48), 256)):
+        nvox = int(np.prod(dims))
+        torch.manual_seed(5)
+        c1 = PatchSampleF._sample_distinct(dev, nvox, num, list(dims))
+        torch.manual_seed(5)
+        c2 = PatchSampleF._sample_distinct(dev, nvox, num, list(dims))
+        assert c1.shape == (num, len(dims)) and c1.dtype == torch.int64 and torch.equal(c1, c2)
+        c = c1.cpu().numpy()
+        assert (c >= 0).all() and (c < np.array(dims)).all()
+        flat = np.ravel_multi_index(tuple(c.T), dims)
+        assert len(np.unique(flat)) == num
+        # the kept values are the first distinct draws, in draw order
+        torch.manual_seed(5)
+        draws = torch.randint(nvox, (2 * num,), device=dev, dtype=torch.int64).cpu().numpy()
+        _, first = np.unique(draws, return_index=True)
+        assert (flat == draws[np.sort(first)][:num]).all()
+    # uniformity: pooled over many calls every octant of the grid gets its share
+    torch.manual_seed(0)
+    allc = torch.cat([PatchSampleF._sample_distinct(dev, 64 ** 3, 512, [64, 64, 64]) for _ in range(40)]).cpu().numpy()
+    octant = (allc >= 32) @ np.array([4, 2, 1])
+    counts = np.bincount(octant, minlength=8) / len(allc)
+    assert np.abs(counts - 0.125).max() < 0.02
+    # the sampler is what the module uses for large grids; small grids (a permutation of everything) keep randperm
+    netF = PatchSampleF(use_mlp=False)
+    feats = [torch.randn(2, 4, 32, 32, 32, device=dev), torch.randn(2, 4, 8, 8, 8, device=dev)]
+    out, ids = netF(feats, 512, None, None)
+    assert out[0].shape == (2 * 512, 4) and ids[0].shape == (512, 3) and ids[1].shape == (512, 3)   # no MLP: [views * P, C]
+    f0 = feats[0][:, :, ids[0][:, 0], ids[0][:, 1], ids[0][:, 2]].permute(0, 2, 1).flatten(0, 1)
+    assert torch.equal(out[0], f0)
+    assert len(torch.unique(ids[1][:, 0] * 64 + ids[1][:, 1] * 8 + ids[1][:, 2])) == 512
