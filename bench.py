@@ -93,6 +93,49 @@ def cpu_baseline(size, forwards, variant="anatomix"):
                       f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
 
 
+def cpu_baseline_step(size):
+    """One contrastive step (two views of a size^3 volume: forward with taps, sampler, MLP heads, six losses, backward,
+    AdamW) on the host: the stock torch modules of the mirror (the same ATen / oneDNN kernels the reference dispatches to),
+    fp32, one warm-up + one timed step."""
+    import contextlib
+    import io
+    from argparse import Namespace
+    import torch
+    import anatomix_amd
+    from anatomix_amd.pretraining import PatchSampleF, SupPatchNCELoss, contrastive_step
+    from oracle import pretrain_inputs as PI
+    from oracle import unet_ref as R
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    kw = R.VARIANTS["anatomix"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = anatomix_amd.Unet(**kw)
+        net.load_state_dict(R.synthetic_state_dict(kw, 0))
+        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+        netF.create_mlp([torch.zeros(1, c, 1, 1, 1) for c in (128, 256, 128, 64, 32, 16)])
+    net.allow_torch_path = True
+    net.train()
+    netF.train()
+    nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+    for c in crits:
+        c.allow_torch_path = True
+    opts = (torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-5), torch.optim.AdamW(netF.parameters(), lr=2e-4, weight_decay=1e-5))
+    vA, vB, seg = PI.step_inputs(size)
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        contrastive_step(net, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts)
+        ts.append(time.perf_counter() - t0)
+    return {"value": round(2.0 / ts[-1], 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 contrastive step (2 views of 1x1x{size}^3, forward + backward + AdamW) after 1 warm-up, fp32, stock torch "
+                      f"modules on {cores} of {avail} host threads: {ts[-1]:.2f} s (warm-up {ts[0]:.2f} s)"}
+
+
 def pmc_traffic(kernel, batch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md prescribes; produced by
@@ -316,8 +359,8 @@ def main():
             "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload != "step":
-            result["cpu_baseline"] = cpu_baseline(S, args.cpu_forwards, args.variant)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_step(S) if args.workload == "step" else cpu_baseline(S, args.cpu_forwards, args.variant)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
