@@ -143,3 +143,26 @@ def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12):
         _lib.check(lib.amx_correlate_ssd(_lib.ptr(f), _lib.ptr(m), ch, h, w, d, int(disp_hw), _lib.ptr(ssd), _lib.ptr(amin),
                                          _lib.ptr(sc), nb, _stream(f.device)))
     return ssd, amin
+
+
+def stage1_inputs(img_fixed, img_moving, model, grid_sp=2, disp_hw=1, downscale_feat_scalar=0.1, fixminclip=None,
+                  fixmaxclip=None, movminclip=None, movmaxclip=None, group=None):
+    """Everything the reference computes between loading the two volumes and its convex solver
+    (run_convex_adam_with_network_feats.py:153-205 -> instance_optimization.run_stage1_registration's ``correlate`` call):
+    min-max + sliding-window features of both volumes, MIND-SSC(1, 2) of both, ``cat(mind, 0.1 * features)`` pooled by
+    ``grid_sp``, and the SSD correlation volume fixed -> moving.  img_* are numpy volumes [H, W, D].
+    Returns a dict(features_fix_smooth, features_mov_smooth, ssd, ssd_argmin, mind_fixed, mind_moving, pred_fixed,
+    pred_moving); all device tensors, no host synchronisation after the inputs are uploaded."""
+    pred_f, pred_m = extract_features(img_fixed, img_moving, model, fixminclip, fixmaxclip, movminclip, movmaxclip, group=group)
+    dev = pred_f.device
+    out = {"pred_fixed": pred_f, "pred_moving": pred_m}
+    smooth = []
+    for name, img, lo, hi, pred in (("fixed", img_fixed, fixminclip, fixmaxclip, pred_f), ("moving", img_moving, movminclip, movmaxclip, pred_m)):
+        im = torch.from_numpy(np.ascontiguousarray(minmax(img, lo, hi)))[None, None, ...].float().to(dev)
+        mind = MINDSSC(im, 1, 2)                                      # merge_features, instance_optimization.py:107-108
+        out["mind_" + name] = mind
+        smooth.append(smooth_merged_features(mind, pred, grid_sp, downscale_feat_scalar))
+    out["features_fix_smooth"], out["features_mov_smooth"] = smooth
+    h, w, d = (int(v) for v in pred_f.shape[-3:])
+    out["ssd"], out["ssd_argmin"] = correlate(smooth[0], smooth[1], disp_hw, grid_sp, (h, w, d), smooth[0].shape[1])
+    return out

@@ -118,3 +118,36 @@ def test_errors_are_reported():
         apply_avg_pool3d(torch.rand(1, 2, 8, 8, 8, device=dev()), 4, 1)
     with pytest.raises(RuntimeError):
         MINDSSC(torch.rand(1, 1, 8, 8, 8), 1, 2)                           # CPU tensor: no CPU path
+
+
+def test_stage1_inputs_composition():
+    """extract -> MIND-SSC -> merged pooled features -> correlation volume as one call equals the pieces (128^3 volumes: one
+    sliding-window position, so the features are the plain forward)."""
+    import sys, os, io, contextlib
+    import anatomix_amd
+    from anatomix_amd.registration import stage1_inputs
+    from oracle import unet_ref as R
+    kw = R.VARIANTS["anatomix"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = anatomix_amd.Unet(**kw)
+    model.load_state_dict(R.synthetic_state_dict(kw, 0))
+    model = model.to(dev()).eval()
+    rs = np.random.RandomState(9)
+    fixed = rs.rand(128, 128, 128).astype(np.float32) * 3 + 1
+    moving = np.roll(fixed, (2, 0, -2), (0, 1, 2)) + rs.rand(128, 128, 128).astype(np.float32) * 0.05
+    res = stage1_inputs(fixed, moving, model, grid_sp=2, disp_hw=1)
+    assert res["features_fix_smooth"].shape == (1, 28, 64, 64, 64) and res["ssd"].shape == (27, 64, 64, 64)
+    norm = (fixed - fixed.min()) / (fixed.max() - fixed.min())
+    with torch.no_grad():
+        feats = model(cu(norm)[None, None])
+    assert (res["pred_fixed"] - feats).abs().max().item() < 2e-3 * feats.abs().max().item()
+    mind = RR.mindssc(norm, 1, 2)
+    want = RR.merged_pooled(mind, res["pred_fixed"][0].cpu().numpy(), 0.1, 2)
+    assert np.abs(res["features_fix_smooth"][0].cpu().numpy() - want).max() < 1e-5
+    ssd_ref, amin_ref = RR.correlate(res["features_fix_smooth"][0].cpu().numpy(), res["features_mov_smooth"][0].cpu().numpy(), 1)
+    assert np.abs(res["ssd"].cpu().numpy() - ssd_ref).max() < 1e-5 * np.abs(ssd_ref).max()
+    assert (res["ssd_argmin"].cpu().numpy() == amin_ref).mean() > 0.999
+    # the moving volume is the fixed one shifted by (2, 0, -2) voxels = (1, 0, -1) grid cells: the SSD minimum finds it
+    want_idx = ((-1 + 1) * 3 + (0 + 1)) * 3 + (1 + 1)
+    inner = res["ssd_argmin"][8:-8, 8:-8, 8:-8]
+    assert (inner == want_idx).float().mean().item() > 0.9
