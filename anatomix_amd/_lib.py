@@ -63,6 +63,7 @@ SYMBOLS = {
     "amx_instance_norm_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_instance_norm": (_I, [_P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _I, _P]),
     "amx_upsample2_trilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "amx_upsample2_trilinear_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "amx_train_scratch_bytes": (C.c_size_t, [_I]),
     "amx_bn_train_forward": (_I, [_P, _P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _P, _P, _P, _P,
                                   C.c_float, _I, _P]),

@@ -66,6 +66,8 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
+hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
+                                               hipStream_t st);
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
 size_t mindssc_scratch_bytes(int H, int W, int D);
 hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int dilation, float* out, void* scratch,
@@ -1092,6 +1094,13 @@ int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, in
   if (num < 1 || n_draws < num || n_draws > 4096) return fail(AMX_ERR_INVALID, "1 <= num <= n_draws <= 4096 (got %d, %d)", num, n_draws);
   if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
   AMX_HIP(amx::launch_sample_coords(d_draws, n_draws, num, d0, d1, d2, d_coords, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int din, int hin, int win, int c, int precision,
+                                     void* stream) {
+  if (!d_gout || !d_gin || c % 8 || n < 1 || din < 1 || hin < 1 || win < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_upsample2_trilinear_backward(d_gout, d_gin, n, din, hin, win, c, precision, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -182,6 +182,46 @@ __global__ void upsample2_trilinear_kernel(const char* __restrict__ in, char* __
   }
 }
 
+// adjoint of upsample2_trilinear: gin [N][D][H][W][C] <- gout [N][2D][2H][2W][C].  Per axis input j collects the outputs
+// 2j-1, 2j, 2j+1, 2j+2 with weights 0.25, 0.75, 0.75, 0.25; indices -1 and 2L fold onto 0 and 2L-1 (the forward's clamps).
+template <typename T>
+__global__ void upsample2_trilinear_bwd_kernel(const char* __restrict__ gout, char* __restrict__ gin, int N, int D, int H,
+                                               int W, int C) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * D * H * W * c8n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = idx % c8n;
+    long long r = idx / c8n;
+    const int x = r % W;
+    r /= W;
+    const int y = r % H;
+    r /= H;
+    const int z = r % D;
+    const int n = r / D;
+    const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < 4; ++a) {
+      int oz = 2 * z - 1 + a;
+      oz = oz < 0 ? 0 : (oz > 2 * D - 1 ? 2 * D - 1 : oz);
+      for (int b = 0; b < 4; ++b) {
+        int oy = 2 * y - 1 + b;
+        oy = oy < 0 ? 0 : (oy > 2 * H - 1 ? 2 * H - 1 : oy);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int ox = 2 * x - 1 + c;
+          ox = ox < 0 ? 0 : (ox > 2 * W - 1 ? 2 * W - 1 : ox);
+          float f[8];
+          unpack8<T>(*(const uint4*)(gout + ((((long long)n * 2 * D + oz) * 2 * H + oy) * 2 * W + ox) * C * 2 + c8 * 16), f);
+          const float w = wt[a] * wt[b] * wt[c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w * f[e];
+        }
+      }
+    }
+    *(uint4*)(gin + idx * 16) = pack8<T>(acc);
+  }
+}
+
 // y = scale[c] * x + shift[c], then the activation, in place (eval-mode BatchNorm applied as its own pass: only
 // used when a feature tap asks for the pre-norm convolution output, network.py:475-529).
 template <typename T>
@@ -269,6 +309,18 @@ hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, i
     hipLaunchKernelGGL(upsample2_trilinear_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
   else
     hipLaunchKernelGGL(upsample2_trilinear_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
+                                               hipStream_t st) {
+  if (C % 8) return hipErrorInvalidValue;
+  const long long total = (long long)N * D * H * W * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(upsample2_trilinear_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)gout, (char*)gin, N, D, H, W, C);
+  else
+    hipLaunchKernelGGL(upsample2_trilinear_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)gout, (char*)gin, N, D, H, W, C);
   return hipGetLastError();
 }
 

@@ -183,7 +183,7 @@ class Unet(nn.Module):
         if not x.is_cuda:
             return "input is not on a GPU device"
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return "autograd is enabled (wrap inference in torch.no_grad()); backward kernels are not implemented yet"
+            return "autograd is enabled on a configuration the differentiable HIP path (anatomix_amd.model.train) does not cover; wrap inference in torch.no_grad()"
         if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
             return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
         if c["norm"] == "batch" and self.training:
@@ -367,7 +367,10 @@ class Unet(nn.Module):
         """Same call contract as network.py:467: tensor without ``layers``; ``(out, feats)`` with
         ``layers``; ``feats`` alone with ``encode_only``."""
         train_reason = None
-        if input.is_cuda and self.training and self._cfg["norm"] == "batch" and not encode_only:
+        wants_grad = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        batch_stats = self.training and self._cfg["norm"] == "batch"
+        instance = self._cfg["norm"] in ("instance", "instance_affine") and wants_grad
+        if input.is_cuda and (batch_stats or instance) and not encode_only:
             # train-mode BatchNorm (batch statistics) and/or autograd: the differentiable HIP path (model/train.py)
             from . import train
             train_reason = train.unsupported_reason(self, input, list(layers))

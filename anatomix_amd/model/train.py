@@ -10,9 +10,11 @@ gradient (MFMA kernel) -> data gradient (forward kernel on the zero-framed gradi
 -> max-pool / upsample / concat adjoints.  Storage precision is ``model.precision`` ("bf16" mirrors the reference's
 bf16 autocast); parameter gradients and BatchNorm statistics are fp32.
 
-Supported configuration (what the reference trains): norm='batch', activation relu/lrelu, pooling='Max',
-interp='nearest', doubleconv either, skip connections either; feature taps at conv / norm / activation ids and at the
-output conv.  Everything else raises (the caller can still opt into the stock-module path).
+Supported configuration: norm 'batch' (batch statistics + running-stat update), 'instance' / 'instance_affine' (the
+same kernels, one sample at a time), conv bias, activation relu/lrelu, pooling 'Max' / 'Avg', interp 'nearest' (fused
+into the concat convs) / 'trilinear' (materialised + its adjoint kernel), doubleconv either; feature taps at conv /
+norm / activation ids and at the output conv.  Everything else raises (the caller can still opt into the stock-module
+path).
 """
 import torch
 import torch.nn as nn
@@ -26,10 +28,10 @@ def unsupported_reason(model, x, layers):
     c = model._cfg
     if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
         return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
-    if c["norm"] != "batch" or c["activation"] not in ("relu", "lrelu") or c["final_act"] != "none":
-        return "the HIP training path covers norm='batch', activation relu/lrelu, final_act='none'"
-    if c["pooling"] != "Max" or c["interp"] != "nearest":
-        return "the HIP training path covers pooling='Max', interp='nearest'"
+    if c["norm"] not in ("batch", "instance", "instance_affine") or c["activation"] not in ("relu", "lrelu") or c["final_act"] != "none":
+        return "the HIP training path covers norm batch / instance / instance_affine, activation relu/lrelu, final_act='none'"
+    if c["pooling"] not in ("Max", "Avg") or c["interp"] not in ("nearest", "trilinear"):
+        return "the HIP training path covers pooling Max / Avg, interp nearest / trilinear"
     if c["input_nc"] != 1 or c["ngf"] % 16 or c["output_nc"] % 16 or c["output_nc"] > 32:
         return "the HIP training path needs input_nc == 1, ngf a multiple of 16, output_nc in {16, 32}"
     if x.dim() != 5 or x.shape[1] != 1 or not x.is_cuda:
@@ -52,11 +54,11 @@ def _module_kinds(model):
     for mod in model.model:
         if isinstance(mod, nn.Conv3d):
             kinds.append("conv")
-        elif isinstance(mod, nn.BatchNorm3d):
+        elif isinstance(mod, (nn.BatchNorm3d, nn.InstanceNorm3d)):
             kinds.append("norm")
         elif isinstance(mod, (nn.ReLU, nn.LeakyReLU)):
             kinds.append("act")
-        elif isinstance(mod, nn.MaxPool3d):
+        elif isinstance(mod, (nn.MaxPool3d, nn.AvgPool3d)):
             kinds.append("pool")
         elif isinstance(mod, nn.Upsample):
             kinds.append("up")
@@ -78,6 +80,7 @@ class _UnetTrainFn(torch.autograd.Function):
     def forward(ctx, model, x, layers, *params):
         dt = _DT[model.precision]
         act = model._cfg["activation"]
+        trilinear = model._cfg["interp"] == "trilinear"
         kinds = _module_kinds(model)
         mods = list(model.model)
         dev = x.device
@@ -99,16 +102,33 @@ class _UnetTrainFn(torch.autograd.Function):
                 if pending_low is not None and not model.use_skip_connection:
                     raise NotImplementedError("upsample without skip connection in the HIP training path")
                 pending_low = None
+                cat_parts = None
+                if in1 is not None and trilinear:
+                    # trilinear: the upsampled tensor is materialised and concatenated (the nearest case is fused into the conv)
+                    name_cat = f"cat{i}"
+                    tensors[name_cat] = torch.cat([tensors[in0], T.upsample2_trilinear(tensors[in1])], dim=-1)
+                    cat_parts, in0, in1 = (in0, in1), name_cat, None
+                bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
                 blk = dict(idx=i, conv=conv, in0=in0, in1=in1, cin=conv.in_channels, cout=conv.out_channels, name=f"y{i}",
-                           alias_ids=[i + 1 + a for a in range(int(has_bn) + int(has_act))])
+                           alias_ids=[i + 1 + a for a in range(int(has_bn) + int(has_act))], cat_parts=cat_parts)
                 if has_bn:
                     bn = mods[i + 1]
-                    X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight)
-                    Y, mean, rstd = T.bn_train_forward(X, bn.weight.detach(), bn.bias.detach(), bn.eps, act if has_act else "none", 0.3,
-                                                       bn.running_mean, bn.running_var,
-                                                       0.1 if bn.momentum is None else bn.momentum)
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked += 1
+                    X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias)
+                    gam = None if bn.weight is None else bn.weight.detach()
+                    bet = None if bn.bias is None else bn.bias.detach()
+                    if isinstance(bn, nn.BatchNorm3d):
+                        Y, mean, rstd = T.bn_train_forward(X, gam, bet, bn.eps, act if has_act else "none", 0.3,
+                                                           bn.running_mean, bn.running_var,
+                                                           0.1 if bn.momentum is None else bn.momentum)
+                        if bn.num_batches_tracked is not None:
+                            bn.num_batches_tracked += 1
+                    else:
+                        # InstanceNorm3d: the same statistics kernels over one sample at a time, no running statistics
+                        Y = torch.empty_like(X)
+                        stats = [T.bn_train_forward(X[s:s + 1], gam, bet, bn.eps, act if has_act else "none", 0.3, out=Y[s:s + 1])[1:]
+                                 for s in range(X.shape[0])]
+                        mean = torch.stack([m for m, _ in stats])
+                        rstd = torch.stack([r for _, r in stats])
                     blk.update(bn=bn, X=X, Y=Y, mean=mean, rstd=rstd, act=act if has_act else "none")
                     tensors[blk["name"]] = Y
                     if i in layers:
@@ -118,7 +138,7 @@ class _UnetTrainFn(torch.autograd.Function):
                             taps[j] = _to_ncdhw(Y)                       # in-place activation aliases the norm output
                     i += 1 + int(has_act)
                 else:                                                    # the bare output conv
-                    out = T.conv_forward(tensors[in0], None, conv.weight, out32=True)
+                    out = T.conv_forward(tensors[in0], None, conv.weight, out32=True, shift=bias)
                     blk.update(bn=None, final=True)
                     tensors[blk["name"]] = out
                 blocks.append(blk)
@@ -128,8 +148,9 @@ class _UnetTrainFn(torch.autograd.Function):
                     skips.append(cur)
             elif k == "pool":
                 dst = f"p{i}"
-                tensors[dst] = T.pool2_max(tensors[cur])
-                ops.append(("pool", cur, dst))
+                avg = isinstance(mods[i], nn.AvgPool3d)
+                tensors[dst] = T.pool2(tensors[cur], 1 if avg else 0)
+                ops.append(("pool", cur, dst, avg))
                 cur = dst
             elif k == "up":
                 pending_low = cur
@@ -159,11 +180,16 @@ class _UnetTrainFn(torch.autograd.Function):
 
         for op in reversed(ctx.ops):
             if op[0] == "pool":
-                _, src, dst = op
+                _, src, dst, avg = op
                 if dst not in grads:
                     continue
                 dp = grads.pop(dst)
-                if src in grads:
+                if avg:                                                 # adjoint of AvgPool3d(2): every child gets dp / 8
+                    n_, d_, h_, w_, c_ = dp.shape
+                    g = (dp * 0.125)[:, :, None, :, None, :, None, :].expand(n_, d_, 2, h_, 2, w_, 2, c_).reshape(
+                        n_, 2 * d_, 2 * h_, 2 * w_, c_)
+                    add_grad(src, g)
+                elif src in grads:
                     T.pool2_max_backward(dp, tensors[src], accumulate_into=grads[src])
                 else:
                     grads[src] = T.pool2_max_backward(dp, tensors[src])
@@ -190,19 +216,36 @@ class _UnetTrainFn(torch.autograd.Function):
                 if dy is None and idx not in dtap:
                     continue                                            # nothing downstream of this block was used
                 fr = frame((n, d, h, w), blk["cout"])
-                if dy is not None:
-                    _, dgamma, dbeta = T.bn_act_backward(dy, blk["Y"], blk["X"], blk["mean"], blk["rstd"], bn.weight.detach(),
+                gam = None if bn.weight is None else bn.weight.detach()
+                if dy is not None and isinstance(bn, nn.BatchNorm3d):
+                    _, dgamma, dbeta = T.bn_act_backward(dy, blk["Y"], blk["X"], blk["mean"], blk["rstd"], gam,
                                                          blk["act"], 0.3, framed=fr)
                     pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgamma, dbeta
+                elif dy is not None:                                    # InstanceNorm3d: per sample
+                    dgs, dbs = [], []
+                    for s_ in range(n):
+                        _, dg_, db_ = T.bn_act_backward(dy[s_:s_ + 1], blk["Y"][s_:s_ + 1], blk["X"][s_:s_ + 1], blk["mean"][s_],
+                                                        blk["rstd"][s_], gam, blk["act"], 0.3, framed=fr[s_:s_ + 1])
+                        dgs.append(dg_)
+                        dbs.append(db_)
+                    if bn.weight is not None:
+                        pgrads[id(bn.weight)], pgrads[id(bn.bias)] = torch.stack(dgs).sum(0), torch.stack(dbs).sum(0)
                 else:
                     T.interior(fr).zero_()
                 if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
                     T.interior(fr).add_(dtap.pop(idx).permute(0, 2, 3, 4, 1).to(dt))
             pgrads[id(conv.weight)] = T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"])
+            if conv.bias is not None:                                   # d bias = sum of the pre-norm gradient over the voxels
+                pgrads[id(conv.bias)] = T.interior(fr).float().sum((0, 1, 2, 3))[: blk["cout"]]
             if blk["in0"] == "x":
                 continue                                                # the network input needs no gradient
             dcat = T.conv_dgrad(fr, conv.weight)
-            if x1 is None:
+            if blk.get("cat_parts") is not None:                        # materialised trilinear concat: split, then the adjoint
+                skip_name, low_name = blk["cat_parts"]
+                cs = tensors[skip_name].shape[-1]
+                add_grad(skip_name, dcat[..., :cs].contiguous())
+                add_grad(low_name, T.upsample2_trilinear_backward(dcat[..., cs: cs + tensors[low_name].shape[-1]]))
+            elif x1 is None:
                 add_grad(blk["in0"], dcat[..., : x0.shape[-1]] if dcat.shape[-1] != x0.shape[-1] else dcat)
             else:
                 c1 = x1.shape[-1]

@@ -70,13 +70,13 @@ def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None,
     return out
 
 
-def bn_train_forward(x, gamma, beta, eps, act="relu", slope=0.3, running_mean=None, running_var=None, momentum=0.1):
-    """BatchNorm3d(train) + activation.  Returns (y, save_mean, save_rstd)."""
+def bn_train_forward(x, gamma, beta, eps, act="relu", slope=0.3, running_mean=None, running_var=None, momentum=0.1, out=None):
+    """BatchNorm3d(train) + activation (one sample at a time: InstanceNorm3d).  Returns (y, save_mean, save_rstd)."""
     lib = _lib.load()
     dev = x.device
     n, c = x.shape[0], x.shape[-1]
     vox = x[0, ..., 0].numel()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     rstd = torch.empty(c, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -157,12 +157,39 @@ def conv_wgrad(dx_framed, x0, x1, cin_real, cout):
     return dw
 
 
-def pool2_max(x):
+def pool2(x, mode):
+    """nn.MaxPool3d(2) (mode 0) / nn.AvgPool3d(2) (mode 1)."""
     lib = _lib.load()
     n, d, h, w, c = x.shape
     out = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.amx_pool2(_lib.ptr(x), _lib.ptr(out), n, d // 2, h // 2, w // 2, c, 0, _PREC[x.dtype], _st(x.device)))
+        _lib.check(lib.amx_pool2(_lib.ptr(x), _lib.ptr(out), n, d // 2, h // 2, w // 2, c, int(mode), _PREC[x.dtype], _st(x.device)))
+    return out
+
+
+def pool2_max(x):
+    return pool2(x, 0)
+
+
+def upsample2_trilinear(x):
+    """nn.Upsample(scale_factor=2, mode='trilinear') on 16-bit NDHWC."""
+    lib = _lib.load()
+    n, d, h, w, c = x.shape
+    out = torch.empty((n, 2 * d, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.amx_upsample2_trilinear(_lib.ptr(x), _lib.ptr(out), n, d, h, w, c, _PREC[x.dtype], _st(x.device)))
+    return out
+
+
+def upsample2_trilinear_backward(g):
+    """Adjoint of upsample2_trilinear: [N, 2D, 2H, 2W, C] -> [N, D, H, W, C]."""
+    lib = _lib.load()
+    n, d2, h2, w2, c = g.shape
+    g = g.contiguous()
+    out = torch.empty((n, d2 // 2, h2 // 2, w2 // 2, c), dtype=g.dtype, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.amx_upsample2_trilinear_backward(_lib.ptr(g), _lib.ptr(out), n, d2 // 2, h2 // 2, w2 // 2, c,
+                                                        _PREC[g.dtype], _st(g.device)))
     return out
 
 

@@ -193,6 +193,11 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
 int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
                             int precision, void* stream);
 
+/* Adjoint of amx_upsample2_trilinear (autograd of nn.Upsample(2, 'trilinear'), network.py:407, in the training path):
+ * d_gout 16-bit [n][2 din][2 hin][2 win][c] -> d_gin [n][din][hin][win][c]. */
+int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int din, int hin, int win, int c, int precision,
+                                     void* stream);
+
 /* ---- Training-path operators (the UNet inside the contrastive step, pretraining/models/supcl_model.py:603-661, runs in
  * train mode and is differentiated).  All activations / gradients: dense 16-bit channels-last [n][d][h][w][c];
  * parameter gradients and statistics fp32.  d_scratch: amx_train_scratch_bytes(c) bytes. */

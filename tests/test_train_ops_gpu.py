@@ -137,3 +137,32 @@ def test_pool2_max_backward_first_max_tie_rule(device, prec):
     acc = torch.ones_like(xd)
     T.pool2_max_backward(cl(dp, dt, device), xd, accumulate_into=acc)
     assert rel_l2(ncdhw(acc), xq.grad + 1.0) < ULP[prec]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 8), (1, 8, 2, 2, 2), (1, 24, 7, 5, 3)])
+def test_trilinear_upsample_and_its_adjoint(device, prec, shape):
+    """nn.Upsample(2, 'trilinear') forward and the adjoint kernel against torch (autograd) on the same rounded operands."""
+    dt = torch.float16 if prec == "f16" else torch.bfloat16
+    torch.manual_seed(sum(shape))
+    n, c, d, h, w = shape
+    x = torch.randn(shape).to(dt).double().requires_grad_(True)
+    g = torch.randn(n, c, 2 * d, 2 * h, 2 * w).to(dt).double()
+    y = F.interpolate(x, scale_factor=2, mode="trilinear")
+    y.backward(g)
+    yd = T.upsample2_trilinear(cl(x.detach().float(), dt, device))
+    gd = T.upsample2_trilinear_backward(cl(g.float(), dt, device))
+    tol = 2e-3 if prec == "f16" else 1.2e-2                   # one rounding of the 16-bit result
+    assert rel_l2(ncdhw(yd), y.detach()) < tol
+    assert rel_l2(ncdhw(gd), x.grad) < tol
+    # adjoint identity <U x, g> == <x, U^T g> on the kernels' own outputs
+    lhs = (ncdhw(yd) * g).sum().item()
+    rhs = (x.detach() * ncdhw(gd)).sum().item()
+    assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + abs(rhs)) + 1e-2
+
+
+def test_avg_pool_forward(device):
+    dt = torch.float16
+    x = torch.randn(2, 16, 8, 4, 6).to(dt)
+    y = T.pool2(cl(x.float(), dt, device), 1)
+    assert rel_l2(ncdhw(y), F.avg_pool3d(x.double(), 2)) < 1e-3

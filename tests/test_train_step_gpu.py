@@ -156,3 +156,70 @@ def test_segmentation_finetuning_composition_trains(device):
         losses.append(loss.item())
     assert all(p.grad is not None for p in net.parameters())
     assert all(b < a for a, b in zip(losses, losses[1:])) and losses[-1] < 0.9 * losses[0], losses
+
+
+@pytest.mark.parametrize("kw,layers", [
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=32, norm="instance", pooling="Avg", interp="trilinear",
+          norm_eps=1e-2), [3, 13, 20, 27, 34]),                                     # the anatomix-dev recipe, shallow
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=1, ngf=16, norm="instance_affine", activation="lrelu"),
+     [0, 3, 5, 10, 13, 17, 20]),
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16, norm="batch", pooling="Avg", interp="trilinear"),
+     [3, 13, 20, 27, 34]),
+])
+def test_instance_norm_avgpool_trilinear_variants_train_on_hip(device, kw, layers):
+    """The other normalisation / pooling / interpolation modes of the reference's Unet through the differentiable HIP path:
+    InstanceNorm3d (per-sample statistics, conv bias), AvgPool3d and trilinear upsampling with their adjoints."""
+    hip, ref = _pair_kw(device, kw, "f16")
+    x = R.synthetic_input(11, 2, (32, 32, 64)).to(device)
+    calls = []
+    from anatomix_amd.model import train as TR
+    orig = TR.forward_train
+    TR.forward_train = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    try:
+        errs, gerrs, cos = _compare(hip, ref, x, layers, device, loss_scale=4096.0)
+    finally:
+        TR.forward_train = orig
+    assert calls, "the call did not go through anatomix_amd.model.train"
+    print("fwd", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-2, errs
+    # a conv bias in front of an InstanceNorm has a zero gradient (the norm removes the mean): both sides hold rounding noise
+    # there, so those entries are checked for smallness instead of direction
+    mods = list(hip.model)
+    dead = set()
+    if kw["norm"].startswith("instance"):
+        for i, m in enumerate(mods):
+            if isinstance(m, torch.nn.Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.InstanceNorm3d) \
+                    and m.bias is not None and i not in layers:   # (a tap at the conv id sees the pre-norm output: live bias)
+                dead.add(f"model.{i}.bias")
+    gp = dict(hip.named_parameters())
+    for k in dead:
+        wk = k.replace(".bias", ".weight")
+        assert gp[k].grad.abs().max().item() < 2e-2 * gp[wk].grad.abs().max().item() + 1e-6, k
+    live = [k for k in gerrs if k not in dead]
+    print("grad worst", max(gerrs[k] for k in live), "min cos", min(cos[k] for k in live))
+    last = [k for k in live if k.startswith(f"model.{len(mods) - 1}.")]
+    assert all(gerrs[k] < 2e-3 for k in last), {k: gerrs[k] for k in last}
+    assert max(gerrs[k] for k in live) < 0.2 and min(cos[k] for k in live) > 0.98
+
+
+def test_anatomix_dev_variant_takes_a_training_step(device):
+    """The 94M InstanceNorm / AvgPool / trilinear variant through forward + backward + AdamW on the HIP path at its smallest
+    legal size (64^3: 2^3 at the bottleneck): finite, every parameter receives a gradient, and the loss goes down."""
+    kw = R.VARIANTS["anatomix-dev"]
+    net = anatomix_amd.Unet(**kw)
+    net.load_state_dict(R.synthetic_state_dict(kw, 1, gain=2 ** 0.5))
+    net.precision = "bf16"
+    net = net.to(device).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    x = R.synthetic_input(3, 1, (64, 64, 64)).to(device)
+    target = torch.randn(1, 32, 64, 64, 64, device=device) * 0.1
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        out = net(x)
+        loss = (out - target).square().mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
