@@ -181,6 +181,33 @@ __global__ void bn_apply_kernel(const char* __restrict__ x, char* __restrict__ y
   }
 }
 
+// 256 % (C / 8) == 0: a thread keeps one 8-channel group for its whole walk -> coefficients in registers, no division
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fast_kernel(const char* __restrict__ x, char* __restrict__ y,
+                                                            const float* __restrict__ ab, long long rows, int C, int act,
+                                                            float slope) {
+  const int c8n = C >> 3, c8 = threadIdx.x % c8n;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = ab[2 * (c8 * 8 + e)];
+    b[e] = ab[2 * (c8 * 8 + e) + 1];
+  }
+  const long long total = rows * c8n;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    float f[8];
+    t_unpack8<T>(*(const uint4*)(x + idx * 16), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = f[e] * a[e] + b[e];
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      f[e] = v;
+    }
+    *(uint4*)(y + idx * 16) = t_pack8<T>(f);
+  }
+}
+
 // ---------------------------------------------------------------- backward of norm + activation
 // partial[blk][c] = (sum dz, sum dz * xhat)
 template <typename T>
@@ -401,7 +428,10 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
   hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)x, partial, rows, C);              \
   hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 1) / 2), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, \
                      rows, C, nblk, ab, save_mean, save_rstd, running_mean, running_var, momentum);                      \
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope)
+  if (256 % c8n == 0)                                                                                                    \
+    hipLaunchKernelGGL(bn_apply_fast_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope); \
+  else                                                                                                                   \
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const char*)x, (char*)y, ab, rows, C, act, slope)
   if (precision == 0) { AMX_BN(f16); } else { AMX_BN(bf16); }
 #undef AMX_BN
   return hipGetLastError();
