@@ -9,6 +9,6 @@ The UNet inside the step runs forward and backward on the HIP kernels (anatomix_
 """
 from .supcon import SupPatchNCELoss
 from .patch_sample import PatchSampleF
-from .step import contrastive_step
+from .step import contrastive_step, GraphedContrastiveStep
 
-__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step"]
+__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep"]

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="step workload: launch every kernel eagerly instead of replaying one HIP graph")
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
     ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev"],
                     help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M)")
@@ -274,8 +275,9 @@ def main():
         netF = netF.to(dev).train()
         nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
         crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
-        opts = (torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5),
-                torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5))
+        cap = not args.no_graph and world == 1        # capturable AdamW keeps its step count on the device
+        opts = (torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap),
+                torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap))
         vA, vB, seg = [t.to(dev) for t in PI.step_inputs(S)]
         vA = (vA + 0.01 * rank).clamp(0, 1)           # a different pair per rank
 
@@ -292,8 +294,16 @@ def main():
                     g.copy_(flat[o:o + g.numel()].view_as(g))
                     o += g.numel()
 
-        step = lambda: contrastive_step(model, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts,
-                                        grad_sync=grad_sync)["out"]
+        if args.no_graph:
+            step = lambda: contrastive_step(model, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts,
+                                            grad_sync=grad_sync)["out"]
+        else:
+            # the whole step replayed from one HIP graph (1 GPU: optimizers included; data parallel: forward + backward in the
+            # graph, then the RCCL all-reduce and AdamW)
+            from anatomix_amd.pretraining import GraphedContrastiveStep
+            graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512,
+                                             grad_sync=grad_sync if world > 1 else None)
+            step = lambda: graphed(vA, vB, seg)["out"]
         units_per_step = world * 2
         grad_ctx = torch.enable_grad()
     if args.sw_volume:
@@ -338,7 +348,7 @@ def main():
         elif args.workload == "step":
             workload = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
                         "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; AdamW), bf16 "
-                        "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels (BASELINE configs[2])")
+                        "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels" + ("" if args.no_graph else ", replayed from one HIP graph") + " (BASELINE configs[2])")
             par = f"data parallel x{world}: one pair per rank, gradients averaged with one all_reduce per network"
             gflop_vol *= 3.0      # forward + data gradient + weight gradient
         else:

@@ -209,3 +209,47 @@ def test_distinct_coordinate_sampler():
     f0 = feats[0][:, :, ids[0][:, 0], ids[0][:, 1], ids[0][:, 2]].permute(0, 2, 1).flatten(0, 1)
     assert torch.equal(out[0], f0)
     assert len(torch.unique(ids[1][:, 0] * 64 + ids[1][:, 1] * 8 + ids[1][:, 2])) == 512
+
+
+def test_graphed_contrastive_step_matches_eager_on_the_same_coordinates():
+    """GraphedContrastiveStep: forward + sampling + heads + losses + backward + gradient norms replayed from one HIP graph.
+    Every replay draws new coordinates; re-running the eager step on the coordinates a replay used must give its numbers."""
+    import contextlib, io
+    from argparse import Namespace
+    import anatomix_amd
+    from anatomix_amd.pretraining import GraphedContrastiveStep, PatchSampleF, SupPatchNCELoss, contrastive_step
+    from oracle import pretrain_inputs as PI, unet_ref as R
+    dev = torch.device("cuda:0")
+    kw = R.VARIANTS["anatomix"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        netG = anatomix_amd.Unet(**kw)
+        netG.load_state_dict(R.synthetic_state_dict(kw, 3, gain=2 ** 0.5))
+        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+        netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+    netG.precision = "bf16"
+    netG, netF = netG.to(dev).train(), netF.to(dev).train()
+    nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+    A, B, seg = [t.to(dev) for t in PI.step_inputs(64)]
+    graphed = GraphedContrastiveStep(netG, netF, crits, PI.NCE_LAYERS, None, num_patches=64, warmup=2)
+    r1 = graphed(A, B, seg)
+    ids1 = [i.clone() for i in r1["sample_ids"]]
+    grads1 = [p.grad.clone() for p in netG.parameters()]
+    # (the eager reference runs on copies: the graph owns the .grad tensors of the captured modules -- resetting them to None
+    # would detach the modules from the memory the replays write)
+    import copy
+    netG2, netF2 = copy.deepcopy(netG), copy.deepcopy(netF)
+    for p in list(netG2.parameters()) + list(netF2.parameters()):
+        p.grad = None
+    ref = contrastive_step(netG2, netF2, crits, A, B, seg, PI.NCE_LAYERS, num_patches=64, optimizers=None, sample_ids=ids1)
+    assert abs(r1["loss"] - ref["loss"]) < 1e-5 * abs(ref["loss"]) and abs(r1["grad_norm_G"] - ref["grad_norm_G"]) < 1e-4 * ref["grad_norm_G"]
+    for g, p in zip(grads1, netG2.parameters()):
+        assert torch.equal(g, p.grad)                       # same kernels, same inputs: bit-identical gradients
+    r2 = graphed(A, B, seg)                                 # second replay: new coordinates, same weights -> a different loss
+    assert not all(torch.equal(a, b) for a, b in zip(ids1, r2["sample_ids"])) and r2["loss"] != r1["loss"]
+    # with capturable optimizers the update is part of the graph and the loss goes down over replays
+    opts = (torch.optim.AdamW(netG.parameters(), lr=1e-3, capturable=True), torch.optim.AdamW(netF.parameters(), lr=1e-3, capturable=True))
+    trained = GraphedContrastiveStep(netG, netF, crits, PI.NCE_LAYERS, opts, num_patches=64, warmup=2)
+    assert trained.opt_in_graph
+    losses = [trained(A, B, seg)["loss"] for _ in range(12)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses

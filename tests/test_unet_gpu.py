@@ -158,3 +158,27 @@ def test_small_volumes_and_wide_outputs(device, kw, size):
         ref = R.forward(x, sd, kw)
     assert y.shape == ref.shape
     assert rel_l2(y, ref) < 1.5e-3, rel_l2(y, ref)
+
+
+def test_forward_is_hip_graph_capturable(device):
+    """No entry of the forward synchronises or touches host memory after load_state_dict, so a forward can be captured in a
+    HIP graph and replayed on new input (include/anatomix_amd.h: 'asynchronous on the given stream')."""
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = anatomix_amd.Unet(**R.VARIANTS["anatomix"])
+    model.load_state_dict(R.synthetic_state_dict(R.VARIANTS["anatomix"], 0))
+    model = model.to(device).eval()
+    x = torch.rand(2, 1, 64, 64, 64, device=device)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(x)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = model(x)
+        x.copy_(torch.rand_like(x))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, model(x))
