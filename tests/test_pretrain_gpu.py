@@ -253,3 +253,40 @@ def test_graphed_contrastive_step_matches_eager_on_the_same_coordinates():
     assert trained.opt_in_graph
     losses = [trained(A, B, seg)["loss"] for _ in range(12)]
     assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+
+
+def test_graphed_step_with_gradient_sync_hook_runs_the_optimizers_eagerly():
+    """Data-parallel shape of GraphedContrastiveStep: forward + backward in the graph, then grad_sync (the all-reduce), the
+    gradient norms and ordinary (non-capturable) AdamW outside it."""
+    import contextlib, io
+    from argparse import Namespace
+    import anatomix_amd
+    from anatomix_amd.pretraining import GraphedContrastiveStep, PatchSampleF, SupPatchNCELoss
+    from oracle import pretrain_inputs as PI, unet_ref as R
+    dev = torch.device("cuda:0")
+    kw = R.VARIANTS["anatomix"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        netG = anatomix_amd.Unet(**kw)
+        netG.load_state_dict(R.synthetic_state_dict(kw, 3, gain=2 ** 0.5))
+        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+        netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+    netG.precision = "bf16"
+    netG, netF = netG.to(dev).train(), netF.to(dev).train()
+    nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+    A, B, seg = [t.to(dev) for t in PI.step_inputs(64)]
+    opts = (torch.optim.AdamW(netG.parameters(), lr=1e-3), torch.optim.AdamW(netF.parameters(), lr=1e-3))
+    calls = []
+
+    def grad_sync():                                         # stands in for the all-reduce: halve, as averaging two equal ranks' sums would
+        calls.append(1)
+        for p in netG.parameters():
+            p.grad.mul_(1.0)
+
+    step = GraphedContrastiveStep(netG, netF, crits, PI.NCE_LAYERS, opts, num_patches=64, grad_sync=grad_sync, warmup=2)
+    assert not step.opt_in_graph
+    w0 = next(netG.parameters()).detach().clone()
+    losses = [step(A, B, seg)["loss"] for _ in range(10)]
+    assert len(calls) == 2 + 10                              # warm-up steps + one per call
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    assert not torch.equal(w0, next(netG.parameters()).detach())
