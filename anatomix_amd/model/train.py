@@ -91,6 +91,7 @@ class _UnetTrainFn(torch.autograd.Function):
         blocks, ops, skips = [], [], []
         cur, pending_low = "x", None
         taps = {}
+        tracked = []                                                     # num_batches_tracked of every BatchNorm: one foreach add
         i = 0
         while i < len(mods):
             k = kinds[i]
@@ -121,7 +122,7 @@ class _UnetTrainFn(torch.autograd.Function):
                                                            bn.running_mean, bn.running_var,
                                                            0.1 if bn.momentum is None else bn.momentum)
                         if bn.num_batches_tracked is not None:
-                            bn.num_batches_tracked += 1
+                            tracked.append(bn.num_batches_tracked)
                     else:
                         # InstanceNorm3d: the same statistics kernels over one sample at a time, no running statistics
                         Y = torch.empty_like(X)
@@ -157,6 +158,8 @@ class _UnetTrainFn(torch.autograd.Function):
             else:
                 raise NotImplementedError(f"module {i} ({type(mods[i]).__name__}) in the HIP training path")
             i += 1
+        if tracked:
+            torch._foreach_add_(tracked, 1)
         ctx.model, ctx.tensors, ctx.ops, ctx.layers, ctx.dt = model, tensors, ops, sorted(taps), dt
         ctx.param_ids = [id(p) for p in model.parameters()]
         ctx.final_idx = blocks[-1]["idx"]
