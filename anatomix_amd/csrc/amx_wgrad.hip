@@ -27,14 +27,18 @@
 
 namespace amx {
 
-constexpr int WG_TY = 4;
-constexpr int WG_RS = 136;            // LDS row stride in halves: >= W + 8 for W <= 128, and 2 * RS = 16 (mod 256)
+// Tile geometry by row width: TY rows of the padded width Wp per item, LDS row stride RS halves (>= Wp + 8; 2 * RS is an odd
+// multiple of 16 bytes mod 256, so the 16 channel rows of a fragment read hit 16 different 16-byte bank groups).  The item
+// always holds TY * Wp / 32 = 16 K-blocks, two per wave: narrow (deep) layers used to run with 4 rows like the wide ones and
+// kept only 4 (W <= 32) of the 8 waves busy.
+constexpr int wg_ty(int Wp) { return Wp <= 32 ? 16 : Wp <= 64 ? 8 : 4; }
+constexpr int wg_rs(int Wp) { return Wp <= 32 ? 40 : Wp <= 64 ? 72 : 136; }
 
 struct WgUnit {                       // staging unit: two adjacent voxels x 8 channels
   uint4 a, b;
 };
 
-template <typename T, bool RING>
+template <typename T, bool RING, int WG_TY, int WG_RS>
 __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, int Wp) {
   typedef typename Ops<T>::vec8 vec8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
     }
     // ---- K-blocks of this item: (row, xb) -> 32 voxels
     const char* dyb = dys + (size_t)db * DY_BYTES;
-    for (int kb = wave; kb < WG_TY * nxb; kb += 8) {
+    const int vrows = p.H - y0 < WG_TY ? p.H - y0 : WG_TY;         // rows of this tile inside the volume (the rest hold zeros)
+    for (int kb = wave; kb < vrows * nxb; kb += 8) {
       const int row = kb / nxb, xb = kb % nxb;
       const int X0 = xb * 32 + kg * 8;                             // multiple of 8 halves = 16 bytes
       const vec8 af = *(const vec8*)(dyb + ((size_t)(row * 16 + m) * RS + X0) * 2);
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* nitems, int* nchunk, int* ipc, int* nyt) {
-  *nyt = (H + WG_TY - 1) / WG_TY;
+  const int ty = wg_ty((W + 31) / 32 * 32);
+  *nyt = (H + ty - 1) / ty;
   *nitems = N * D * *nyt;
   const int npairs = (Cout / 16) * (CinPad / 16);
   int nc = (1024 + npairs - 1) / npairs;
@@ -252,28 +258,34 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
   p.nchunk = nchunk; p.items_per_chunk = ipc; p.nitems = nitems; p.nyt = nyt;
   const int Wp = (p.W + 31) / 32 * 32;
   if (Wp > 128) return hipErrorInvalidValue;                       // WG_RS covers W <= 128
-  const size_t dyb = (size_t)WG_TY * 16 * WG_RS * 2, plb = (size_t)(WG_TY + 2) * 16 * WG_RS * 2;
+  const int ty = wg_ty(Wp), rs = wg_rs(Wp);
+  const size_t dyb = (size_t)ty * 16 * rs * 2, plb = (size_t)(ty + 2) * 16 * rs * 2;
   const size_t red = (size_t)4 * 27 * 64 * 4 * sizeof(float);
   const bool ring = p.D >= 3;
   size_t lds = ring ? 2 * dyb + 4 * plb : dyb + 3 * plb;
   if (lds < red) lds = red;
   const int npairs = (p.Cout / 16) * (CinPad / 16);
-#define AMX_WG(T, R)                                                                                                         \
+#define AMX_WG2(T, R, TY, RS)                                                                                                \
   {                                                                                                                          \
     static bool done = false;                                                                                                \
     if (!done) {                                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         160 * 1024);                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<T, R, TY, RS>,                                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
       if (e != hipSuccess) return e;                                                                                         \
       done = true;                                                                                                           \
     }                                                                                                                        \
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<T, R>), dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);                        \
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<T, R, TY, RS>), dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);                \
+  }
+#define AMX_WG(T, R)                                                                                                         \
+  {                                                                                                                          \
+    if (Wp <= 32) AMX_WG2(T, R, 16, 40) else if (Wp <= 64) AMX_WG2(T, R, 8, 72) else AMX_WG2(T, R, 4, 136)                   \
   }
   if (precision == 0) {
     if (ring) AMX_WG(f16, true) else AMX_WG(f16, false)
   } else {
     if (ring) AMX_WG(bf16, true) else AMX_WG(bf16, false)
   }
+#undef AMX_WG2
 #undef AMX_WG
   const long long E = (long long)npairs * 27 * 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 15) / 16)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
