@@ -1,6 +1,6 @@
 """GPU: a short run of the randomised parity sweep (tools/fuzz_gpu.py): random single convs (channel mixes, odd sizes,
-upsample+concat, activations, both precisions, planar output) and random networks (every norm / pool / interp mix, random
-feature taps) against the CPU references."""
+upsample+concat, activations, both precisions, planar output), conv backwards, random networks (every norm / pool / interp
+mix, random feature taps), registration-feature kernels and projection heads against the CPU references."""
 import os
 import subprocess
 import sys

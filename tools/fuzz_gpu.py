@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-nconv = nnet = nbwd = nfail = 0
+nconv = nnet = nbwd = nfail = nreg = nmlp = 0
 import torch.nn.functional as F
 from anatomix_amd.model import train_ops as T
 
@@ -22,11 +22,91 @@ def cl(x, dt):
 
 def ncdhw(x):
     return x.detach().cpu().double().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def fuzz_regfeat():
+    """MIND-SSC / merged pooling / correlation volume at random sizes against the CPU oracle."""
+    import numpy as np
+    from oracle import registration_ref as RR
+    from anatomix_amd.registration import MINDSSC, correlate, smooth_merged_features
+    rs = np.random.RandomState(rng.randint(0, 1 << 30))
+    shape = tuple(rng.randint(4, m) for m in (20, 24, 40))
+    radius, dil = rng.choice([(1, 1), (1, 2), (2, 2), (2, 3), (1, 4)])
+    img = rs.rand(*shape).astype(np.float32)
+    for _ in range(2):                                               # smooth a little: white noise amplifies fp32 rounding
+        img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, 1, 2)) / 4
+    bad = 0
+    got = MINDSSC(torch.from_numpy(img).to(dev)[None, None], radius, dil)[0].cpu().numpy()
+    e = float(np.abs(got - RR.mindssc(img, radius, dil)).max())
+    if not e < 5e-5:
+        bad += 1
+        print("MIND FAIL", shape, radius, dil, e)
+    c, g = rng.randint(1, 20), rng.choice([1, 2, 2, 3, 4])
+    if min(shape) >= g:
+        feats = rs.randn(c, *shape).astype(np.float32)
+        got = smooth_merged_features(torch.from_numpy(RR.mindssc(img, 1, 2)).to(dev)[None], torch.from_numpy(feats).to(dev)[None], g, 0.1)
+        want = RR.merged_pooled(RR.mindssc(img, 1, 2), feats, 0.1, g)
+        e = float(np.abs(got[0].cpu().numpy() - want).max())
+        if not e < 5e-6:
+            bad += 1
+            print("POOLCAT FAIL", shape, c, g, e)
+    hw, ch = rng.choice([1, 1, 2, 3]), rng.randint(1, 30)
+    h, w, d = (rng.randint(2, m) for m in (10, 12, 20))
+    fix, mov = rs.rand(ch, h, w, d).astype(np.float32), rs.rand(ch, h, w, d).astype(np.float32)
+    ssd, amin = correlate(torch.from_numpy(fix).to(dev)[None], torch.from_numpy(mov).to(dev)[None], hw, 1, (h, w, d), ch)
+    ref, ref_amin = RR.correlate(fix, mov, hw)
+    e = float(np.abs(ssd.cpu().numpy() - ref).max() / np.abs(ref).max())
+    if not (e < 1e-5 and (amin.cpu().numpy() == ref_amin).mean() > 0.99):
+        bad += 1
+        print("CORRELATE FAIL", (ch, h, w, d), hw, e)
+    return bad
+
+
+def fuzz_mlp():
+    """Projection head forward + backward at random shapes against float64 modules."""
+    import copy
+    import torch.nn as nn
+    from anatomix_amd.pretraining import mlp_head
+    n, cin, width = rng.randint(2, 2048), 4 * rng.randint(1, 64), 8 * rng.randint(1, 40)
+    n_mlps, act = rng.choice([2, 3]), rng.choice(["relu", "lrelu"])
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    A = (lambda: nn.ReLU(inplace=True)) if act == "relu" else (lambda: nn.LeakyReLU(0.3, inplace=True))
+    mods = [nn.Linear(cin, width, bias=False), nn.BatchNorm1d(width), A()]
+    for _ in range(n_mlps - 2):
+        mods += [nn.Linear(width, width, bias=False), nn.BatchNorm1d(width), A()]
+    mods += [nn.Linear(width, width, bias=False), nn.BatchNorm1d(width, affine=False)]
+    ref = nn.Sequential(*mods).double().train()
+    hip = copy.deepcopy(ref).float().to(dev).train()
+    x64 = torch.randn(n, cin, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(n, width, dtype=torch.float64)
+    y64 = ref(x64)
+    (y64 * gy).sum().backward()
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    y = mlp_head.run_head(hip, x)
+    (y * gy.float().to(dev)).sum().backward()
+    # L2-relative: a pre-activation within fp32 rounding of zero flips one ReLU mask bit between the fp32 and the fp64 run
+    # (~1 run in 15 at these sizes); that changes ONE sample's gradient row by a few per cent -- visible in a max-abs metric,
+    # ~1e-3 in L2 -- and is not an error of the kernels
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
+    errs = [rel(y, y64.detach()), rel(x.grad, x64.grad)] + [rel(p.grad, q.grad) for p, q in zip(hip.parameters(), ref.parameters())]
+    # tiny batches make BatchNorm ill-conditioned (rstd ~ 1/sqrt(eps)): scale the bound with 1/sqrt(n)
+    tol = 5e-3 * max(1.0, (64.0 / n) ** 0.5)
+    if not (errs[0] < 1e-5 * max(1.0, (64.0 / n) ** 0.5) and max(errs) < tol):
+        print("MLP FAIL", dict(n=n, cin=cin, width=width, n_mlps=n_mlps, act=act), max(errs))
+        return 1
+    return 0
+
 devnull = open(os.devnull, "w")
 while time.time() < t_end:
     try:
         pick = rng.random()
-        if pick < 0.2:
+        if pick < 0.08:
+            nreg += 1
+            nfail += fuzz_regfeat()
+        elif pick < 0.14:
+            nmlp += 1
+            nfail += fuzz_mlp()
+        elif pick < 0.3:
             # ---- conv backward: weight gradient + data gradient against torch autograd (double, rounded operands)
             dt = rng.choice([torch.bfloat16, torch.float16])
             up = rng.random() < 0.4
@@ -66,7 +146,7 @@ while time.time() < t_end:
             if not ok:
                 nfail += 1
                 print("BWD FAIL", dict(dt=str(dt), c0=c0, c1=c1, cin=cin, cout=cout, size=size, n=n), "e_w", e_w, "e_x", e_x)
-        elif pick < 0.65:
+        elif pick < 0.7:
             prec = rng.choice(["f16", "bf16"])
             up = rng.random() < 0.35
             c0 = rng.choice([16, 32, 48, 64, 128]); c1 = rng.choice([16, 32, 64, 128]) if up else 0
@@ -132,4 +212,5 @@ while time.time() < t_end:
         nfail += 1
         print("EXCEPTION", type(ex).__name__, str(ex)[:300])
         traceback.print_exc(limit=2)
-print(f"fuzz: {nconv} convs, {nbwd} conv backwards, {nnet} networks, {nfail} failures in {budget:.0f} s")
+print(f"fuzz: {nconv} convs, {nbwd} conv backwards, {nnet} networks, {nreg} registration-feature cases, {nmlp} projection heads, "
+      f"{nfail} failures in {budget:.0f} s")
