@@ -66,6 +66,8 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
+hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D, int H, int W, long long dn, long long dz,
+                               long long dy, long long dx, int accumulate, int precision, hipStream_t st);
 hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
                                                hipStream_t st);
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
@@ -1101,6 +1103,22 @@ int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int
                                      void* stream) {
   if (!d_gout || !d_gin || c % 8 || n < 1 || din < 1 || hin < 1 || win < 1) return fail(AMX_ERR_INVALID, "bad argument");
   AMX_HIP(amx::launch_upsample2_trilinear_backward(d_gout, d_gin, n, din, hin, win, c, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_export_ncdhw(const void* d_src, int c, int n, int d, int hh, int w, float* d_out, int precision, void* stream) {
+  if (!d_src || !d_out || c % 8 || c < 8 || n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_export_ncdhw(d_src, c, nullptr, 0, 0, n, d, hh, w, d_out, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int hh, int w, long long dst_sn, long long dst_sz,
+                     long long dst_sy, long long dst_sx, int accumulate, int precision, void* stream) {
+  if (!d_src || !d_dst || c % 8 || c < 8 || n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_INVALID, "bad argument");
+  if (dst_sx < (long long)c * 2 || (dst_sx & 15) || (dst_sy & 15) || (dst_sz & 15) || (dst_sn & 15) || ((size_t)d_dst & 15))
+    return fail(AMX_ERR_INVALID, "destination strides must be multiples of 16 bytes with a voxel pitch >= 2 * c");
+  AMX_HIP(amx::launch_import_ncdhw(d_src, d_dst, n, c, d, hh, w, dst_sn, dst_sz, dst_sy, dst_sx, accumulate, precision,
+                                   (hipStream_t)stream));
   return AMX_OK;
 }
 

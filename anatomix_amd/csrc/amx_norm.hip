@@ -315,6 +315,36 @@ __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const
   }
 }
 
+// The reverse copy for the training path: fp32 planar [N][C][D][H][W] -> 16-bit channels-last, written through BYTE strides
+// (so the interior of a zero-framed gradient buffer can be the destination), optionally accumulating into what is there.
+// One thread = one voxel x 8 channels: eight coalesced plane reads, one 16-byte store.  Cs = channels of the source tensor,
+// Cd = channel pitch of the destination voxel (>= Cs: e.g. one real channel padded to 16 is not needed here, Cs % 8 == 0).
+template <typename T>
+__global__ void import_ncdhw_kernel(const float* __restrict__ src, char* __restrict__ dst, int N, int C, int D, int H, int W,
+                                    long long dn, long long dz, long long dy, long long dx, int accumulate) {
+  const int c8n = C >> 3;
+  const long long vox = (long long)D * H * W;
+  const long long total = (long long)N * c8n * vox;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long v = idx % vox;
+    const long long r = idx / vox;
+    const int c8 = r % c8n, n = r / c8n;
+    const int x = v % W, y = (v / W) % H, z = v / ((long long)W * H);
+    const float* sp = src + ((long long)n * C + c8 * 8) * vox + v;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = sp[e * vox];
+    char* o = dst + n * dn + z * dz + y * dy + x * dx + c8 * 16;
+    if (accumulate) {
+      float g[8];
+      unpack8<T>(*(const uint4*)o, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += g[e];
+    }
+    *(uint4*)o = pack8<T>(f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- launchers
 size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * 65536 * 2 + (size_t)N * C * 2) * sizeof(float); }
 
@@ -390,6 +420,18 @@ hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C
   else
     hipLaunchKernelGGL(export_ncdhw_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1,
                        up_shift, N, D, H, W, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D, int H, int W, long long dn, long long dz,
+                               long long dy, long long dx, int accumulate, int precision, hipStream_t st) {
+  if (C % 8 || C < 8) return hipErrorInvalidValue;
+  const long long total = (long long)N * (C / 8) * D * H * W;
+  const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(import_ncdhw_kernel<f16>, dim3(blocks), dim3(256), 0, st, src, (char*)dst, N, C, D, H, W, dn, dz, dy, dx, accumulate);
+  else
+    hipLaunchKernelGGL(import_ncdhw_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (char*)dst, N, C, D, H, W, dn, dz, dy, dx, accumulate);
   return hipGetLastError();
 }
 

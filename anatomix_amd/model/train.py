@@ -72,7 +72,7 @@ def _to_cl(t, dt):            # fp32 NCDHW -> 16-bit NDHWC
 
 
 def _to_ncdhw(t):             # 16-bit NDHWC -> fp32 NCDHW
-    return t.permute(0, 4, 1, 2, 3).float().contiguous()
+    return T.export_ncdhw(t) if t.shape[-1] % 8 == 0 else t.permute(0, 4, 1, 2, 3).float().contiguous()
 
 
 class _UnetTrainFn(torch.autograd.Function):
@@ -207,15 +207,18 @@ class _UnetTrainFn(torch.autograd.Function):
                 if g is None:
                     continue
                 fr = frame((n, d, h, w), blk["cout"])
-                T.interior(fr).copy_(g.permute(0, 2, 3, 4, 1))
+                T.import_ncdhw(g, T.interior(fr))
             else:
                 name = blk["name"]
                 dy = grads.pop(name, None)
                 bn = blk["bn"]
                 for j in blk["alias_ids"]:                              # taps that alias the activated output
                     if j in dtap:
-                        gj = _to_cl(dtap.pop(j), dt)
-                        dy = gj if dy is None else dy + gj
+                        if dy is None:
+                            dy = torch.empty_like(blk["Y"])
+                            T.import_ncdhw(dtap.pop(j), dy)
+                        else:
+                            dy = T.import_ncdhw(dtap.pop(j), dy, accumulate=True)   # dy is owned by this backward: in place
                 if dy is None and idx not in dtap:
                     continue                                            # nothing downstream of this block was used
                 fr = frame((n, d, h, w), blk["cout"])
@@ -236,7 +239,7 @@ class _UnetTrainFn(torch.autograd.Function):
                 else:
                     T.interior(fr).zero_()
                 if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
-                    T.interior(fr).add_(dtap.pop(idx).permute(0, 2, 3, 4, 1).to(dt))
+                    T.import_ncdhw(dtap.pop(idx), T.interior(fr), accumulate=True)
             pgrads[id(conv.weight)] = T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"])
             if conv.bias is not None:                                   # d bias = sum of the pre-norm gradient over the voxels
                 pgrads[id(conv.bias)] = T.interior(fr).float().sum((0, 1, 2, 3))[: blk["cout"]]

@@ -201,3 +201,29 @@ def pool2_max_backward(dp, inp, accumulate_into=None):
         _lib.check(lib.amx_pool2_max_backward(_lib.ptr(dp), _lib.ptr(inp), _lib.ptr(din), n, do, ho, wo, c,
                                               int(accumulate_into is not None), _PREC[dp.dtype], _st(dp.device)))
     return din
+
+
+def export_ncdhw(x):
+    """16-bit NDHWC -> fp32 NCDHW (a feature tap handed back to torch)."""
+    lib = _lib.load()
+    n, d, h, w, c = x.shape
+    x = x.contiguous()
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.amx_export_ncdhw(_lib.ptr(x), c, n, d, h, w, _lib.ptr(out), _PREC[x.dtype], _st(x.device)))
+    return out
+
+
+def import_ncdhw(g, dst, accumulate=False):
+    """fp32 NCDHW gradient -> 16-bit NDHWC view ``dst`` [N, D, H, W, C'] (C' >= C channels per voxel; any strides that are
+    multiples of 16 bytes, e.g. the interior of a framed buffer), optionally adding to it."""
+    lib = _lib.load()
+    g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
+    n, c, d, h, w = g.shape
+    es = dst.element_size()
+    sn, sz, sy, sx, sc = [s * es for s in dst.stride()]
+    assert sc == es and tuple(dst.shape[:4]) == (n, d, h, w) and dst.shape[4] >= c
+    with torch.cuda.device(g.device):
+        _lib.check(lib.amx_import_ncdhw(_lib.ptr(g), ctypes.c_void_p(dst.data_ptr()), n, c, d, h, w, sn, sz, sy, sx,
+                                        int(accumulate), _PREC[dst.dtype], _st(g.device)))
+    return dst

@@ -193,6 +193,15 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
 int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
                             int precision, void* stream);
 
+/* Layout conversions between the library's 16-bit channels-last activations and torch's fp32 NCDHW tensors, for the
+ * feature taps of the differentiable forward (network.py:475-529 returns the taps as fp32 NCDHW tensors) and their
+ * gradients coming back: export  d_src 16-bit [n][d][h][w][c] -> d_out fp32 [n][c][d][h][w];
+ * import  d_src fp32 [n][c][d][h][w] -> d_dst 16-bit through byte strides (voxel pitch dst_sx >= 2 c; lets the interior of
+ * a zero-framed gradient buffer be the destination), adding to the destination when accumulate != 0.  c % 8 == 0. */
+int amx_export_ncdhw(const void* d_src, int c, int n, int d, int hh, int w, float* d_out, int precision, void* stream);
+int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int hh, int w, long long dst_sn, long long dst_sz,
+                     long long dst_sy, long long dst_sx, int accumulate, int precision, void* stream);
+
 /* Adjoint of amx_upsample2_trilinear (autograd of nn.Upsample(2, 'trilinear'), network.py:407, in the training path):
  * d_gout 16-bit [n][2 din][2 hin][2 win][c] -> d_gin [n][din][hin][win][c]. */
 int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int din, int hin, int win, int c, int precision,

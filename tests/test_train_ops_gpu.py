@@ -166,3 +166,21 @@ def test_avg_pool_forward(device):
     x = torch.randn(2, 16, 8, 4, 6).to(dt)
     y = T.pool2(cl(x.float(), dt, device), 1)
     assert rel_l2(ncdhw(y), F.avg_pool3d(x.double(), 2)) < 1e-3
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_layout_export_and_strided_accumulating_import(device, prec):
+    dt = DT[prec]
+    torch.manual_seed(3)
+    x = torch.randn(2, 24, 5, 6, 7).to(dt)
+    xd = cl(x.float(), dt, device)
+    out = T.export_ncdhw(xd)
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), x.float())
+    g = torch.randn(2, 24, 5, 6, 7, device=device)
+    framed = T.new_framed(2, 5, 6, 7, 32, dt, device)                       # wider voxel pitch than the source: channels 24..31 stay 0
+    T.import_ncdhw(g, T.interior(framed))
+    want = g.permute(0, 2, 3, 4, 1).to(dt)
+    assert torch.equal(T.interior(framed)[..., :24], want) and T.interior(framed)[..., 24:].abs().max().item() == 0
+    assert framed[:, :2].abs().max().item() == 0 and framed[:, :, :, -2:].abs().max().item() == 0   # the frame is untouched
+    T.import_ncdhw(g, T.interior(framed), accumulate=True)
+    assert torch.equal(T.interior(framed)[..., :24], (want.float() + g.permute(0, 2, 3, 4, 1)).to(dt))
