@@ -368,7 +368,7 @@ class Unet(nn.Module):
         ``layers``; ``feats`` alone with ``encode_only``."""
         train_reason = None
         wants_grad = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
-        batch_stats = self.training and self._cfg["norm"] == "batch"
+        batch_stats = self._cfg["norm"] == "batch" and (self.training or wants_grad)   # eval + autograd: frozen statistics
         instance = self._cfg["norm"] in ("instance", "instance_affine") and wants_grad
         if input.is_cuda and (batch_stats or instance) and not encode_only:
             # train-mode BatchNorm (batch statistics) and/or autograd: the differentiable HIP path (model/train.py)

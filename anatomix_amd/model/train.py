@@ -10,8 +10,8 @@ gradient (MFMA kernel) -> data gradient (forward kernel on the zero-framed gradi
 -> max-pool / upsample / concat adjoints.  Storage precision is ``model.precision`` ("bf16" mirrors the reference's
 bf16 autocast); parameter gradients and BatchNorm statistics are fp32.
 
-Supported configuration: norm 'batch' (batch statistics + running-stat update), 'instance' / 'instance_affine' (the
-same kernels, one sample at a time), conv bias, activation relu/lrelu, pooling 'Max' / 'Avg', interp 'nearest' (fused
+Supported configuration: norm 'batch' (batch statistics + running-stat update; layers in eval mode use their frozen
+running statistics, folded into the conv), 'instance' / 'instance_affine' (the same kernels, one sample at a time), conv bias, activation relu/lrelu, pooling 'Max' / 'Avg', interp 'nearest' (fused
 into the concat convs) / 'trilinear' (materialised + its adjoint kernel), doubleconv either; feature taps at conv /
 norm / activation ids and at the output conv.  Everything else raises (the caller can still opt into the stock-module
 path).
@@ -39,9 +39,6 @@ def unsupported_reason(model, x, layers):
     m = 1 << c["num_downs"]
     if any(s % m or (s >> c["num_downs"]) < 2 for s in x.shape[2:]) or x.shape[4] < 32 or x.shape[4] > 128:
         return "spatial dims must be divisible by 2^num_downs, >= 2 at the bottleneck, 32 <= W <= 128"
-    if any(isinstance(mod, nn.BatchNorm3d) and not mod.training for mod in model.model):
-        # the reference can freeze the statistics of single layers (pretraining/models/base_model.py:175-184)
-        return "BatchNorm layers switched to eval inside a train-mode network are not implemented in the HIP training path"
     kinds = _module_kinds(model)
     for l in layers:
         if not (0 <= l < len(kinds)) or kinds[l] not in ("conv", "norm", "act"):
@@ -112,7 +109,33 @@ class _UnetTrainFn(torch.autograd.Function):
                 bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
                 blk = dict(idx=i, conv=conv, in0=in0, in1=in1, cin=conv.in_channels, cout=conv.out_channels, name=f"y{i}",
                            alias_ids=[i + 1 + a for a in range(int(has_bn) + int(has_act))], cat_parts=cat_parts)
-                if has_bn:
+                if has_bn and isinstance(mods[i + 1], nn.BatchNorm3d) and not mods[i + 1].training:
+                    # BatchNorm with frozen statistics (the reference freezes single layers, pretraining/models/
+                    # base_model.py:175-184; also a whole network in eval mode under autograd): y = act(a * conv(x) + b) with
+                    # a, b from the running statistics -- folded into the conv's weights and shift, no norm kernels at all
+                    bn = mods[i + 1]
+                    gam = None if bn.weight is None else bn.weight.detach().float()
+                    bet = None if bn.bias is None else bn.bias.detach().float()
+                    a = (bn.running_var.float() + bn.eps).rsqrt()
+                    if gam is not None:
+                        a = a * gam
+                    b = -bn.running_mean.float() * a
+                    if bet is not None:
+                        b = b + bet
+                    if bias is not None:
+                        b = b + bias * a
+                    Y = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1],
+                                       conv.weight.detach().float() * a.view(-1, 1, 1, 1, 1), act if has_act else "none", 0.3,
+                                       shift=b.contiguous())
+                    blk.update(bn=bn, frozen=True, a=a, Y=Y, act=act if has_act else "none")
+                    tensors[blk["name"]] = Y
+                    if i in layers:                                      # pre-norm tap: the raw convolution, computed only when asked for
+                        taps[i] = _to_ncdhw(T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias))
+                    for j in blk["alias_ids"]:
+                        if j in layers:
+                            taps[j] = _to_ncdhw(Y)
+                    i += 1 + int(has_act)
+                elif has_bn:
                     bn = mods[i + 1]
                     X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias)
                     gam = None if bn.weight is None else bn.weight.detach()
@@ -223,7 +246,19 @@ class _UnetTrainFn(torch.autograd.Function):
                     continue                                            # nothing downstream of this block was used
                 fr = frame((n, d, h, w), blk["cout"])
                 gam = None if bn.weight is None else bn.weight.detach()
-                if dy is not None and isinstance(bn, nn.BatchNorm3d):
+                if dy is not None and blk.get("frozen"):
+                    # du = dy * act'(y) (bare activation adjoint); d gamma / d beta from the recovered pre-activation u; then the
+                    # gradient of the raw convolution output is a * du and everything downstream is the ordinary conv adjoint
+                    T.bn_act_backward(dy, blk["Y"], None, None, None, None, blk["act"], 0.3, framed=fr)
+                    du = T.interior(fr)[..., : blk["cout"]]
+                    if bn.weight is not None:
+                        duf, yf = du.float(), blk["Y"][..., : blk["cout"]].float()
+                        u = yf if blk["act"] != "lrelu" else torch.where(yf > 0, yf, yf / 0.3)
+                        s1 = duf.sum((0, 1, 2, 3))
+                        pgrads[id(bn.bias)] = s1
+                        pgrads[id(bn.weight)] = ((duf * u).sum((0, 1, 2, 3)) - bn.bias.detach().float() * s1) / bn.weight.detach().float()
+                    du.mul_(blk["a"].to(dt))
+                elif dy is not None and isinstance(bn, nn.BatchNorm3d):
                     _, dgamma, dbeta = T.bn_act_backward(dy, blk["Y"], blk["X"], blk["mean"], blk["rstd"], gam,
                                                          blk["act"], 0.3, framed=fr)
                     pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgamma, dbeta

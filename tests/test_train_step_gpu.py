@@ -223,3 +223,34 @@ def test_anatomix_dev_variant_takes_a_training_step(device):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("mode", ["some_layers_frozen", "whole_network_eval"])
+def test_frozen_batchnorm_statistics_under_autograd(device, mode):
+    """BatchNorm layers in eval mode inside a differentiated network (the reference freezes the statistics of single layers,
+    pretraining/models/base_model.py:175-184; a fully eval-mode network under autograd is the same thing everywhere): the
+    running statistics fold into the conv, gradients flow to the conv and to the norm's affine parameters."""
+    kw = dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16, activation="lrelu")
+    layers = [3, 13, 20, 27, 34] if mode == "some_layers_frozen" else [4, 13, 21, 34]
+    hip, ref = _pair_kw(device, kw, "f16")
+    frozen = []
+    for net in (hip, ref):
+        if mode == "whole_network_eval":
+            net.eval()
+        else:
+            for i, m in enumerate(net.model):
+                if isinstance(m, torch.nn.BatchNorm3d) and i % 2 == 0:          # every other norm layer (ids 4, 14, 18, ...)
+                    m.eval()
+                    if net is hip:
+                        frozen.append(i)
+    before = {i: hip.model[i].running_mean.clone() for i in frozen}
+    x = R.synthetic_input(11, 2, (32, 32, 64)).to(device)
+    errs, gerrs, cos = _compare(hip, ref, x, layers, device, loss_scale=4096.0)
+    print("fwd", {k: f"{v:.2e}" for k, v in errs.items()}, "grad worst", max(gerrs.values()), "min cos", min(cos.values()))
+    assert max(errs.values()) < 1e-2, errs
+    last = [k for k in gerrs if k.startswith(f"model.{len(hip.model) - 1}.")]
+    assert all(gerrs[k] < 2e-3 for k in last)
+    assert max(gerrs.values()) < 0.2 and min(cos.values()) > 0.98, (max(gerrs.values()), min(cos.values()))
+    for i in frozen:                                                             # frozen layers keep their statistics
+        assert torch.equal(before[i], hip.model[i].running_mean)
+        assert int(hip.model[i].num_batches_tracked) == 0
