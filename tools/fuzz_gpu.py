@@ -88,10 +88,13 @@ def fuzz_mlp():
     # (~1 run in 15 at these sizes); that changes ONE sample's gradient row by a few per cent -- visible in a max-abs metric,
     # ~1e-3 in L2 -- and is not an error of the kernels
     rel = lambda a, b: ((a.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
-    errs = [rel(y, y64.detach()), rel(x.grad, x64.grad)] + [rel(p.grad, q.grad) for p, q in zip(hip.parameters(), ref.parameters())]
-    # tiny batches make BatchNorm ill-conditioned (rstd ~ 1/sqrt(eps)): scale the bound with 1/sqrt(n)
-    tol = 5e-3 * max(1.0, (64.0 / n) ** 0.5)
-    if not (errs[0] < 1e-5 * max(1.0, (64.0 / n) ** 0.5) and max(errs) < tol):
+    pairs = [(x.grad, x64.grad)] + [(p.grad, q.grad) for p, q in zip(hip.parameters(), ref.parameters())]
+    errs = [rel(y, y64.detach())] + [rel(a, b) for a, b in pairs]
+    cond = max(1.0, (64.0 / n) ** 0.5)               # tiny batches make BatchNorm ill-conditioned (rstd ~ 1/sqrt(eps))
+    # (a flipped unit also moves its column's BatchNorm sums, i.e. every row a little: ~1/n of the gradient, ~1e-2 in L2 at
+    # most; a wrong kernel is an O(1) error) -- forward tight, gradients to 3e-2
+    ok = errs[0] < 1e-5 * cond and max(errs) < 3e-2 * cond
+    if not ok:
         print("MLP FAIL", dict(n=n, cin=cin, width=width, n_mlps=n_mlps, act=act), max(errs))
         return 1
     return 0
