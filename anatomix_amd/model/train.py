@@ -13,7 +13,7 @@ bf16 autocast); parameter gradients and BatchNorm statistics are fp32.
 Supported configuration: norm 'batch' (batch statistics + running-stat update; layers in eval mode use their frozen
 running statistics, folded into the conv), 'instance' / 'instance_affine' (the same kernels, one sample at a time), conv bias, activation relu/lrelu, pooling 'Max' / 'Avg', interp 'nearest' (fused
 into the concat convs) / 'trilinear' (materialised + its adjoint kernel), doubleconv either; feature taps at conv /
-norm / activation ids and at the output conv.  Everything else raises (the caller can still opt into the stock-module
+norm / activation / pool / upsample ids and at the output conv.  Everything else raises (the caller can still opt into the stock-module
 path).
 """
 import torch
@@ -41,8 +41,10 @@ def unsupported_reason(model, x, layers):
         return "spatial dims must be divisible by 2^num_downs, >= 2 at the bottleneck, 32 <= W <= 128"
     kinds = _module_kinds(model)
     for l in layers:
-        if not (0 <= l < len(kinds)) or kinds[l] not in ("conv", "norm", "act"):
-            return "feature taps are implemented at conv / norm / activation ids"
+        if not (0 <= l < len(kinds)) or kinds[l] not in ("conv", "norm", "act", "pool", "up"):
+            return "feature taps are implemented at conv / norm / activation / pool / upsample ids"
+        if kinds[l] == "up" and not c["use_skip_connection"]:
+            return "a tap at an upsample id without skip connections is not implemented in the HIP training path"
     return None
 
 
@@ -88,6 +90,7 @@ class _UnetTrainFn(torch.autograd.Function):
         blocks, ops, skips = [], [], []
         cur, pending_low = "x", None
         taps = {}
+        up_taps = {}                                                     # upsample id -> (skip tensor, low-resolution tensor)
         tracked = []                                                     # num_batches_tracked of every BatchNorm: one foreach add
         i = 0
         while i < len(mods):
@@ -174,15 +177,29 @@ class _UnetTrainFn(torch.autograd.Function):
                 dst = f"p{i}"
                 avg = isinstance(mods[i], nn.AvgPool3d)
                 tensors[dst] = T.pool2(tensors[cur], 1 if avg else 0)
-                ops.append(("pool", cur, dst, avg))
+                ops.append(("pool", cur, dst, avg, i))
                 cur = dst
+                if i in layers:
+                    taps[i] = _to_ncdhw(tensors[dst])
             elif k == "up":
                 pending_low = cur
+                if i in layers:
+                    # the reference takes this tap AFTER torch.cat((skip, upsampled), 1) (network.py:500-502): materialised
+                    # only when asked for -- the convolution that follows still reads skip and low-resolution tensor directly
+                    low = tensors[cur]
+                    up = T.upsample2_trilinear(low) if trilinear else \
+                        low[:, :, None, :, None, :, None, :].expand(low.shape[0], low.shape[1], 2, low.shape[2], 2, low.shape[3], 2,
+                                                                     low.shape[4]).reshape(low.shape[0], 2 * low.shape[1],
+                                                                                           2 * low.shape[2], 2 * low.shape[3],
+                                                                                           low.shape[4])
+                    taps[i] = _to_ncdhw(torch.cat([tensors[skips[-1]], up], dim=-1))
+                    up_taps[i] = (skips[-1], cur)
             else:
                 raise NotImplementedError(f"module {i} ({type(mods[i]).__name__}) in the HIP training path")
             i += 1
         if tracked:
             torch._foreach_add_(tracked, 1)
+        ctx.up_taps, ctx.trilinear = up_taps, trilinear
         ctx.model, ctx.tensors, ctx.ops, ctx.layers, ctx.dt = model, tensors, ops, sorted(taps), dt
         ctx.param_ids = [id(p) for p in model.parameters()]
         ctx.final_idx = blocks[-1]["idx"]
@@ -204,9 +221,32 @@ class _UnetTrainFn(torch.autograd.Function):
                 frames[key] = T.shared_framed(shape[0], shape[1], shape[2], shape[3], c, dt, tensors["x"].device)
             return frames[key]
 
+        # gradients of taps taken at upsample ids: split the concatenated gradient, skip part as is, upsampled part through the
+        # adjoint of the interpolation
+        for uid, (skip_name, low_name) in ctx.up_taps.items():
+            if uid not in dtap:
+                continue
+            g = dtap.pop(uid)
+            cs = tensors[skip_name].shape[-1]
+            gs = torch.empty_like(tensors[skip_name])
+            add_grad(skip_name, T.import_ncdhw(g[:, :cs], gs))
+            low = tensors[low_name]
+            gu = torch.empty((low.shape[0], 2 * low.shape[1], 2 * low.shape[2], 2 * low.shape[3], low.shape[4]), dtype=dt,
+                             device=low.device)
+            T.import_ncdhw(g[:, cs:], gu)
+            if ctx.trilinear:
+                add_grad(low_name, T.upsample2_trilinear_backward(gu))
+            else:
+                n_, d_, h_, w_, c_ = low.shape
+                add_grad(low_name, gu.reshape(n_, d_, 2, h_, 2, w_, 2, c_).float().sum((2, 4, 6)).to(dt))
         for op in reversed(ctx.ops):
             if op[0] == "pool":
-                _, src, dst, avg = op
+                _, src, dst, avg, pid = op
+                if pid in dtap:                                         # tap at the pool id: gradient of the pooled tensor
+                    if dst in grads:
+                        T.import_ncdhw(dtap.pop(pid), grads[dst], accumulate=True)
+                    else:
+                        grads[dst] = T.import_ncdhw(dtap.pop(pid), torch.empty_like(tensors[dst]))
                 if dst not in grads:
                     continue
                 dp = grads.pop(dst)

@@ -254,3 +254,26 @@ def test_frozen_batchnorm_statistics_under_autograd(device, mode):
     for i in frozen:                                                             # frozen layers keep their statistics
         assert torch.equal(before[i], hip.model[i].running_mean)
         assert int(hip.model[i].num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize("interp,pooling", [("nearest", "Max"), ("trilinear", "Avg")])
+def test_taps_at_pool_and_upsample_ids_are_differentiable(device, interp, pooling):
+    """Feature taps at MaxPool / AvgPool ids (the pooled tensor) and at Upsample ids (taken AFTER the concat with the skip,
+    network.py:500-502) through the differentiable HIP path."""
+    kw = dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16, interp=interp, pooling=pooling)
+    hip, ref = _pair_kw(device, kw, "f16")
+    kinds = [type(m).__name__ for m in hip.model]
+    layers = [i for i, k in enumerate(kinds) if k in ("MaxPool3d", "AvgPool3d", "Upsample")] + [len(kinds) - 1]
+    assert len(layers) == 5
+    x = R.synthetic_input(11, 2, (32, 32, 64)).to(device)
+    errs, gerrs, cos = _compare(hip, ref, x, layers, device, loss_scale=4096.0)
+    print("fwd", {k: f"{v:.2e}" for k, v in errs.items()}, "grad worst", max(gerrs.values()), "min cos", min(cos.values()))
+    assert max(errs.values()) < 1e-2, errs
+    # The gradient noise floor of comparing two nearby forwards (ReLU / arg-max flips, see the shallow-network test) depends on
+    # the configuration -- this Max/nearest one sits at ~0.27 / cos 0.967 with the output tap alone -- so the taps are judged
+    # against that floor: they must not add error (a wrong adjoint of a tap is an O(1) change of everything upstream of it).
+    hip0, ref0 = _pair_kw(device, kw, "f16")
+    _, gerrs0, cos0 = _compare(hip0, ref0, x, [len(kinds) - 1], device, loss_scale=4096.0)
+    assert max(gerrs.values()) < max(gerrs0.values()) + 0.05 and min(cos.values()) > min(cos0.values()) - 0.02, \
+        (max(gerrs.values()), max(gerrs0.values()), min(cos.values()), min(cos0.values()))
+    assert max(gerrs.values()) < 0.35 and min(cos.values()) > 0.95
