@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_norm_kernel(const float* __restri
 // (multiple of 4), so all global accesses are aligned float4.  blockIdx.z splits R (partials summed by mlp_reduce_kernel).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                       float* __restrict__ Cm, int M, int N, int R, int r_per_split) {
+                                                       float* __restrict__ Cm, int M, int N, int R, int r_per_split,
+                                                       float scale = 1.f) {
   __shared__ float As[16][68], Bs[16][68];
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int rbeg = blockIdx.z * r_per_split, rend = min(R, rbeg + r_per_split);
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mm = m0 + ty * 4 + i, nn = n0 + tx * 4;
-    if (mm < M && nn < N) *(float4*)(Cz + (size_t)mm * N + nn) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    if (mm < M && nn < N)
+      *(float4*)(Cz + (size_t)mm * N + nn) = make_float4(scale * acc[i][0], scale * acc[i][1], scale * acc[i][2], scale * acc[i][3]);
   }
 }
 
@@ -311,6 +313,19 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
   if (splits > 1) mlp_reduce_kernel<<<(m * k + 255) / 256, 256, 0, st>>>(wpart, dw, m * k, splits);
   // dX [n][k] = dZ [n][m] W [m][k]
   if (dx) mlp_gemm_kernel<true, false><<<dim3((k + 63) / 64, (n + 63) / 64, 1), 256, 0, st>>>(dz, w, dx, n, k, m, m);
+  return hipGetLastError();
+}
+
+// C (+ z * M * N for split z) = scale * op(A) op(B) over R split `splits` ways -- the same register-tiled kernel, for the two
+// GEMMs of the contrastive loss (amx_supcon.hip).  Every contiguous storage dimension must be a multiple of 4.
+hipError_t launch_small_gemm(bool ta, bool tb, const float* A, const float* B, float* Cm, int M, int N, int R, int splits,
+                             float scale, hipStream_t st) {
+  const int rps = ((R + splits - 1) / splits + 15) / 16 * 16;
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
+  if (ta && tb) mlp_gemm_kernel<true, true><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  else if (ta) mlp_gemm_kernel<true, false><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  else if (tb) mlp_gemm_kernel<false, true><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  else mlp_gemm_kernel<false, false><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
   return hipGetLastError();
 }
 

@@ -259,6 +259,9 @@ size_t supcon_scratch_bytes(int N, int C) {
   return ((size_t)(1 + SC_KSPLIT) * N * C + (size_t)N * N + (size_t)4 * N + 64) * sizeof(float);
 }
 
+hipError_t launch_small_gemm(bool ta, bool tb, const float* A, const float* B, float* Cm, int M, int N, int R, int splits,
+                             float scale, hipStream_t st);   // amx_mlp.hip
+
 hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
                          int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st) {
   float* xn = (float*)scratch;
@@ -272,13 +275,28 @@ hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, flo
   hipLaunchKernelGGL(sc_normalize_kernel, dim3(N), blk, 0, st, feat, xn, inv, C);
   hipLaunchKernelGGL(sc_count_kernel, dim3(N), blk, 0, st, labels, cnt, N);
   hipLaunchKernelGGL(sc_wsum_kernel, dim3(1), blk, 0, st, cnt, wsum, N, rarity, sqrt_mode);
-  hipLaunchKernelGGL(sc_gemm_nt_kernel, dim3((N + BM - 1) / BM, (N + BM - 1) / BM), blk, 0, st, xn, xn, S, N, N, C,
-                     1.f / temperature);
+  const bool fast = !(N & 3) && !(C & 3);          // the register-tiled GEMM of amx_mlp.hip moves aligned float4s
+  if (fast) {
+    hipError_t e = launch_small_gemm(true, true, xn, xn, S, N, N, C, 1, 1.f / temperature, st);   // S = xn xn^T / T
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(sc_gemm_nt_kernel, dim3((N + BM - 1) / BM, (N + BM - 1) / BM), blk, 0, st, xn, xn, S, N, N, C,
+                       1.f / temperature);
+  }
   hipLaunchKernelGGL(sc_rows_kernel, dim3(N), blk, 0, st, S, labels, cnt, wsum, rowloss, N, rarity, balance, sqrt_mode);
   hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), blk, 0, st, rowloss, loss, N);
   if (grad) {
-    hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM, SC_KSPLIT), blk, 0, st, S, xn, dxn, N, C,
-                       1.f / temperature);
+    if (fast) {
+      // dxn = (G + G^T) xn / T as four partial products (two row halves of G xn, two of G^T xn) that sc_dnorm adds in order
+      static_assert(SC_KSPLIT == 4, "sc_dnorm sums SC_KSPLIT partials");
+      hipError_t e = launch_small_gemm(true, false, S, xn, dxn, N, C, N, 2, 1.f / temperature, st);
+      if (e != hipSuccess) return e;
+      e = launch_small_gemm(false, false, S, xn, dxn + (size_t)2 * N * C, N, C, N, 2, 1.f / temperature, st);
+      if (e != hipSuccess) return e;
+    } else {
+      hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM, SC_KSPLIT), blk, 0, st, S, xn, dxn, N, C,
+                         1.f / temperature);
+    }
     hipLaunchKernelGGL(sc_dnorm_kernel, dim3(N), blk, 0, st, xn, dxn, inv, grad, C, N);
   }
   return hipGetLastError();
