@@ -64,6 +64,7 @@ SYMBOLS = {
     "amx_instance_norm": (_I, [_P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _I, _P]),
     "amx_upsample2_trilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "amx_upsample2_trilinear_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "amx_upcat_split_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_export_ncdhw": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "amx_import_ncdhw": (_I, [_P, _P, _I, _I, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _P]),
     "amx_train_scratch_bytes": (C.c_size_t, [_I]),

@@ -66,6 +66,8 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
+hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
+                              int acc_skip, int precision, hipStream_t st);
 hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D, int H, int W, long long dn, long long dz,
                                long long dy, long long dx, int accumulate, int precision, hipStream_t st);
 hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
@@ -1119,6 +1121,15 @@ int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int h
     return fail(AMX_ERR_INVALID, "destination strides must be multiples of 16 bytes with a voxel pitch >= 2 * c");
   AMX_HIP(amx::launch_import_ncdhw(d_src, d_dst, n, c, d, hh, w, dst_sn, dst_sz, dst_sy, dst_sx, accumulate, precision,
                                    (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0, int c1,
+                             int accumulate_skip, int precision, void* stream) {
+  if (!d_dcat || !d_dskip || !d_dlow || n < 1 || dlow < 1 || hlow < 1 || wlow < 1 || c0 < 8 || c1 < 8 || c0 % 8 || c1 % 8)
+    return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_upcat_split(d_dcat, d_dskip, d_dlow, n, dlow, hlow, wlow, c0, c1, accumulate_skip, precision,
+                                  (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -364,6 +364,53 @@ __global__ __launch_bounds__(256) void pad_fold_kernel(const char* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- adjoint of cat(skip, nearest_up2(low)) in one pass
+// dcat [N][D][H][W][c0 + c1] (the data gradient of a concat conv) -> dskip [N][D][H][W][c0] (= or += the first c0 channels)
+// and dlow [N][D/2][H/2][W/2][c1] = sum of the 8 children of every low-resolution voxel (fp32 sum, one rounding).
+// One thread = one low-resolution voxel x one 8-channel group of EITHER part: the 8 children are read once.
+template <typename T>
+__global__ void upcat_split_kernel(const char* __restrict__ dcat, char* __restrict__ dskip, char* __restrict__ dlow, int N,
+                                   int Dl, int Hl, int Wl, int c0, int c1, int acc_skip) {
+  const int C = c0 + c1, g0 = c0 >> 3, g1 = c1 >> 3, G = g0 + g1;
+  const long long total = (long long)N * Dl * Hl * Wl * G;
+  const int W = 2 * Wl, H = 2 * Hl, D = 2 * Dl;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = idx % G;
+    long long r = idx / G;
+    const int xl = r % Wl;
+    r /= Wl;
+    const int yl = r % Hl;
+    r /= Hl;
+    const int zl = r % Dl;
+    const int n = r / Dl;
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zl + (k >> 2), y = 2 * yl + ((k >> 1) & 1), x = 2 * xl + (k & 1);
+      const long long v = (((long long)n * D + z) * H + y) * W + x;
+      float f[8];
+      t_unpack8<T>(*(const uint4*)(dcat + (v * C + g * 8) * 2), f);
+      if (g < g0) {                                           // skip part: plain copy (or accumulate) per full-resolution voxel
+        char* o = dskip + (v * c0 + g * 8) * 2;
+        if (acc_skip) {
+          float old[8];
+          t_unpack8<T>(*(const uint4*)o, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += old[e];
+        }
+        *(uint4*)o = t_pack8<T>(f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += f[e];
+      }
+    }
+    if (g >= g0) {
+      const long long vl = (((long long)n * Dl + zl) * Hl + yl) * Wl + xl;
+      *(uint4*)(dlow + (vl * c1 + (g - g0) * 8) * 2) = t_pack8<T>(sum);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- max-pool adjoint
 // one thread = one pooled voxel x 8 channels; writes all 8 children of the window (dp at the first maximum, else 0)
 template <typename T>
@@ -480,6 +527,19 @@ hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, 
   else
     hipLaunchKernelGGL(pool2_max_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)dp, (const char*)in, (char*)din, N,
                        Do, Ho, Wo, C, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
+                              int acc_skip, int precision, hipStream_t st) {
+  if (c0 % 8 || c1 % 8 || c0 < 8 || c1 < 8) return hipErrorInvalidValue;
+  const int blocks = grid_for((long long)N * Dl * Hl * Wl * ((c0 + c1) / 8));
+  if (precision == 0)
+    hipLaunchKernelGGL(upcat_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl,
+                       Hl, Wl, c0, c1, acc_skip);
+  else
+    hipLaunchKernelGGL(upcat_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl,
+                       Hl, Wl, c0, c1, acc_skip);
   return hipGetLastError();
 }
 

@@ -330,9 +330,17 @@ class _UnetTrainFn(torch.autograd.Function):
                 add_grad(blk["in0"], dcat[..., : x0.shape[-1]] if dcat.shape[-1] != x0.shape[-1] else dcat)
             else:
                 c1 = x1.shape[-1]
-                add_grad(blk["in0"], dcat[..., :c0].contiguous())
-                up = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1)
-                add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))   # adjoint of the nearest x2 upsample
+                if dcat.shape[-1] == c0 + c1 and c0 % 8 == 0 and c1 % 8 == 0:
+                    # one pass: skip channels out (accumulated in place when the skip already has a gradient), the 8 children of
+                    # every low-resolution voxel summed (adjoint of the nearest x2 upsample)
+                    prev = grads.get(blk["in0"])
+                    dskip, dlow = T.upcat_split_backward(dcat, c0, c1, skip_into=prev)
+                    grads[blk["in0"]] = dskip
+                    add_grad(blk["in1"], dlow)
+                else:
+                    add_grad(blk["in0"], dcat[..., :c0].contiguous())
+                    up = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1)
+                    add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))
         return (None, None, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
 
 

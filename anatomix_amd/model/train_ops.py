@@ -227,3 +227,17 @@ def import_ncdhw(g, dst, accumulate=False):
         _lib.check(lib.amx_import_ncdhw(_lib.ptr(g), ctypes.c_void_p(dst.data_ptr()), n, c, d, h, w, sn, sz, sy, sx,
                                         int(accumulate), _PREC[dst.dtype], _st(g.device)))
     return dst
+
+
+def upcat_split_backward(dcat, c0, c1, skip_into=None):
+    """Adjoint of cat(skip, nearest_up2(low)): dcat [N, D, H, W, c0 + c1(+pad)] -> (dskip [N, D, H, W, c0], dlow [N, D/2, H/2, W/2,
+    c1]) in one pass; ``skip_into`` accumulates the skip part into an existing gradient."""
+    lib = _lib.load()
+    n, d, h, w, c = dcat.shape
+    assert c == c0 + c1 and dcat.is_contiguous()
+    dskip = skip_into if skip_into is not None else torch.empty((n, d, h, w, c0), dtype=dcat.dtype, device=dcat.device)
+    dlow = torch.empty((n, d // 2, h // 2, w // 2, c1), dtype=dcat.dtype, device=dcat.device)
+    with torch.cuda.device(dcat.device):
+        _lib.check(lib.amx_upcat_split_backward(_lib.ptr(dcat), _lib.ptr(dskip), _lib.ptr(dlow), n, d // 2, h // 2, w // 2, c0, c1,
+                                                int(skip_into is not None), _PREC[dcat.dtype], _st(dcat.device)))
+    return dskip, dlow

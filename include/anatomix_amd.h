@@ -193,6 +193,13 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
 int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int hin, int win, int c,
                             int precision, void* stream);
 
+/* Adjoint of torch.cat((skip, nn.Upsample(2, 'nearest')(low)), 1) (network.py:500-502, 545) applied to the data gradient of the
+ * concat conv: d_dcat 16-bit [n][2 dlow][2 hlow][2 wlow][c0 + c1] -> d_dskip [n][2 dlow][2 hlow][2 wlow][c0] (first c0
+ * channels; added to the existing content when accumulate_skip) and d_dlow [n][dlow][hlow][wlow][c1] (sum of the 8 children of
+ * every low-resolution voxel).  One pass over d_dcat. */
+int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0, int c1,
+                             int accumulate_skip, int precision, void* stream);
+
 /* Layout conversions between the library's 16-bit channels-last activations and torch's fp32 NCDHW tensors, for the
  * feature taps of the differentiable forward (network.py:475-529 returns the taps as fp32 NCDHW tensors) and their
  * gradients coming back: export  d_src 16-bit [n][d][h][w][c] -> d_out fp32 [n][c][d][h][w];

@@ -184,3 +184,19 @@ def test_layout_export_and_strided_accumulating_import(device, prec):
     assert framed[:, :2].abs().max().item() == 0 and framed[:, :, :, -2:].abs().max().item() == 0   # the frame is untouched
     T.import_ncdhw(g, T.interior(framed), accumulate=True)
     assert torch.equal(T.interior(framed)[..., :24], (want.float() + g.permute(0, 2, 3, 4, 1)).to(dt))
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_upcat_split_backward(device, prec):
+    """Adjoint of cat(skip, nearest_up2(low)) in one pass against the torch formulation."""
+    dt = DT[prec]
+    torch.manual_seed(4)
+    n, c0, c1, d, h, w = 2, 16, 40, 6, 4, 10
+    dcat = torch.randn(n, d, h, w, c0 + c1).to(dt).to(device)
+    dskip, dlow = T.upcat_split_backward(dcat, c0, c1)
+    assert torch.equal(dskip, dcat[..., :c0])
+    want = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1).float().sum((2, 4, 6)).to(dt)
+    assert (dlow.float() - want.float()).abs().max().item() <= ULP[prec] * 4 * want.float().abs().max().item()
+    prev = torch.randn(n, d, h, w, c0).to(dt).to(device)
+    acc, _ = T.upcat_split_backward(dcat, c0, c1, skip_into=prev.clone())
+    assert torch.equal(acc, (prev.float() + dcat[..., :c0].float()).to(dt))
