@@ -256,6 +256,72 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__
   }
 }
 
+// The same product on 32 x 32 tiles, 2 x 2 outputs per thread: four times the workgroups for the shapes where the 64 x 64 kernel
+// leaves most of the 256 CUs idle (1024 x 256 x 256: 64 workgroups, each serialising 16 chunks of 256 FMAs per thread).
+// Threads 0..127 stage the A chunk, 128..255 the B chunk (one float4 each).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ Cm, int M, int N, int R, int r_per_split,
+                                                         float scale) {
+  __shared__ float As[16][36], Bs[16][36];
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int rbeg = blockIdx.z * r_per_split, rend = min(R, rbeg + r_per_split);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool isb = threadIdx.x >= 128;
+  const int t = threadIdx.x & 127;
+  const float* P = isb ? B : A;
+  const bool T = isb ? TB : TA;
+  const int o0 = isb ? n0 : m0, O = isb ? N : M;
+  auto fetch = [&](int r0) -> float4 {
+    if (!T) {                                                 // storage [R][O]
+      const int r = r0 + (t >> 3), o = o0 + (t & 7) * 4;
+      return (r < rend && o < O) ? *(const float4*)(P + (size_t)r * O + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int o = o0 + (t >> 2), r = r0 + (t & 3) * 4;         // storage [O][R]
+    if (o >= O || r >= rend) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *(const float4*)(P + (size_t)o * R + r);
+    if (r + 1 >= rend) v.y = 0.f;
+    if (r + 2 >= rend) v.z = 0.f;
+    if (r + 3 >= rend) v.w = 0.f;
+    return v;
+  };
+  auto stash = [&](float4 v) {
+    float(*S)[36] = isb ? Bs : As;
+    if (!T) {
+      *(float4*)&S[t >> 3][(t & 7) * 4] = v;
+    } else {
+      const int o = t >> 2, r = (t & 3) * 4;
+      S[r][o] = v.x;
+      S[r + 1][o] = v.y;
+      S[r + 2][o] = v.z;
+      S[r + 3][o] = v.w;
+    }
+  };
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float4 pv = fetch(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += 16) {
+    __syncthreads();
+    stash(pv);
+    __syncthreads();
+    if (r0 + 16 < rend) pv = fetch(r0 + 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 a = *(const float2*)&As[r][ty * 2];
+      const float2 b = *(const float2*)&Bs[r][tx * 2];
+      acc[0][0] += a.x * b.x;
+      acc[0][1] += a.x * b.y;
+      acc[1][0] += a.y * b.x;
+      acc[1][1] += a.y * b.y;
+    }
+  }
+  float* Cz = Cm + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mm = m0 + ty * 2 + i, nn = n0 + tx * 2;
+    if (mm < M && nn < N) *(float2*)(Cz + (size_t)mm * N + nn) = make_float2(scale * acc[i][0], scale * acc[i][1]);
+  }
+}
+
 // out[i] = part[0][i] + part[1][i] + ... in that order
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int count,
                                                          int splits) {
@@ -268,13 +334,23 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict
 
 constexpr int MLP_WSPLIT = 8;   // row splits of the weight-gradient GEMM (its reduction runs over the n rows)
 
+template <bool TA, bool TB>
+static void gemm_dispatch(const float* A, const float* B, float* Cm, int M, int N, int R, int splits, int rps, float scale,
+                          hipStream_t st) {
+  const long long wg64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * splits;
+  if (wg64 < 200)
+    mlp_gemm32_kernel<TA, TB><<<dim3((N + 31) / 32, (M + 31) / 32, splits), 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  else
+    mlp_gemm_kernel<TA, TB><<<dim3((N + 63) / 64, (M + 63) / 64, splits), 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+}
+
 static inline int rows_per_thread(int n) { return n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8; }
 
 hipError_t launch_mlp_layer_forward(const float* x, int n, int k, const float* w, int m, const float* gamma, const float* beta,
                                     float eps, int act, float slope, float* z, float* y, float* mean, float* rstd, float* rmean,
                                     float* rvar, float momentum, hipStream_t st) {
   // z [n][m] = x [n][k] w^T [k][m]
-  mlp_gemm_kernel<true, true><<<dim3((m + 63) / 64, (n + 63) / 64, 1), 256, 0, st>>>(x, w, z, n, m, k, k);
+  gemm_dispatch<true, true>(x, w, z, n, m, k, 1, k, 1.f, st);
   const dim3 grid(m / MLP_CB);
 #define AMX_MLP_FWD(RPT) \
   mlp_bn_fwd_kernel<RPT><<<grid, 256, 0, st>>>(z, n, m, gamma, beta, eps, act, slope, y, mean, rstd, rmean, rvar, momentum)
@@ -309,10 +385,10 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
   // dW [m][k] = dZ^T [m][n] X [n][k]: the reduction runs over the rows, split MLP_WSPLIT ways, partials summed in order
   const int splits = n >= 16 * MLP_WSPLIT ? MLP_WSPLIT : 1;
   const int rps = ((n + splits - 1) / splits + 15) / 16 * 16;
-  mlp_gemm_kernel<false, false><<<dim3((k + 63) / 64, (m + 63) / 64, splits), 256, 0, st>>>(dz, x, splits > 1 ? wpart : dw, m, k, n, rps);
+  gemm_dispatch<false, false>(dz, x, splits > 1 ? wpart : dw, m, k, n, splits, rps, 1.f, st);
   if (splits > 1) mlp_reduce_kernel<<<(m * k + 255) / 256, 256, 0, st>>>(wpart, dw, m * k, splits);
   // dX [n][k] = dZ [n][m] W [m][k]
-  if (dx) mlp_gemm_kernel<true, false><<<dim3((k + 63) / 64, (n + 63) / 64, 1), 256, 0, st>>>(dz, w, dx, n, k, m, m);
+  if (dx) gemm_dispatch<true, false>(dz, w, dx, n, k, m, 1, m, 1.f, st);
   return hipGetLastError();
 }
 
@@ -321,11 +397,10 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
 hipError_t launch_small_gemm(bool ta, bool tb, const float* A, const float* B, float* Cm, int M, int N, int R, int splits,
                              float scale, hipStream_t st) {
   const int rps = ((R + splits - 1) / splits + 15) / 16 * 16;
-  const dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
-  if (ta && tb) mlp_gemm_kernel<true, true><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
-  else if (ta) mlp_gemm_kernel<true, false><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
-  else if (tb) mlp_gemm_kernel<false, true><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
-  else mlp_gemm_kernel<false, false><<<grid, 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  if (ta && tb) gemm_dispatch<true, true>(A, B, Cm, M, N, R, splits, rps, scale, st);
+  else if (ta) gemm_dispatch<true, false>(A, B, Cm, M, N, R, splits, rps, scale, st);
+  else if (tb) gemm_dispatch<false, true>(A, B, Cm, M, N, R, splits, rps, scale, st);
+  else gemm_dispatch<false, false>(A, B, Cm, M, N, R, splits, rps, scale, st);
   return hipGetLastError();
 }
 
