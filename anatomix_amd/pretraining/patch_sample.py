@@ -1,4 +1,6 @@
 """PatchSampleF with the reference's constructor and call contract (pretraining_networks.py:264-519)."""
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -77,52 +79,65 @@ class PatchSampleF(nn.Module):
             _lib.check(lib.amx_sample_coords(_lib.ptr(draws), 2 * num, num, d[0], d[1], d[2], _lib.ptr(coords), st))
         return coords[:, 3 - len(dims):]
 
-    def forward(self, feats, num_patches=64, patch_ids=None, mask=None, verbose=False):
+    def forward(self, feats, num_patches=64, patch_ids=None, mask=None, verbose=False, streams=None):
+        """``streams`` (extension, CUDA only): one stream per feature map; layer k's sampling and head then run on streams[k]
+        (which first waits for the caller's stream), so the independent per-layer chains can overlap.  The outputs stay on
+        those streams: the caller continues each layer's work there and joins the streams itself."""
         return_ids, return_feats = [], []
         ndims = feats[0].dim() - 2
         if ndims not in (2, 3):
             raise NotImplementedError
         if self.use_mlp and not self.mlp_init:
             self.create_mlp(feats)
+        ambient = torch.cuda.current_stream(feats[0].device) if streams is not None else None
         for k, feat in enumerate(feats):
-            if num_patches > 0:
-                if patch_ids is not None:
-                    coords = patch_ids[k].to(feat.device)
-                else:
-                    if mask is not None:
-                        m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
-                        fg = torch.where(m > 0)[2:]
-                        perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
-                        coords = torch.stack([f[perm] for f in fg], dim=1)
-                    else:
-                        # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
-                        # unravelling of k (no host round trip anywhere on this path)
-                        nvox = feat[0, 0].numel()
-                        dims = list(feat.shape[2:])
-                        num = int(min(num_patches, nvox))
-                        if feat.is_cuda and nvox >= 8 * num and 2 * num <= 4096:
-                            coords = self._sample_distinct(feat.device, nvox, num, dims)
-                        else:
-                            flat = torch.randperm(nvox, device=feat.device)[:num]
-                            cs = []
-                            for a in range(ndims - 1, -1, -1):
-                                cs.append(flat % dims[a])
-                                flat = torch.div(flat, dims[a], rounding_mode="floor")
-                            coords = torch.stack(cs[::-1], dim=1)
-                idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
-                x_sample = feat[idx]                                   # [views, C, P]
-            else:
-                x_sample, coords = feat.flatten(2), []
-            nviews, nc, nsample = x_sample.size()
-            x_sample = x_sample.permute(0, 2, 1).flatten(0, 1)         # [views * P, C]
+            if streams is not None:
+                streams[k].wait_stream(ambient)
+            with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
+                x_sample, coords = self._one_layer(k, feat, num_patches, patch_ids, mask)
             return_ids.append(coords)
-            if self.use_mlp:
-                mlp = getattr(self, "mlp_%d" % k)
-                # train-mode heads of the structure the reference builds run on the HIP kernels (one call per head and
-                # direction); anything else -- eval mode, CPU tensors, exotic shapes -- goes through the stock modules
-                if x_sample.is_cuda and mlp_head.unsupported_reason(mlp, x_sample) is None:
-                    x_sample = mlp_head.run_head(mlp, x_sample).view(nviews, nsample, -1)
-                else:
-                    x_sample = mlp(x_sample).view(nviews, nsample, -1)
             return_feats.append(x_sample)
         return return_feats, return_ids
+
+    def _one_layer(self, k, feat, num_patches, patch_ids, mask):
+        """Sampling + gather + head of feature map k (pretraining_networks.py:432-511)."""
+        ndims = feat.dim() - 2
+        if num_patches > 0:
+            if patch_ids is not None:
+                coords = patch_ids[k].to(feat.device)
+            else:
+                if mask is not None:
+                    m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
+                    fg = torch.where(m > 0)[2:]
+                    perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
+                    coords = torch.stack([f[perm] for f in fg], dim=1)
+                else:
+                    # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
+                    # unravelling of k (no host round trip anywhere on this path)
+                    nvox = feat[0, 0].numel()
+                    dims = list(feat.shape[2:])
+                    num = int(min(num_patches, nvox))
+                    if feat.is_cuda and nvox >= 8 * num and 2 * num <= 4096:
+                        coords = self._sample_distinct(feat.device, nvox, num, dims)
+                    else:
+                        flat = torch.randperm(nvox, device=feat.device)[:num]
+                        cs = []
+                        for a in range(ndims - 1, -1, -1):
+                            cs.append(flat % dims[a])
+                            flat = torch.div(flat, dims[a], rounding_mode="floor")
+                        coords = torch.stack(cs[::-1], dim=1)
+            idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
+            x_sample = feat[idx]                                   # [views, C, P]
+        else:
+            x_sample, coords = feat.flatten(2), []
+        nviews, nc, nsample = x_sample.size()
+        x_sample = x_sample.permute(0, 2, 1).flatten(0, 1)         # [views * P, C]
+        if self.use_mlp:
+            mlp = getattr(self, "mlp_%d" % k)
+            # train-mode heads of the structure the reference builds run on the HIP kernels (one call per head and
+            # direction); anything else -- eval mode, CPU tensors, exotic shapes -- goes through the stock modules
+            if x_sample.is_cuda and mlp_head.unsupported_reason(mlp, x_sample) is None:
+                x_sample = mlp_head.run_head(mlp, x_sample).view(nviews, nsample, -1)
+            else:
+                x_sample = mlp(x_sample).view(nviews, nsample, -1)
+        return x_sample, coords

@@ -2,8 +2,24 @@
 (forward supcl_model.py:723-770, calculate_NCE_loss 801-843, optimize_parameters 603-661)."""
 from collections import OrderedDict
 
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
+
+_PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
+_STREAMS = {}
+
+
+def _layer_streams(device, n):
+    """One side stream per nce layer, created once per device."""
+    key = (device.type, device.index)
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
 
 
 def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights, num_patches, lambda_nce,
@@ -13,13 +29,32 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         nce_weights = [1.0 / len(nce_layers)] * len(nce_layers)
     reals = torch.cat((real_A, real_B), dim=0) if real_B is not None else real_A
     out, feat_kq = netG(reals, list(nce_layers), False)
-    pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False)
+    # The per-layer chains (sampling -> head -> loss, and their adjoints) are independent of each other and made of small
+    # kernels that each occupy a fraction of the GPU: on CUDA they run on one stream per layer so they overlap -- autograd runs
+    # a node's backward on the stream of its forward, so the adjoint chains overlap too -- and join before the sum.
+    # (only while a HIP graph is being captured: launched eagerly, the extra stream switches cost the host more than the overlap
+    # returns -- 16.9 vs 15.8 ms -- while a replayed graph gets the parallel branches for free: 12.6 -> 11.8 ms)
+    streams = _layer_streams(reals.device, len(feat_kq)) if (reals.is_cuda and _PARALLEL_HEADS and
+                                                             torch.cuda.is_current_stream_capturing()) else None
+    ambient = torch.cuda.current_stream(reals.device) if streams is not None else None
+    pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
+    parts, layer_losses = [], []
+    for k, (f_kq, sid, crit, layer, w, feat) in enumerate(zip(pooled, ids, criterions, nce_layers, nce_weights, feat_kq)):
+        with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
+            loss = crit(f_kq, seg_A, sid, feat.size()[2:])
+            part = loss.mean() * w * lambda_nce
+            det = loss.detach().mean()
+        if streams is not None:
+            part.record_stream(ambient)
+            det.record_stream(ambient)
+        parts.append(part)
+        layer_losses.append(det)
+    if streams is not None:
+        for s in streams:
+            ambient.wait_stream(s)
     total = 0.0
-    layer_losses = []
-    for f_kq, sid, crit, layer, w, feat in zip(pooled, ids, criterions, nce_layers, nce_weights, feat_kq):
-        loss = crit(f_kq, seg_A, sid, feat.size()[2:])
-        total = total + loss.mean() * w * lambda_nce
-        layer_losses.append(loss.detach().mean())
+    for part in parts:
+        total = total + part
     (total / grad_accum_iters).backward()
     return total, layer_losses, ids, out
 
