@@ -216,7 +216,12 @@ void build_plan(amx_unet* h) {
 // widest tensor materialised at a level: its own width, or (trilinear) the upsampled image of the level below it
 int level_channels(const amx_unet* h, int level) {
   const int own = h->cfg.ngf << level;
-  return (h->cfg.interp == AMX_INTERP_TRILINEAR && level < h->cfg.num_downs) ? 2 * own : own;
+  int c = (h->cfg.interp == AMX_INTERP_TRILINEAR && level < h->cfg.num_downs) ? 2 * own : own;
+  // the output conv's result is staged in a level-0 slot when it leaves through the export pass (W < 32 or output_nc > 32):
+  // output_nc may exceed ngf.  (Sizing this by ngf alone overran the slot for output_nc = 64 -- silent while the bytes behind
+  // the workspace were unused, wrong results / faults once the allocator had neighbours there.)
+  if (level == 0 && h->cfg.output_nc > c) c = h->cfg.output_nc;
+  return c;
 }
 
 struct Profiler {

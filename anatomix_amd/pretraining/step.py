@@ -44,10 +44,7 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
             loss = crit(f_kq, seg_A, sid, feat.size()[2:])
             part = loss.mean() * w * lambda_nce
             det = loss.detach().mean()
-        if streams is not None:
-            part.record_stream(ambient)
-            det.record_stream(ambient)
-        parts.append(part)
+        parts.append(part)                                    # (kept alive until after the backward: no cross-stream reuse)
         layer_losses.append(det)
     if streams is not None:
         for s in streams:

@@ -186,3 +186,14 @@ def test_forward_is_hip_graph_capturable(device):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(y, model(x))
+
+
+def test_results_do_not_depend_on_memory_nobody_wrote():
+    """tools/poison_check.py: unusual configurations (wide output conv, tiny volumes, the dev variant) after filling the
+    allocator's free memory with NaNs / large values.  Caught the level-0 arena slot being sized by ngf while an output conv with
+    more channels than ngf was staged in it."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "poison_check.py")], capture_output=True, text=True, timeout=300)
+    tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:]
+    assert out.returncode == 0 and tail == "poison check: 0 bad results", out.stdout[-2000:] + out.stderr[-2000:]
