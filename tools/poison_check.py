@@ -26,6 +26,8 @@ CASES = [
     (dict(dimension=3, input_nc=1, output_nc=64, num_downs=1, ngf=16), (32, 32, 32)),
     (dict(dimension=3, input_nc=1, output_nc=16, num_downs=3, ngf=16, doubleconv=False), (16, 16, 24)),
     (dict(dimension=3, input_nc=1, output_nc=16, num_downs=4, ngf=16), (32, 32, 32)),
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=16), (16, 16, 16)),       # export path, output_nc > ngf, W < 32
+    (dict(dimension=3, input_nc=1, output_nc=128, num_downs=1, ngf=16, use_skip_connection=False), (32, 32, 64)),
     (dict(dimension=3, input_nc=1, output_nc=32, num_downs=5, ngf=32, norm="instance", pooling="Avg", interp="trilinear", norm_eps=1e-2), (64, 64, 64)),
 ]
 bad = 0
@@ -44,6 +46,16 @@ for kind in ("nan", "rand", "nan"):
                 y = m(x.to(dev)).cpu()
             e = rel_l2(y, ref)
             ok = bool(torch.isfinite(y).all()) and e < 2e-2
+            if rep == 0 and kw.get("norm", "batch") == "batch":            # the feature-tap forward shares the arena
+                nmod = len(m.model)
+                layers = [0, nmod // 3, nmod // 2, nmod - 1]
+                poison(kind)
+                with torch.no_grad():
+                    yt, feats = m(x.to(dev), layers)
+                    _, rfeats = R.forward(x, sd, kw, layers=layers)
+                et = max([rel_l2(yt.cpu(), ref)] + [rel_l2(a.cpu(), b) for a, b in zip(feats, rfeats)])
+                ok = ok and et < 2e-2
+                e = max(e, et)
             if not ok:
                 bad += 1
                 print("BAD", kind, kw.get("output_nc"), kw.get("num_downs"), size, "rep", rep, "rel_l2", e, "finite", bool(torch.isfinite(y).all()), flush=True)
