@@ -100,8 +100,15 @@ def fuzz_mlp():
     return 0
 
 devnull = open(os.devnull, "w")
+POISON = os.environ.get("AMX_FUZZ_POISON", "0") == "1"   # refill the allocator's free memory with NaNs every few cases
+ncase = 0
 while time.time() < t_end:
     try:
+        ncase += 1
+        if POISON and ncase % 5 == 0:
+            blocks = [torch.empty(64 << 20, dtype=torch.float32, device=dev).fill_(float("nan")) for _ in range(8)]
+            torch.cuda.synchronize()
+            del blocks
         pick = rng.random()
         if pick < 0.08:
             nreg += 1
