@@ -144,11 +144,42 @@ class Unet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _mark_dirty(self):
         self._weights_dirty = True
+        self.__dict__["_sig_tensors"] = None
+
+    # The native handle and the workspace belong to ONE module object on ONE device.  copy.copy / copy.deepcopy / pickling /
+    # nn.DataParallel replicas (which copy __dict__) must not share them: a copy starts without a handle and builds its own on
+    # its first HIP forward (sharing the raw pointer would be a use-after-free on the first re-create and a double free in
+    # __del__; ctypes pointers do not pickle either).
+    _PER_OBJECT_STATE = ("_handle", "_handle_key", "_workspace", "_uploaded_sig", "_sig_tensors")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._PER_OBJECT_STATE:
+            state[k] = None
+        state["_weights_dirty"] = True
+        return state
+
+    def __copy__(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__getstate__())
+        return new
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        for k in self._PER_OBJECT_STATE:
+            replica.__dict__[k] = None
+        replica.__dict__["_weights_dirty"] = True
+        return replica
 
     def _param_signature(self):
         """In-place updates (optimizer steps, nn.init.*, net.apply(init_func) as pretraining_networks.py:687-715 does) bump
-        every tensor's version counter: comparing them per call catches changes no hook sees."""
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        every tensor's version counter: comparing them per call catches changes no hook sees.  The tensor list itself is
+        cached (it only changes through _apply / load_state_dict / train, which mark the weights dirty), so the per-forward
+        cost is one pass over ~100 (pointer, version) pairs, not a walk of the module tree."""
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:
+            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
 
     def _weights_stale(self):
         return self._weights_dirty or getattr(self, "_uploaded_sig", None) != self._param_signature()
@@ -194,8 +225,10 @@ class Unet(nn.Module):
             return "activation not implemented in the HIP path"
         if c["interp"] not in _lib.INTERP or c["pooling"] not in _lib.POOL:
             return f"interp='{c['interp']}' / pooling='{c['pooling']}' is not implemented in the HIP path"
-        if c["input_nc"] != 1 or c["ngf"] % 16 or c["output_nc"] % 16:
-            return "HIP path needs input_nc == 1 and ngf, output_nc multiples of 16"
+        if c["input_nc"] != 1 or c["ngf"] not in (16, 32) or c["output_nc"] % 16 or c["output_nc"] < 16:
+            return "HIP path needs input_nc == 1, ngf in {16, 32} (the stem kernel) and output_nc a positive multiple of 16"
+        if c["num_downs"] < 1 or c["num_downs"] > 7 or (c["ngf"] << c["num_downs"]) > 2048:
+            return "HIP path needs 1 <= num_downs <= 7 and at most 2048 channels at the bottleneck"
         if x.dim() != 5 or x.shape[1] != 1:
             return "expected input of shape [N, 1, D, H, W]"
         return None

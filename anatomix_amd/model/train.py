@@ -48,6 +48,15 @@ def unsupported_reason(model, x, layers):
     return None
 
 
+def _bn_momentum(bn):
+    """torch: momentum=None means a cumulative moving average, factor 1 / num_batches_tracked (counted including this batch)."""
+    if bn.momentum is not None:
+        return bn.momentum
+    if bn.num_batches_tracked is None:
+        raise NotImplementedError("BatchNorm3d(momentum=None) without num_batches_tracked in the HIP training path")
+    return 1.0 / (int(bn.num_batches_tracked.item()) + 1)
+
+
 def _module_kinds(model):
     kinds = []
     for mod in model.model:
@@ -146,7 +155,7 @@ class _UnetTrainFn(torch.autograd.Function):
                     if isinstance(bn, nn.BatchNorm3d):
                         Y, mean, rstd = T.bn_train_forward(X, gam, bet, bn.eps, act if has_act else "none", 0.3,
                                                            bn.running_mean, bn.running_var,
-                                                           0.1 if bn.momentum is None else bn.momentum)
+                                                           _bn_momentum(bn))
                         if bn.num_batches_tracked is not None:
                             tracked.append(bn.num_batches_tracked)
                     else:
@@ -211,6 +220,7 @@ class _UnetTrainFn(torch.autograd.Function):
         model, tensors, dt = ctx.model, ctx.tensors, ctx.dt
         dtap = {l: g for l, g in zip(ctx.layers, dtaps) if g is not None}
         grads, pgrads, frames = {}, {}, {}
+        dx_in = None
 
         def add_grad(name, g):
             grads[name] = g if name not in grads else grads[name] + g
@@ -319,7 +329,9 @@ class _UnetTrainFn(torch.autograd.Function):
             if conv.bias is not None:                                   # d bias = sum of the pre-norm gradient over the voxels
                 pgrads[id(conv.bias)] = T.interior(fr).float().sum((0, 1, 2, 3))[: blk["cout"]]
             if blk["in0"] == "x":
-                continue                                                # the network input needs no gradient
+                if ctx.needs_input_grad[1]:                             # d loss / d image: the stem's data gradient (channel 0 of
+                    dx_in = T.conv_dgrad(fr, conv.weight)[..., 0].float().unsqueeze(1)   # the 16-channel padded result)
+                continue
             dcat = T.conv_dgrad(fr, conv.weight)
             if blk.get("cat_parts") is not None:                        # materialised trilinear concat: split, then the adjoint
                 skip_name, low_name = blk["cat_parts"]
@@ -341,7 +353,7 @@ class _UnetTrainFn(torch.autograd.Function):
                     add_grad(blk["in0"], dcat[..., :c0].contiguous())
                     up = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1)
                     add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))
-        return (None, None, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
+        return (None, dx_in, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
 
 
 def forward_train(model, x, layers):

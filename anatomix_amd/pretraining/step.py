@@ -64,7 +64,8 @@ def _grad_norms(netG, netF):
 
 
 def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights=None, num_patches=512,
-                     lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1, grad_sync=None):
+                     lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1, grad_sync=None, do_step=None,
+                     iters=None):
     """Two aligned views through the shared network with feature taps, same-coordinate patch sampling, per-layer
     SupPatchNCELoss, weighted sum, backward and (optionally) the optimizer steps.
 
@@ -72,14 +73,26 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
     netF: PatchSampleF; criterions: one SupPatchNCELoss per nce layer; nce_weights default 1/len (supcl_model.py:388-393);
     optimizers: (opt_G, opt_F) or None (gradients only); sample_ids: captured coordinates per layer or None (randperm);
     grad_sync: callable run between backward and the optimizer steps (data parallel: the gradient all-reduce).
+    grad_accum_iters > 1 (supcl_model.py:618-661): the loss is divided by it on every call and the gradients accumulate; the
+    optimizers step (and are zeroed) only on calls where ``do_step`` is true -- pass it directly, or pass the reference's
+    running ``iters`` counter and it is ``iters % grad_accum_iters == 0``.  With optimizers and grad_accum_iters > 1 one of
+    the two must be given: stepping on every call would shrink the gradients instead of accumulating them.
     Returns an OrderedDict(loss, per_layer, grad_norm_G, grad_norm_F, sample_ids, out).
     """
+    if do_step is None:
+        if iters is not None:
+            do_step = iters % grad_accum_iters == 0
+        elif optimizers is not None and grad_accum_iters > 1:
+            raise ValueError("contrastive_step: with optimizers and grad_accum_iters > 1 pass do_step= or iters= "
+                             "(the reference steps when iters % grad_accum_iters == 0, supcl_model.py:628)")
+        else:
+            do_step = True
     total, layer_losses, ids, out = _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights,
                                                      num_patches, lambda_nce, sample_ids, grad_accum_iters)
-    if grad_sync is not None:
+    if grad_sync is not None and do_step:
         grad_sync()
     gG, gF = _grad_norms(netG, netF)
-    if optimizers is not None:
+    if optimizers is not None and do_step:
         for opt in optimizers:
             opt.step()
         for opt in optimizers:

@@ -8,27 +8,34 @@ Jacobian utilities) is downstream of the feature path and not part of this packa
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from .. import _lib
-from ..model.load_from_hf import ANATOMIX_VARIANTS, _load_handling_compile
+from ..model.load_from_hf import ANATOMIX_VARIANTS, _load_handling_compile, load_from_hf  # noqa: F401
 from ..model.network import Unet
 from .sliding_window import sliding_window_inference
 
 
-def load_model(ckpt_path=None, hf_variant=None, output_nc=16, num_downs=4, ngf=16, norm="batch", interp="nearest",
-               pooling="Max", device=None):
-    """convex_adam_utils.py:16-78: build the Unet (positional argument order of the reference), load a
-    checkpoint (plain state_dict, optionally ``_orig_mod.``-prefixed) and put it in eval mode on `device`."""
+def load_model(ckpt_path=None, hf_variant=None, *, num_downs=4, ngf=16, output_nc=16, norm="batch", interp="nearest",
+               pooling="Max", device=None, weights_path=None):
+    """convex_adam_utils.py:16-78.  Exactly one of ``ckpt_path`` / ``hf_variant``; the architecture arguments are
+    keyword-only and only used with ``ckpt_path`` (a variant brings its own).  ``hf_variant`` goes through
+    ``load_from_hf`` (Hub download, or the local ``weights_path=`` extension of this package where there is no network),
+    so the returned model ALWAYS carries loaded weights.  Returned in eval mode on ``device`` (default: cuda if present)."""
+    if (ckpt_path is None) == (hf_variant is None):
+        raise ValueError("Provide exactly one of `ckpt_path` or `hf_variant`.")
     if hf_variant is not None:
-        kw = ANATOMIX_VARIANTS[hf_variant]["unet_kwargs"]
-        model = Unet(**kw)
+        model = load_from_hf(hf_variant, weights_path=weights_path)
+    elif ckpt_path == "scratch":
+        raise ValueError("'scratch' is not supported for registration; registration requires pretrained weights.")
     else:
+        if not os.path.isfile(ckpt_path):
+            raise FileNotFoundError(f"Checkpoint file not found: {ckpt_path}")
         model = Unet(3, 1, output_nc, num_downs, ngf=ngf, norm=norm, interp=interp, pooling=pooling)
-    if ckpt_path is not None:
-        _load_handling_compile(model, torch.load(ckpt_path, map_location="cpu"))
+        model = _load_handling_compile(model, torch.load(ckpt_path, map_location="cpu"))
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     model.to(device)

@@ -89,3 +89,54 @@ def test_library_exports_every_declared_symbol():
     assert lib.amx_version() == 100
     for name in declared:
         assert hasattr(lib, name)
+
+
+def test_load_model_contract(tmp_path):
+    """convex_adam_utils.py:16-78: exactly one of ckpt_path / hf_variant, missing file is an error, architecture arguments
+    keyword-only, and the model that comes back always has the checkpoint's weights."""
+    from anatomix_amd.registration import load_model
+    with pytest.raises(ValueError, match="exactly one"):
+        load_model()
+    with pytest.raises(ValueError, match="exactly one"):
+        load_model("a.pth", "anatomix")
+    with pytest.raises(FileNotFoundError):
+        load_model(str(tmp_path / "missing.pth"))
+    with pytest.raises(ValueError, match="scratch"):
+        load_model("scratch")
+    with pytest.raises(TypeError):
+        load_model(None, None, 16)                       # architecture arguments are keyword-only, as in the reference
+    kw = R.VARIANTS["anatomix"]
+    sd = R.synthetic_state_dict(kw, 3)
+    path = tmp_path / "anatomix.pth"
+    torch.save({"_orig_mod." + k: v for k, v in sd.items()}, path)
+    for m in (load_model(str(path), device="cpu"), load_model(hf_variant="anatomix", weights_path=str(path), device="cpu")):
+        assert not m.training and torch.equal(m.model[0].weight, sd["model.0.weight"])
+        assert torch.equal(m.model[1].running_var, sd["model.1.running_var"])
+
+
+def test_copies_do_not_share_the_native_handle():
+    """The C handle and the workspace belong to one module object: copies (copy / deepcopy / DataParallel replicas) start
+    without one instead of sharing a raw pointer."""
+    import copy
+    m = anatomix_amd.Unet(**R.VARIANTS["anatomix"])
+    m._handle, m._handle_key, m._workspace, m._weights_dirty = object(), (0, "f16"), torch.zeros(4), False
+    try:
+        for c in (copy.copy(m), copy.deepcopy(m), m._replicate_for_data_parallel()):
+            assert c._handle is None and c._handle_key is None and c._workspace is None and c._weights_dirty
+        assert m._handle is not None and not m._weights_dirty
+    finally:
+        m._handle = None                                  # not a real handle: keep __del__ away from it
+
+
+def test_hip_gate_mirrors_the_library_limits():
+    """Configurations the C side would refuse are refused by the Python gate with a reason (so allow_torch_path applies)."""
+    dev_like = torch.zeros(1, 1, 32, 32, 32)
+    for kwargs in (dict(ngf=48), dict(ngf=64), dict(ngf=16, output_nc=8)):
+        kw = dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16)
+        kw.update(kwargs)
+        m = anatomix_amd.Unet(**kw).eval()
+        class _X:                                         # is_cuda is checked first: a stand-in for a GPU tensor
+            is_cuda = True; requires_grad = False; shape = dev_like.shape
+            def dim(self): return 5
+        with torch.no_grad():
+            assert m.hip_unsupported_reason(_X()) is not None, kwargs
