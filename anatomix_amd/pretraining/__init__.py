@@ -10,5 +10,6 @@ The UNet inside the step runs forward and backward on the HIP kernels (anatomix_
 from .supcon import SupPatchNCELoss
 from .patch_sample import PatchSampleF
 from .step import contrastive_step, GraphedContrastiveStep
+from .data_parallel import GradientBuckets
 
-__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep"]
+__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep", "GradientBuckets"]

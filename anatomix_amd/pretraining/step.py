@@ -65,14 +65,16 @@ def _grad_norms(netG, netF):
 
 def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights=None, num_patches=512,
                      lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1, grad_sync=None, do_step=None,
-                     iters=None):
+                     iters=None, grad_buckets=None):
     """Two aligned views through the shared network with feature taps, same-coordinate patch sampling, per-layer
     SupPatchNCELoss, weighted sum, backward and (optionally) the optimizer steps.
 
     netG: Unet (train mode: BatchNorm batch statistics over the two views, supcl_model.py:735-742);
     netF: PatchSampleF; criterions: one SupPatchNCELoss per nce layer; nce_weights default 1/len (supcl_model.py:388-393);
     optimizers: (opt_G, opt_F) or None (gradients only); sample_ids: captured coordinates per layer or None (randperm);
-    grad_sync: callable run between backward and the optimizer steps (data parallel: the gradient all-reduce).
+    grad_sync: callable run between backward and the optimizer steps (data parallel: the gradient all-reduce);
+    grad_buckets: a ``data_parallel.GradientBuckets`` over (netG, netF) -- its ``sync()`` is the gradient all-reduce and its
+    ``zero()`` replaces ``optimizer.zero_grad()`` (the gradients are views into its flat buffers and must survive the step).
     grad_accum_iters > 1 (supcl_model.py:618-661): the loss is divided by it on every call and the gradients accumulate; the
     optimizers step (and are zeroed) only on calls where ``do_step`` is true -- pass it directly, or pass the reference's
     running ``iters`` counter and it is ``iters % grad_accum_iters == 0``.  With optimizers and grad_accum_iters > 1 one of
@@ -89,14 +91,20 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
             do_step = True
     total, layer_losses, ids, out = _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights,
                                                      num_patches, lambda_nce, sample_ids, grad_accum_iters)
-    if grad_sync is not None and do_step:
-        grad_sync()
+    if do_step:
+        if grad_sync is not None:
+            grad_sync()
+        if grad_buckets is not None:
+            grad_buckets.sync()
     gG, gF = _grad_norms(netG, netF)
     if optimizers is not None and do_step:
         for opt in optimizers:
             opt.step()
-        for opt in optimizers:
-            opt.zero_grad()
+        if grad_buckets is not None:
+            grad_buckets.zero()
+        else:
+            for opt in optimizers:
+                opt.zero_grad()
     # ONE host synchronisation per step, after everything is enqueued (the reference reads every scalar with .item() as it
     # goes, supcl_model.py:841; that only paces the host, the values are the same)
     scalars = torch.stack([total.detach(), gG.detach(), gF.detach()] + layer_losses).tolist()
@@ -118,13 +126,19 @@ class GraphedContrastiveStep:
     Returns the same OrderedDict as ``contrastive_step`` (ONE host synchronisation per call, for the scalars)."""
 
     def __init__(self, netG, netF, criterions, nce_layers, optimizers, nce_weights=None, num_patches=512, lambda_nce=1.0,
-                 grad_sync=None, warmup=3):
+                 grad_sync=None, warmup=3, grad_buckets=None):
         self.netG, self.netF, self.criterions, self.nce_layers = netG, netF, criterions, list(nce_layers)
         self.optimizers, self.nce_weights, self.num_patches, self.lambda_nce = optimizers, nce_weights, num_patches, lambda_nce
+        self.grad_buckets = grad_buckets
+        if grad_buckets is not None and grad_sync is None and grad_buckets.world > 1:
+            grad_sync = grad_buckets.sync
         self.grad_sync, self.warmup = grad_sync, warmup
         self.graph = None
-        self.opt_in_graph = grad_sync is None and optimizers is not None and all(
-            o.defaults.get("capturable", False) for o in optimizers)
+        self.tail_graph = None
+        capturable = optimizers is None or all(o.defaults.get("capturable", False) for o in optimizers)
+        self.opt_in_graph = grad_sync is None and optimizers is not None and capturable
+        # data parallel: [graph: forward + backward] -> gradient all-reduce (eager, RCCL) -> [second graph: norms + optimizers]
+        self.tail_in_own_graph = grad_sync is not None and capturable
 
     def _eager(self):
         return _forward_backward(self.netG, self.netF, self.criterions, self.A, self.B, self.seg, self.nce_layers,
@@ -153,11 +167,20 @@ class GraphedContrastiveStep:
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            if self.grad_buckets is not None:
+                self.grad_buckets.zero()                    # part of every replay: the flat gradient buffers start from zero
             self.total, self.layer_losses, self.ids, self.out = self._eager()
             if self.opt_in_graph or (self.grad_sync is None and self.optimizers is None):
                 self.scalars = self._tail(self.total, self.layer_losses)
+        if self.tail_in_own_graph:
+            self.tail_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.tail_graph):
+                self.tail_scalars = self._tail(self.total, self.layer_losses)
 
     def _zero(self):
+        if self.grad_buckets is not None:
+            self.grad_buckets.zero()
+            return
         for net in (self.netG, self.netF):
             for p in net.parameters():
                 p.grad = None
@@ -176,7 +199,11 @@ class GraphedContrastiveStep:
         else:
             if self.grad_sync is not None:
                 self.grad_sync()
-            scalars = self._tail(self.total, self.layer_losses)
+            if self.tail_graph is not None:
+                self.tail_graph.replay()
+                scalars = self.tail_scalars
+            else:
+                scalars = self._tail(self.total, self.layer_losses)
         vals = scalars.tolist()
         per_layer = OrderedDict((str(layer), v) for layer, v in zip(self.nce_layers, vals[3:]))
         return OrderedDict(loss=vals[0], per_layer=per_layer, grad_norm_G=vals[1], grad_norm_F=vals[2], sample_ids=self.ids,

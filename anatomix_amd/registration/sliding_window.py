@@ -20,8 +20,15 @@ Two execution paths:
     place, so neither the window stack nor the per-window predictions are materialised.
 
 Multi-GPU: windows are independent, so with ``group=`` (a torch.distributed process group) they are
-dealt to ranks in contiguous z-ordered runs; each rank accumulates its own windows and ONE
-``all_reduce(SUM)`` of (sum_w*f, sum_w) precedes the normalisation -- the only exchange step.
+dealt to ranks in contiguous z-ordered runs; each rank accumulates its own windows.  The ONE exchange
+step is a z-slab reduce-scatter: the volume's z axis is cut into ``world`` slabs,
+rank s owns slab s, and every rank sends to each owner only the planes of (sum_w*f, sum_w) it
+actually touched inside that owner's slab (a rank's windows span ~roi + a few scan intervals of z, so
+most (rank, slab) pairs exchange nothing) as direct point-to-point transfers -- on RCCL they run
+concurrently over the fully connected xGMI links instead of around a ring.  The owner sums what it
+receives and normalises ITS slab only; ``return_slab=True`` leaves the result sharded (what a
+throughput-oriented caller wants), the default all-gathers the normalised slabs so that every rank
+returns the full tensor, like the single-process call.
 """
 from __future__ import annotations
 
@@ -91,8 +98,11 @@ def _fused_ok(predictor, inputs) -> bool:
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable,
                              overlap: float = 0.25, mode: str = "constant", sigma_scale: float = 0.125,
-                             padding_mode: str = "constant", cval: float = 0.0, group=None) -> torch.Tensor:
-    """inputs [B,C,D,H,W] -> [B,Cout,D,H,W]; same call contract as the reference's use of MONAI."""
+                             padding_mode: str = "constant", cval: float = 0.0, group=None, return_slab: bool = False):
+    """inputs [B,C,D,H,W] -> [B,Cout,D,H,W]; same call contract as the reference's use of MONAI.
+    ``group``: shard the windows over the ranks of a process group (see the module docstring);
+    ``return_slab`` (only with ``group``): return ``(slab [B,Cout,z1-z0,H,W], z0, z1)`` -- this rank's normalised z-slab --
+    instead of gathering the full volume on every rank."""
     if isinstance(roi_size, int):
         roi_size = (roi_size,) * 3
     roi = tuple(int(r) for r in roi_size)
@@ -140,22 +150,84 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
             probe = predictor(inputs[:1, :, :roi[0], :roi[1], :roi[2]])
             acc = torch.zeros((B, probe.shape[1]) + size, dtype=probe.dtype, device=probe.device)
     if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-    if acc.is_cuda and acc.dtype == torch.float32:
-        lib = _lib.load()
-        st = ctypes.c_void_p(torch.cuda.current_stream(acc.device).cuda_stream)
-        vox = size[0] * size[1] * size[2]
-        with torch.cuda.device(acc.device):
-            for b in range(B):
-                _lib.check(lib.amx_sw_normalize(_lib.ptr(acc[b]), _lib.ptr(cnt), acc.shape[1], vox, st))
+        touched = []
+        for r in range(world):
+            run = starts[len(starts) * r // world: len(starts) * (r + 1) // world]
+            touched.append((min(s3[0] for s3 in run), max(s3[0] for s3 in run) + roi[0]) if run else (0, 0))
+        slab, z0, z1 = _exchange_slabs(acc, cnt, touched, rank, world, group)
+        _normalize(slab, cnt[z0:z1].contiguous())
+        if return_slab:
+            if need_pad:
+                raise ValueError("return_slab needs a volume at least as large as the roi (no padding)")
+            return slab, z0, z1
+        acc = _gather_slabs(slab, size[0], world, group)
     else:
-        acc = acc / cnt
+        _normalize(acc, cnt)
     if need_pad:
         zs, ys, xs = pads[4], pads[2], pads[0]
         acc = acc[:, :, zs:zs + orig[0], ys:ys + orig[1], xs:xs + orig[2]]
     return acc
+
+
+def _normalize(acc, cnt):
+    """acc[b, c] /= cnt in place (acc [B,C,d,H,W] contiguous, cnt [d,H,W] contiguous)."""
+    if acc.is_cuda and acc.dtype == torch.float32 and acc.is_contiguous() and cnt.is_contiguous() and acc.numel():
+        lib = _lib.load()
+        st = ctypes.c_void_p(torch.cuda.current_stream(acc.device).cuda_stream)
+        vox = cnt.numel()
+        with torch.cuda.device(acc.device):
+            for b in range(acc.shape[0]):
+                _lib.check(lib.amx_sw_normalize(_lib.ptr(acc[b]), _lib.ptr(cnt), acc.shape[1], vox, st))
+    else:
+        acc /= cnt
+
+
+def slab_bounds(depth: int, world: int) -> List[int]:
+    """z-slab s = [bounds[s], bounds[s + 1])."""
+    return [depth * r // world for r in range(world + 1)]
+
+
+def _exchange_slabs(acc, cnt, touched, rank, world, group):
+    """z-slab reduce-scatter of (acc [B,C,D,H,W], cnt [D,H,W]) by direct point-to-point transfers of the touched planes.
+    Returns this rank's summed slab of acc (contiguous) and its z range; cnt[z0:z1] is summed in place."""
+    import torch.distributed as dist
+    B, C, D, H, W = acc.shape
+    bounds = slab_bounds(D, world)
+    z0, z1 = bounds[rank], bounds[rank + 1]
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None and group is not dist.group.WORLD else (lambda r: r)
+    ops, recvs, keep = [], [], []
+    for s in range(world):
+        a, b = max(touched[rank][0], bounds[s]), min(touched[rank][1], bounds[s + 1])
+        if s != rank and a < b:       # my contribution to slab s: B*C planes-stacks of acc + one of cnt, in one message
+            buf = torch.cat([acc[:, :, a:b].reshape(B * C, b - a, H, W), cnt[a:b].unsqueeze(0)])
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, peer(s), group))
+    for r in range(world):
+        a, b = max(touched[r][0], z0), min(touched[r][1], z1)
+        if r != rank and a < b:
+            buf = torch.empty((B * C + 1, b - a, H, W), dtype=acc.dtype, device=acc.device)
+            recvs.append((a, b, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer(r), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    slab = acc[:, :, z0:z1].contiguous()
+    for a, b, buf in recvs:           # fixed order (ascending source rank): deterministic sums
+        slab[:, :, a - z0:b - z0] += buf[:-1].view(B, C, b - a, H, W)
+        cnt[a:b] += buf[-1]
+    return slab, z0, z1
+
+
+def _gather_slabs(slab, depth, world, group):
+    """all_gather of the normalised slabs (padded to the tallest one) -> the full [B,C,D,H,W] tensor on every rank."""
+    import torch.distributed as dist
+    B, C, _, H, W = slab.shape
+    bounds = slab_bounds(depth, world)
+    tall = max(bounds[r + 1] - bounds[r] for r in range(world))
+    mine = slab if slab.shape[2] == tall else F.pad(slab, (0, 0, 0, 0, 0, tall - slab.shape[2]))
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine.contiguous(), group=group)
+    return torch.cat([parts[r][:, :, : bounds[r + 1] - bounds[r]] for r in range(world)], dim=2)
 
 
 FUSED_WINDOW_BATCH = 4     # windows per amx_unet_forward_windows call (fills the chip on the deep levels)

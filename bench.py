@@ -38,7 +38,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="128^3 windows per step per GPU (sliding-window batch)")
     ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "strict", "f16x2", "bf16x2"],
+                    help="storage precision of the HIP path; strict (= bf16x2) / f16x2: split hi+lo 16-bit operands, three MFMAs per "
+                         "product, fp32-grade results (the reference's inference callers run fp32)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default N=1 run only: skip the short secondary workloads (anatomix-dev, 256^3 sliding window, contrastive step, "
+                         "strict precision) that are reported in the `secondary` object of the JSON line")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous plumbing only (gloo, no GPU work): prints a stub line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="step workload: launch every kernel eagerly instead of replaying one HIP graph")
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
@@ -220,37 +226,48 @@ def step_roofline(torch, dev, S):
             "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: re-exec this script under torch.distributed.run, one rank per
+    GPU of this node (rendezvous on 127.0.0.1), and pass its exit code on.  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Ctx:
+    pass
+
+
+def build_model(ctx, variant, precision):
     import anatomix_amd
     from oracle import unet_ref as R      # only for the synthetic weights/input generators + cpu_baseline
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)", file=sys.stderr)
-        sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    kw = R.VARIANTS[args.variant]
-    sys.stdout.flush()
-    devnull = open(os.devnull, "w")
-    so, sys.stdout = sys.stdout, devnull             # the constructor prints two lines (reference parity)
-    model = anatomix_amd.Unet(**kw)
-    sys.stdout = so
+    kw = R.VARIANTS[variant]
+    so, sys.stdout = sys.stdout, open(os.devnull, "w")      # the constructor prints two lines (reference parity)
+    try:
+        model = anatomix_amd.Unet(**kw)
+    finally:
+        sys.stdout = so
     model.load_state_dict(R.synthetic_state_dict(kw, 0), strict=True)
-    model.precision = args.precision
-    model = model.to(dev).eval()
-    S, B = args.size, args.batch
+    model.precision = precision
+    return model.to(ctx.dev).eval()
+
+
+def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, precision="f16", steps=100, warmup=10, batch=4, size=128,
+                 no_graph=False, with_cpu=True, cpu_forwards=6):
+    """One measured workload -> the result dict of the JSON line (rank 0; None on the other ranks)."""
+    torch, dist, dev, world, rank = ctx.torch, ctx.dist, ctx.dev, ctx.world, ctx.rank
+    from oracle import unet_ref as R
+    model = build_model(ctx, variant, precision)
+    S, B = size, batch
     x = R.synthetic_input(100 + rank, B, (S, S, S)).to(dev)      # resident before the timed region
 
     def barrier():
@@ -262,65 +279,60 @@ def main():
     step = lambda: model(x)
     units_per_step = world * B          # 128^3 volumes all ranks process per step
     grad_ctx = torch.no_grad()
-    if args.workload == "step":
+    dp_note = ""
+    if workload == "step":
         from argparse import Namespace
-        from anatomix_amd.pretraining import PatchSampleF, SupPatchNCELoss, contrastive_step
+        from anatomix_amd.pretraining import GradientBuckets, PatchSampleF, SupPatchNCELoss, contrastive_step
         from oracle import pretrain_inputs as PI      # synthetic two-view inputs only
         model.precision = "bf16"                      # the reference trains under bf16 autocast
         model.train()
-        so, sys.stdout = sys.stdout, devnull
-        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
-        netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
-        sys.stdout = so
+        so, sys.stdout = sys.stdout, open(os.devnull, "w")
+        try:
+            netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+            netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+        finally:
+            sys.stdout = so
         netF = netF.to(dev).train()
         nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
         crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
-        cap = not args.no_graph and world == 1        # capturable AdamW keeps its step count on the device
+        cap = not no_graph                            # capturable AdamW keeps its step count on the device
         opts = (torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap),
                 torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap))
         vA, vB, seg = [t.to(dev) for t in PI.step_inputs(S)]
         vA = (vA + 0.01 * rank).clamp(0, 1)           # a different pair per rank
-
-        def grad_sync():                              # plain data parallel: average the gradients over the ranks (RCCL)
-            if world == 1:
-                return
-            for net in (model, netF):
-                gs = [p.grad for p in net.parameters() if p.grad is not None]
-                flat = torch.cat([g.reshape(-1) for g in gs])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat /= world
-                o = 0
-                for g in gs:
-                    g.copy_(flat[o:o + g.numel()].view_as(g))
-                    o += g.numel()
-
-        if args.no_graph:
+        # plain data parallel: the gradients of both networks live in flat buckets that RCCL averages in place
+        buckets = GradientBuckets((model, netF), bucket_mb=16.0, overlap=no_graph) if world > 1 else None
+        if buckets is not None:
+            dp_note = f"; gradients in {len(buckets.buckets)} flat buckets ({buckets.nbytes / 1e6:.1f} MB), async all_reduce each"
+        if no_graph:
             step = lambda: contrastive_step(model, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts,
-                                            grad_sync=grad_sync)["out"]
+                                            grad_buckets=buckets)["out"]
         else:
-            # the whole step replayed from one HIP graph (1 GPU: optimizers included; data parallel: forward + backward in the
-            # graph, then the RCCL all-reduce and AdamW)
+            # the whole step replayed from HIP graphs (1 GPU: one graph, optimizers included; data parallel: forward + backward
+            # in one graph, the RCCL all-reduces of the buckets, then gradient norms + AdamW in a second graph)
             from anatomix_amd.pretraining import GraphedContrastiveStep
-            graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512,
-                                             grad_sync=grad_sync if world > 1 else None)
+            graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512, grad_buckets=buckets)
             step = lambda: graphed(vA, vB, seg)["out"]
         units_per_step = world * 2
         grad_ctx = torch.enable_grad()
-    if args.sw_volume:
+    if sw_volume:
         from anatomix_amd.registration.sliding_window import sliding_window_inference, window_starts
-        V = args.sw_volume
+        V = sw_volume
         vol = R.synthetic_input(101, 1, (V, V, V)).to(dev)          # every rank holds the volume
         group = dist.group.WORLD if world > 1 else None
-        step = lambda: sliding_window_inference(vol, (S, S, S), 2, model, overlap=0.8, mode="gaussian",
-                                                sigma_scale=0.25, group=group)
+        if world > 1:      # results stay sharded: every rank keeps its normalised z-slab
+            step = lambda: sliding_window_inference(vol, (S, S, S), 2, model, overlap=0.8, mode="gaussian", sigma_scale=0.25,
+                                                    group=group, return_slab=True)[0]
+        else:
+            step = lambda: sliding_window_inference(vol, (S, S, S), 2, model, overlap=0.8, mode="gaussian", sigma_scale=0.25)
         units_per_step = len(window_starts((V, V, V), (S, S, S), 0.8))
 
     with grad_ctx:
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             y = step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             y = step()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -328,49 +340,131 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ms_step = elapsed / args.steps * 1e3
-    value = units_per_step * args.steps / elapsed
+    ms_step = elapsed / steps * 1e3
+    value = units_per_step * steps / elapsed
     assert torch.isfinite(y).all()
 
     result = None
     if rank == 0:
-        if args.workload == "step":
+        if workload == "step":
             roofline = step_roofline(torch, dev, S)
         else:
             roofline = forward_roofline(torch, model, x, B)
-        gflop_vol = (GFLOP_PER_VOLUME_6M if args.variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
-        name = "anatomix 6M UNet (ngf=16,num_downs=4)" if args.variant == "anatomix" else \
+        gflop_vol = (GFLOP_PER_VOLUME_6M if variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
+        name = "anatomix 6M UNet (ngf=16,num_downs=4)" if variant == "anatomix" else \
             "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)"
-        if args.sw_volume:
-            workload = (f"{name}: sliding-window feature extraction of one 1x{args.sw_volume}^3 volume = {units_per_step} windows "
-                        f"of {S}^3 per step (overlap 0.8, gaussian 0.25), fused gaussian accumulate (BASELINE configs[1])")
-            par = f"windows dealt to {world} rank(s), one all_reduce(SUM) of the accumulators" if world > 1 else "1 GPU"
-        elif args.workload == "step":
-            workload = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
-                        "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; AdamW), bf16 "
-                        "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels" + ("" if args.no_graph else ", replayed from one HIP graph") + " (BASELINE configs[2])")
-            par = f"data parallel x{world}: one pair per rank, gradients averaged with one all_reduce per network"
+        storage = {"f16": "16-bit (f16) channels-last activations, fp32 accumulate",
+                   "bf16": "16-bit (bf16) channels-last activations, fp32 accumulate"}.get(
+            precision, f"split hi+lo 16-bit operands ({'bf16x2' if precision == 'strict' else precision}: three MFMAs per product), "
+                       "fp32 accumulate -- fp32-grade results")
+        if sw_volume:
+            workload_s = (f"{name}: sliding-window feature extraction of one 1x{sw_volume}^3 volume = {units_per_step} windows "
+                          f"of {S}^3 per step (overlap 0.8, gaussian 0.25), fused gaussian accumulate (BASELINE configs[1]); {storage}")
+            par = (f"windows dealt to {world} rank(s) in z-ordered runs; one exchange step: z-slab reduce-scatter by direct "
+                   "point-to-point transfers of the touched planes; results stay sharded") if world > 1 else "1 GPU"
+        elif workload == "step":
+            workload_s = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
+                          "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; AdamW), bf16 "
+                          "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels" +
+                          ("" if no_graph else ", replayed from HIP graphs") + " (BASELINE configs[2])")
+            par = f"data parallel x{world}: one pair per rank" + dp_note
             gflop_vol *= 3.0      # forward + data gradient + weight gradient
         else:
-            workload = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
-                        "sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, 16-bit channels-last "
-                        "activations, fp32 accumulate")
+            workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
+                          f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}")
             par = f"replicas x{world} (no data-path collective)"
         result = {
-            "metric": ("128^3 volumes/sec through the contrastive pretraining step (6M UNet)" if args.workload == "step" else
-                       "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if args.variant == "anatomix" else "94M dev UNet")),
+            "metric": ("128^3 volumes/sec through the contrastive pretraining step (6M UNet)" if workload == "step" else
+                       "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if variant == "anatomix" else "94M dev UNet")),
             "value": round(value, 2), "unit": "volumes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "strong" if args.sw_volume else "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.workload == "step" else args.precision,
-            "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {args.variant} architecture)",
-            "config": {"workload": workload, "batch_per_gpu": 1 if args.sw_volume else (2 if args.workload == "step" else B), "window": S, "parallelism": par},
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong" if sw_volume else "weak", "vs_baseline": None,
+            "dtype": "bf16" if workload == "step" else ("bf16x2" if precision == "strict" else precision),
+            "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {variant} architecture)",
+            "config": {"workload": workload_s, "batch_per_gpu": 1 if sw_volume else (2 if workload == "step" else B), "window": S,
+                       "parallelism": par},
             "end_to_end_TFLOPs": round(value * gflop_vol / 1e3, 1),
             "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_step(S) if args.workload == "step" else cpu_baseline(S, args.cpu_forwards, args.variant)
+        if world == 1 and with_cpu:
+            result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else cpu_baseline(S, cpu_forwards, variant)
+    del model, x, y
+    torch.cuda.empty_cache()
+    return result
+
+
+def secondary_workloads(ctx, args):
+    """Short driver-timed runs of the other BASELINE configs, attached to the default N=1 line (each with its own roofline)."""
+    S = args.size
+    plan = [
+        ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
+        ("anatomix_dev", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=2)),
+        ("anatomix_dev_strict", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=2)),
+        ("sliding_window_256", dict(variant="anatomix", sw_volume=2 * S, steps=3, warmup=1)),
+        ("contrastive_step", dict(variant="anatomix", workload="step", steps=10, warmup=1)),
+    ]
+    out = {}
+    for name, kw in plan:
+        t0 = time.perf_counter()
+        try:
+            r = run_workload(ctx, size=S, with_cpu=False, **kw)
+            keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "end_to_end_TFLOPs",
+                                      "end_to_end_mfma_frac", "roofline")}
+            keep["workload"] = r["config"]["workload"]
+            keep["batch_per_gpu"] = r["config"]["batch_per_gpu"]
+            keep["roofline"].pop("per_kernel", None)
+            keep["wall_s"] = round(time.perf_counter() - t0, 1)
+            out[name] = keep
+        except Exception as e:                       # a failing secondary must not take the headline down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup}))
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world > 1 and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
+    ctx = Ctx()
+    ctx.torch, ctx.dist, ctx.world, ctx.rank = torch, dist, world, rank
+    ctx.dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(ctx.dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=ctx.dev)
+
+    result = run_workload(ctx, variant=args.variant, workload=args.workload, sw_volume=args.sw_volume, precision=args.precision,
+                          steps=args.steps, warmup=args.warmup, batch=args.batch, size=args.size, no_graph=args.no_graph,
+                          with_cpu=not args.no_cpu_baseline, cpu_forwards=args.cpu_forwards)
+    headline = args.variant == "anatomix" and args.workload == "forward" and not args.sw_volume and args.precision == "f16"
+    if rank == 0 and world == 1 and headline and not args.no_secondary:
+        result["secondary"] = secondary_workloads(ctx, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

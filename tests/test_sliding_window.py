@@ -88,25 +88,33 @@ def _dist_worker(rank, world, port, out):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     pred = _conv_predictor()
     torch.manual_seed(1)
-    x = torch.rand(1, 1, 40, 33, 48)
-    y = sliding_window_inference(x, (16, 16, 32), 2, pred, overlap=0.8, mode="gaussian", sigma_scale=0.25,
-                                 group=dist.group.WORLD)
-    if rank == 0:
-        torch.save(y, out)
+    x = torch.rand(2, 1, 40, 33, 48)
+    kw = dict(overlap=0.8, mode="gaussian", sigma_scale=0.25, group=dist.group.WORLD)
+    y = sliding_window_inference(x, (16, 16, 32), 2, pred, **kw)                        # gathered: full volume on every rank
+    slab, z0, z1 = sliding_window_inference(x, (16, 16, 32), 2, pred, return_slab=True, **kw)
+    torch.save(dict(y=y, slab=slab, z0=z0, z1=z1), f"{out}.{rank}")
     dist.destroy_process_group()
 
 
-def test_window_sharding_over_two_ranks_matches_single_process(tmp_path):
-    """N > 1 path on CPU: windows dealt to 2 gloo ranks, one all_reduce of (sum w*f, sum w)."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_sharding_over_ranks_matches_single_process(tmp_path, world):
+    """N > 1 path on CPU (gloo): windows dealt to the ranks in z-ordered runs, ONE exchange step -- the z-slab reduce-scatter by
+    direct transfers of the touched planes -- then each rank normalises its own slab; gathered and sharded results."""
     import socket
     import torch.multiprocessing as mp
+    from anatomix_amd.registration.sliding_window import slab_bounds
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "y.pt")
-    mp.spawn(_dist_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_dist_worker, args=(world, port, out), nprocs=world, join=True)
     pred = _conv_predictor()
     torch.manual_seed(1)
-    x = torch.rand(1, 1, 40, 33, 48)
+    x = torch.rand(2, 1, 40, 33, 48)
     ref = sliding_window_inference(x, (16, 16, 32), 2, pred, overlap=0.8, mode="gaussian", sigma_scale=0.25)
-    assert torch.allclose(torch.load(out), ref, rtol=1e-5, atol=1e-6)
+    bounds = slab_bounds(40, world)
+    for r in range(world):
+        d = torch.load(f"{out}.{r}")
+        assert torch.allclose(d["y"], ref, rtol=1e-5, atol=1e-6)
+        assert (d["z0"], d["z1"]) == (bounds[r], bounds[r + 1])
+        assert torch.allclose(d["slab"], ref[:, :, d["z0"]:d["z1"]], rtol=1e-5, atol=1e-6)
