@@ -13,7 +13,8 @@ NORM = {"none": 0, "batch": 1, "instance": 2, "instance_affine": 3}
 ACT = {"none": 0, "relu": 1, "lrelu": 2}
 POOL = {"Max": 0, "Avg": 1}
 INTERP = {"nearest": 0, "trilinear": 1}
-PRECISION = {"f16": 0, "fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1}
+# "strict" = bf16x2: split hi + lo operands, fp32-grade results with fp32's exponent range (include/anatomix_amd.h)
+PRECISION = {"f16": 0, "fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1, "f16x2": 2, "bf16x2": 3, "strict": 3, "fp32": 3}
 
 
 class UnetCfg(C.Structure):

@@ -244,9 +244,12 @@ struct Arena {
   std::vector<std::vector<bool>> used;
 };
 
+// strict precision (AMX_PREC_F16X2 / AMX_PREC_BF16X2): every stored voxel holds [hi(C) | lo(C)] 16-bit channels
+inline bool is_split(int precision) { return precision >= AMX_PREC_F16X2; }
+
 size_t level_bytes(const amx_unet* h, int level, int n, int d, int hh, int w) {
   const size_t vox = (size_t)(d >> level) * (hh >> level) * (w >> level);
-  return align_up((size_t)n * vox * level_channels(h, level) * 2, 256);
+  return align_up((size_t)n * vox * level_channels(h, level) * 2 * (is_split(h->cfg.precision) ? 2 : 1), 256);
 }
 
 int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
@@ -280,6 +283,8 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   // two run once per window (windows overlap: their accumulations must stay ordered on the stream); every layer
   // in between runs on the whole batch of windows.
   const amx_unet_cfg& c = h->cfg;
+  const bool split = is_split(c.precision);
+  const long long eb = split ? 4 : 2;          // bytes per stored channel value (hi + lo halves in strict precision)
   if (int e = check_shape(h, n, d, hh, w)) return e;
   for (const ConvLayer& L : h->convs)
     if (!L.loaded) return fail(AMX_ERR_NOT_LOADED, "conv model.%d has no parameters", L.module_idx);
@@ -352,10 +357,10 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         const Tensor& lo = cur;
         // nearest: `lo` is the half-resolution tensor, read through >> 1; trilinear: already materialised at this level
         const int lw = cur_is_full_up ? dw : dw / 2, lh = cur_is_full_up ? dh : dh / 2, ld = cur_is_full_up ? dd : dd / 2;
-        const long long lx = (long long)lo.C * 2, ly = lx * lw, lz = ly * lh;
+        const long long lx = (long long)lo.C * eb, ly = lx * lw, lz = ly * lh;
         p.up_shift = cur_is_full_up ? 0 : 1;
         if (have_skip) {
-          const long long sx = (long long)pend_skip.C * 2, sy = sx * dw, sz = sy * dh;
+          const long long sx = (long long)pend_skip.C * eb, sy = sx * dw, sz = sy * dh;
           p.src0 = A.slot[pend_skip.level][pend_skip.slot];
           p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = pend_skip.C;
           p.src1 = A.slot[lo.level][lo.slot];
@@ -367,7 +372,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
         }
       } else {
-        const long long sx = (long long)cur.C * 2, sy = sx * dw, sz = sy * dh;
+        const long long sx = (long long)cur.C * eb, sy = sx * dw, sz = sy * dh;
         p.src0 = A.slot[cur.level][cur.slot];
         p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = cur.C; p.C1 = 0;
       }
@@ -418,7 +423,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         out.slot = grab(lv);
         if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
         p.out = A.slot[lv][out.slot];
-        p.ox = (long long)L.cout * 2; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
+        p.ox = (long long)L.cout * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
       }
       if (prof) {
         amx_launch_record r;
@@ -426,15 +431,16 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         r.module_idx = L.module_idx; r.cin = L.cin; r.cout = L.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
         const double vox = (double)n * dd * dh * dw;
         r.flops = 2.0 * 27.0 * L.cin * L.cout * vox;
-        const double in_b = cur.slot < 0 ? 4.0 * vox : (p.C0 * vox + p.C1 * vox / 8.0) * 2.0;
-        const double out_b = L.is_final ? 4.0 * L.cout * vox : 2.0 * L.cout * vox;
-        r.bytes = in_b + out_b + 2.0 * 27.0 * L.cin * L.cout;
+        const double up_div = cur_is_full_up ? 1.0 : 8.0;      // nearest: the low-resolution tensor is read, not its 8x image
+        const double in_b = cur.slot < 0 ? 4.0 * vox : (p.C0 * vox + p.C1 * vox / up_div) * (double)eb;
+        const double out_b = L.is_final ? 4.0 * L.cout * vox : (double)eb * L.cout * vox;
+        r.bytes = in_b + out_b + (double)eb * 27.0 * L.cin * L.cout;
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
       // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue
       {
         size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
-        if (!L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
+        if (!split && !L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
             cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout / 16) {
           fused_pool.level = lv + 1; fused_pool.C = L.cout; fused_pool.slot = grab(lv + 1);
           if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
@@ -445,7 +451,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       }
       if (p.src0_f32c1 && (L.is_final || L.cout > 32))
         return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
-      const bool use_upcat = !p.src0_f32c1 && !raw_bn && L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p);
+      const bool use_upcat = !split && !p.src0_f32c1 && !raw_bn && L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p);
       if (use_upcat) p.wpk = (const char*)L.wpk_up;
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, c.precision, st);
@@ -488,7 +494,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           memset(&r, 0, sizeof r);
           snprintf(r.kernel, sizeof r.kernel, "instnorm+act");
           r.module_idx = L.norm_idx; r.cin = r.cout = L.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
-          r.bytes = 2.0 * L.cout * (double)n * dd * dh * dw * 3.0;
+          r.bytes = (double)eb * L.cout * (double)n * dd * dh * dw * 3.0;
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
@@ -541,7 +547,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
         memset(&r, 0, sizeof r);
         snprintf(r.kernel, sizeof r.kernel, "pool2<%s>", c.pooling == AMX_POOL_AVG ? "avg" : "max");
         r.module_idx = (int)i; r.cin = r.cout = cur.C; r.n = n; r.d = d >> lv; r.h = hh >> lv; r.w = w >> lv;
-        r.bytes = 2.0 * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 9.0;
+        r.bytes = (double)eb * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 9.0;
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
       AMX_HIP(amx::launch_pool2(A.slot[cur.level][cur.slot], A.slot[lv][out.slot], n, d >> lv, hh >> lv,
@@ -567,7 +573,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           memset(&r, 0, sizeof r);
           snprintf(r.kernel, sizeof r.kernel, "upsample2<trilinear>");
           r.module_idx = (int)i; r.cin = r.cout = cur.C; r.n = n; r.d = d >> lv; r.h = hh >> lv; r.w = w >> lv;
-          r.bytes = 2.0 * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 1.125;
+          r.bytes = (double)eb * cur.C * (double)n * (d >> lv) * (hh >> lv) * (w >> lv) * 1.125;
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_upsample2_trilinear(A.slot[cur.level][cur.slot], A.slot[lv][up.slot], n, d >> cur.level,
@@ -623,7 +629,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   if (cfg->activation < AMX_ACT_NONE || cfg->activation > AMX_ACT_LRELU || cfg->final_act < AMX_ACT_NONE ||
       cfg->final_act > AMX_ACT_LRELU)
     return fail(AMX_ERR_INVALID, "unsupported activation");
-  if (cfg->precision != AMX_PREC_F16 && cfg->precision != AMX_PREC_BF16)
+  if (cfg->precision < AMX_PREC_F16 || cfg->precision > AMX_PREC_BF16X2)
     return fail(AMX_ERR_INVALID, "unsupported precision %d", cfg->precision);
   amx_unet* h = new amx_unet();
   h->cfg = *cfg;
@@ -634,9 +640,9 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     // Q is chosen for the reference operating point (128^3 windows): level l runs at W = 128>>l.
     const int w_at = h->pack_w >> L.level;
     L.q = amx::conv_pick_q(L.cout, w_at > 0 ? w_at : 1);
-    const size_t wbytes = (size_t)L.cout * L.cin_pad * 28 * 2;
+    const size_t wbytes = (size_t)L.cout * L.cin_pad * 28 * 2 * (is_split(cfg->precision) ? 2 : 1);   // strict: [Wh | Wl]
     hipError_t e = hipMalloc(&L.wpk, wbytes);
-    if (e == hipSuccess && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
+    if (e == hipSuccess && !is_split(cfg->precision) && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     if (e == hipSuccess && cfg->norm == AMX_NORM_BATCH_EVAL && L.norm_idx >= 0) e = hipMalloc(&L.wpk_raw, wbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
@@ -835,7 +841,7 @@ size_t amx_conv3d_packed_bytes(int cin, int cout) {
   const int cin_pad = (cin + 15) / 16 * 16;
   size_t bytes = (size_t)cout * cin_pad * 28 * 2;
   if (cin == 48 && cout == 16) bytes = (bytes + 255) / 256 * 256 + amx::conv_upcat16_packed_bytes();
-  return bytes;
+  return 2 * bytes;     // room for the [Wh | Wl] packing of the strict precisions
 }
 
 static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
@@ -848,6 +854,8 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
   if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
   if (d < 2 || hh < 2 || w < 2) return fail(AMX_ERR_SHAPE, "reflect padding needs >= 2 voxels per axis");
   hipStream_t st = (hipStream_t)stream;
+  if (precision < AMX_PREC_F16 || precision > AMX_PREC_BF16X2) return fail(AMX_ERR_INVALID, "unsupported precision %d", precision);
+  const long long eb = is_split(precision) ? 4 : 2;    // strict precision: x0 / x1 / out16 voxels hold [hi(C) | lo(C)]
   const int q = amx::conv_pick_q(cout, w);
   if (d_out32 && (q > 2 || w < 32)) return fail(AMX_ERR_INVALID, "fp32 planar output needs cout <= 32 and w >= 32");
   if (cin_real < 1 || cin_real > c0 + c1 || cout_real < 1 || cout_real > cout || (weight_mode != 0 && weight_mode != 1))
@@ -857,22 +865,22 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
   memset(&p, 0, sizeof p);
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
   p.src0 = (const char*)d_x0; p.C0 = c0;
-  p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
+  p.s0x = (long long)c0 * eb; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
   if (c1) {
     p.src1 = (const char*)d_x1; p.C1 = c1; p.up_shift = 1;
-    p.s1x = (long long)c1 * 2; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
+    p.s1x = (long long)c1 * eb; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
   }
   p.wpk = (const char*)d_wpk;
   p.bias = d_shift;
   p.act = act; p.slope = slope;
   if (d_out16) {
     p.out = (char*)d_out16;
-    p.ox = (long long)cout * 2; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+    p.ox = (long long)cout * eb; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
   } else {
     p.out32 = d_out32;
     p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
   }
-  if (weight_mode == 0 && cin_real == 48 && c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
+  if (!is_split(precision) && weight_mode == 0 && cin_real == 48 && c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
     char* up = (char*)d_wpk + ((size_t)cout * (c0 + c1) * 28 * 2 + 255) / 256 * 256;
     AMX_HIP(amx::launch_pack_upcat16(d_weight, d_scale, up, precision, st));
     p.wpk = up;

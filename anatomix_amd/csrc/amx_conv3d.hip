@@ -28,10 +28,14 @@ namespace amx {
 // Row m of MFMA tile q in cout group cg is output channel cg*16Q + (m>>2)*4Q + q*4 + (m&3), so
 // that after the MFMA every lane owns 4Q CONSECUTIVE output channels (wide epilogue stores).
 // -------------------------------------------------------------------------------------------
+// split (strict precision): per cout group the chunk axis is doubled, [Wh chunks | Wl chunks], Wl = the residual of the
+// rounding of Wh (conv3d_k3_v2's SPLIT mode).
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal) {
-  const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8;
+                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
+                                    int split) {
+  const int nchunk_phys = CinPad / 16 * (split ? 2 : 1);
+  const long long total = (long long)(Cout / 16) * nchunk_phys * kSteps * 64 * 8;
   const int nchunk = CinPad / 16;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -42,8 +46,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     r /= Q;
     const int s = r % kSteps;
     r /= kSteps;
-    const int chunk = r % nchunk;
-    const int cg = r / nchunk;
+    const int chunk2 = r % nchunk_phys;
+    const int cg = r / nchunk_phys;
+    const int part = chunk2 >= nchunk;
+    const int chunk = chunk2 - part * nchunk;
     const int m = lane & 15, g = lane >> 4;
     const int cout = cg * 16 * Q + (m >> 2) * 4 * Q + q * 4 + (m & 3);
     const int tap = (g >> 1) ? tapB_index(s) : tapA_index(s);
@@ -58,7 +64,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
       }
       if (scale) v *= scale[cout];
     }
-    wpk[idx] = (T)v;
+    wpk[idx] = part ? (T)(v - (float)(T)v) : (T)v;
   }
 }
 
@@ -82,12 +88,12 @@ __global__ void fold_norm_kernel(const float* gamma, const float* beta, const fl
 
 // 2x2x2 stride-2 pooling on channels-last 16-bit tensors (nn.MaxPool3d(2) / nn.AvgPool3d(2),
 // network.py:297,368).  One thread = one output voxel x 8 channels (16 B).
-template <typename T, int AVG>
+template <typename T, int AVG, bool SPLIT>
 __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out, int N, int Do,
                              int Ho, int Wo, int C) {
   const int c8n = C >> 3;
   const long long total = (long long)N * Do * Ho * Wo * c8n;
-  const long long sx = (long long)C * 2, sy = sx * (Wo * 2), sz = sy * (Ho * 2);
+  const long long sx = (long long)C * 2 * (SPLIT ? 2 : 1), sy = sx * (Wo * 2), sz = sy * (Ho * 2);
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = idx % c8n;
@@ -102,24 +108,36 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
     float m[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const uint4 raw = *(const uint4*)(base + (k >> 2) * sz + ((k >> 1) & 1) * sy + (k & 1) * sx);
+      const char* vp = base + (k >> 2) * sz + ((k >> 1) & 1) * sy + (k & 1) * sx;
+      const uint4 raw = *(const uint4*)vp;
       const unsigned wv[4] = {raw.x, raw.y, raw.z, raw.w};
+      uint4 rawl = make_uint4(0, 0, 0, 0);
+      if (SPLIT) rawl = *(const uint4*)(vp + C * 2);
+      const unsigned wl[4] = {rawl.x, rawl.y, rawl.z, rawl.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const unsigned short bits = (unsigned short)(wv[e >> 1] >> ((e & 1) * 16));
-        const float f = (float)__builtin_bit_cast(T, bits);
+        float f = (float)__builtin_bit_cast(T, bits);
+        if (SPLIT) f += (float)__builtin_bit_cast(T, (unsigned short)(wl[e >> 1] >> ((e & 1) * 16)));   // exact: hi + lo fits fp32
         if (k == 0) m[e] = f;
         else m[e] = AVG ? m[e] + f : (f > m[e] ? f : m[e]);
       }
     }
-    unsigned o[4];
+    unsigned o[4], ol[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a = AVG ? m[2 * e] * 0.125f : m[2 * e];
       const float bq = AVG ? m[2 * e + 1] * 0.125f : m[2 * e + 1];
       o[e] = (unsigned)to_bits<T>(a) | ((unsigned)to_bits<T>(bq) << 16);
+      if (SPLIT) ol[e] = (unsigned)to_bits<T>(a - (float)(T)a) | ((unsigned)to_bits<T>(bq - (float)(T)bq) << 16);
     }
-    *(uint4*)(out + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (SPLIT) {
+      char* op = out + (idx / c8n) * (sx) + c8 * 16;
+      *(uint4*)op = make_uint4(o[0], o[1], o[2], o[3]);
+      *(uint4*)(op + C * 2) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    } else {
+      *(uint4*)(out + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -147,7 +165,7 @@ const char* last_conv_zm_kernel_name();
 
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (conv_zmarch_eligible(p) && Q == p.Cout / 16) {   // narrow full/half-resolution layers: z-marching ring kernel
+  if (precision < 2 && conv_zmarch_eligible(p) && Q == p.Cout / 16) {   // narrow full/half-resolution layers: z-marching ring kernel
     hipError_t e = launch_conv_zmarch(p, precision, st);
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
     return e;
@@ -161,14 +179,15 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
                                int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal) {
-  const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8;
+  const int split = precision >= 2;
+  const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8 * (split ? 2 : 1);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  if (precision == 0)
+  if ((precision & 1) == 0)
     hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk,
-                       CinReal, CinPad, Cout, Q, mode, CoutReal);
+                       CinReal, CinPad, Cout, Q, mode, CoutReal, split);
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale,
-                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal);
+                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split);
   return hipGetLastError();
 }
 
@@ -184,11 +203,16 @@ hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo
                         int precision, hipStream_t st) {
   const long long total = (long long)N * Do * Ho * Wo * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define AMX_POOL(T, A)                                                                            \
-  hipLaunchKernelGGL((pool2_kernel<T, A>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, \
+#define AMX_POOL(T, A, S)                                                                            \
+  hipLaunchKernelGGL((pool2_kernel<T, A, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, \
                      N, Do, Ho, Wo, C)
-  if (precision == 0) { if (avg) AMX_POOL(f16, 1); else AMX_POOL(f16, 0); }
-  else { if (avg) AMX_POOL(bf16, 1); else AMX_POOL(bf16, 0); }
+  switch (precision) {
+    case 0: if (avg) AMX_POOL(f16, 1, false); else AMX_POOL(f16, 0, false); break;
+    case 1: if (avg) AMX_POOL(bf16, 1, false); else AMX_POOL(bf16, 0, false); break;
+    case 2: if (avg) AMX_POOL(f16, 1, true); else AMX_POOL(f16, 0, true); break;
+    case 3: if (avg) AMX_POOL(bf16, 1, true); else AMX_POOL(bf16, 0, true); break;
+    default: return hipErrorInvalidValue;
+  }
 #undef AMX_POOL
   return hipGetLastError();
 }

@@ -38,7 +38,9 @@ struct StemCfg {
   static_assert(AHEAD > TZ && R * NDMA <= 60, "ring / vmcnt range");
 };
 
-template <typename T, int Q, int TY, int TX, int TZ, int NC, int R>
+// SPLIT (strict precision): the gathered fp32 taps are split into hi + lo 16-bit halves in registers, the packed weights
+// hold [Wh | Wl], three MFMAs (Wh*xh, Wh*xl, Wl*xh) replace one, and the output voxel holds [hi(Cout) | lo(Cout)].
+template <typename T, int Q, int TY, int TX, int TZ, int NC, int R, bool SPLIT>
 __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvParams p, int zseg, int nseg) {
   typedef StemCfg<TY, TX, TZ, NC, R> C;
   typedef typename Ops<T>::vec8 vec8;
@@ -110,9 +112,12 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
 
   // ================================ consumer wave ================================
   const int li = lane & 15, g = lane >> 4;
-  vec8 wreg[Q];
+  vec8 wreg[Q], wlo[SPLIT ? Q : 1];
 #pragma unroll
   for (int q = 0; q < Q; ++q) wreg[q] = *(const vec8*)(p.wpk + q * 1024 + lane * 16);
+  if (SPLIT)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) wlo[q] = *(const vec8*)(p.wpk + (Q + q) * 1024 + lane * 16);
   f32x4 bias[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) bias[q] = p.bias ? *(const f32x4*)(p.bias + g * 4 * Q + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -146,18 +151,23 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
     for (int c = 0; c < CTW; ++c) {
       const int cx = c % XT, cy = c / XT;
       const int toff = (cy * HX + cx * 16) * 4;
-      vec8 bf;
+      vec8 bf, bl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int imm = ((e / 3) * HX + e % 3) * 4 + toff;
         const float f = *(const float*)(smem + (e < 3 ? be[e] : own) + imm);
         bf[e] = (T)f;
+        if (SPLIT) bl[e] = (T)(f - (float)bf[e]);
       }
       float v[4 * Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         f32x4 acc = bias[q];
         if (!(p.dbg & 2)) acc = Ops<T>::mfma(wreg[q], bf, acc);
+        if (SPLIT) {
+          acc = Ops<T>::mfma(wreg[q], bl, acc);
+          acc = Ops<T>::mfma(wlo[q], bf, acc);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float f = acc[j];
@@ -174,6 +184,14 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
       for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
       if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
       else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+      if (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < 2 * Q; ++j)
+          w[j] = (unsigned)to_bits<T>(v[2 * j] - (float)(T)v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1] - (float)(T)v[2 * j + 1]) << 16);
+        char* dlo = dst + p.Cout * 2;
+        if (Q == 1) *(uint2*)dlo = make_uint2(w[0], w[1]);
+        else *(uint4*)dlo = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
@@ -184,10 +202,11 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
 // k = 8*g + e <-> tap as described above; row m of tile q is channel (m>>2)*4Q + q*4 + (m&3).
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk,
-                                 int Q) {
+                                 int Q, int split) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Q * 512) return;
-  const int e = idx & 7, lane = (idx >> 3) & 63, q = idx >> 9;
+  if (idx >= Q * 512 * (split ? 2 : 1)) return;
+  const int part = idx / (Q * 512);                 // split: [Wh tiles | Wl tiles]
+  const int e = idx & 7, lane = (idx >> 3) & 63, q = (idx >> 9) % Q;
   const int m = lane & 15, g = lane >> 4;
   const int cout = (m >> 2) * 4 * Q + q * 4 + (m & 3);
   int tap = -1;
@@ -195,17 +214,18 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __res
   else if (e < 3) tap = e * 9 + 8;
   float v = 0.f;
   if (tap >= 0) v = w[cout * 27 + tap] * (scale ? scale[cout] : 1.f);
-  wpk[idx] = (T)v;
+  wpk[idx] = part ? (T)(v - (float)(T)v) : (T)v;
 }
 
 static thread_local char g_kernel_name4[64] = "";
 const char* last_conv_stem_kernel_name() { return g_kernel_name4; }
 
-template <typename T, int Q>
+template <typename T, int Q, bool SPLIT>
 static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   constexpr int TY = 8, TX = 32, TZ = 2, NC = 8, R = 10;
   typedef StemCfg<TY, TX, TZ, NC, R> C;
-  snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem<%s,q%d,%dx%dx%d,c%d+l1,r%d>", __is_same(T, f16) ? "f16" : "bf16", Q,
+  snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem<%s,q%d,%dx%dx%d,c%d+l1,r%d>",
+           __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q,
            TZ, TY, TX, NC, R);
   static int dbg = -1;
   if (dbg < 0) {
@@ -222,7 +242,7 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
-  hipLaunchKernelGGL((conv3d_stem_kernel<T, Q, TY, TX, TZ, NC, R>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
+  hipLaunchKernelGGL((conv3d_stem_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
                      C::LDS_BYTES, st, p, zseg, nseg);
   return hipGetLastError();
 }
@@ -230,16 +250,22 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
 hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st) {
   const int Q = p.Cout / 16;
   if (Q != 1 && Q != 2) return hipErrorInvalidValue;
-  if (precision == 0) return Q == 1 ? launch_stem_t<f16, 1>(p, st) : launch_stem_t<f16, 2>(p, st);
-  return Q == 1 ? launch_stem_t<bf16, 1>(p, st) : launch_stem_t<bf16, 2>(p, st);
+  switch (precision) {
+    case 0: return Q == 1 ? launch_stem_t<f16, 1, false>(p, st) : launch_stem_t<f16, 2, false>(p, st);
+    case 1: return Q == 1 ? launch_stem_t<bf16, 1, false>(p, st) : launch_stem_t<bf16, 2, false>(p, st);
+    case 2: return Q == 1 ? launch_stem_t<f16, 1, true>(p, st) : launch_stem_t<f16, 2, true>(p, st);
+    case 3: return Q == 1 ? launch_stem_t<bf16, 1, true>(p, st) : launch_stem_t<bf16, 2, true>(p, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st) {
-  const int Q = Cout / 16;
-  if (precision == 0)
-    hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((Q * 512 + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q);
+  const int Q = Cout / 16, split = precision >= 2;
+  const int n = Q * 512 * (split ? 2 : 1);
+  if ((precision & 1) == 0)
+    hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q, split);
   else
-    hipLaunchKernelGGL(pack_stem_kernel<bf16>, dim3((Q * 512 + 255) / 256), dim3(256), 0, st, w, scale, (bf16*)wpk, Q);
+    hipLaunchKernelGGL(pack_stem_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (bf16*)wpk, Q, split);
   return hipGetLastError();
 }
 

@@ -85,13 +85,19 @@ __device__ __forceinline__ void advance_item(ItemCoord& c, const ConvParams& p) 
 // buffers and the MFMA waves only multiply and store; the two sides meet through LDS counters (no workgroup barrier).
 // Reason (cycle trace of 128 -> 128 @16^3, batch 4): per stage a MFMA wave spent ~2050 cycles ISSUING its share of the
 // next stage's DMA (a VMEM instruction blocks its wave while the memory queue is full) next to ~2250 cycles of MFMAs.
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW, int NBUF>
+//
+// SPLIT (strict precision): every activation tensor holds 2*C 16-bit channels per voxel, [hi(C) | lo(C)] with value = hi + lo
+// (lo = the rounding residual of hi), and the packed weights hold [Wh | Wl] the same way.  The conv then runs three times the
+// stages -- Wh*xh, Wh*xl, Wl*xh, the dropped Wl*xl term is 2^-16 (bf16) / 2^-22 (f16) relative -- into the same fp32
+// accumulators, and the epilogue splits the fp32 result into hi / lo again.  Everything else (halo staging, LDS-DMA, tap
+// steps) is unchanged: a stage is still 16 channels of one tensor behind one base pointer.
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW, int NBUF, bool SPLIT>
 __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(const ConvParams p) {
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
   typedef typename Ops<T>::vec8 vec8;
   constexpr int HY = C::HY, HX = C::HX, PLANE = C::PLANE, HALO = C::HALO, NW = C::NW;
   constexpr int WOFF = C::WOFF, CTW = C::CTW, LX = C::LX, LY = C::LY, XT = C::XT, YT = C::YT;
-  constexpr int NPEND = OUTMODE == 0 ? 2 * Q : 4 * Q;   // 32-bit words kept per column tile until the store
+  constexpr int NPEND = OUTMODE == 0 ? (SPLIT ? 4 * Q : 2 * Q) : 4 * Q;   // 32-bit words kept per column tile until the store
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -107,8 +113,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   int jw = blockIdx.x;
   if ((G & 7) == 0) jw = (jw & 7) * (G >> 3) + (jw >> 3);
   const int it0 = (int)(items * jw / G), it1 = (int)(items * (jw + 1) / G);
-  const int nchunk = (p.C0 + p.C1) >> 4;
-  const int nstage = nchunk / NCH;
+  const int nchunk = (p.C0 + p.C1) >> 4;                  // 16-channel chunks of the LOGICAL input
+  const int nstage = (SPLIT ? 3 : 1) * nchunk / NCH;
   const int T_total = (it1 - it0) * nstage;
   if (T_total <= 0) return;
   const bool resident = NLW == 0 && nstage == 1 && ncg == 1;     // weights + bias loaded once per workgroup
@@ -173,11 +179,14 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     const int gx = reflect_clamp(x0 + hxl - 1, p.W);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const int ch = (stage * NCH + k) << 4;                // wave-uniform
+      const int vch = stage * NCH + k;                      // wave-uniform; SPLIT: virtual chunk in [0, 3 * nchunk)
+      const int part = SPLIT ? vch / nchunk : 0;            // 0: Wh * xh   1: Wh * xl   2: Wl * xh
+      const int ch = (vch - part * nchunk) << 4;
       const bool second = ch >= p.C0;
       const int sh = second ? p.up_shift : 0;
-      const char* base = second ? p.src1 + (long long)it.n * p.s1n + (ch - p.C0) * 2
-                                : p.src0 + (long long)it.n * p.s0n + ch * 2;
+      const int lo_off = part == 1 ? (second ? p.C1 : p.C0) * 2 : 0;    // the lo half follows the hi half of the voxel
+      const char* base = second ? p.src1 + (long long)it.n * p.s1n + (ch - p.C0) * 2 + lo_off
+                                : p.src0 + (long long)it.n * p.s0n + ch * 2 + lo_off;
       const long long sz = second ? p.s1z : p.s0z, sy = second ? p.s1y : p.s0y;
       const int xoff = (gx >> sh) * (int)(second ? p.s1x : p.s0x);
       if (C::LOWUP && second && p.up_shift) {
@@ -233,7 +242,11 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     }
     if (with_weights) {
       // packed weights of these sub-chunks: linear copy, 1 KiB per instruction
-      const char* ws = p.wpk + ((long long)it.cg * nchunk + (long long)stage * NCH) * C::WSUB;
+      // SPLIT: packed as [cg][Wh chunks | Wl chunks]; parts 0 and 1 read Wh, part 2 reads Wl
+      const int vch0 = stage * NCH, part0 = SPLIT ? vch0 / nchunk : 0;
+      const long long wchunk = SPLIT ? (long long)it.cg * 2 * nchunk + (vch0 - part0 * nchunk) + (part0 == 2 ? nchunk : 0)
+                                     : (long long)it.cg * nchunk + vch0;
+      const char* ws = p.wpk + wchunk * C::WSUB;
       constexpr int NWI = NCH * C::WSUB / 1024;
       for (int j = iw; j < NWI; j += INW) {
         ++dma_count;
@@ -297,12 +310,17 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
         const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
         if (!full && !((zl + cz < p.D) & (yl + cy * LY < p.H) & (xl + cx * LX < p.W))) continue;
         char* dst = lbase + cz * p.oz + (cy * LY) * p.oy + (cx * LX) * p.ox;
-        if (Q == 1) {
-          *(uint2*)dst = make_uint2(pend[c][0], pend[c][1]);
-        } else {
 #pragma unroll
-          for (int j = 0; j < Q / 2; ++j)
-            *(uint4*)(dst + j * 16) = make_uint4(pend[c][4 * j], pend[c][4 * j + 1], pend[c][4 * j + 2], pend[c][4 * j + 3]);
+        for (int half = 0; half < (SPLIT ? 2 : 1); ++half) {          // SPLIT: hi channels, then the lo channels Cout further on
+          char* d = dst + half * (p.Cout * 2);
+          const int o = half * 2 * Q;
+          if (Q == 1) {
+            *(uint2*)d = make_uint2(pend[c][o], pend[c][o + 1]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < Q / 2; ++j)
+              *(uint4*)(d + j * 16) = make_uint4(pend[c][o + 4 * j], pend[c][o + 4 * j + 1], pend[c][o + 4 * j + 2], pend[c][o + 4 * j + 3]);
+          }
         }
       }
     } else {
@@ -384,7 +402,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     }
 
     // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
-    const bool up_stage = C::LOWUP && p.up_shift && ((cu_stage * NCH) << 4) >= p.C0;
+    const bool up_stage = C::LOWUP && p.up_shift && (((cu_stage * NCH) % nchunk) << 4) >= p.C0;
     if (!(p.dbg & 2) && up_stage) {
       // the stage buffer holds the LOW-RES halo of 16 upsampled channels
       constexpr int LXH = C::LXH;
@@ -455,6 +473,13 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
 #pragma unroll
         for (int j = 0; j < 2 * Q; ++j)
           pend[c][j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+        if (SPLIT) {
+#pragma unroll
+          for (int j = 0; j < 2 * Q; ++j) {
+            const float r0 = v[2 * j] - (float)(T)v[2 * j], r1 = v[2 * j + 1] - (float)(T)v[2 * j + 1];
+            pend[c][2 * Q + j] = (unsigned)to_bits<T>(r0) | ((unsigned)to_bits<T>(r1) << 16);
+          }
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 4 * Q; ++j) pend[c][j] = __builtin_bit_cast(unsigned, v[j]);
@@ -475,16 +500,17 @@ const char* last_conv_v2_kernel_name() { return g_kernel_name2; }
 
 static int g_num_cus = 0;
 
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
+template <typename T, bool SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
 static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
+  const char* tn = __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16");
   if (NLW)
     snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d+l%d,b%d,q%d,nch%d,o%d>",
-             __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, NLW, NBUF, Q, NCH, OUTMODE);
+             tn, C::TZ, C::TY, C::TX, C::NW, NLW, NBUF, Q, NCH, OUTMODE);
   else
     snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
-             __is_same(T, f16) ? "f16" : "bf16", C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
-  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF>;
+             tn, C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
+  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF, SPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -538,46 +564,51 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
 // Loader-wave mode (4 loader waves, ring of 3 buffers) where three stage buffers fit the LDS -- the deep, small levels,
 // whose stages are short: 128 -> 128 @16^3 32 -> 27 us, 384 -> 128 @16^3 66 -> 52 us, 256 -> 256 @8^3 36 -> 30 us at batch 4.
 // With only two buffers the loaders cannot run ahead and the classic barrier pipeline is faster (96 -> 32 @64^3: 202 vs 223 us).
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+template <typename T, bool SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
 static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
   static int classic = -1;
   if (classic < 0) classic = getenv("AMX_V2_CLASSIC") ? 1 : 0;
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C0;
   constexpr bool can = 3 * C0::BUF + 64 <= 160 * 1024 && NWZ * NWY <= 8;
   if constexpr (can) {
-    if (!classic) return launch_cfg2<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, 4, 3>(p, st);
+    if (!classic) return launch_cfg2<T, SPLIT, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, 4, 3>(p, st);
   }
-  return launch_cfg2<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>(p, st);
+  return launch_cfg2<T, SPLIT, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>(p, st);
 }
 
-template <typename T, int OUTMODE>
+template <typename T, int OUTMODE, bool SPLIT>
 static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   const int nch = (p.C0 + p.C1) / 16;
   if (p.W >= 32) {
-    if (Q == 1) return launch_pick<T, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
-    if (Q == 2) return launch_pick<T, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
-    if (OUTMODE == 0 && Q == 4) return launch_pick<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
+    if (Q == 1) return launch_pick<T, SPLIT, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
+    if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
+    if (OUTMODE == 0 && Q == 4) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
     return hipErrorInvalidValue;
   }
   if (OUTMODE == 1) return hipErrorInvalidValue;
   if (p.W >= 16) {
-    if (Q == 1) return launch_pick<T, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
-    if (Q == 2) return launch_pick<T, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);       // brick 4x4x16, 8 waves
-    if (Q == 4) return launch_pick<T, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);
+    if (Q == 1) return launch_pick<T, SPLIT, 1, 2, 16, 4, 1, 1, 1, 0>(p, st);
+    if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);       // brick 4x4x16, 8 waves
+    if (Q == 4) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);
   }
   if (Q == 1) {
-    if (nch % 2 == 0) return launch_pick<T, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
-    return launch_pick<T, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
+    if (nch % 2 == 0) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
+    return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
   }
-  if (Q == 2) return launch_pick<T, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
-  if (Q == 4) return launch_pick<T, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
+  if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
+  if (Q == 4) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (precision == 0) return planar ? launch_conv2_t<f16, 1>(p, Q, st) : launch_conv2_t<f16, 0>(p, Q, st);
-  return planar ? launch_conv2_t<bf16, 1>(p, Q, st) : launch_conv2_t<bf16, 0>(p, Q, st);
+  switch (precision) {
+    case 0: return planar ? launch_conv2_t<f16, 1, false>(p, Q, st) : launch_conv2_t<f16, 0, false>(p, Q, st);
+    case 1: return planar ? launch_conv2_t<bf16, 1, false>(p, Q, st) : launch_conv2_t<bf16, 0, false>(p, Q, st);
+    case 2: return planar ? launch_conv2_t<f16, 1, true>(p, Q, st) : launch_conv2_t<f16, 0, true>(p, Q, st);
+    case 3: return planar ? launch_conv2_t<bf16, 1, true>(p, Q, st) : launch_conv2_t<bf16, 0, true>(p, Q, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace amx

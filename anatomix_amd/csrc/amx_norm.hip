@@ -30,6 +30,29 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Strict precision (SPLIT): a voxel holds [hi(C) | lo(C)] 16-bit channels, value = hi + lo.  load8 / store8 move one
+// 8-channel group of one voxel: `p` points at the group's hi half, the lo half sits `lo_off` = 2*C bytes further on.
+template <typename T, bool SPLIT>
+__device__ __forceinline__ void load8(const char* p, int lo_off, float (&f)[8]) {
+  unpack8<T>(*(const uint4*)p, f);
+  if (SPLIT) {
+    float g[8];
+    unpack8<T>(*(const uint4*)(p + lo_off), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+  }
+}
+template <typename T, bool SPLIT>
+__device__ __forceinline__ void store8(char* p, int lo_off, const float (&f)[8]) {
+  *(uint4*)p = pack8<T>(f);
+  if (SPLIT) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f[e] - (float)(T)f[e];
+    *(uint4*)(p + lo_off) = pack8<T>(r);
+  }
+}
+
 // slabs per sample in the statistics pass: enough blocks to fill the chip on the big planes, >= 8 loads per
 // thread on the small ones, and nblk * C <= 65536 so the partial-sum scratch stays at 512 KiB per sample
 __host__ __device__ inline int in_num_blocks(long long vox, int C) {
@@ -40,23 +63,24 @@ __host__ __device__ inline int in_num_blocks(long long vox, int C) {
 }
 
 // grid (kInBlocks, N), block 256.  partial[n][blk][c][2]
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ x, float* __restrict__ partial, long long vox,
                                                       int C) {
+  constexpr int M = SPLIT ? 2 : 1;
   extern __shared__ float red[];                       // [256/c8n rows][C][2]
   const int c8n = C >> 3;
   const int n = blockIdx.y, blk = blockIdx.x;
   const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
-  const char* xs = x + (long long)n * vox * C * 2;
+  const char* xs = x + (long long)n * vox * C * 2 * M;
   float K[8];
-  unpack8<T>(*(const uint4*)(xs + c8 * 16), K);       // the channel's first voxel: shift of the sums
+  unpack8<T>(*(const uint4*)(xs + c8 * 16), K);       // the channel's first voxel (its hi half): shift of the sums
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long per = (vox + gridDim.x - 1) / gridDim.x;
   const long long v0 = (long long)blk * per, v1 = v0 + per < vox ? v0 + per : vox;
   if (vrow < nrow)
     for (long long v = v0 + vrow; v < v1; v += nrow) {
       float f[8];
-      unpack8<T>(*(const uint4*)(xs + (v * C + c8 * 8) * 2), f);
+      load8<T, SPLIT>(xs + (v * C * M + c8 * 8) * 2, C * 2, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = f[e] - K[e];
@@ -86,7 +110,7 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ 
 
 // grid (C/8, N), block 256 = 8 channels x 32 partial lanes.  ab[n][c][2] = (a, b) with y = a*x + b.
 // Lane l adds partials l, l+32, ... in order, then the 32 lane sums are added in lane order: fixed order, no atomics.
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
                                                          const float* gamma, const float* beta, float eps, long long vox,
                                                          int C, int nblk, float* __restrict__ ab) {
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
       s1 += red[0][threadIdx.x][k];
       s2 += red[1][threadIdx.x][k];
     }
-    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C + cc) * 2);
+    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C * (SPLIT ? 2 : 1) + cc) * 2);
     const float K = (float)__builtin_bit_cast(T, kb);
     const double m1 = s1 / (double)vox;
     double var = s2 / (double)vox - m1 * m1;              // biased variance, shift invariant
@@ -121,7 +145,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
   }
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox, int C, int N, int act,
                                 float slope) {
   const int c8n = C >> 3;
@@ -131,7 +155,8 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
     const long long nv = idx / c8n;
     const int n = nv / vox;
     float f[8];
-    unpack8<T>(*(const uint4*)(x + idx * 16), f);
+    char* xp = SPLIT ? x + nv * (C * 4) + c8 * 16 : x + idx * 16;
+    load8<T, SPLIT>(xp, C * 2, f);
     const float* q = ab + ((long long)n * C + c8 * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -140,7 +165,7 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
       f[e] = v;
     }
-    *(uint4*)(x + idx * 16) = pack8<T>(f);
+    store8<T, SPLIT>(xp, C * 2, f);
   }
 }
 
@@ -148,7 +173,7 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
 // group for its whole grid-stride walk (the stride is a multiple of C / 8), so its 16 coefficients sit in registers and the
 // loop has no 64-bit division -- the generic kernel above spends more time on index arithmetic and coefficient loads than on
 // memory (3.2 vs 4.6 TB/s on the 268 MB level-0 tensors of anatomix-dev).
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox,
                                                             int C, int act, float slope) {
   const int c8n = C >> 3, c8 = threadIdx.x % c8n, n = blockIdx.y;
@@ -160,10 +185,14 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
     b[e] = q[2 * e + 1];
   }
   const long long total = vox * c8n;
-  char* xs = x + (long long)n * total * 16;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+  char* xs = x + (long long)n * total * 16 * (SPLIT ? 2 : 1);
+  // SPLIT: a thread's group index c8 is fixed, its voxel advances by (gridDim.x * 256) / c8n per iteration
+  const long long vstep = (long long)gridDim.x * 256 / c8n;
+  long long vv = (blockIdx.x * 256ll + threadIdx.x) / c8n;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256, vv += vstep) {
     float f[8];
-    unpack8<T>(*(const uint4*)(xs + idx * 16), f);
+    char* xp = SPLIT ? xs + vv * (C * 4) + c8 * 16 : xs + idx * 16;
+    load8<T, SPLIT>(xp, C * 2, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * a[e] + b[e];
@@ -171,7 +200,7 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
       f[e] = v;
     }
-    *(uint4*)(xs + idx * 16) = pack8<T>(f);
+    store8<T, SPLIT>(xp, C * 2, f);
   }
 }
 
@@ -180,9 +209,10 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
 // vectors once and writes eight outputs -- cache reads equal the output bytes instead of 8x (the per-output version was
 // L1-bound at 2.0 TB/s on the 537 MB level-0 tensor of anatomix-dev).  Cells run from -1 to L-1 per axis with clamped
 // inputs, which reproduces the border rows (output 0 and 2L-1) of align_corners=False.  One block per (n, cz, cy).
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __restrict__ in, char* __restrict__ out, int N,
                                                                   int D, int H, int W, int C) {
+  constexpr int M = SPLIT ? 2 : 1;
   const int c8n = C >> 3;
   int r = blockIdx.x;
   const int cy = r % (H + 1) - 1;
@@ -191,7 +221,7 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
   const int n = r / (D + 1);
   const int z0 = cz < 0 ? 0 : cz, z1 = cz + 1 < D ? cz + 1 : D - 1;
   const int y0 = cy < 0 ? 0 : cy, y1 = cy + 1 < H ? cy + 1 : H - 1;
-  const long long rowb = (long long)W * C * 2;
+  const long long rowb = (long long)W * C * 2 * M;
   const char* rows[4] = {in + (((long long)n * D + z0) * H + y0) * rowb, in + (((long long)n * D + z0) * H + y1) * rowb,
                          in + (((long long)n * D + z1) * H + y0) * rowb, in + (((long long)n * D + z1) * H + y1) * rowb};
   const long long orowb = 2 * rowb;                        // bytes of one output row
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
     float v[8][8];                                         // [(zi, yi, xi)][channel]
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      unpack8<T>(*(const uint4*)(rows[k >> 1] + ((k & 1 ? x1 : x0) * C + c8 * 8) * 2), v[k]);
+      load8<T, SPLIT>(rows[k >> 1] + ((k & 1 ? x1 : x0) * C * M + c8 * 8) * 2, C * 2, v[k]);
 #pragma unroll
     for (int o = 0; o < 8; ++o) {                          // output (pz, py, px): 0 = odd position 2c+1, 1 = even position 2c+2
       const int pz = o >> 2, py = (o >> 1) & 1, px = o & 1;
@@ -216,7 +246,7 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += wt * v[k][e];
       }
-      *(uint4*)(out + (((long long)n * 2 * D + oz) * 2 * H + oy) * orowb + ((long long)ox * C + c8 * 8) * 2) = pack8<T>(acc);
+      store8<T, SPLIT>(out + (((long long)n * 2 * D + oz) * 2 * H + oy) * orowb + ((long long)ox * C * M + c8 * 8) * 2, C * 2, acc);
     }
   }
 }
@@ -263,7 +293,7 @@ __global__ void upsample2_trilinear_bwd_kernel(const char* __restrict__ gout, ch
 
 // y = scale[c] * x + shift[c], then the activation, in place (eval-mode BatchNorm applied as its own pass: only
 // used when a feature tap asks for the pre-norm convolution output, network.py:475-529).
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                   long long nvox, int C, int act, float slope) {
   const int c8n = C >> 3;
@@ -271,7 +301,8 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = idx % c8n;
     float f[8];
-    unpack8<T>(*(const uint4*)(x + idx * 16), f);
+    char* xp = SPLIT ? x + (idx / c8n) * (C * 4) + c8 * 16 : x + idx * 16;
+    load8<T, SPLIT>(xp, C * 2, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
@@ -279,7 +310,7 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
       f[e] = v;
     }
-    *(uint4*)(x + idx * 16) = pack8<T>(f);
+    store8<T, SPLIT>(xp, C * 2, f);
   }
 }
 
@@ -287,9 +318,10 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
 // callers.  Channels [0,C0) come from src0 (full resolution), [C0,C0+C1) from src1, read through >> up_shift
 // (the tap at an nn.Upsample id is taken after torch.cat((skip, up), 1), network.py:500-502).
 // One thread = one voxel x 8 channels; a wavefront writes 64 consecutive floats of each of its 8 planes.
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const char* __restrict__ src1, int C1, int up_shift,
                                     int N, int D, int H, int W, float* __restrict__ out) {
+  constexpr int M = SPLIT ? 2 : 1;
   const int C = C0 + C1, c8n = C >> 3;
   const long long vox = (long long)D * H * W;
   const long long total = (long long)N * c8n * vox;
@@ -300,15 +332,17 @@ __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const
     const int c8 = r % c8n, n = r / c8n;
     const int c = c8 * 8;
     const char* sp;
+    int lo_off = C0 * 2;
     if (c < C0) {
-      sp = src0 + (((long long)n * vox + v) * C0 + c) * 2;
+      sp = src0 + (((long long)n * vox + v) * C0 * M + c) * 2;
     } else {
+      lo_off = C1 * 2;
       const int x = v % W, y = (v / W) % H, z = v / ((long long)W * H);
       const long long lv = (((long long)n * ld + (z >> up_shift)) * lh + (y >> up_shift)) * lw + (x >> up_shift);
-      sp = src1 + (lv * C1 + (c - C0)) * 2;
+      sp = src1 + (lv * C1 * M + (c - C0)) * 2;
     }
     float f[8];
-    unpack8<T>(*(const uint4*)sp, f);
+    load8<T, SPLIT>(sp, lo_off, f);
     float* o = out + ((long long)n * C + c) * vox + v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e * vox] = f[e];
@@ -360,17 +394,23 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   const size_t lds = (size_t)nrow * C * 2 * sizeof(float);
   const long long total = (long long)N * vox * c8n;
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define AMX_IN(T)                                                                                                   \
-  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
-  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
+#define AMX_IN(T, S)                                                                                                   \
+  hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
+  hipLaunchKernelGGL((in_finalize_kernel<T, S>), dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
                      nblk, ab);                                                                                 \
   if (256 % c8n == 0) {                                                                                          \
     const long long per = vox * c8n;                                                                             \
     const int bx = (int)((per + 255) / 256 > 4096 ? 4096 : (per + 255) / 256);                                   \
-    hipLaunchKernelGGL(in_apply_fast_kernel<T>, dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope); \
+    hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope); \
   } else                                                                                                         \
-    hipLaunchKernelGGL(in_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope)
-  if (precision == 0) { AMX_IN(f16); } else { AMX_IN(bf16); }
+    hipLaunchKernelGGL((in_apply_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope)
+  switch (precision) {
+    case 0: { AMX_IN(f16, false); } break;
+    case 1: { AMX_IN(bf16, false); } break;
+    case 2: { AMX_IN(f16, true); } break;
+    case 3: { AMX_IN(bf16, true); } break;
+    default: return hipErrorInvalidValue;
+  }
 #undef AMX_IN
   return hipGetLastError();
 }
@@ -378,10 +418,15 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
                                       hipStream_t st) {
   const unsigned blocks = (unsigned)((long long)N * (D + 1) * (H + 1));
-  if (precision == 0)
-    hipLaunchKernelGGL(upsample2_trilinear_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
-  else
-    hipLaunchKernelGGL(upsample2_trilinear_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C);
+#define AMX_UP(T, S) hipLaunchKernelGGL((upsample2_trilinear_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C)
+  switch (precision) {
+    case 0: AMX_UP(f16, false); break;
+    case 1: AMX_UP(bf16, false); break;
+    case 2: AMX_UP(f16, true); break;
+    case 3: AMX_UP(bf16, true); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef AMX_UP
   return hipGetLastError();
 }
 
@@ -402,10 +447,15 @@ hipError_t launch_affine_act(void* x, const float* scale, const float* shift, in
   if (C % 8) return hipErrorInvalidValue;
   const long long total = (long long)N * vox * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-  if (precision == 0)
-    hipLaunchKernelGGL(affine_act_kernel<f16>, dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope);
-  else
-    hipLaunchKernelGGL(affine_act_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope);
+#define AMX_AA(T, S) hipLaunchKernelGGL((affine_act_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope)
+  switch (precision) {
+    case 0: AMX_AA(f16, false); break;
+    case 1: AMX_AA(bf16, false); break;
+    case 2: AMX_AA(f16, true); break;
+    case 3: AMX_AA(bf16, true); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef AMX_AA
   return hipGetLastError();
 }
 
@@ -414,12 +464,15 @@ hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C
   if (C0 % 8 || C1 % 8 || C0 + C1 < 8) return hipErrorInvalidValue;
   const long long total = (long long)N * ((C0 + C1) / 8) * D * H * W;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-  if (precision == 0)
-    hipLaunchKernelGGL(export_ncdhw_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1,
-                       up_shift, N, D, H, W, out);
-  else
-    hipLaunchKernelGGL(export_ncdhw_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1,
-                       up_shift, N, D, H, W, out);
+#define AMX_EX(T, S) hipLaunchKernelGGL((export_ncdhw_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1, up_shift, N, D, H, W, out)
+  switch (precision) {
+    case 0: AMX_EX(f16, false); break;
+    case 1: AMX_EX(bf16, false); break;
+    case 2: AMX_EX(f16, true); break;
+    case 3: AMX_EX(bf16, true); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef AMX_EX
   return hipGetLastError();
 }
 

@@ -26,6 +26,9 @@ _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "b
 
 def unsupported_reason(model, x, layers):
     c = model._cfg
+    if model.precision not in _DT:
+        return (f"the HIP training path stores activations in f16 / bf16 (the reference trains under bf16 autocast); "
+                f"precision '{model.precision}' is an inference mode")
     if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
         return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
     if c["norm"] not in ("batch", "instance", "instance_affine") or c["activation"] not in ("relu", "lrelu") or c["final_act"] != "none":

@@ -3,14 +3,19 @@ over the ranks before the optimizer steps (the reference i
 batches through ``--grad_accum_iters``, supcl_model.py:618-661 -- N ranks x 1 pair is the same average as N accumulated
 pairs, each pair with its own BatchNorm batch statistics).
 
-``GradientBuckets`` keeps every parameter's ``.grad`` as a VIEW into a few flat fp32 buffers:
-  * no pack / unpack passes around the collective (the all-reduce runs on the memory autograd accumulated into, and the
-    optimizer reads the reduced values through the same views);
+``GradientBuckets`` owns a few flat fp32 buffers with one VIEW per parameter:
+  * after the backward, ``collect()`` copies every gradient into its view (one multi-tensor copy per bucket) and points
+    ``p.grad`` at the view, so the collective runs on the flat memory and the optimizer reads the reduced values through the
+    same views -- no unpack pass;
   * a handful of large messages instead of ~130 small ones: xGMI is point-to-point, a ring step is bound by one link
     (~153 GB/s), so the 27.4 MB of the 6M UNet + the MLP heads go out as <= ``bucket_mb``-sized buckets, last layers first;
-  * buckets are reduced asynchronously (``async_op=True``) and waited for together; in eager mode
-    (``overlap=True``) a bucket is launched from a post-accumulate hook as soon as its last gradient has landed, so the
-    projection heads' bucket travels while the UNet backward is still running.
+  * buckets are reduced asynchronously (``async_op=True``) and waited for together; in eager mode (``overlap=True``) a bucket
+    is collected and launched from a post-accumulate hook as soon as its last gradient exists, so the projection heads'
+    bucket travels while the UNet backward is still running;
+  * ``release()`` (instead of ``optimizer.zero_grad()``) detaches the parameters from the views again, so that the next
+    backward hands autograd fresh gradients.  (Letting autograd accumulate IN PLACE into the views is not graph-safe: an
+    AccumulateGrad node outlives the iteration that made it and adds on the stream it was created on, outside a capture --
+    measured: HSA memory-aperture fault at the first replay.)
 Backend-agnostic (RCCL on the GPUs, gloo in the CPU tests): SUM all-reduce + one in-place scale.
 """
 from __future__ import annotations
@@ -27,17 +32,21 @@ class GradientBuckets:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets: List[torch.Tensor] = []
-        self._pending = []
+        self.params: List[List[torch.nn.Parameter]] = []      # per bucket
+        self.views: List[List[torch.Tensor]] = []
+        self._launched = set()
+        self._collected = set()
         self._handles = []
         self._remaining = []
+        self.overlap = bool(overlap) and self.world > 1
         limit = max(int(bucket_mb * (1 << 20)) // 4, 1)
         for net in nets:
             params = [p for p in net.parameters() if p.requires_grad]
-            if not params:
-                continue
             # reverse order: the gradients of the last layers exist first
             groups, cur, cur_n = [], [], 0
             for p in reversed(params):
+                if p.dtype != torch.float32:
+                    raise TypeError("GradientBuckets expects fp32 parameters (the reference keeps fp32 master weights under autocast)")
                 if cur and cur_n + p.numel() > limit:
                     groups.append(cur)
                     cur, cur_n = [], 0
@@ -47,15 +56,15 @@ class GradientBuckets:
                 groups.append(cur)
             for grp in groups:
                 flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
-                o = 0
+                views, o = [], 0
                 for p in grp:
-                    if p.dtype != torch.float32:
-                        raise TypeError("GradientBuckets expects fp32 parameters (the reference keeps fp32 master weights under autocast)")
-                    p.grad = flat[o:o + p.numel()].view_as(p)
+                    views.append(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
                 b = len(self.buckets)
                 self.buckets.append(flat)
-                if overlap and self.world > 1:
+                self.params.append(grp)
+                self.views.append(views)
+                if self.overlap:
                     remaining = {"n": len(grp), "total": len(grp)}
                     self._remaining.append(remaining)
 
@@ -63,37 +72,61 @@ class GradientBuckets:
                         remaining["n"] -= 1
                         if remaining["n"] == 0:
                             remaining["n"] = remaining["total"]
+                            self._collect_bucket(b)
                             self._launch(b)
                     for p in grp:
                         p.register_post_accumulate_grad_hook(hook)
-        self.overlap = overlap and self.world > 1
 
     @property
     def nbytes(self):
         return sum(b.numel() * 4 for b in self.buckets)
 
-    def zero(self):
-        """Replaces optimizer.zero_grad(): the views stay, the buffers are cleared (graph-capturable)."""
-        for b in self.buckets:
-            b.zero_()
+    def _collect_bucket(self, b):
+        if b in self._collected:
+            return
+        self._collected.add(b)
+        dst, src = [], []
+        for p, v in zip(self.params[b], self.views[b]):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params[b], self.views[b]):
+            p.grad = v
+
+    def collect(self):
+        """Gradients -> flat buckets (one multi-tensor copy per bucket); ``p.grad`` becomes the bucket view.  Graph-capturable."""
+        for b in range(len(self.buckets)):
+            self._collect_bucket(b)
 
     def _launch(self, b):
-        self._pending.append(b)
+        if b in self._launched or self.world == 1:
+            return
+        self._launched.add(b)
         self._handles.append(self.dist.all_reduce(self.buckets[b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def sync(self):
-        """Average every bucket over the ranks.  Call between backward and the optimizer steps."""
-        if self.world == 1:
-            return
-        launched = set(self._pending)
-        for b in range(len(self.buckets)):
-            if b not in launched:
+        """Average every bucket over the ranks.  Call between backward (+ collect) and the optimizer steps."""
+        self.collect()
+        if self.world > 1:
+            for b in range(len(self.buckets)):
                 self._launch(b)
-        for h in self._handles:
-            h.wait()
-        inv = 1.0 / self.world
-        for b in self.buckets:
-            b.mul_(inv)
-        self._pending, self._handles = [], []
+            for h in self._handles:
+                h.wait()
+            inv = 1.0 / self.world
+            for b in self.buckets:
+                b.mul_(inv)
+        self._launched, self._handles = set(), []
         for r in self._remaining:          # a parameter that received no gradient this step must not skew the next count
             r["n"] = r["total"]
+
+    def release(self):
+        """Replaces ``optimizer.zero_grad()``: the next backward produces fresh gradients (``p.grad = None``)."""
+        self._collected = set()
+        for grp in self.params:
+            for p in grp:
+                p.grad = None

@@ -73,14 +73,16 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
     netF: PatchSampleF; criterions: one SupPatchNCELoss per nce layer; nce_weights default 1/len (supcl_model.py:388-393);
     optimizers: (opt_G, opt_F) or None (gradients only); sample_ids: captured coordinates per layer or None (randperm);
     grad_sync: callable run between backward and the optimizer steps (data parallel: the gradient all-reduce);
-    grad_buckets: a ``data_parallel.GradientBuckets`` over (netG, netF) -- its ``sync()`` is the gradient all-reduce and its
-    ``zero()`` replaces ``optimizer.zero_grad()`` (the gradients are views into its flat buffers and must survive the step).
+    grad_buckets: a ``data_parallel.GradientBuckets`` over (netG, netF) -- its ``sync()`` gathers the gradients into flat
+    buckets and all-reduces them, its ``release()`` replaces ``optimizer.zero_grad()``.
     grad_accum_iters > 1 (supcl_model.py:618-661): the loss is divided by it on every call and the gradients accumulate; the
     optimizers step (and are zeroed) only on calls where ``do_step`` is true -- pass it directly, or pass the reference's
     running ``iters`` counter and it is ``iters % grad_accum_iters == 0``.  With optimizers and grad_accum_iters > 1 one of
     the two must be given: stepping on every call would shrink the gradients instead of accumulating them.
     Returns an OrderedDict(loss, per_layer, grad_norm_G, grad_norm_F, sample_ids, out).
     """
+    if grad_buckets is not None and grad_buckets.overlap and grad_accum_iters > 1:
+        raise ValueError("GradientBuckets(overlap=True) reduces a bucket as soon as one backward filled it: not with grad_accum_iters > 1")
     if do_step is None:
         if iters is not None:
             do_step = iters % grad_accum_iters == 0
@@ -101,10 +103,12 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
         for opt in optimizers:
             opt.step()
         if grad_buckets is not None:
-            grad_buckets.zero()
+            grad_buckets.release()
         else:
             for opt in optimizers:
                 opt.zero_grad()
+    elif grad_buckets is not None and do_step:
+        grad_buckets.release()
     # ONE host synchronisation per step, after everything is enqueued (the reference reads every scalar with .item() as it
     # goes, supcl_model.py:841; that only paces the host, the values are the same)
     scalars = torch.stack([total.detach(), gG.detach(), gF.detach()] + layer_losses).tolist()
@@ -126,7 +130,7 @@ class GraphedContrastiveStep:
     Returns the same OrderedDict as ``contrastive_step`` (ONE host synchronisation per call, for the scalars)."""
 
     def __init__(self, netG, netF, criterions, nce_layers, optimizers, nce_weights=None, num_patches=512, lambda_nce=1.0,
-                 grad_sync=None, warmup=3, grad_buckets=None):
+                 grad_sync=None, warmup=3, grad_buckets=None, tail_graph=True):
         self.netG, self.netF, self.criterions, self.nce_layers = netG, netF, criterions, list(nce_layers)
         self.optimizers, self.nce_weights, self.num_patches, self.lambda_nce = optimizers, nce_weights, num_patches, lambda_nce
         self.grad_buckets = grad_buckets
@@ -138,7 +142,7 @@ class GraphedContrastiveStep:
         capturable = optimizers is None or all(o.defaults.get("capturable", False) for o in optimizers)
         self.opt_in_graph = grad_sync is None and optimizers is not None and capturable
         # data parallel: [graph: forward + backward] -> gradient all-reduce (eager, RCCL) -> [second graph: norms + optimizers]
-        self.tail_in_own_graph = grad_sync is not None and capturable
+        self.tail_in_own_graph = bool(tail_graph) and grad_sync is not None and capturable
 
     def _eager(self):
         return _forward_backward(self.netG, self.netF, self.criterions, self.A, self.B, self.seg, self.nce_layers,
@@ -167,9 +171,9 @@ class GraphedContrastiveStep:
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            if self.grad_buckets is not None:
-                self.grad_buckets.zero()                    # part of every replay: the flat gradient buffers start from zero
             self.total, self.layer_losses, self.ids, self.out = self._eager()
+            if self.grad_buckets is not None:
+                self.grad_buckets.collect()                 # part of every replay: fresh gradients -> the flat buckets
             if self.opt_in_graph or (self.grad_sync is None and self.optimizers is None):
                 self.scalars = self._tail(self.total, self.layer_losses)
         if self.tail_in_own_graph:
@@ -179,7 +183,7 @@ class GraphedContrastiveStep:
 
     def _zero(self):
         if self.grad_buckets is not None:
-            self.grad_buckets.zero()
+            self.grad_buckets.release()
             return
         for net in (self.netG, self.netF):
             for p in net.parameters():

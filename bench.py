@@ -308,8 +308,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             step = lambda: contrastive_step(model, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512, optimizers=opts,
                                             grad_buckets=buckets)["out"]
         else:
-            # the whole step replayed from HIP graphs (1 GPU: one graph, optimizers included; data parallel: forward + backward
-            # in one graph, the RCCL all-reduces of the buckets, then gradient norms + AdamW in a second graph)
+            # the whole step replayed from a HIP graph (1 GPU: optimizers included; data parallel: forward + backward in the
+            # graph, then the RCCL all-reduces of the buckets, gradient norms and AdamW)
             from anatomix_amd.pretraining import GraphedContrastiveStep
             graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512, grad_buckets=buckets)
             step = lambda: graphed(vA, vB, seg)["out"]

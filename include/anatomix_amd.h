@@ -39,7 +39,14 @@ enum { AMX_NORM_NONE = 0, AMX_NORM_BATCH_EVAL = 1, AMX_NORM_INSTANCE = 2, AMX_NO
 enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_LRELU = 2 };
 enum { AMX_POOL_MAX = 0, AMX_POOL_AVG = 1 };
 enum { AMX_INTERP_NEAREST = 0, AMX_INTERP_TRILINEAR = 1 };
-enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1 };
+/* Storage precision of activations and packed weights (every MFMA accumulates in fp32).
+ *   F16 / BF16     one 16-bit value per element;
+ *   F16X2 / BF16X2 "strict": every element is a hi + lo pair of 16-bit values (22 / 16 mantissa bits), a voxel stores
+ *                  [hi(C) | lo(C)], each product runs as three MFMAs (Wh*xh + Wh*xl + Wl*xh).  fp32-grade results --
+ *                  the reference's inference callers run the network in fp32
+ *                  (anatomix/registration/convex_adam_utils.py:194-219: .float().cuda(), no autocast).  BF16X2 keeps
+ *                  fp32's exponent range; F16X2 is ~8x more accurate but overflows beyond 65504 like F16. */
+enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1, AMX_PREC_F16X2 = 2, AMX_PREC_BF16X2 = 3 };
 
 /* Constructor arguments of anatomix/model/network.py:262-279 (Unet.__init__) that shape the
  * arithmetic.  dimension is fixed at 3, pad_type at 'reflect', residual_connection at False. */
@@ -57,7 +64,8 @@ typedef struct amx_unet_cfg {
   int32_t interp;         /* AMX_INTERP_* <- interp=    network.py:276,407 */
   int32_t doubleconv;     /* network.py:273 */
   int32_t use_skip;       /* network.py:277 */
-  int32_t precision;      /* AMX_PREC_*: storage type of activations / weights (fp32 accumulate) */
+  int32_t precision;      /* AMX_PREC_*: storage type of activations / weights (fp32 accumulate); the *X2 values are the
+                           * strict mode that meets the reference's fp32 results to ~1e-5 */
 } amx_unet_cfg;
 
 typedef struct amx_unet amx_unet_t;

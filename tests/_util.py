@@ -7,7 +7,36 @@ import torch.nn.functional as F
 
 from anatomix_amd import _lib
 
-TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16}
+TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16, "f16x2": torch.float16, "bf16x2": torch.bfloat16, "strict": torch.bfloat16}
+SPLIT = {"f16x2", "bf16x2", "strict"}
+
+
+def split_pair(x, dtype):
+    """fp32 -> (hi, lo) of the strict precisions: hi = round(x), lo = round(x - hi)."""
+    hi = x.to(dtype)
+    lo = (x - hi.float()).to(dtype)
+    return hi, lo
+
+
+def to_ndhwc_split(x_ncdhw, dtype):
+    """NCDHW fp32 -> channels-last [N, D, H, W, 2C] with the voxel layout [hi(C) | lo(C)]."""
+    hi, lo = split_pair(x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().float(), dtype)
+    return torch.cat((hi, lo), dim=-1).contiguous()
+
+
+def from_ndhwc_split(x):
+    """[N, D, H, W, 2C] split storage -> NCDHW fp32 (hi + lo)."""
+    c = x.shape[-1] // 2
+    return (x[..., :c].float() + x[..., c:].float()).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def q_storage(t, precision):
+    """The value a tensor takes when stored in `precision` (one 16-bit rounding, or the hi + lo pair)."""
+    dt = TORCH_T[precision]
+    if precision in SPLIT:
+        hi, lo = split_pair(t.float(), dt)
+        return hi.float() + lo.float()
+    return t.to(dt).float()
 
 
 def to_ndhwc(x_ncdhw, dtype):
@@ -32,11 +61,13 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
     """Calls amx_conv3d_k3_reflect.  x0/x1: NCDHW float CPU tensors (x1 half resolution or None)."""
     lib = _lib.load()
     tdt = TORCH_T[precision]
+    split = precision in SPLIT
     n, c0, d, h, ww = x0.shape
     cout = w.shape[0]
     c1 = 0 if x1 is None else x1.shape[1]
-    dx0 = to_ndhwc(x0, tdt).to(device)
-    dx1 = None if x1 is None else to_ndhwc(x1, tdt).to(device)
+    pack = (lambda t: to_ndhwc_split(t, tdt)) if split else (lambda t: to_ndhwc(t, tdt))
+    dx0 = pack(x0).to(device)
+    dx1 = None if x1 is None else pack(x1).to(device)
     dw = w.reshape(cout, c0 + c1, 27).contiguous().float().to(device)
     dsc = None if scale is None else scale.float().to(device)
     dsh = None if shift is None else shift.float().to(device)
@@ -45,7 +76,7 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
         out = torch.full((n, cout, d, h, ww), float("nan"), dtype=torch.float32, device=device)
         o16, o32 = None, out
     else:
-        out = torch.full((n, d, h, ww, cout), float("nan"), dtype=tdt, device=device)
+        out = torch.full((n, d, h, ww, cout * (2 if split else 1)), float("nan"), dtype=tdt, device=device)
         o16, o32 = out, None
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc),
@@ -53,13 +84,14 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
                                          _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), st))
     torch.cuda.synchronize(device)
     out = out.cpu()
-    return out if planar else from_ndhwc(out.float())
+    if planar:
+        return out
+    return from_ndhwc_split(out) if split else from_ndhwc(out.float())
 
 
 def ref_conv(x0, x1, w, scale, shift, act, precision, slope=0.3):
     """CPU reference with the SAME input/weight rounding as the kernel, fp32 accumulation."""
-    tdt = TORCH_T[precision]
-    q = lambda t: t.to(tdt).float()
+    q = lambda t: q_storage(t, precision)
     x = q(x0)
     if x1 is not None:
         x = torch.cat((x, F.interpolate(q(x1), scale_factor=2, mode="nearest")), dim=1)
@@ -68,6 +100,24 @@ def ref_conv(x0, x1, w, scale, shift, act, precision, slope=0.3):
         wf = (w.float() * scale.float()[:, None, None, None, None]).double()   # kernel scales in fp32
     wq = q(wf.float())
     y = F.conv3d(F.pad(x.double(), (1,) * 6, mode="reflect"), wq.double())
+    if shift is not None:
+        y = y + shift.double()[None, :, None, None, None]
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, slope)
+    return y.float()
+
+
+def ref_conv_fp64(x0, x1, w, scale, shift, act, slope=0.3):
+    """The convolution on the un-rounded fp32 operands, accumulated in fp64."""
+    x = x0.double()
+    if x1 is not None:
+        x = torch.cat((x, F.interpolate(x1.double(), scale_factor=2, mode="nearest")), dim=1)
+    wf = w.double()
+    if scale is not None:
+        wf = wf * scale.double()[:, None, None, None, None]
+    y = F.conv3d(F.pad(x, (1,) * 6, mode="reflect"), wf)
     if shift is not None:
         y = y + shift.double()[None, :, None, None, None]
     if act == 1:

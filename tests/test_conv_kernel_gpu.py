@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import TORCH_T, max_rel, ref_conv, ref_conv_upcat_merged, rel_l2, run_conv
+from _util import TORCH_T, max_rel, ref_conv, ref_conv_fp64, ref_conv_upcat_merged, rel_l2, run_conv
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,30 @@ def test_conv_matches_cpu(device, case, precision):
     assert (err <= tol).all(), f"max err {err.max().item():.3e} rel_l2 {rel_l2(got, ref):.3e}"
 
 
-@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x2"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d+%d_o%d_%dx%dx%d_n%d_a%d" % (c[0], c[1], c[2], *c[3], c[4], c[5]))
+def test_conv_strict_precision_matches_fp64(device, case, precision):
+    """Strict precision: operands stored as hi + lo pairs ([hi(C) | lo(C)] per voxel), three MFMAs per product, the fp32
+    result split into hi + lo again.  Reference: fp64 convolution of the SAME (hi + lo) operand values.  What remains is the
+    dropped Wl * xl term (2^-16 / 2^-22 relative), fp32 accumulation, and the split rounding of the output."""
+    c0, c1, cout, (d, h, w), n, act = case
+    rs = np.random.RandomState(hash((c0, c1, cout, d, h, w)) & 0xFFFF)
+    x0 = torch.from_numpy(rs.randn(n, c0, d, h, w).astype(np.float32))
+    x1 = torch.from_numpy(rs.randn(n, c1, d // 2, h // 2, w // 2).astype(np.float32)) if c1 else None
+    wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy((rs.randn(cout) * 0.1).astype(np.float32))
+    got = run_conv(device, x0, x1, wgt, scale, shift, act, precision)
+    ref = ref_conv(x0, x1, wgt, scale, shift, act, precision)
+    assert torch.isfinite(got).all()
+    tol = 2e-5 if precision == "bf16x2" else 4e-6      # f16x2: what is left is fp32 accumulation over up to 10368 terms
+    assert rel_l2(got, ref) < tol and max_rel(got, ref) < 4 * tol, (rel_l2(got, ref), max_rel(got, ref))
+    # and against the un-rounded fp32 operands: the whole point of the mode
+    full = ref_conv_fp64(x0, x1, wgt, scale, shift, act)
+    assert rel_l2(got, full) < (3e-5 if precision == "bf16x2" else 4e-6), rel_l2(got, full)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16", "f16x2", "bf16x2"])
 @pytest.mark.parametrize("cout,c0,c1", [(16, 16, 0), (32, 32, 0), (16, 16, 32)])
 def test_conv_planar_fp32_output(device, cout, c0, c1, precision):
     """Final-layer epilogue: fp32 NCDHW, no output rounding -> tight tolerance."""
@@ -67,9 +90,9 @@ def test_conv_planar_fp32_output(device, cout, c0, c1, precision):
     x1 = torch.from_numpy(rs.randn(2, c1, d // 2, h // 2, w // 2).astype(np.float32)) if c1 else None
     wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
     got = run_conv(device, x0, x1, wgt, None, None, 0, precision, planar=True)
-    ref = (ref_conv_upcat_merged if c1 else ref_conv)(x0, x1, wgt, None, None, 0, precision)
+    ref = (ref_conv_upcat_merged if (c1 and precision in ("f16", "bf16")) else ref_conv)(x0, x1, wgt, None, None, 0, precision)
     assert torch.isfinite(got).all()
-    assert max_rel(got, ref) < 2e-5, max_rel(got, ref)
+    assert max_rel(got, ref) < (4e-5 if precision == "bf16x2" else 2e-5), max_rel(got, ref)
 
 
 def test_conv_transpose_detecting(device):

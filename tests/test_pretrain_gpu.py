@@ -290,3 +290,43 @@ def test_graphed_step_with_gradient_sync_hook_runs_the_optimizers_eagerly():
     assert len(calls) == 2 + 10                              # warm-up steps + one per call
     assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
     assert not torch.equal(w0, next(netG.parameters()).detach())
+
+
+def test_graphed_step_with_gradient_buckets():
+    """The data-parallel shape bench.py runs for N > 1, exercised on one GPU: gradients are views into GradientBuckets' flat
+    buffers, [graph 1: forward + backward + gather of the gradients into the buckets] -> bucket sync (the RCCL all-reduce; a
+    no-op on one rank, forced through the same code path here) -> [graph 2: gradient norms + capturable AdamW]."""
+    import contextlib, io
+    from argparse import Namespace
+    import anatomix_amd
+    from anatomix_amd.pretraining import GradientBuckets, GraphedContrastiveStep, PatchSampleF, SupPatchNCELoss
+    from oracle import pretrain_inputs as PI, unet_ref as R
+    dev = torch.device("cuda:0")
+    kw = R.VARIANTS["anatomix"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        netG = anatomix_amd.Unet(**kw)
+        netG.load_state_dict(R.synthetic_state_dict(kw, 3, gain=2 ** 0.5))
+        netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+        netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+    netG.precision = "bf16"
+    netG, netF = netG.to(dev).train(), netF.to(dev).train()
+    nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+    A, B, seg = [t.to(dev) for t in PI.step_inputs(64)]
+    opts = (torch.optim.AdamW(netG.parameters(), lr=1e-3, capturable=True), torch.optim.AdamW(netF.parameters(), lr=1e-3, capturable=True))
+    buckets = GradientBuckets((netG, netF), bucket_mb=8.0)
+    assert 2 <= len(buckets.buckets) <= 8 and buckets.nbytes == 4 * sum(p.numel() for n in (netG, netF) for p in n.parameters())
+    calls = []
+    step = GraphedContrastiveStep(netG, netF, crits, PI.NCE_LAYERS, opts, num_patches=64, warmup=2, grad_buckets=buckets,
+                                  grad_sync=lambda: calls.append(1))
+    assert not step.opt_in_graph and step.tail_in_own_graph
+    w0 = next(netG.parameters()).detach().clone()
+    recs = [step(A, B, seg) for _ in range(10)]
+    assert step.tail_graph is not None
+    losses = [r["loss"] for r in recs]
+    assert len(calls) == 2 + 10
+    flat_ptrs = {v.data_ptr() for vs in buckets.views for v in vs}
+    assert all(p.grad.data_ptr() in flat_ptrs for p in netG.parameters())      # the optimizer reads the bucket views
+    assert all(np.isfinite(losses)) and all(r["grad_norm_G"] > 0 for r in recs)
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    assert not torch.equal(w0, next(netG.parameters()).detach())

@@ -277,3 +277,18 @@ def test_taps_at_pool_and_upsample_ids_are_differentiable(device, interp, poolin
     assert max(gerrs.values()) < max(gerrs0.values()) + 0.05 and min(cos.values()) > min(cos0.values()) - 0.02, \
         (max(gerrs.values()), max(gerrs0.values()), min(cos.values()), min(cos0.values()))
     assert max(gerrs.values()) < 0.35 and min(cos.values()) > 0.95
+
+
+def test_gradient_with_respect_to_the_input_image(device):
+    """A caller that differentiates through the network input (x.requires_grad) gets the stem's data gradient, as the
+    reference's stock modules give it -- not None."""
+    kw = dict(dimension=3, input_nc=1, output_nc=16, num_downs=1, ngf=16)
+    hip, ref = _pair_kw(device, kw, "f16")
+    x = torch.rand(1, 1, 32, 32, 32, device=device)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(1, 16, 32, 32, 32, device=device)
+    (hip(xa) * g).sum().backward()
+    (_ref_forward(ref, xb, []) * g).sum().backward()
+    assert xa.grad is not None and xa.grad.shape == x.shape
+    err = ((xa.grad - xb.grad).norm() / xb.grad.norm()).item()
+    assert err < 2e-2, err                                    # f16 storage through two BatchNorm(train) blocks
