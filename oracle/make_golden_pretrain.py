@@ -39,6 +39,59 @@ def crit(weigh_rarity, balance, mode):
                                      weighting_mode=mode))
 
 
+def step_record(size, prefix, out):
+    """One full two-view step of the REFERENCE modules at size^3 (train-mode BatchNorm, fp32, no autocast: CPU)."""
+    kw = R.VARIANTS["anatomix"]
+    netG = RefUnet(**kw)
+    netG.load_state_dict(R.synthetic_state_dict(kw, 3, gain=2 ** 0.5), strict=True)
+    netG.train()
+    A, B, seg = PI.step_inputs(size)
+    reals = torch.cat((A, B), 0)
+    out_seg, feat_kq = netG(reals, PI.NCE_LAYERS, False)
+    netF = PatchSampleF(use_mlp=True, init_type="normal", init_gain=0.02, nc=PI.NETF_NC, gpu_ids=[], n_mlps=3)
+    netF.create_mlp(feat_kq)
+    netF.load_state_dict(PI.mlp_state_dict([f.shape[1] for f in feat_kq], seed=9), strict=True)
+    netF.train()
+    torch.manual_seed(13)
+    pooled, ids = netF(feat_kq, PI.NUM_PATCHES, None, None, False)
+    for k, sid in enumerate(ids):
+        out[f"{prefix}|ids|{k}"] = sid.numpy().astype(np.int16)
+    c = crit(False, False, "raw")
+    total = 0.0
+    per_layer = []
+    for f_kq, sid, feat in zip(pooled, ids, feat_kq):
+        l = c(f_kq, seg, sid, feat.size()[2:])
+        per_layer.append(l.item())
+        total = total + l.mean() * (1.0 / len(PI.NCE_LAYERS))
+    total.backward()
+    gG = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netG.parameters() if p.grad is not None))
+    gF = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netF.parameters() if p.grad is not None))
+    out[f"{prefix}|per_layer"] = np.array(per_layer)
+    out[f"{prefix}|total"] = np.array(total.item())
+    out[f"{prefix}|grad_norm_G"] = np.array(gG.item())
+    out[f"{prefix}|grad_norm_F"] = np.array(gF.item())
+    for name, prm in netG.named_parameters():            # per-parameter gradient norm + a few seeded probes of every layer
+        g = prm.grad.double().reshape(-1)
+        idx = np.random.RandomState(sum(map(ord, name))).randint(0, g.numel(), min(256, g.numel()))
+        out[f"{prefix}|gnorm|{name}"] = np.array(g.norm().item())
+        out[f"{prefix}|gidx|{name}"] = idx.astype(np.int64)
+        out[f"{prefix}|gval|{name}"] = g[idx].numpy().astype(np.float32)
+    out[f"{prefix}|out_probe"] = out_seg.detach().reshape(-1)[:: 9973].numpy().astype(np.float32)
+    out[f"{prefix}|bn1_running_mean"] = netG.model[1].running_mean.numpy().copy()
+    print(prefix, "per-layer", per_layer, "total", total.item(), "gG", gG.item(), "gF", gF.item())
+
+
+def main_step128():
+    """`python oracle/make_golden_pretrain.py --step128`: the two-view step record at the 128^3 operating size of BASELINE
+    configs[2] (per-layer losses, total, gradient norms, per-parameter gradient norms and probes) in its own small file."""
+    torch.set_num_threads(8)
+    out = {}
+    step_record(128, "step128", out)
+    path = os.path.join(ROOT, "tests", "golden", "pretrain_step128_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) / 1e6, "MB")
+
+
 def main():
     torch.set_num_threads(8)
     out = {}
@@ -113,4 +166,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--step128" in sys.argv:
+        main_step128()
+    else:
+        main()
