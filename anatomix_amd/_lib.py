@@ -52,6 +52,7 @@ SYMBOLS = {
     "amx_unet_forward_profiled": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, _P, C.POINTER(LaunchRecord), _I,
                                         C.POINTER(_I)]),
     "amx_unet_module_info": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "amx_unet_numerics_status": (_I, [_P, _I, _P]),
     "amx_unet_forward_taps": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, C.POINTER(_I), _I, C.POINTER(_P), _I, _P]),
     "amx_unet_forward_window": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_unet_forward_windows": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
@@ -98,6 +99,10 @@ class AmxError(RuntimeError):
     pass
 
 
+class AmxOverflowError(AmxError, FloatingPointError):
+    """AMX_ERR_OVERFLOW: f16 / f16x2 storage met a value outside the f16 range (include/anatomix_amd.h)."""
+
+
 def load():
     """dlopen the in-tree library and declare prototypes.  Raises if it has not been built."""
     global _lib
@@ -118,7 +123,8 @@ def load():
 
 def check(status: int):
     if status != 0:
-        raise AmxError(f"anatomix_amd error {status}: {load().amx_last_error().decode()}")
+        cls = AmxOverflowError if status == -6 else AmxError
+        raise cls(f"anatomix_amd error {status}: {load().amx_last_error().decode()}")
 
 
 def ptr(t):

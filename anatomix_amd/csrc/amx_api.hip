@@ -34,11 +34,12 @@ const char* last_conv_upcat_kernel_name();
 bool conv_zmarch_can_pool(const ConvParams& p);
 size_t instnorm_scratch_bytes(int N, int C);
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
-                           float slope, void* scratch, int precision, hipStream_t st);
+                           float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr);
+hipError_t launch_poison_if_flag(const int* flag, float* y, long long count, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
                                       hipStream_t st);
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
-                             float slope, int precision, hipStream_t st);
+                             float slope, int precision, hipStream_t st, int* oflow = nullptr);
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
                                float* out, int precision, hipStream_t st);
 const char* last_conv_kernel_name();
@@ -133,6 +134,8 @@ struct amx_unet {
   std::vector<int> encoder_idx, decoder_idx;
   std::vector<int> mod_c, mod_level;  // per module: channels / resolution level of `feat` after it (post-concat for Upsample)
   int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
+  int* d_flag = nullptr;    // device: raised by any epilogue that was about to store a value outside the f16 range (or NaN)
+  int* h_flag = nullptr;    // pinned host mirror, refreshed by an async copy at the end of every forward
 };
 
 namespace {
@@ -273,11 +276,11 @@ struct TapReq {
 };
 
 // One forward.  in_*: fp32 single-channel input view (byte strides); out: fp32 planar output view.
-int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
-                float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
-                const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
-                hipStream_t st, Profiler* prof = nullptr, const long long* x_offs = nullptr,
-                const long long* y_offs = nullptr, const TapReq* taps = nullptr) {
+int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
+                     float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
+                     const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
+                     hipStream_t st, Profiler* prof, const long long* x_offs,
+                     const long long* y_offs, const TapReq* taps) {
   // x_offs / y_offs (host arrays, element offsets, sliding-window mode): sample i reads its window at
   // x + x_offs[i] and accumulates into y + y_offs[i].  Only the stem and the output conv see the volume, so those
   // two run once per window (windows overlap: their accumulations must stay ordered on the stream); every layer
@@ -381,6 +384,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
                     L.module_idx, L.cin_pad, p.C0 + p.C1);
       p.wpk = (const char*)L.wpk;
       p.bias = L.shift;
+      p.oflow = h->d_flag;
       const bool inorm = L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE);
       // InstanceNorm needs the whole (n, c) plane of RAW conv outputs first: the conv stores un-activated values
       // and amx::launch_instnorm normalises + activates them in place afterwards
@@ -483,7 +487,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
       if (raw_bn) {
         AMX_HIP(export_slot(out, tap_conv));
         AMX_HIP(amx::launch_affine_act(A.slot[lv][out.slot], L.scale, L.shift, n, (long long)dd * dh * dw, L.cout,
-                                       act_on ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st));
+                                       act_on ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st, h->d_flag));
       } else if (tap_conv && !L.is_final && inorm) {
         AMX_HIP(export_slot(out, tap_conv));     // the stored raw convolution output, before the instance norm below
       }
@@ -498,7 +502,7 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
-                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st));
+                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag));
       }
       if (final_via_export)
         AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st));
@@ -604,11 +608,49 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   return AMX_OK;
 }
 
+// An f16 overflow (or a NaN) seen by an earlier forward of this handle is reported by the NEXT call; the forward that
+// produced it has already had its output overwritten with NaN on the device (poison_if_flag).
+int pending_numerics_error(amx_unet* h) {
+  if (h->h_flag && *(volatile int*)h->h_flag) {
+    *(volatile int*)h->h_flag = 0;
+    (void)hipMemsetAsync(h->d_flag, 0, sizeof(int), nullptr);
+    return fail(AMX_ERR_OVERFLOW, "a previous forward of this network produced values outside the f16 range (or NaN) in %s storage; "
+                "its output was overwritten with NaN.  Use precision bf16 or strict (bf16x2), which keep fp32's exponent range",
+                h->cfg.precision == AMX_PREC_F16X2 ? "f16x2" : "f16");
+  }
+  return AMX_OK;
+}
+
+int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, long long xs_y,
+                float* y, long long ys_n, long long ys_c, long long ys_z, long long ys_y,
+                const float* wmap, int n, int d, int hh, int w, void* ws, size_t ws_bytes,
+                hipStream_t st, Profiler* prof = nullptr, const long long* x_offs = nullptr,
+                const long long* y_offs = nullptr, const TapReq* taps = nullptr) {
+  if (int e = pending_numerics_error(h)) return e;
+  int rc = run_forward_impl(h, x, xs_n, xs_z, xs_y, y, ys_n, ys_c, ys_z, ys_y, wmap, n, d, hh, w, ws, ws_bytes, st, prof, x_offs,
+                            y_offs, taps);
+  const bool f16_storage = h->cfg.precision == AMX_PREC_F16 || h->cfg.precision == AMX_PREC_F16X2;
+  if (rc == AMX_OK && f16_storage && h->d_flag) {
+    // the output tensor (plain forward: dense [n][Cout][d][hh][w]; windows: the accumulation volume is the caller's, its
+    // extent is not known here -- the flag and the status call cover that path) is poisoned when the flag is up
+    if (!wmap && !x_offs && !(taps && taps->stop >= 0))
+      AMX_HIP(amx::launch_poison_if_flag(h->d_flag, y, (long long)n * h->cfg.output_nc * d * hh * w, st));
+    AMX_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
 int amx_version(void) { return AMX_VERSION; }
+
+int amx_unet_numerics_status(amx_unet_t* h, int synchronize, void* stream) {
+  if (!h) return fail(AMX_ERR_INVALID, "null handle");
+  if (synchronize) AMX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return pending_numerics_error(h);
+}
 const char* amx_last_error(void) { return g_err.c_str(); }
 
 int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
@@ -656,12 +698,22 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
       return fail(AMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
     }
   }
+  hipError_t e = hipMalloc((void**)&h->d_flag, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(h->d_flag, 0, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flag, sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    amx_unet_destroy(h);
+    return fail(AMX_ERR_HIP, "hipMalloc (status flag): %s", hipGetErrorString(e));
+  }
+  *h->h_flag = 0;
   *out = h;
   return AMX_OK;
 }
 
 void amx_unet_destroy(amx_unet_t* h) {
   if (!h) return;
+  if (h->d_flag) (void)hipFree(h->d_flag);
+  if (h->h_flag) (void)hipHostFree(h->h_flag);
   for (ConvLayer& L : h->convs) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);

@@ -56,6 +56,8 @@ struct ConvParams {
   float* stats;                // optional per-(n,c) {sum, sumsq} fp32 accumulators (instance norm)
   char* out2;                  // optional second output: 2x2x2 MAX-POOLED copy of `out` (16-bit NDHWC, dense), fused
   long long qn, qz, qy, qx;    //   into the epilogue of the z-marching kernel (nn.MaxPool3d(2), network.py:368)
+  int* oflow;                  // optional device flag: set to 1 when a value that is about to be stored in f16 is out of the
+                               //   f16 range (|v| > 65504) or NaN -- see amx_unet_numerics_status (include/anatomix_amd.h)
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
 };
 

@@ -130,6 +130,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   const int yl = y0 + wrow, xl = x0 + li;
   char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 * Q;
 
+  bool bad = false;
   for (int s = 0; s < nsteps; ++s) {
     {
       int need = TZ * s + TZ + 2;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
           float f = acc[j];
           if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[q * 4 + j] = f;
         }
       }
@@ -196,6 +198,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
   }
+  if (RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
 
 // Stem weights: fp32 [Cout][1][3][3][3] (* folded norm gain) -> [q][lane 64][8] A fragments with

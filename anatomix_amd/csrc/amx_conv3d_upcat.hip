@@ -205,6 +205,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
   float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4) * p.pc + (long long)yl * p.py + xl
                                 : nullptr;
 
+  bool bad = false;
   for (int s = 0; s < nsteps; ++s) {
     {
       int need = 2 * s + 4, needl = s + 3;                   // skip planes q <= 2s+3 and low planes ql <= s+2
@@ -276,6 +277,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
           float f = acc[c][j];
           if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[j] = f;
         }
         if (OUTMODE == 0) {
@@ -296,6 +298,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
       }
     }
   }
+  if (OUTMODE == 0 && RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
 
 // Weights for conv3d_upcat16: fp32 w[16][48][27] (* folded gain) ->

@@ -457,6 +457,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     cu_stage = 0;
 
     // ---- item finished: activation + pack into the pending registers (stored next iteration)
+    bool bad = false;
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
       float v[4 * Q];
@@ -467,6 +468,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
           float f = acc[c][q][j];
           if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[q * 4 + j] = f;
         }
       if (OUTMODE == 0) {
@@ -485,6 +487,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
         for (int j = 0; j < 4 * Q; ++j) pend[c][j] = __builtin_bit_cast(unsigned, v[j]);
       }
     }
+    if (OUTMODE == 0 && RangeCheck<T>::on) raise_flag(p.oflow, bad);
     pd = cu;
     pending = true;
     advance_item(cu, p);

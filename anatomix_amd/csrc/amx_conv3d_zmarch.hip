@@ -235,6 +235,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
                                                (long long)(xl >> 1) * p.qx + cb * 2
                                           : nullptr;
 
+  bool bad = false;
   for (int s = 0; s < nsteps; ++s) {
     {
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
@@ -351,6 +352,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
           float f = acc[tz][cy][j];
           if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
           else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+          if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[j] = f;
           pooled[j] = f > pooled[j] ? f : pooled[j];
         }
@@ -418,6 +420,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
       }
     }
   }
+  if (OUTMODE == 0 && RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
 
 static thread_local char g_kernel_name3[64] = "";

@@ -18,6 +18,21 @@ template <> struct Ops<bf16> {
   }
 };
 
+// f16 storage overflows at 65504; bf16 shares fp32's exponent range.  Epilogues that store f16 (or f16x2) values test them
+// with RangeCheck<T>::bad and raise ConvParams::oflow -- an overflow must never turn into silent Inf (or, behind a ReLU or
+// max-pool, silently finite) features.
+template <typename T> struct RangeCheck {
+  static constexpr bool on = false;
+  static __device__ __forceinline__ bool bad(float) { return false; }
+};
+template <> struct RangeCheck<f16> {
+  static constexpr bool on = true;
+  static __device__ __forceinline__ bool bad(float v) { return !(__builtin_fabsf(v) <= 65504.f); }   // also true for NaN
+};
+__device__ __forceinline__ void raise_flag(int* flag, bool bad) {
+  if (bad && flag) __atomic_store_n(flag, 1, __ATOMIC_RELAXED);
+}
+
 __device__ __forceinline__ int reflect_clamp(int g, int n) {
   g = g < 0 ? -g : g;                 // -1 -> 1
   g = g >= n ? 2 * n - 2 - g : g;     //  n -> n-2

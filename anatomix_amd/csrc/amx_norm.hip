@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
 
 template <typename T, bool SPLIT>
 __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox, int C, int N, int act,
-                                float slope) {
+                                float slope, int* oflow) {
+  bool bad = false;
   const int c8n = C >> 3;
   const long long total = (long long)N * vox * c8n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -163,10 +164,12 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
       float v = f[e] * q[2 * e] + q[2 * e + 1];
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
     store8<T, SPLIT>(xp, C * 2, f);
   }
+  if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
 
 // Same pass when 256 % (C / 8) == 0 (every power-of-two channel count): gridDim.y = sample, a thread keeps ONE 8-channel
@@ -175,7 +178,8 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
 // memory (3.2 vs 4.6 TB/s on the 268 MB level-0 tensors of anatomix-dev).
 template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox,
-                                                            int C, int act, float slope) {
+                                                            int C, int act, float slope, int* oflow) {
+  bool bad = false;
   const int c8n = C >> 3, c8 = threadIdx.x % c8n, n = blockIdx.y;
   const float* q = ab + ((long long)n * C + c8 * 8) * 2;
   float a[8], b[8];
@@ -198,10 +202,12 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
       float v = f[e] * a[e] + b[e];
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
     store8<T, SPLIT>(xp, C * 2, f);
   }
+  if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
 
 // out [N][2D][2H][2W][C] <- in [N][D][H][W][C].  Cell formulation: the 2 x 2 x 2 outputs (2z+1..2z+2, 2y+1..2y+2,
@@ -295,7 +301,8 @@ __global__ void upsample2_trilinear_bwd_kernel(const char* __restrict__ gout, ch
 // used when a feature tap asks for the pre-norm convolution output, network.py:475-529).
 template <typename T, bool SPLIT>
 __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  long long nvox, int C, int act, float slope) {
+                                  long long nvox, int C, int act, float slope, int* oflow) {
+  bool bad = false;
   const int c8n = C >> 3;
   const long long total = nvox * c8n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -308,10 +315,12 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
       float v = f[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
     store8<T, SPLIT>(xp, C * 2, f);
   }
+  if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
 
 // Feature tap: 16-bit channels-last -> fp32 NCDHW [N][C0+C1][D][H][W], the layout the reference hands to its
@@ -379,11 +388,24 @@ __global__ void import_ncdhw_kernel(const float* __restrict__ src, char* __restr
   }
 }
 
+// Last launch of a forward: if any epilogue raised the range flag, the network output is overwritten with NaN -- the
+// features a caller holds after an f16 overflow are unmistakably invalid, whatever the caller does with status codes.
+__global__ void poison_if_flag_kernel(const int* __restrict__ flag, float* __restrict__ y, long long count) {
+  if (*flag == 0) return;
+  const float nan = __builtin_nanf("");
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) y[i] = nan;
+}
+
+hipError_t launch_poison_if_flag(const int* flag, float* y, long long count, hipStream_t st) {
+  hipLaunchKernelGGL(poison_if_flag_kernel, dim3(2048), dim3(256), 0, st, flag, y, count);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------- launchers
 size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * 65536 * 2 + (size_t)N * C * 2) * sizeof(float); }
 
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
-                           float slope, void* scratch, int precision, hipStream_t st) {
+                           float slope, void* scratch, int precision, hipStream_t st, int* oflow) {
   if (C % 8) return hipErrorInvalidValue;
   float* partial = (float*)scratch;
   float* ab = partial + (size_t)N * 65536 * 2;
@@ -401,9 +423,9 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   if (256 % c8n == 0) {                                                                                          \
     const long long per = vox * c8n;                                                                             \
     const int bx = (int)((per + 255) / 256 > 4096 ? 4096 : (per + 255) / 256);                                   \
-    hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope); \
+    hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope, oflow); \
   } else                                                                                                         \
-    hipLaunchKernelGGL((in_apply_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope)
+    hipLaunchKernelGGL((in_apply_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope, oflow)
   switch (precision) {
     case 0: { AMX_IN(f16, false); } break;
     case 1: { AMX_IN(bf16, false); } break;
@@ -443,11 +465,11 @@ hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int 
 }
 
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
-                             float slope, int precision, hipStream_t st) {
+                             float slope, int precision, hipStream_t st, int* oflow) {
   if (C % 8) return hipErrorInvalidValue;
   const long long total = (long long)N * vox * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define AMX_AA(T, S) hipLaunchKernelGGL((affine_act_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope)
+#define AMX_AA(T, S) hipLaunchKernelGGL((affine_act_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, scale, shift, (long long)N * vox, C, act, slope, oflow)
   switch (precision) {
     case 0: AMX_AA(f16, false); break;
     case 1: AMX_AA(bf16, false); break;

@@ -309,6 +309,18 @@ class Unet(nn.Module):
                                             need, stream))
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
+    def check_numerics(self, synchronize=True):
+        """Raises ``_lib.AmxOverflowError`` if a forward of this module (f16 / f16x2 storage) produced values outside the f16
+        range since the last check; the output of that forward was overwritten with NaN on the device.  With
+        ``synchronize`` the current stream is drained first, so every forward enqueued so far is covered.  The same error is
+        raised by the next forward if nobody asked in between."""
+        if self._handle is None:
+            return
+        dev = torch.device("cuda", self._handle_key[0]) if self._handle_key[0] is not None else torch.device("cuda")
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.load().amx_unet_numerics_status(self._handle, int(bool(synchronize)), stream))
+
     def forward_hip_taps(self, x, layers, encode_only=False):
         """Unet.forward(input, layers, encode_only) (network.py:475-529) on the HIP kernels.  Features are fp32 NCDHW
         tensors collected in traversal order; with ``encode_only`` the forward stops after module ``layers[-1]``."""

@@ -263,4 +263,7 @@ def _run_fused(inputs, roi, starts, wmap, model, cnt):
             for (z, y, xx) in grp:
                 _lib.check(lib.amx_sw_count(_lib.ptr(cnt), size[0], size[1], size[2], z, y, xx, roi[0], roi[1], roi[2],
                                             _lib.ptr(wm), st))
+        if model.precision in ("f16", "fp16", "float16", "f16x2") and not torch.cuda.is_current_stream_capturing():
+            # the accumulation volume leaves the library here: one synchronising range check per volume (f16 storage only)
+            model.check_numerics(synchronize=True)
     return acc

@@ -32,7 +32,8 @@ typedef enum amx_status {
   AMX_ERR_SHAPE = -2,       /* spatial size not divisible by 2^num_downs, bottleneck < 2, ... */
   AMX_ERR_NOT_LOADED = -3,  /* forward before every conv received its parameters */
   AMX_ERR_WORKSPACE = -4,   /* workspace too small / misaligned */
-  AMX_ERR_HIP = -5          /* a HIP runtime call failed */
+  AMX_ERR_HIP = -5,         /* a HIP runtime call failed */
+  AMX_ERR_OVERFLOW = -6     /* f16 / f16x2 storage: a value outside the f16 range (or a NaN) was produced */
 } amx_status;
 
 enum { AMX_NORM_NONE = 0, AMX_NORM_BATCH_EVAL = 1, AMX_NORM_INSTANCE = 2, AMX_NORM_INSTANCE_AFFINE = 3 };
@@ -111,6 +112,17 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int w_h, int 
  * d_x: fp32 [n][input_nc][d][h][w]; d_y: fp32 [n][output_nc][d][h][w] (both NCDHW contiguous). */
 int amx_unet_forward(amx_unet_t* h, const float* d_x, float* d_y, int n, int d, int hh, int w,
                      void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Range safety of the f16 / f16x2 storage modes.  f16 overflows at 65504; folded BatchNorm gains of a real checkpoint are
+ * unbounded, and an Inf that meets a ReLU or a max-pool can come out finite and wrong.  Every epilogue that stores f16
+ * values therefore tests them, and when one is out of range (or NaN):
+ *   - the forward that produced it has its output tensor overwritten with NaN on the device (last launch of the
+ *     forward; sliding-window accumulation volumes are the caller's and are covered by the status call);
+ *   - the NEXT call on this handle, or this function, returns AMX_ERR_OVERFLOW once (amx_last_error says which mode to
+ *     switch to) and clears the condition.
+ * synchronize != 0 waits for `stream` first, so the answer covers every forward enqueued so far.  bf16 / bf16x2 keep
+ * fp32's exponent range (they overflow where the fp32 reference does) and never raise it. */
+int amx_unet_numerics_status(amx_unet_t* h, int synchronize, void* stream);
 
 /* Channels and resolution level (spatial size = input size >> level) of `feat` after Unet.model[module_idx]
  * as Unet.forward's `layers` branch sees it: for an nn.Upsample id that is AFTER torch.cat((skip, up), 1)
