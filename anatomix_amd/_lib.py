@@ -78,6 +78,8 @@ SYMBOLS = {
     "amx_conv3d_wgrad_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I, _I]),
     "amx_conv3d_wgrad": (_I, [_P, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _I,
                               _I, _P, _I, _P, C.c_size_t, _I, _P]),
+    "amx_attention_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "amx_attention_qknorm_rope": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "amx_supcon_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_supcon_loss": (_I, [_P, _P, _I, _I, C.c_float, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_mlp_head_forward": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, C.c_float, _P, _P, _P, _P, _P]),

@@ -35,6 +35,10 @@ bool conv_zmarch_can_pool(const ConvParams& p);
 size_t instnorm_scratch_bytes(int N, int C);
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr);
+size_t attention_scratch_bytes(int b, int heads, int n);
+hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
+                            const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
+                            float* out, void* scratch, hipStream_t st);
 hipError_t launch_poison_if_flag(const int* flag, float* y, long long count, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
                                       hipStream_t st);
@@ -1028,6 +1032,26 @@ int amx_conv3d_wgrad(const void* d_dy, long long dy_sn, long long dy_sz, long lo
   }
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
   AMX_HIP(amx::launch_wgrad(p, cin_real, d_dw, accumulate, d_scratch, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_attention_scratch_bytes(int b, int heads, int n, int head_dim) {
+  if (b < 1 || heads < 1 || n < 1 || head_dim < 2 || head_dim > 80) return 0;
+  return amx::attention_scratch_bytes(b, heads, n);
+}
+
+int amx_attention_qknorm_rope(const float* d_q, const float* d_k, const float* d_v, const float* d_qn_w, const float* d_qn_b,
+                              const float* d_kn_w, const float* d_kn_b, float norm_eps, const float* d_rope, int n_prefix, int b,
+                              int n, int heads, int head_dim, float* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
+  if (!d_q || !d_k || !d_v || !d_out || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
+  if (b < 1 || n < 1 || heads < 1 || head_dim < 2 || head_dim > 80 || (head_dim & 1))
+    return fail(AMX_ERR_INVALID, "attention: head_dim must be even and <= 80 (got %d), b, n, heads >= 1", head_dim);
+  if ((!d_qn_w) != (!d_qn_b) || (!d_kn_w) != (!d_kn_b)) return fail(AMX_ERR_INVALID, "attention: norm weight and bias go together");
+  if (n_prefix < 0 || n_prefix > n) return fail(AMX_ERR_INVALID, "attention: 0 <= n_prefix <= n");
+  if (scratch_bytes < amx::attention_scratch_bytes(b, heads, n) || ((uintptr_t)d_scratch & 15))
+    return fail(AMX_ERR_WORKSPACE, "attention scratch needs %zu bytes, 16-byte aligned", amx::attention_scratch_bytes(b, heads, n));
+  AMX_HIP(amx::launch_attention(d_q, d_k, d_v, d_qn_w, d_qn_b, d_kn_w, d_kn_b, norm_eps, d_rope, n_prefix, b, n, heads, head_dim, d_out,
+                                d_scratch, (hipStream_t)stream));
   return AMX_OK;
 }
 

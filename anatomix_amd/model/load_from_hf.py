@@ -24,6 +24,14 @@ ANATOMIX_VARIANTS = {
                             pooling="Avg", interp="trilinear", norm_eps=1e-2),
         "output_channels": 32,
     },
+    # load_from_hf.py:25-35 -- the 3D ViT (PrimusV2-S); body restated, see anatomix_amd/model/vit3d/architectures.py
+    "anatomix-dev-vit": {
+        "vit_kwargs": dict(input_channels=1, num_classes=32, embed_dim=396, eva_depth=12, eva_numheads=6,
+                           patch_embed_size=(8, 8, 8), input_shape=(128, 128, 128), num_register_tokens=8, init_values=0.1,
+                           scale_attn_inner=True, qk_norm=True, out_norm="demean", out_norm_eps=1e-2, register_init_std=0.02,
+                           in_eps=1e-2),
+        "output_channels": 32,
+    },
 }
 
 
@@ -39,7 +47,11 @@ def build_variant(variant):
     """Un-initialised model of a registered variant."""
     if variant not in ANATOMIX_VARIANTS:
         raise ValueError(f"Unknown variant {variant!r}. Known: {sorted(ANATOMIX_VARIANTS)}")
-    return Unet(**ANATOMIX_VARIANTS[variant]["unet_kwargs"])
+    config = ANATOMIX_VARIANTS[variant]
+    if "vit_kwargs" in config:                          # load_from_hf.py:74-76
+        from .vit3d import PrimusV2
+        return PrimusV2(**config["vit_kwargs"])
+    return Unet(**config["unet_kwargs"])
 
 
 def load_from_hf(variant, repo_id=DEFAULT_REPO, revision=None, map_location="cpu", weights_path=None):

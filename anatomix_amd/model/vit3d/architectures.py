@@ -1,0 +1,308 @@
+"""``anatomix-dev-vit``: the PrimusV2 3D ViT with the call surface of ``anatomix.model.vit3d.PrimusV2``
+(reference: anatomix/model/vit3d/architectures.py:231-260 + ``_PrimusExtensions`` :89-165, tokenizer deep_tokenizer.py:12-149,
+registry entry load_from_hf.py:25-35).
+
+The reference class is a thin subclass of ``dynamic_network_architectures.architectures.primus.PrimusV2`` (PyPI package
+``dynamic-network-architectures==0.4.4``, requirements.txt:17; its EVA blocks come from ``timm``).  That package is neither in
+the reference tree nor in this image, so the network body is RESTATED here from the published architecture (see
+oracle/vit_ref.py for every assumption) -- **parity with the upstream package is unpinned**: constructor keywords, the
+``forward(x, layers, encode_only)`` contract, the wrapper's extensions (per-head QK LayerNorm, register-token init,
+``ChannelDemean`` output norm, tokenizer ``in_eps``) and the arithmetic of the published blocks are reproduced; upstream
+state_dict key names and a few hyper-parameters of the tokenizer / decoder could not be checked.
+
+What runs where: for CUDA inputs under ``torch.no_grad()`` the attention core of every block -- QK-LayerNorm, rotary
+embedding and softmax(q k^T) v for 4104 tokens x 6 heads x head_dim 66, 63 % of the model's FLOPs -- is ONE call into
+libanatomix_amd.so (``amx_attention_qknorm_rope``: MFMA flash attention, csrc/amx_attention.hip).  The plain linears and the
+small convolutional tokenizer / decoder are stock torch modules (vendor GEMM / MIOpen).  Under autograd or on the CPU the same
+attention math runs as torch ops (training the ViT is not part of the accelerated path).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _lib
+
+# architectures.py:20-25
+PRIMUS_CONFIGS = {
+    "S": {"eva_depth": 12, "eva_numheads": 6, "embed_dim": 396},
+    "B": {"eva_depth": 12, "eva_numheads": 12, "embed_dim": 792},
+    "M": {"eva_depth": 16, "eva_numheads": 12, "embed_dim": 864},
+    "L": {"eva_depth": 24, "eva_numheads": 16, "embed_dim": 1056},
+}
+
+
+class ChannelDemean(nn.Module):
+    """architectures.py:28-33: subtract each channel's spatial mean."""
+
+    def forward(self, x):
+        return x - x.mean(dim=(2, 3, 4), keepdim=True)
+
+
+class ChannelLayerNorm(nn.Module):
+    """architectures.py:36-52: standardise over the channel axis, no affine."""
+
+    def __init__(self, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(dim=1, keepdim=True)
+        var = x.var(dim=1, unbiased=False, keepdim=True)
+        return (x - mean) / torch.sqrt(var + self.eps)
+
+
+class LayerNormNd(nn.Module):
+    """Channel-wise LayerNorm with affine parameters on [B, C, ...] tensors (the upstream decoder's norm)."""
+
+    def __init__(self, c, eps=1e-6):
+        super().__init__()
+        self.weight, self.bias, self.eps = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c)), eps
+
+    def forward(self, x):
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        x = (x - u) / torch.sqrt(s + self.eps)
+        shape = (1, -1) + (1,) * (x.dim() - 2)
+        return x * self.weight.view(shape) + self.bias.view(shape)
+
+
+def build_out_norm(mode, num_classes, eps):
+    """architectures.py:55-86."""
+    if isinstance(mode, bool):
+        mode = "instance" if mode else "none"
+    mode = (mode or "none").lower()
+    if mode in ("none", "identity", "off"):
+        return nn.Identity()
+    if mode in ("instance", "instancenorm", "in"):
+        return nn.InstanceNorm3d(num_classes, eps=eps, affine=False)
+    if mode in ("demean", "center"):
+        return ChannelDemean()
+    if mode in ("layernorm", "layer", "ln"):
+        return ChannelLayerNorm(eps=eps)
+    if mode in ("layernorm_affine", "layernorm-affine", "ln_affine"):
+        return LayerNormNd(num_classes, eps=eps)
+    raise ValueError(f"unsupported output normalization: {mode!r}")
+
+
+class _ConvNormAct(nn.Module):
+    def __init__(self, cin, cout, eps):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, 3, padding=1)
+        self.norm = nn.InstanceNorm3d(cout, eps=eps, affine=True)
+
+    def forward(self, x):
+        return F.leaky_relu(self.norm(self.conv(x)), 0.01)
+
+
+class _ResidualDown(nn.Module):
+    """BasicBlockD with stride 2: conv-IN-LeakyReLU-conv-IN + [AvgPool(2) -> 1x1 conv -> IN], LeakyReLU."""
+
+    def __init__(self, cin, cout, eps):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cout, 3, stride=2, padding=1)
+        self.norm1 = nn.InstanceNorm3d(cout, eps=eps, affine=True)
+        self.conv2 = nn.Conv3d(cout, cout, 3, padding=1)
+        self.norm2 = nn.InstanceNorm3d(cout, eps=eps, affine=True)
+        self.skip = nn.Conv3d(cin, cout, 1, bias=False)
+        self.skip_norm = nn.InstanceNorm3d(cout, eps=eps, affine=True)
+
+    def forward(self, x):
+        y = self.norm2(self.conv2(F.leaky_relu(self.norm1(self.conv1(x)), 0.01)))
+        return F.leaky_relu(y + self.skip_norm(self.skip(F.avg_pool3d(x, 2))), 0.01)
+
+
+class PatchEmbedDeeper(nn.Module):
+    """deep_tokenizer.py:12-68: stem + three stride-2 residual stages + 1x1x1 projection, InstanceNorm eps = ``in_eps``."""
+
+    def __init__(self, input_channels=3, embed_dim=864, base_features=32, depth_per_level=(1, 1, 1), in_eps=1e-5):
+        super().__init__()
+        if tuple(depth_per_level) != (1, 1, 1):
+            raise NotImplementedError("PatchEmbedDeeper: one block per level (the PrimusV2 default) is implemented")
+        self.stem = _ConvNormAct(input_channels, base_features, in_eps)
+        widths, cin, stages = [base_features * 2 ** k for k in range(3)], base_features, []
+        for c in widths:
+            stages.append(_ResidualDown(cin, c, in_eps))
+            cin = c
+        self.stages = nn.Sequential(*stages)
+        self.proj = nn.Conv3d(cin, embed_dim, 1)
+
+    def forward(self, x):
+        return self.proj(self.stages(self.stem(x)))
+
+
+class PatchDecode(nn.Module):
+    def __init__(self, patch_size, embed_dim, out_channels):
+        super().__init__()
+        nst = int(round(math.log2(max(patch_size))))
+        red = (embed_dim / (2 * out_channels)) ** (1.0 / nst)
+        r8 = lambda v: int(max(8, round((v + 1e-6) / 8) * 8))
+        ch = [embed_dim] + [r8(embed_dim / red ** (k + 1)) for k in range(nst)]
+        ch[-1] = out_channels
+        stages = [nn.Sequential(nn.ConvTranspose3d(ch[k], ch[k + 1], 2, stride=2), LayerNormNd(ch[k + 1]), nn.GELU())
+                  for k in range(nst - 1)]
+        stages.append(nn.ConvTranspose3d(ch[-2], ch[-1], 2, stride=2))
+        self.decode = nn.Sequential(*stages)
+
+    def forward(self, x):
+        return self.decode(x)
+
+
+def build_rope_table(grid, head_dim, temperature=10000.0):
+    """[N, 2 * head_dim] fp32: per token [sin | cos], each band repeated for its (even, odd) channel pair."""
+    nb = head_dim // (2 * len(grid))
+    bands = 1.0 / (temperature ** (torch.arange(nb, dtype=torch.float64) / nb))
+    axes = torch.meshgrid(*[torch.arange(s, dtype=torch.float64) for s in grid], indexing="ij")
+    ang = (torch.stack(axes, dim=-1).reshape(-1, len(grid), 1) * bands).reshape(-1, len(grid) * nb)
+    return torch.cat((ang.sin().repeat_interleave(2, -1), ang.cos().repeat_interleave(2, -1)), -1).float()
+
+
+def _rope(x, table):
+    hd = x.shape[-1]
+    rot = torch.stack((-x[..., 1::2], x[..., ::2]), -1).reshape(x.shape)
+    return x * table[:, hd:] + rot * table[:, :hd]
+
+
+class EvaAttention(nn.Module):
+    def __init__(self, dim, num_heads, qk_norm, scale_attn_inner):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.q_proj, self.k_proj, self.v_proj = nn.Linear(dim, dim), nn.Linear(dim, dim, bias=False), nn.Linear(dim, dim)
+        self.q_norm = nn.LayerNorm(self.head_dim) if qk_norm else None        # architectures.py:108-115
+        self.k_norm = nn.LayerNorm(self.head_dim) if qk_norm else None
+        self.norm = nn.LayerNorm(dim) if scale_attn_inner else nn.Identity()
+        self.proj = nn.Linear(dim, dim)
+        self._scratch = None
+
+    def core_hip(self, q, k, v, table, n_prefix):
+        """q, k, v fp32 [B, N, E] -> attention output [B, N, E]: one C-ABI call."""
+        lib = _lib.load()
+        B, N, E = q.shape
+        dev = q.device
+        out = torch.empty_like(q)
+        with torch.cuda.device(dev):
+            nb = lib.amx_attention_scratch_bytes(B, self.num_heads, N, self.head_dim)
+            if nb == 0:
+                raise _lib.AmxError(f"attention: unsupported shape (heads {self.num_heads}, head_dim {self.head_dim})")
+            if self._scratch is None or self._scratch.numel() < nb or self._scratch.device != dev:
+                self._scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+            qn = self.q_norm
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.amx_attention_qknorm_rope(
+                _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(qn.weight if qn else None), _lib.ptr(qn.bias if qn else None),
+                _lib.ptr(self.k_norm.weight if qn else None), _lib.ptr(self.k_norm.bias if qn else None),
+                float(qn.eps if qn else 1e-5), _lib.ptr(table), int(n_prefix), B, N, self.num_heads, self.head_dim, _lib.ptr(out),
+                _lib.ptr(self._scratch), nb, st))
+        return out
+
+    def core_torch(self, q, k, v, table, n_prefix):
+        B, N, E = q.shape
+        sh = lambda t: t.reshape(B, N, self.num_heads, self.head_dim).transpose(1, 2)
+        q, k, v = sh(q), sh(k), sh(v)
+        if self.q_norm is not None:
+            q, k = self.q_norm(q), self.k_norm(k)
+        if table is not None:
+            q = torch.cat((q[:, :, :n_prefix], _rope(q[:, :, n_prefix:], table)), 2)
+            k = torch.cat((k[:, :, :n_prefix], _rope(k[:, :, n_prefix:], table)), 2)
+        return F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, E)
+
+    def forward(self, x, table, n_prefix):
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        use_hip = x.is_cuda and not torch.is_grad_enabled() and q.dtype == torch.float32
+        y = self.core_hip(q.contiguous(), k.contiguous(), v.contiguous(), table, n_prefix) if use_hip else \
+            self.core_torch(q, k, v, table, n_prefix)
+        return self.proj(self.norm(y))
+
+
+class SwiGLU(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1_g, self.fc1_x = nn.Linear(dim, hidden), nn.Linear(dim, hidden)
+        self.norm = nn.LayerNorm(hidden, eps=1e-6)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.norm(F.silu(self.fc1_g(x)) * self.fc1_x(x)))
+
+
+class EvaBlock(nn.Module):
+    def __init__(self, dim, num_heads, hidden, init_values, qk_norm, scale_attn_inner):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = EvaAttention(dim, num_heads, qk_norm, scale_attn_inner)
+        self.gamma_1 = nn.Parameter(init_values * torch.ones(dim)) if init_values is not None else None
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = SwiGLU(dim, hidden)
+        self.gamma_2 = nn.Parameter(init_values * torch.ones(dim)) if init_values is not None else None
+
+    def forward(self, x, table, n_prefix):
+        a = self.attn(self.norm1(x), table, n_prefix)
+        x = x + (a if self.gamma_1 is None else self.gamma_1 * a)
+        m = self.mlp(self.norm2(x))
+        return x + (m if self.gamma_2 is None else self.gamma_2 * m)
+
+
+class Eva(nn.Module):
+    def __init__(self, dim, depth, num_heads, grid, hidden, init_values, qk_norm, scale_attn_inner):
+        super().__init__()
+        self.pos_embed = nn.Parameter(torch.zeros(1, int(torch.tensor(grid).prod()), dim))
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.blocks = nn.ModuleList(EvaBlock(dim, num_heads, hidden, init_values, qk_norm, scale_attn_inner) for _ in range(depth))
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+
+
+class PrimusV2(nn.Module):
+    """Constructor keywords of the reference wrapper (architectures.py:168-260).  Dropout / drop-path / patch-drop rates are
+    accepted and must be zero (inference path)."""
+
+    def __init__(self, input_channels, num_classes, embed_dim, patch_embed_size, eva_depth=24, eva_numheads=16, input_shape=None,
+                 num_register_tokens=0, init_values=None, scale_attn_inner=False, qk_norm=False, out_norm="none", out_norm_eps=1e-5,
+                 register_init_std=1e-6, in_eps=1e-5, drop_path_rate=0.0, patch_drop_rate=0.0, proj_drop_rate=0.0,
+                 attn_drop_rate=0.0, mlp_ratio=4 * 2 / 3):
+        super().__init__()
+        if tuple(patch_embed_size) != (8, 8, 8):
+            raise ValueError("PrimusV2's deeper patch embed is hardwired to an 8x stride")          # pretraining_networks.py:116-118
+        if any(r != 0 for r in (drop_path_rate, patch_drop_rate, proj_drop_rate, attn_drop_rate)):
+            raise NotImplementedError("PrimusV2 (anatomix_amd): dropout / drop-path / patch-drop are not implemented")
+        if input_shape is None or embed_dim % eva_numheads:
+            raise ValueError("input_shape is required and embed_dim must be divisible by eva_numheads")
+        self.grid = tuple(int(s) // 8 for s in input_shape)
+        self.num_register_tokens = int(num_register_tokens)
+        self.down_projection = PatchEmbedDeeper(input_channels, embed_dim, 32, (1, 1, 1), in_eps)
+        self.eva = Eva(embed_dim, eva_depth, eva_numheads, self.grid, int(embed_dim * mlp_ratio), init_values, qk_norm, scale_attn_inner)
+        self.up_projection = PatchDecode(patch_embed_size, embed_dim, num_classes)
+        self.register_tokens = None
+        if self.num_register_tokens > 0:
+            self.register_tokens = nn.Parameter(torch.randn(1, self.num_register_tokens, embed_dim) * register_init_std)
+        self.out_norm = build_out_norm(out_norm, num_classes, out_norm_eps)
+        self.register_buffer("rope_table", build_rope_table(self.grid, embed_dim // eva_numheads), persistent=False)
+
+    def _body(self, x):
+        feat = self.down_projection(x)
+        B, E = feat.shape[:2]
+        if tuple(feat.shape[2:]) != self.grid:
+            raise ValueError(f"PrimusV2 was built for inputs of {tuple(8 * g for g in self.grid)} (got {tuple(x.shape[2:])})")
+        tok = feat.flatten(2).transpose(1, 2) + self.eva.pos_embed
+        nreg = self.num_register_tokens
+        if nreg:
+            tok = torch.cat((self.register_tokens.expand(B, -1, -1), tok), 1)
+        for blk in self.eva.blocks:
+            tok = blk(tok, self.rope_table, nreg)
+        tok = self.eva.norm(tok)[:, nreg:]
+        return self.up_projection(tok.transpose(1, 2).reshape(B, E, *self.grid))
+
+    def forward(self, x, layers=None, encode_only=False, verbose=False, ret_mask=False):
+        """architectures.py:122-165: a nonempty ``layers`` asks for the final volume as the sole feature; a boolean ``layers`` is
+        the upstream positional ``ret_mask`` (no patch dropout here: the mask is all ones)."""
+        if isinstance(layers, bool):
+            ret_mask, layers = layers, None
+        output = self.out_norm(self._body(x))
+        if ret_mask:
+            return output, torch.ones((x.shape[0], 1) + self.grid, dtype=torch.bool, device=x.device)
+        if layers:
+            return [output] if encode_only else (output, [output])
+        return output

@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="step workload: launch every kernel eagerly instead of replaying one HIP graph")
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
-    ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev"],
-                    help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M)")
+    ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev", "anatomix-dev-vit"],
+                    help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M); "
+                         "anatomix-dev-vit = BASELINE configs[4] (26M PrimusV2 3D ViT, MFMA attention path)")
     ap.add_argument("--workload", default="forward", choices=["forward", "step"],
                     help="step = BASELINE configs[2]: one contrastive pretraining step per rank (two views of one 128^3 "
                          "volume through the 6M UNet with taps, patch sampling + MLPs, six SupCon losses, backward, "
@@ -98,6 +99,27 @@ def cpu_baseline(size, forwards, variant="anatomix"):
     return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{len(ts)} forwards of one 1x1x{size}^3 volume, fp32 eval, torch CPU (oneDNN) with {cores} of "
                       f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
+
+
+def cpu_baseline_vit():
+    """oracle restatement of the ViT (oracle/vit_ref.py) on one 1x1x128^3 volume, fp32, host threads."""
+    import torch
+    from oracle import vit_ref as V
+    kw = V.VIT_VARIANTS["anatomix-dev-vit"]
+    sd = V.synthetic_state_dict(kw, 0)
+    x = V.synthetic_input(100, 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        V.forward(x, sd, kw)
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward of one 1x1x128^3 volume, fp32, torch CPU with {cores} of {avail} host threads: {dt:.1f} s"}
 
 
 def cpu_baseline_step(size):
@@ -247,9 +269,63 @@ class Ctx:
     pass
 
 
+def vit_gflop_per_volume():
+    """Algorithmic FLOPs of one anatomix-dev-vit forward (2 * MACs of every conv / linear / attention product)."""
+    from oracle import vit_ref as V
+    kw = V.VIT_VARIANTS["anatomix-dev-vit"]
+    pl = V.vit_plan(kw)
+    e, n, hid = kw["embed_dim"], int(__import__("numpy").prod(pl["grid"])) + kw["num_register_tokens"], pl["hidden"]
+    side = kw["input_shape"][0]
+    f = 2.0 * 27 * 1 * pl["base"] * side ** 3
+    cin, s = pl["base"], side
+    for c in pl["stages"]:
+        s //= 2
+        f += 2.0 * (27 * cin * c + 27 * c * c + cin * c) * s ** 3
+        cin = c
+    f += 2.0 * cin * e * s ** 3
+    f += kw["eva_depth"] * (2.0 * n * (4 * e * e + 3 * e * hid) + 4.0 * n * n * e)
+    for a, b in zip(pl["dec"][:-1], pl["dec"][1:]):
+        s *= 2
+        f += 2.0 * a * b * s ** 3
+    return f / 1e9
+
+
+def vit_roofline(ctx, model, batch):
+    """The ViT's dominant kernel is the fused attention core (63 % of the FLOPs): timed alone with events on the launch stream."""
+    torch, dev = ctx.torch, ctx.dev
+    att = model.eva.blocks[0].attn
+    n = model.rope_table.shape[0] + model.num_register_tokens
+    e = att.num_heads * att.head_dim
+    q, k, v = [torch.randn(batch, n, e, device=dev) for _ in range(3)]
+    with torch.no_grad():
+        for _ in range(3):
+            att.core_hip(q, k, v, model.rope_table, model.num_register_tokens)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            att.core_hip(q, k, v, model.rope_table, model.num_register_tokens)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    flops = 4.0 * batch * n * n * e
+    bytes_ = 4.0 * 4 * batch * n * e
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "attn_prep + attn_fwd (QK-LayerNorm + rotary + flash attention), %d tokens x %d heads x %d" % (n, att.num_heads, att.head_dim),
+            "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
+            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
+
+
 def build_model(ctx, variant, precision):
     import anatomix_amd
     from oracle import unet_ref as R      # only for the synthetic weights/input generators + cpu_baseline
+    if variant == "anatomix-dev-vit":
+        from anatomix_amd.model.load_from_hf import build_variant
+        from oracle import vit_ref as V
+        model = build_variant(variant)
+        model.load_state_dict(V.synthetic_state_dict(V.VIT_VARIANTS[variant], 0), strict=True)
+        return model.to(ctx.dev).eval()
     kw = R.VARIANTS[variant]
     so, sys.stdout = sys.stdout, open(os.devnull, "w")      # the constructor prints two lines (reference parity)
     try:
@@ -346,13 +422,18 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
 
     result = None
     if rank == 0:
+        vit = variant == "anatomix-dev-vit"
         if workload == "step":
             roofline = step_roofline(torch, dev, S)
+        elif vit:
+            roofline = vit_roofline(ctx, model, B)
         else:
             roofline = forward_roofline(torch, model, x, B)
-        gflop_vol = (GFLOP_PER_VOLUME_6M if variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
+        gflop_vol = vit_gflop_per_volume() if vit else \
+            (GFLOP_PER_VOLUME_6M if variant == "anatomix" else GFLOP_PER_VOLUME_DEV) * (S / 128.0) ** 3
         name = "anatomix 6M UNet (ngf=16,num_downs=4)" if variant == "anatomix" else \
-            "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)"
+            ("anatomix-dev-vit 26M PrimusV2-S 3D ViT (conv tokenizer, 4096+8 tokens, 12 EVA blocks, 6 heads x 66)" if vit else
+             "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)")
         storage = {"f16": "16-bit (f16) channels-last activations, fp32 accumulate",
                    "bf16": "16-bit (bf16) channels-last activations, fp32 accumulate"}.get(
             precision, f"split hi+lo 16-bit operands ({'bf16x2' if precision == 'strict' else precision}: three MFMAs per product), "
@@ -372,14 +453,21 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         else:
             workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
                           f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}")
+            if vit:
+                workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]); attention core (QK-LayerNorm "
+                              "+ rotary + softmax(qk^T)v) on the hand-written MFMA kernel with f16 operands / fp32 softmax and "
+                              "accumulate, linears and tokenizer / decoder convolutions on the vendor libraries in fp32; the network "
+                              "body restates published algorithms (parity with the upstream package unpinned)")
             par = f"replicas x{world} (no data-path collective)"
         result = {
             "metric": ("128^3 volumes/sec through the contrastive pretraining step (6M UNet)" if workload == "step" else
-                       "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if variant == "anatomix" else "94M dev UNet")),
+                       "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if variant == "anatomix" else
+                                                                      ("26M 3D ViT" if vit else "94M dev UNet"))),
             "value": round(value, 2), "unit": "volumes/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong" if sw_volume else "weak", "vs_baseline": None,
-            "dtype": "bf16" if workload == "step" else ("bf16x2" if precision == "strict" else precision),
+            "dtype": "bf16" if workload == "step" else ("f16 attention / f32 linears" if vit else
+                                                        ("bf16x2" if precision == "strict" else precision)),
             "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {variant} architecture)",
             "config": {"workload": workload_s, "batch_per_gpu": 1 if sw_volume else (2 if workload == "step" else B), "window": S,
                        "parallelism": par},
@@ -388,7 +476,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             "roofline": roofline,
         }
         if world == 1 and with_cpu:
-            result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else cpu_baseline(S, cpu_forwards, variant)
+            result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else \
+                (cpu_baseline_vit() if vit else cpu_baseline(S, cpu_forwards, variant))
     del model, x, y
     torch.cuda.empty_cache()
     return result
@@ -401,6 +490,7 @@ def secondary_workloads(ctx, args):
         ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
         ("anatomix_dev", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=2)),
         ("anatomix_dev_strict", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=2)),
+        ("anatomix_dev_vit", dict(variant="anatomix-dev-vit", steps=10, warmup=3, batch=2)),
         ("sliding_window_256", dict(variant="anatomix", sw_volume=2 * S, steps=3, warmup=1)),
         ("contrastive_step", dict(variant="anatomix", workload="step", steps=10, warmup=1)),
     ]

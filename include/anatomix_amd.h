@@ -275,6 +275,20 @@ int amx_conv3d_wgrad(const void* d_dy, long long dy_sn, long long dy_sz, long lo
                      int c0, const void* d_x1, int c1, int cin_real, int cout, int n, int d, int hh, int w, float* d_dw,
                      int accumulate, void* d_scratch, size_t scratch_bytes, int precision, void* stream);
 
+/* Fused attention core of the 3D ViT variant `anatomix-dev-vit` (PrimusV2-S: anatomix/model/vit3d/architectures.py:231-260,
+ * registry entry load_from_hf.py:25-35; the blocks themselves live in the third-party dynamic-network-architectures / timm
+ * packages, see oracle/vit_ref.py).  Replaces, inside every EVA block, the sequence
+ *     q, k = q_norm(q), k_norm(k)                  per-head nn.LayerNorm(head_dim), the wrapper's qk_norm (architectures.py:108-115)
+ *     q, k = rope(q), rope(k)                      on the tokens after the n_prefix register tokens (x*cos + rot(x)*sin)
+ *     out  = softmax(q k^T / sqrt(head_dim)) v     torch F.scaled_dot_product_attention
+ * d_q / d_k / d_v / d_out: fp32 [b][n][heads*head_dim] (the layout the q / k / v projections produce and the output
+ * projection consumes).  d_*n_w / d_*n_b: fp32 [head_dim] or NULL (no QK norm).  d_rope: fp32 [n - n_prefix][2*head_dim] =
+ * per token [sin | cos], or NULL.  head_dim even, <= 80.  f16 MFMA operands, fp32 LayerNorm / rotation / softmax / accumulate. */
+size_t amx_attention_scratch_bytes(int b, int heads, int n, int head_dim);
+int amx_attention_qknorm_rope(const float* d_q, const float* d_k, const float* d_v, const float* d_qn_w, const float* d_qn_b,
+                              const float* d_kn_w, const float* d_kn_b, float norm_eps, const float* d_rope, int n_prefix, int b,
+                              int n, int heads, int head_dim, float* d_out, void* d_scratch, size_t scratch_bytes, void* stream);
+
 /* SupPatchNCELoss.forward + its backward (pretraining/models/supcl_model.py:73-226) for one nce layer.
  * d_feat: fp32 [n][c], n = views * patches anchors in (view, patch) order (features.view(ntps * num_patches, nc),
  * supcl_model.py:134); d_labels: int32 [n], the segmentation class of every anchor (the label gather of :100-112,
