@@ -27,10 +27,12 @@ namespace amx {
 constexpr int kAttKRow = 104;         // halves per Qp / Kp row (208 B)
 constexpr int kAttDV = 80;            // head_dim padded to 5 output tiles of 16
 constexpr int kAttBN = 64;            // keys per block
-constexpr int kAttBM = 128;           // queries per workgroup
+constexpr int kAttQT = 2;             // 16-query tiles per wave (measured: QT = 1 halves the work per staged K / V tile and is slower at batch 2)
+constexpr int kAttBM = 4 * 16 * kAttQT;  // queries per workgroup (4 waves)
+constexpr int kAttPad = 128;          // token padding of the operand buffers
 constexpr int kAttVRow = 72;          // halves per V^T row in LDS (144 B)
 
-__host__ __device__ inline int att_npad(int n) { return (n + kAttBM - 1) / kAttBM * kAttBM; }
+__host__ __device__ inline int att_npad(int n) { return (n + kAttPad - 1) / kAttPad * kAttPad; }
 
 // grid (ceil(n_pad / 4), heads, b), block 256 = 4 tokens x 64 lanes.  One wave = one token of one head: lane d < hd holds channel d.
 __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -91,34 +93,36 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
   if (lane + 64 < kAttDV) vo[(long long)(lane + 64) * npad] = (f16)(a1 ? v[src + lane + 64] : 0.f);
 }
 
-// grid (n_pad / 128, heads, b), block 256.
+// grid (n_pad / kAttBM, heads, b), block 256.  LDS: two (K, V^T) tile buffers -- block t+1 is committed while block t is multiplied,
+// one barrier per key block.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Qp, const f16* __restrict__ Kp,
                                                        const f16* __restrict__ Vt, int n, int heads, int hd, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) char smem[kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2];
-  char* sK = smem;
-  char* sV = smem + kAttBN * kAttKRow * 2;
+  constexpr int QT = kAttQT, BUF = kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, npad = att_npad(n);
   const long long bh = (long long)b * heads + h;
-  const int q0 = blockIdx.x * kAttBM + wave * 32;
+  const int q0 = blockIdx.x * kAttBM + wave * 16 * QT;
   const f16* Kbase = Kp + bh * npad * kAttKRow;
   const f16* Vbase = Vt + bh * kAttDV * npad;
 
   // Q^T B fragments: lane (i, g) holds Q[query q0 + 16 qt + i][32 kk + 8 g .. + 7]
-  f16x8 qf[2][3];
+  f16x8 qf[QT][3];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk)
       qf[qt][kk] = *(const f16x8*)(Qp + (bh * npad + q0 + qt * 16 + li) * kAttKRow + kk * 32 + g * 8);
 
-  f32x4 acc_o[2][5];
+  f32x4 acc_o[QT][5];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) acc_o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-3.0e38f, -3.0e38f}, l_run[2] = {0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -3.0e38f; l_run[qt] = 0.f; }
 
   // global -> register prefetch of one key block: K tile = 64 x 208 B contiguous (832 x 16 B), V^T tile = 80 rows x 128 B
   constexpr int KV16 = kAttBN * kAttKRow * 2 / 16, VV16 = kAttDV * 8;
@@ -136,7 +140,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
       if (idx < VV16) pv[r] = *(const uint4*)((const char*)(Vbase + (long long)(idx >> 3) * npad + blk * kAttBN) + (idx & 7) * 16);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* sK = smem + buf * BUF;
+    char* sV = sK + kAttBN * kAttKRow * 2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int idx = tid + r * 256;
@@ -151,16 +157,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
 
   const int nblk = (n + kAttBN - 1) / kAttBN;
   prefetch(0);
+  commit(0);
+  if (nblk > 1) prefetch(1);
   for (int blk = 0; blk < nblk; ++blk) {
-    __syncthreads();                   // every wave is done with the previous block's tiles
-    commit();
-    __syncthreads();
-    if (blk + 1 < nblk) prefetch(blk + 1);
+    __syncthreads();                   // buffer blk & 1 is complete; every wave has left buffer (blk + 1) & 1 (block blk - 1)
+    if (blk + 1 < nblk) {
+      commit((blk + 1) & 1);
+      if (blk + 2 < nblk) prefetch(blk + 2);
+    }
+    const char* sK = smem + (blk & 1) * BUF;
+    const char* sV = sK + kAttBN * kAttKRow * 2;
 
     // ---- S^T = K Q^T : acc_s[qt][kt], lane (i, g) holds scores of query i for keys 16 kt + 4 g + j
-    f32x4 acc_s[2][4];
+    f32x4 acc_s[QT][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) acc_s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
       for (int kk = 0; kk < 3; ++kk) {
         const f16x8 kf = *(const f16x8*)(sK + (kt * 16 + li) * (kAttKRow * 2) + kk * 64 + g * 16);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][kk], acc_s[qt][kt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][kk], acc_s[qt][kt], 0, 0, 0);
       }
     if ((blk + 1) * kAttBN > n) {      // keys beyond the sequence (last block only)
 #pragma unroll
@@ -177,14 +188,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (blk * kAttBN + kt * 16 + 4 * g + j >= n) {
-            acc_s[0][kt][j] = -3.0e38f;
-            acc_s[1][kt][j] = -3.0e38f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc_s[qt][kt][j] = -3.0e38f;
           }
     }
     // ---- online softmax (exp2 domain), probabilities straight into the B fragments of O^T += V^T P^T
-    f16x8 pf[2][2];
+    f16x8 pf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float mx = acc_s[qt][0][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -193,14 +204,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f(m_run[qt] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
       m_run[qt] = m_new;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = exp2f(acc_s[qt][kt][j] - m_new);
+          const float pr = __builtin_amdgcn_exp2f(acc_s[qt][kt][j] - m_new);
           ps += pr;
           pf[qt][kt >> 1][(kt & 1) * 4 + j] = (f16)pr;
         }
@@ -220,12 +231,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
         const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
         const f16x8 vf = __builtin_bit_cast(f16x8, raw);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
       }
   }
   // ---- epilogue: the row sums were kept per lane (4 of every 16 keys): add the four lane groups, normalise, store
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float l = l_run[qt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
