@@ -30,6 +30,8 @@ constexpr int kAttBN = 64;            // keys per block
 constexpr int kAttQT = 2;             // 16-query tiles per wave (measured: QT = 1 halves the work per staged K / V tile and is slower at batch 2)
 constexpr int kAttBM = 4 * 16 * kAttQT;  // queries per workgroup (4 waves)
 constexpr int kAttPad = 128;          // token padding of the operand buffers
+constexpr int kAttNLW = 2;            // loader waves
+constexpr int kAttNBUF = 3;           // ring depth (key blocks in flight); 5 measured the same: the MFMA waves, not the loaders, set the pace
 constexpr int kAttVRow = 72;          // halves per V^T row in LDS (144 B)
 
 __host__ __device__ inline int att_npad(int n) { return (n + kAttPad - 1) / kAttPad * kAttPad; }
@@ -47,10 +49,11 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
   const long long row = ((long long)b * heads + h) * npad + tok;
   f16* qo = Qp + row * kAttKRow;
   f16* ko = Kp + row * kAttKRow;
-  f16* vo = Vt + ((long long)b * heads + h) * kAttDV * npad + tok;
+  // V^T block-major: [b][h][key block][dv 80][72 halves] (a block's tile is contiguous, rows already padded for the LDS banks)
+  f16* vo = Vt + (((long long)b * heads + h) * (npad / kAttBN) + tok / kAttBN) * (kAttDV * kAttVRow) + (tok % kAttBN);
   if (tok >= n) {                      // padding rows: zeros (their scores are masked, their V columns add nothing)
     for (int d = lane; d < kAttKRow; d += 64) { qo[d] = (f16)0.f; ko[d] = (f16)0.f; }
-    for (int d = lane; d < kAttDV; d += 64) vo[(long long)d * npad] = (f16)0.f;
+    for (int d = lane; d < kAttDV; d += 64) vo[d * kAttVRow] = (f16)0.f;
     return;
   }
   const long long src = ((long long)b * n + tok) * heads * hd + (long long)h * hd;
@@ -89,24 +92,72 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
     qo[lane + 64] = (f16)(a1 ? q1v : 0.f);
     ko[lane + 64] = (f16)(a1 ? k1v : 0.f);
   }
-  vo[(long long)lane * npad] = (f16)(a0 ? v[src + lane] : 0.f);
-  if (lane + 64 < kAttDV) vo[(long long)(lane + 64) * npad] = (f16)(a1 ? v[src + lane + 64] : 0.f);
+  vo[lane * kAttVRow] = (f16)(a0 ? v[src + lane] : 0.f);
+  if (lane + 64 < kAttDV) vo[(lane + 64) * kAttVRow] = (f16)(a1 ? v[src + lane + 64] : 0.f);
 }
 
-// grid (n_pad / kAttBM, heads, b), block 256.  LDS: two (K, V^T) tile buffers -- block t+1 is committed while block t is multiplied,
-// one barrier per key block.
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Qp, const f16* __restrict__ Kp,
+typedef __attribute__((address_space(1))) const void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+
+// grid (n_pad / kAttBM, heads, b), block (4 + kAttNLW) * 64 = 4 MFMA waves (32 queries each) + kAttNLW LOADER waves.
+// K tile (64 keys x 208 B) and V^T tile (80 rows x 144 B, stored block-major with the padded rows already in place) are each one
+// contiguous chunk of global memory: the loader wave moves them with LDS-DMA (1 KiB per instruction, no VGPR round trip) into a
+// ring of three buffers, runs up to two key blocks ahead with counted vmcnt waits and meets the MFMA waves through LDS counters
+// (amx_device.h) -- no workgroup barrier in the loop.
+__global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16* __restrict__ Qp, const f16* __restrict__ Kp,
                                                        const f16* __restrict__ Vt, int n, int heads, int hd, float* __restrict__ out) {
-  constexpr int QT = kAttQT, BUF = kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int QT = kAttQT, KB = kAttBN * kAttKRow * 2, VB = kAttDV * kAttVRow * 2, BUF = KB + VB, NBUF = kAttNBUF;
+  constexpr int NDMA = (BUF + 1023) / 1024, NLW = kAttNLW;  // 1 KiB pieces per key block (the last one partial)
+  constexpr int PER = (NDMA + NLW - 1) / NLW;               // pieces per loader wave and block (waves without a last piece pad the count)
+  static_assert(BUF % 16 == 0 && PER * 2 <= 60 && NLW <= 8, "tile size / vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * BUF + 64 B of counters
+  int* ready = (int*)(smem + NBUF * BUF);                 // per loader wave: key blocks landed (8 slots, unused = INT_MAX)
+  int* done = ready + 8;                                   // per MFMA wave: key blocks finished (8 slots, unused = INT_MAX)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, npad = att_npad(n);
   const long long bh = (long long)b * heads + h;
-  const int q0 = blockIdx.x * kAttBM + wave * 16 * QT;
-  const f16* Kbase = Kp + bh * npad * kAttKRow;
-  const f16* Vbase = Vt + bh * kAttDV * npad;
+  const int nblk = (n + kAttBN - 1) / kAttBN, nblk_pad = npad / kAttBN;
+  if (tid < 16) ready[tid] = ((tid >= NLW && tid < 8) || tid >= 8 + 4) ? 0x7fffffff : 0;
+  __syncthreads();
 
+  if (wave >= 4) {
+    // =============================== loader wave lw: pieces j = lw, lw + NLW, ... ===============================
+    const int lw = wave - 4;
+    const char* kbase = (const char*)(Kp + bh * npad * kAttKRow);
+    const char* vbase = (const char*)(Vt + bh * nblk_pad * (kAttDV * kAttVRow));
+    const unsigned a_ready = lds_addr(ready + lw), a_done = lds_addr(done);
+    for (int blk = 0; blk < nblk; ++blk) {
+      if (blk >= NBUF)                                    // buffer blk % NBUF is free once every MFMA wave finished block blk - NBUF
+        while (__builtin_amdgcn_readfirstlane(flag_min8_asm(a_done)) < blk - NBUF + 1) __builtin_amdgcn_s_sleep(1);
+      char* buf = smem + (blk % NBUF) * BUF;
+      const char* ks = kbase + (long long)blk * KB;
+      const char* vs = vbase + (long long)blk * VB;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int j = lw + k * NLW;
+        int off = j * 1024 + lane * 16;                    // K tile first, V^T tile behind it -- the same order as in the buffer
+        // a wave without a piece in the last round re-fetches its first one: every wave then has exactly PER instructions per
+        // block in flight, which is what the counted wait below relies on
+        const int jj = j * 1024 < BUF ? j : lw;
+        off = jj * 1024 + lane * 16;
+        if (off < BUF) {
+          const char* src = off < KB ? ks + off : vs + (off - KB);
+          __builtin_amdgcn_global_load_lds((att_gptr_t)src, (att_lptr_t)(buf + jj * 1024), 16, 0, 0);
+        }
+      }
+      if (blk > 0) {                                      // block blk - 1 has landed once only this block's pieces are in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        flag_store_asm(a_ready, blk);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_store_asm(a_ready, nblk);
+    return;
+  }
+
+  const int q0 = blockIdx.x * kAttBM + wave * 16 * QT;
   // Q^T B fragments: lane (i, g) holds Q[query q0 + 16 qt + i][32 kk + 8 g .. + 7]
   f16x8 qf[QT][3];
 #pragma unroll
@@ -114,7 +165,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk)
       qf[qt][kk] = *(const f16x8*)(Qp + (bh * npad + q0 + qt * 16 + li) * kAttKRow + kk * 32 + g * 8);
-
   f32x4 acc_o[QT][5];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
@@ -123,50 +173,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
   float m_run[QT], l_run[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -3.0e38f; l_run[qt] = 0.f; }
-
-  // global -> register prefetch of one key block: K tile = 64 x 208 B contiguous (832 x 16 B), V^T tile = 80 rows x 128 B
-  constexpr int KV16 = kAttBN * kAttKRow * 2 / 16, VV16 = kAttDV * 8;
-  uint4 pk[4], pv[3];
-  auto prefetch = [&](int blk) {
-    const char* ks = (const char*)(Kbase + (long long)blk * kAttBN * kAttKRow);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = tid + r * 256;
-      if (idx < KV16) pk[r] = *(const uint4*)(ks + idx * 16);
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int idx = tid + r * 256;
-      if (idx < VV16) pv[r] = *(const uint4*)((const char*)(Vbase + (long long)(idx >> 3) * npad + blk * kAttBN) + (idx & 7) * 16);
-    }
-  };
-  auto commit = [&](int buf) {
-    char* sK = smem + buf * BUF;
-    char* sV = sK + kAttBN * kAttKRow * 2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = tid + r * 256;
-      if (idx < KV16) *(uint4*)(sK + idx * 16) = pk[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int idx = tid + r * 256;
-      if (idx < VV16) *(uint4*)(sV + (idx >> 3) * (kAttVRow * 2) + (idx & 7) * 16) = pv[r];
-    }
+  // max over the four lanes that share a query (lane, lane ^ 16, lane ^ 32): row swaps, VALU only
+  auto max4 = [](float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, x);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
   };
 
-  const int nblk = (n + kAttBN - 1) / kAttBN;
-  prefetch(0);
-  commit(0);
-  if (nblk > 1) prefetch(1);
   for (int blk = 0; blk < nblk; ++blk) {
-    __syncthreads();                   // buffer blk & 1 is complete; every wave has left buffer (blk + 1) & 1 (block blk - 1)
-    if (blk + 1 < nblk) {
-      commit((blk + 1) & 1);
-      if (blk + 2 < nblk) prefetch(blk + 2);
+    while (true) {                     // every loader wave's share of this block has landed
+      int m = flag_load(ready);
+#pragma unroll
+      for (int i = 1; i < NLW; ++i) {
+        const int r = flag_load(ready + i);
+        m = r < m ? r : m;
+      }
+      if (m >= blk + 1) break;
+      __builtin_amdgcn_s_sleep(1);
     }
-    const char* sK = smem + (blk & 1) * BUF;
-    const char* sV = sK + kAttBN * kAttKRow * 2;
+    asm volatile("" ::: "memory");
+    const char* sK = smem + (blk % NBUF) * BUF;
+    const char* sV = sK + KB;
 
     // ---- S^T = K Q^T : acc_s[qt][kt], lane (i, g) holds scores of query i for keys 16 kt + 4 g + j
     f32x4 acc_s[QT][4];
@@ -201,9 +231,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mx = fmaxf(mx, acc_s[qt][kt][j]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_new = fmaxf(m_run[qt], max4(mx));
       const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
       m_run[qt] = m_new;
       float ps = 0.f;
@@ -233,6 +261,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of this block's tiles has returned: the buffer may be refilled
+    flag_store(done + wave, blk + 1);
   }
   // ---- epilogue: the row sums were kept per lane (4 of every 16 keys): add the four lane groups, normalise, store
 #pragma unroll
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
 
 size_t attention_scratch_bytes(int b, int heads, int n) {
   const size_t npad = att_npad(n);
-  return (size_t)b * heads * npad * (2 * kAttKRow + kAttDV) * sizeof(f16);
+  return (size_t)b * heads * npad * (2 * kAttKRow + kAttDV * kAttVRow / kAttBN) * sizeof(f16);
 }
 
 hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
@@ -268,7 +298,14 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, cons
   f16* Vt = Kp + (size_t)b * heads * npad * kAttKRow;
   hipLaunchKernelGGL(attn_prep_kernel, dim3((npad + 3) / 4, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
                      n_prefix, n, heads, hd, Qp, Kp, Vt);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(npad / kAttBM, heads, b), dim3(256), 0, st, Qp, Kp, Vt, n, heads, hd, out);
+  constexpr int LDS = kAttNBUF * (kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2) + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
   return hipGetLastError();
 }
 
