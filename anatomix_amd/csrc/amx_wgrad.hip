@@ -58,45 +58,65 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
   const int ci0 = seg1 ? cit * 16 - p.C0 : cit * 16;
   const int sh = seg1 ? p.up_shift : 0;
 
-  // two 16-byte global loads per unit, eight 32-bit LDS writes (transposed: channel rows, x along the row)
+  // two 16-byte global loads per unit, eight 32-bit LDS writes (transposed: channel rows, x along the row).
+  // A thread's units (u = tid + 512 k) keep their tile coordinates for the whole chunk: the decomposition of u (divisions by the
+  // run-time row width) and everything else that does not depend on the item is done ONCE here -- inside the item loop those
+  // divisions were ~500 VALU instructions per thread and item, more than the item's MFMA time.
   const int hwp = Wp / 2, hwh = (Wp + 2) / 2;
   const int ndy = WG_TY * hwp * 2, npl = (WG_TY + 2) * hwh * 2;
-  auto load_dy = [&](int u, int n, int z, int y0) -> WgUnit {
-    const int half = u & 1, xp = (u >> 1) % hwp, row = (u >> 1) / hwp, x = 2 * xp;
+  struct UnitDy { int row, lds; long long ga, gb; bool ok, oka, okb; } udy[NDY];
+  struct UnitPl { int hr, lds; long long ga, gb; bool ok, oka, okb; } upl[NPL];
+#pragma unroll
+  for (int k = 0; k < NDY; ++k) {
+    const int u = tid + k * 512, half = u & 1, xp = (u >> 1) % hwp, row = (u >> 1) / hwp, x = 2 * xp;
+    udy[k].ok = u < ndy; udy[k].row = row;
+    udy[k].lds = ((row * 16 + half * 8) * RS + x) * 2;
+    udy[k].ga = (long long)x * p.yx + cot * 32 + half * 16; udy[k].gb = udy[k].ga + p.yx;
+    udy[k].oka = x < p.W; udy[k].okb = x + 1 < p.W;
+  }
+  const long long sxs = seg1 ? p.s1x : p.s0x;
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int u = tid + k * 512, half = u & 1, xp = (u >> 1) % hwh, hr = (u >> 1) / hwh, xh = 2 * xp;
+    upl[k].ok = u < npl; upl[k].hr = hr;
+    upl[k].lds = ((hr * 16 + half * 8) * RS + xh) * 2;
+    upl[k].ga = (long long)(reflect_clamp(xh - 1, p.W) >> sh) * sxs + ci0 * 2 + half * 16;
+    upl[k].gb = (long long)(reflect_clamp(xh, p.W) >> sh) * sxs + ci0 * 2 + half * 16;
+    upl[k].oka = xh <= p.W + 1; upl[k].okb = xh + 1 <= p.W + 1;
+  }
+  auto load_dy = [&](int k, int n, int z, int y0) -> WgUnit {
     WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    if (u < ndy && y0 + row < p.H) {
-      const char* b = p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + row) * p.yy + cot * 32 + half * 16;
-      if (x < p.W) r.a = *(const uint4*)(b + (long long)x * p.yx);
-      if (x + 1 < p.W) r.b = *(const uint4*)(b + (long long)(x + 1) * p.yx);
+    if (udy[k].ok && y0 + udy[k].row < p.H) {
+      const char* b = p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + udy[k].row) * p.yy;
+      if (udy[k].oka) r.a = *(const uint4*)(b + udy[k].ga);
+      if (udy[k].okb) r.b = *(const uint4*)(b + udy[k].gb);
     }
     return r;
   };
-  auto load_pl = [&](int u, int n, int zz, int y0) -> WgUnit {      // zz: full-resolution plane index (already reflected)
-    const int half = u & 1, xp = (u >> 1) % hwh, hr = (u >> 1) / hwh, xh = 2 * xp;
+  auto load_pl = [&](int k, int n, int zz, int y0) -> WgUnit {      // zz: full-resolution plane index (already reflected)
     WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    if (u < npl) {
-      const int z2 = zz >> sh, yy = reflect_clamp(y0 + hr - 1, p.H) >> sh;
-      const char* b = seg1 ? p.src1 + (long long)n * p.s1n + (long long)z2 * p.s1z + (long long)yy * p.s1y + ci0 * 2 + half * 16
-                           : p.src0 + (long long)n * p.s0n + (long long)z2 * p.s0z + (long long)yy * p.s0y + ci0 * 2 + half * 16;
-      const long long sx = seg1 ? p.s1x : p.s0x;
-      if (xh <= p.W + 1) r.a = *(const uint4*)(b + (long long)(reflect_clamp(xh - 1, p.W) >> sh) * sx);
-      if (xh + 1 <= p.W + 1) r.b = *(const uint4*)(b + (long long)(reflect_clamp(xh, p.W) >> sh) * sx);
+    if (upl[k].ok) {
+      const int z2 = zz >> sh, yy = reflect_clamp(y0 + upl[k].hr - 1, p.H) >> sh;
+      const char* b = seg1 ? p.src1 + (long long)n * p.s1n + (long long)z2 * p.s1z + (long long)yy * p.s1y
+                           : p.src0 + (long long)n * p.s0n + (long long)z2 * p.s0z + (long long)yy * p.s0y;
+      if (upl[k].oka) r.a = *(const uint4*)(b + upl[k].ga);
+      if (upl[k].okb) r.b = *(const uint4*)(b + upl[k].gb);
     }
     return r;
   };
-  auto store_unit = [&](char* base, int rowc, int x, int half, const WgUnit& v) {   // rowc = tile row; x even
+  auto store_unit = [&](char* at, const WgUnit& v) {                // at: LDS address of (channel row e = 0, even x)
     const unsigned a[4] = {v.a.x, v.a.y, v.a.z, v.a.w}, b[4] = {v.b.x, v.b.y, v.b.z, v.b.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const unsigned lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (b[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-      *(unsigned*)(base + ((size_t)(rowc * 16 + half * 8 + e) * RS + x) * 2) = lo | (hi << 16);
+      *(unsigned*)(at + e * RS * 2) = lo | (hi << 16);
     }
   };
-  auto store_dy = [&](int u, int buf, const WgUnit& v) {
-    if (u < ndy) store_unit(dys + (size_t)buf * DY_BYTES, (u >> 1) / hwp, 2 * ((u >> 1) % hwp), u & 1, v);
+  auto store_dy = [&](int k, int buf, const WgUnit& v) {
+    if (udy[k].ok) store_unit(dys + (size_t)buf * DY_BYTES + udy[k].lds, v);
   };
-  auto store_pl = [&](int u, int slot, const WgUnit& v) {
-    if (u < npl) store_unit(ins + (size_t)slot * PLANE_BYTES, (u >> 1) / hwh, 2 * ((u >> 1) % hwh), u & 1, v);
+  auto store_pl = [&](int k, int slot, const WgUnit& v) {
+    if (upl[k].ok) store_unit(ins + (size_t)slot * PLANE_BYTES + upl[k].lds, v);
   };
 
   f32x4 acc[27];
@@ -107,6 +127,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
   const int item0 = chunk * p.items_per_chunk;
   const int item1 = item0 + p.items_per_chunk < p.nitems ? item0 + p.items_per_chunk : p.nitems;
   int db = 0;                                                       // dY buffer of the current item
+  WgUnit ra_dy[NDY], ra_pl[NPL];                                    // requested one item ago, stored after this item's sweep
+  bool ra_valid = false;
   for (int item = item0; item < item1; ++item) {
     const int z = item % p.D;                                       // z fastest: consecutive items march along z
     const int r = item / p.D;
@@ -118,60 +140,92 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
     const bool cold = !RING || item == item0 || z == 0;
     if (cold) {
       __syncthreads();                                              // previous item's fragments are consumed
-      for (int u = tid; u < ndy; u += 512) store_dy(u, db, load_dy(u, n, z, y0));
+#pragma unroll
+      for (int k = 0; k < NDY; ++k) store_dy(k, db, load_dy(k, n, z, y0));
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
         if (RING && kz == 2 && slot[2] == slot[0]) continue;        // z = 0 or D-1: the reflected plane is already staged
         const int zz = reflect_clamp(z + kz - 1, p.D);
-        for (int u = tid; u < npl; u += 512) store_pl(u, slot[kz], load_pl(u, n, zz, y0));
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) store_pl(k, slot[kz], load_pl(k, n, zz, y0));
       }
       __syncthreads();
     }
-    // ---- prefetch the next item's new data into registers (RING, next item = z + 1 of the same tile)
+    // ---- register prefetch, TWO items deep (RING; the next items are z + 1, z + 2 of the same tile): what item z + 1 needs
+    //      (its dY rows and plane z + 2) was requested during item z - 1 and is written to LDS after this item's sweep; what
+    //      item z + 2 needs is requested now.  One item deep, the ~2 us HBM latency of the request was longer than a sweep and
+    //      every item ended waiting for its loads (8800 cycles per item against 1700 of MFMAs).
     const bool has_next = RING && item + 1 < item1 && z + 1 < p.D;
-    const bool next_plane = has_next && z + 2 < p.D;
-    WgUnit rdy[NDY], rpl[NPL];
-    if (has_next) {
+    const bool has_next2 = has_next && item + 2 < item1 && z + 2 < p.D;
+    if (cold) ra_valid = false;
+    if (has_next && !ra_valid) {                                    // first item of a run: request item z + 1's data now (exposed once)
 #pragma unroll
-      for (int k = 0; k < NDY; ++k) rdy[k] = load_dy(tid + k * 512, n, z + 1, y0);
-      if (next_plane)
+      for (int k = 0; k < NDY; ++k) ra_dy[k] = load_dy(k, n, z + 1, y0);
+      if (z + 2 < p.D)
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) rpl[k] = load_pl(tid + k * 512, n, z + 2, y0);
+        for (int k = 0; k < NPL; ++k) ra_pl[k] = load_pl(k, n, z + 2, y0);
     }
-    // ---- K-blocks of this item: (row, xb) -> 32 voxels
+    WgUnit rb_dy[NDY], rb_pl[NPL];
+    if (has_next2) {
+#pragma unroll
+      for (int k = 0; k < NDY; ++k) rb_dy[k] = load_dy(k, n, z + 2, y0);
+      if (z + 3 < p.D)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) rb_pl[k] = load_pl(k, n, z + 3, y0);
+    }
+    // ---- K-blocks of this item: (row, xb) -> 32 voxels.  A wave owns the two K-blocks (rows r0, r0 + 1) of one x block: the four
+    //      halo rows r0 .. r0 + 3 they touch are read ONCE per kz and feed both rows (row r uses halo rows r + ky), i.e. 8 + 2 / 3
+    //      fragment reads per 18 MFMAs instead of 12 + 2 / 3 -- a third of the LDS traffic, which (with its bank conflicts) paced
+    //      this kernel.
     const char* dyb = dys + (size_t)db * DY_BYTES;
     const int vrows = p.H - y0 < WG_TY ? p.H - y0 : WG_TY;         // rows of this tile inside the volume (the rest hold zeros)
-    for (int kb = wave; kb < vrows * nxb; kb += 8) {
-      const int row = kb / nxb, xb = kb % nxb;
-      const int X0 = xb * 32 + kg * 8;                             // multiple of 8 halves = 16 bytes
-      const vec8 af = *(const vec8*)(dyb + ((size_t)(row * 16 + m) * RS + X0) * 2);
+    {
+      const int xb = wave % nxb, r0 = (wave / nxb) * 2;
+      if (r0 < vrows) {
+        const int X0 = xb * 32 + kg * 8;                           // multiple of 8 halves = 16 bytes
+        const vec8 af0 = *(const vec8*)(dyb + ((size_t)(r0 * 16 + m) * RS + X0) * 2);
+        const vec8 af1 = *(const vec8*)(dyb + ((size_t)((r0 + 1) * 16 + m) * RS + X0) * 2);   // zeros when r0 + 1 is outside
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz)
+        for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const char* bp = ins + (size_t)slot[kz] * PLANE_BYTES + ((size_t)((row + ky) * 16 + m) * RS + X0) * 2;
-          const uint4 B0 = *(const uint4*)bp, B1 = *(const uint4*)(bp + 16);   // halo x = X0 .. X0 + 15  (= x - 1 ..)
-          const unsigned b0[4] = {B0.x, B0.y, B0.z, B0.w};                       // kx = 0
-          const unsigned b1[4] = {__builtin_amdgcn_alignbit(B0.y, B0.x, 16), __builtin_amdgcn_alignbit(B0.z, B0.y, 16),
-                                  __builtin_amdgcn_alignbit(B0.w, B0.z, 16), __builtin_amdgcn_alignbit(B1.x, B0.w, 16)};   // kx = 1
-          const unsigned b2[4] = {B0.y, B0.z, B0.w, B1.x};                       // kx = 2
-          const int t0 = (kz * 3 + ky) * 3;
-          acc[t0] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b0), acc[t0]);
-          acc[t0 + 1] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
-          acc[t0 + 2] = Ops<T>::mfma(af, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
-        }
+          for (int hr = 0; hr < 4; ++hr) {
+            const char* bp = ins + (size_t)slot[kz] * PLANE_BYTES + ((size_t)((r0 + hr) * 16 + m) * RS + X0) * 2;
+            const uint4 B0 = *(const uint4*)bp, B1 = *(const uint4*)(bp + 16);   // halo x = X0 .. X0 + 15  (= x - 1 ..)
+            const unsigned b0[4] = {B0.x, B0.y, B0.z, B0.w};                       // kx = 0
+            const unsigned b1[4] = {__builtin_amdgcn_alignbit(B0.y, B0.x, 16), __builtin_amdgcn_alignbit(B0.z, B0.y, 16),
+                                    __builtin_amdgcn_alignbit(B0.w, B0.z, 16), __builtin_amdgcn_alignbit(B1.x, B0.w, 16)};   // kx = 1
+            const unsigned b2[4] = {B0.y, B0.z, B0.w, B1.x};                       // kx = 2
+            if (hr < 3) {                                          // row r0, ky = hr
+              const int t0 = (kz * 3 + hr) * 3;
+              acc[t0] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b0), acc[t0]);
+              acc[t0 + 1] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+              acc[t0 + 2] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+            }
+            if (hr > 0) {                                          // row r0 + 1, ky = hr - 1
+              const int t0 = (kz * 3 + hr - 1) * 3;
+              acc[t0] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b0), acc[t0]);
+              acc[t0 + 1] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+              acc[t0 + 2] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+            }
+          }
+      }
     }
     if (has_next) {
       // slot (z + 2) & 3 and the other dY buffer are not read by this item, and the item that read them last ended with
       // the barrier below
 #pragma unroll
-      for (int k = 0; k < NDY; ++k) store_dy(tid + k * 512, db ^ 1, rdy[k]);
-      if (next_plane)
+      for (int k = 0; k < NDY; ++k) store_dy(k, db ^ 1, ra_dy[k]);
+      if (z + 2 < p.D)
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) store_pl(tid + k * 512, (z + 2) & 3, rpl[k]);
+        for (int k = 0; k < NPL; ++k) store_pl(k, (z + 2) & 3, ra_pl[k]);
       db ^= 1;
       __syncthreads();
     }
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) ra_dy[k] = rb_dy[k];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) ra_pl[k] = rb_pl[k];
+    ra_valid = has_next2;
   }
   // ---- sum the 8 waves through LDS (3 rounds), wave 0 writes the partial
   float* red = (float*)smem;                                        // [4 waves][27][64][4] floats = 108 KiB

@@ -61,7 +61,9 @@ def test_bn_train_forward_and_backward(device, prec, shape):
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,size", [(16, 16, (8, 16, 32)), (32, 16, (6, 10, 12)), (64, 128, (4, 4, 4)), (1, 16, (8, 8, 40)),
-                                            (16, 32, (2, 2, 2)), (128, 64, (8, 8, 8))])
+                                            (16, 32, (2, 2, 2)), (128, 64, (8, 8, 8)),
+                                            # W a multiple of 64, H of 4, D >= 3: the transpose-read kernel (amx_wgrad_tr.hip)
+                                            (16, 16, (5, 8, 64)), (32, 32, (3, 4, 128)), (16, 32, (9, 12, 64)), (1, 16, (4, 8, 128))])
 def test_conv_dgrad_and_wgrad(device, prec, cin, cout, size):
     dt = DT[prec]
     g = torch.Generator().manual_seed(2)
@@ -92,7 +94,8 @@ def test_conv_dgrad_and_wgrad(device, prec, cin, cout, size):
 
 
 @pytest.mark.parametrize("prec", ["bf16"])
-@pytest.mark.parametrize("c0,c1,cout,size", [(16, 32, 16, (8, 8, 32)), (32, 64, 32, (4, 8, 12)), (128, 256, 128, (4, 4, 4))])
+@pytest.mark.parametrize("c0,c1,cout,size", [(16, 32, 16, (8, 8, 32)), (32, 64, 32, (4, 8, 12)), (128, 256, 128, (4, 4, 4)),
+                                              (16, 32, 16, (6, 8, 64)), (32, 64, 32, (4, 4, 128))])   # transpose-read kernel
 def test_wgrad_and_dgrad_of_upsample_concat_conv(device, prec, c0, c1, cout, size):
     dt = DT[prec]
     g = torch.Generator().manual_seed(3)
