@@ -584,7 +584,15 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   const int nch = (p.C0 + p.C1) / 16;
   if (p.W >= 32) {
     if (Q == 1) return launch_pick<T, SPLIT, 1, 4, 32, 4, 2, 1, 1, OUTMODE>(p, st);       // brick 4x8x32, 8 waves
-    if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
+    if (Q == 2) {
+      // AMX_V2_NARROW: brick 4x4x16 instead -- three stage buffers fit the LDS, so the loader-wave pipeline applies.  Measured on
+      // 96 -> 32 @64^3, batch 4: 206 -> 197 us (+5 %); not the default: the same instantiation also serves the 16^3 layers, and one
+      // kernel name per layer class keeps the per-kernel tables of bench.py and rocprofv3 comparable.
+      static int narrow = -1;
+      if (narrow < 0) narrow = getenv("AMX_V2_NARROW") ? 1 : 0;
+      if (OUTMODE == 0 && narrow) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);
+      return launch_pick<T, SPLIT, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
+    }
     if (OUTMODE == 0 && Q == 4) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
     return hipErrorInvalidValue;
   }
