@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 cd $REPO
 f=$(ls $OUT/${TAG}_pmc_FETCH_SIZE/*counter_collection.csv | head -1)
