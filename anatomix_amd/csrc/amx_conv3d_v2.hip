@@ -172,7 +172,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   ItemCoord cu = nx;   // item being multiplied
   int nx_stage = 0, cu_stage = 0;
 
-  // ---- issue the LDS-DMA of one (item, stage) into pipeline buffer `bsel01`
+  // ---- issue the LDS-DMA of one (item, stage) into pipeline buffer `bsel01` (inline asm, see dma16_asm)
+#define AMX_DMA16(src, dst) dma16_asm((const void*)(src), (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(dst)))
   auto issue = [&](const ItemCoord& it, int stage, int bsel01, bool with_weights) {
     char* buf = smem + bsel01 * C::BUF;
     const int z0 = it.bz * C::TZ, y0 = it.by * C::TY, x0 = it.bx * C::TX;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
           char* dst = buf + k * HALO + j * (C::RRL * C::LXH * 16);   // uniform
           dma_count += 2;
           if (dl2 < C::RRL && r < C::NROWL) {
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+            AMX_DMA16(src, dst);
+            AMX_DMA16(src + 16, dst + PLANE);
           }
         }
       } else if (C::RR == 1) {
@@ -220,8 +221,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
           char* dst = buf + k * HALO + j * (HX * 16);          // uniform LDS row base
           dma_count += 2;
           if (dma_lane) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(row + xoff + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+            AMX_DMA16(row + xoff, dst);
+            AMX_DMA16(row + xoff + 16, dst + PLANE);
           }
         }
       } else {
@@ -234,8 +235,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
           char* dst = buf + k * HALO + j * (C::RR * HX * 16);   // uniform
           dma_count += 2;
           if (dma_lane && r < C::NROW) {
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + 16), (lptr_t)(dst + PLANE), 16, 0, 0);
+            AMX_DMA16(src, dst);
+            AMX_DMA16(src + 16, dst + PLANE);
           }
         }
       }
@@ -250,14 +251,12 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
       constexpr int NWI = NCH * C::WSUB / 1024;
       for (int j = iw; j < NWI; j += INW) {
         ++dma_count;
-        __builtin_amdgcn_global_load_lds((gptr_t)(ws + j * 1024 + lane * 16), (lptr_t)(buf + WOFF + j * 1024), 16,
-                                         0, 0);
+        AMX_DMA16(ws + j * 1024 + lane * 16, buf + WOFF + j * 1024);
       }
       if (iw == INW - 1 && stage == 0 && p.bias) {     // bias rides with the item's first stage
         ++dma_count;
         if (lane < 4 * Q)
-          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.bias + (it.cg * 16 * Q) * 4 + lane * 16),
-                                           (lptr_t)(buf + C::BIASOFF), 16, 0, 0);
+          AMX_DMA16((const char*)p.bias + (it.cg * 16 * Q) * 4 + lane * 16, buf + C::BIASOFF);
       }
     }
   };
@@ -359,6 +358,14 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     issue(nx, nx_stage, 0, true);
     step_next();
   }
+  const bool late_issuer = !NLW && NW == 8 && wave >= 4 && !(p.dbg & 16);
+  bool issue_due = false;
+  constexpr int kLateStep = 3;
+  auto late_issue = [&](int t) {
+    issue(nx, nx_stage, (t + 1) & 1, !resident);
+    step_next();
+    issue_due = false;
+  };
   AMX_STAMP();
   for (int t = 0; t < T_total; ++t) {
     if (NLW) {
@@ -379,8 +386,14 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
       __syncthreads();                                   // every wave's DMA(t) landed; buffer (t+1)&1 is free
       AMX_STAMP();
       if (t + 1 < T_total && !(p.dbg & 1)) {
-        issue(nx, nx_stage, (t + 1) & 1, !resident);
-        step_next();
+        // Waves i and i + 4 share a SIMD.  If all eight issued their DMA share here the matrix pipes would idle for the ~1300
+        // cycles that takes (a DMA instruction blocks its wave while the memory queue is full); the upper four therefore issue
+        // theirs a few steps into the sweep, while their SIMD partners -- done issuing -- multiply.
+        if (late_issuer) issue_due = true;
+        else {
+          issue(nx, nx_stage, (t + 1) & 1, !resident);
+          step_next();
+        }
       }
     }
     AMX_STAMP();
@@ -403,51 +416,72 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
 
     // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
     const bool up_stage = C::LOWUP && p.up_shift && (((cu_stage * NCH) % nchunk) << 4) >= p.C0;
+    // Both sweeps are software-pipelined one step deep by hand: the fragments of step i+1 are requested before the MFMAs of
+    // step i, and scheduling fences keep that order (left alone, hipcc issues a step's reads right before a full
+    // `s_waitcnt lgkmcnt(0)` and exposes the LDS latency every four MFMAs -- measured 38 % MFMA-busy with the DMA switched off).
     if (!(p.dbg & 2) && up_stage) {
       // the stage buffer holds the LOW-RES halo of 16 upsampled channels
       constexpr int LXH = C::LXH;
-#pragma unroll
-      for (int s = 0; s < kSteps; ++s) {
+      vec8 fa[2][Q], fb[2][CTW];
+      auto load_step = [&](const int s, const int set) {
         const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
         const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
-        vec8 a[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) a[q] = *(const vec8*)(wbuf + WOFF + (s * Q + q) * 1024 + lane * 16);
+        for (int q = 0; q < Q; ++q) fa[set][q] = *(const vec8*)(wbuf + WOFF + (s * Q + q) * 1024 + lane * 16);
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
           const int cx = c % XT, cy = (c / XT) % YT;
           const int rowc = ((cy + ky - 1) >> 1) + 1;               // low row of the tile for tap ky (lo lanes)
           const int ubase = s < 9 ? U1[kz] : (s < 12 ? ((cy & 1) ? U2o[kz] : U2e[kz]) : (s == 12 ? Uz : U2o[2]));
-          const vec8 bf = *(const vec8*)(buf + ubase + (rowc * LXH + cx * 8) * 16);
-#pragma unroll
-          for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(a[q], bf, acc[c][q]);
+          fb[set][c] = *(const vec8*)(buf + ubase + (rowc * LXH + cx * 8) * 16);
         }
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) {
+        if (s + 1 < kSteps) load_step(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(fa[s & 1][q], fb[s & 1][c], acc[c][q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!NLW && s == kLateStep && issue_due) late_issue(t);
       }
     } else if (!(p.dbg & 2)) {
+      constexpr int TS = NCH * kSteps;
+      vec8 fa[2][Q], fb[2][CTW];
+      auto load_step = [&](const int i, const int set) {
+        const int k = i / kSteps, s = i - k * kSteps;
+        const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
+        const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
+        const int kx = s < 9 ? 0 : 2;
+        const int tapoff = ((kz * HY + ky) * HX + kx) * 16;
+        const int bsel = s < 9 ? base_d1 : (s < 12 ? base_dx : (s == 12 ? base_dz : base_d0));
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
+        for (int q = 0; q < Q; ++q)
+          fa[set][q] = *(const vec8*)(wbuf + WOFF + ((k * kSteps + s) * Q + q) * 1024 + lane * 16);
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-          const int kz = s < 9 ? s / 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : 2));
-          const int ky = s < 9 ? s % 3 : (s < 12 ? 0 : 2);
-          const int kx = s < 9 ? 0 : 2;
-          const int tapoff = ((kz * HY + ky) * HX + kx) * 16;
-          const int bsel = s < 9 ? base_d1 : (s < 12 ? base_dx : (s == 12 ? base_dz : base_d0));
-          vec8 a[Q];
-#pragma unroll
-          for (int q = 0; q < Q; ++q)
-            a[q] = *(const vec8*)(wbuf + WOFF + ((k * kSteps + s) * Q + q) * 1024 + lane * 16);
-#pragma unroll
-          for (int c = 0; c < CTW; ++c) {
-            const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
-            const int coff = ((cz * HY + cy * LY) * HX + cx * LX) * 16;
-            const vec8 bf = *(const vec8*)(buf + bsel + k * HALO + tapoff + coff);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(a[q], bf, acc[c][q]);
-          }
+        for (int c = 0; c < CTW; ++c) {
+          const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+          const int coff = ((cz * HY + cy * LY) * HX + cx * LX) * 16;
+          fb[set][c] = *(const vec8*)(buf + bsel + k * HALO + tapoff + coff);
         }
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int i = 0; i < TS; ++i) {
+        if (i + 1 < TS) load_step(i + 1, (i + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[c][q] = Ops<T>::mfma(fa[i & 1][q], fb[i & 1][c], acc[c][q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!NLW && i == kLateStep && issue_due) late_issue(t);
       }
     }
+    if (!NLW && issue_due) late_issue(t);          // sweep skipped (debug ablation)
     AMX_STAMP();
     if (NLW) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this stage has returned: the buffer may be refilled

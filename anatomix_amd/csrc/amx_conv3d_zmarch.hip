@@ -281,7 +281,11 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) F[buf][r] = *(const vec8*)(smem + b1[pl] + koff + (r * HX) * 16);
 #pragma unroll
+#ifdef AMX_ZM_FAKE
+          for (int cy = 0; cy < 2; ++cy) H[buf][cy] = F[buf][cy + 1];
+#else
           for (int cy = 0; cy < 2; ++cy) H[buf][cy] = *(const vec8*)(smem + bx3[pl] + koff + (cy * HX + 2) * 16);
+#endif
         };
         auto mma_plane = [&](int buf, int pl) {
 #pragma unroll
@@ -319,8 +323,12 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
           const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
 #pragma unroll
           for (int cy = 0; cy < 2; ++cy) {
+#ifdef AMX_ZM_FAKE
+            const vec8 s0 = wreg[k][cy], s1 = wreg[k][cy + 2];
+#else
             const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
             const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
+#endif
             acc[tz][cy] = Ops<T>::mfma(wreg[k][12], s0, acc[tz][cy]);
             acc[tz][cy] = Ops<T>::mfma(wreg[k][13], s1, acc[tz][cy]);
           }

@@ -84,6 +84,16 @@ __device__ __forceinline__ void flag_store(int* p, int v) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
+// LDS-DMA of 16 bytes per lane, written as inline asm: lane l's 16 bytes land at lds_base + 16 l (lds_base wave-uniform).
+// Why not the builtin: with a builtin LDS-DMA pending in a wave hipcc falls back to `s_waitcnt lgkmcnt(0)` for every LDS read of
+// that wave (no counted waits), which exposes the read latency in an MFMA sweep that runs beside its own prefetch.  The caller
+// orders the data with its own `s_waitcnt vmcnt` + barrier / flag, as it has to with the builtin.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 is "reserved": nothing else in these kernels uses it
+__device__ __forceinline__ void dma16_asm(const void* g, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 __device__ __forceinline__ void flag_store_asm(unsigned addr, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }

@@ -23,10 +23,11 @@ with torch.no_grad():
     h = blk.norm1(tok)
     q, k, v = blk.attn.q_proj(h), blk.attn.k_proj(h), blk.attn.v_proj(h)
     t_core, _ = timed(lambda: blk.attn.core_hip(q, k, v, m.rope_table, 8))
+    t_core_torch, _ = timed(lambda: blk.attn.core_torch(q, k, v, m.rope_table, 8))
     t_qkv, _ = timed(lambda: (blk.attn.q_proj(h), blk.attn.k_proj(h), blk.attn.v_proj(h)))
     t_mlp, _ = timed(lambda: blk.mlp(blk.norm2(tok)))
     t_ln, _ = timed(lambda: blk.norm1(tok))
     vol = tok[:, 8:].transpose(1, 2).reshape(B, 396, 16, 16, 16).contiguous()
     t_dec, _ = timed(lambda: m.up_projection(vol))
     t_all, _ = timed(lambda: m(x))
-print(f"B={B}: total {t_all:.2f} ms | tokenizer {t_tok:.2f} | one block {t_blk:.3f} (x12 = {12*t_blk:.2f}): attention core {t_core:.3f}, qkv linears {t_qkv:.3f}, mlp+norm2 {t_mlp:.3f}, one LayerNorm {t_ln:.3f} | decoder {t_dec:.2f}")
+print(f"B={B}: total {t_all:.2f} ms | tokenizer {t_tok:.2f} | one block {t_blk:.3f} (x12 = {12*t_blk:.2f}): attention core {t_core:.3f} (same core as torch ops, fp32: {t_core_torch:.3f}), qkv linears {t_qkv:.3f}, mlp+norm2 {t_mlp:.3f}, one LayerNorm {t_ln:.3f} | decoder {t_dec:.2f}")
