@@ -202,6 +202,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
   const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
   const int yl = y0 + py, xl = x0 + 2 * li + px;
   char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 : nullptr;
+  char* out_w = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (g >> 1) * 16 : nullptr;
   float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)(g * 4) * p.pc + (long long)yl * p.py + xl
                                 : nullptr;
 
@@ -267,7 +268,33 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
 
-    if (zo < ze && !(p.dbg & 4)) {
+    if (OUTMODE == 0 && zo < ze && !(p.dbg & 4) && !(p.dbg & 32)) {
+      // 16-bit channels-last output: the lane groups g and g ^ 1 exchange one row each (v_permlane16_swap), so that a lane
+      // stores 8 consecutive channels of ONE voxel -- one 16-byte store per lane and row pair instead of two 8-byte ones.
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float f = acc[2 * cp + h][j];
+            if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
+            else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+            if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
+            v[j] = f;
+          }
+          pk[h][0] = (unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+          pk[h][1] = (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        const int row = 2 * (2 * cp + (g & 1));            // even g: row of c = 2 cp, odd g: row of c = 2 cp + 1
+        if (!full_xy && !((yl + row < p.H) & (xl < p.W))) continue;
+        *(uint4*)(out_w + (long long)zo * p.oz + row * p.oy) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+    } else if (zo < ze && !(p.dbg & 4)) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (!full_xy && !((yl + 2 * c < p.H) & (xl < p.W))) continue;

@@ -224,6 +224,9 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
   const int yl = y0 + wrow, xl = x0 + wcx * 16 + li;
   char* out_l = OUTMODE == 0 ? p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + cb * 2 : nullptr;
   float* out32_l = OUTMODE == 1 ? p.out32 + (long long)n * p.pn + (long long)cb * p.pc + (long long)yl * p.py + xl : nullptr;
+  constexpr bool WIDE = OUTMODE == 0 && NS == 0 && QT == 1;
+  // WIDE: lane (g, li) stores channels 8 (g >> 1) .. + 7 of voxel (row yl + (g & 1), xl)
+  char* out_w = WIDE ? p.out + (long long)n * p.on + (long long)(yl + (g & 1)) * p.oy + (long long)xl * p.ox + (g >> 1) * 16 : nullptr;
   // fp32 planar output with 16-byte stores needs x-quads that never straddle a row and aligned planes
   const bool vec_planar = OUTMODE == 1 && !(p.W & 3) && !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) &&
                           !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
@@ -281,11 +284,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) F[buf][r] = *(const vec8*)(smem + b1[pl] + koff + (r * HX) * 16);
 #pragma unroll
-#ifdef AMX_ZM_FAKE
-          for (int cy = 0; cy < 2; ++cy) H[buf][cy] = F[buf][cy + 1];
-#else
           for (int cy = 0; cy < 2; ++cy) H[buf][cy] = *(const vec8*)(smem + bx3[pl] + koff + (cy * HX + 2) * 16);
-#endif
         };
         auto mma_plane = [&](int buf, int pl) {
 #pragma unroll
@@ -323,12 +322,8 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
           const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
 #pragma unroll
           for (int cy = 0; cy < 2; ++cy) {
-#ifdef AMX_ZM_FAKE
-            const vec8 s0 = wreg[k][cy], s1 = wreg[k][cy + 2];
-#else
             const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
             const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
-#endif
             acc[tz][cy] = Ops<T>::mfma(wreg[k][12], s0, acc[tz][cy]);
             acc[tz][cy] = Ops<T>::mfma(wreg[k][13], s1, acc[tz][cy]);
           }
@@ -352,6 +347,34 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 #pragma unroll
     for (int tz = 0; tz < 2; ++tz) {
       const int zo = zs + s * TZ + tz;
+      if (WIDE && !(p.dbg & 32)) {
+        // Cout = 16, 16-bit channels-last output: the rows cy = 0 / 1 of a lane quartet (g, g ^ 1) are exchanged with one
+        // v_permlane16_swap per dword so that every lane owns 8 consecutive channels of ONE voxel: one 16-byte store per lane
+        // (a wave instruction = two 512-byte rows) instead of two 8-byte ones.
+        unsigned pk[2][2];
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float f = acc[tz][cy][j];
+            if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
+            else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
+            if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
+            v[j] = f;
+            pooled[j] = f > pooled[j] ? f : pooled[j];
+          }
+          pk[cy][0] = (unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+          pk[cy][1] = (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+        }
+        // odd rows of pk[0] <-> even rows of pk[1]: even g keeps row cy = 0 (its own 4 channels + the 4 of g + 1), odd g row cy = 1
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        if (zo >= ze) continue;
+        if (!full_xy && !((yl + (g & 1) < p.H) & (xl < p.W))) continue;
+        *(uint4*)(out_w + (long long)zo * p.oz) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        continue;
+      }
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) {
         float v[4];
