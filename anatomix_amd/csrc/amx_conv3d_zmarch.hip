@@ -239,6 +239,16 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
                                           : nullptr;
 
   bool bad = false;
+  // optional cycle trace (AMX_TRACE=1): consumer waves 0 and 4 of a few workgroups stamp s_memtime per phase
+  unsigned long long* trace = (p.dbg & 8) && (wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 512
+                                  ? (unsigned long long*)p.stats + ((long long)blockIdx.x * 2 + (wave >> 2)) * 128 : nullptr;
+  int tcount = 0;
+#define AMX_ZSTAMP()                                                             \
+  do {                                                                           \
+    if (trace && tcount < 128) trace[tcount] = __builtin_readcyclecounter();     \
+    ++tcount;                                                                    \
+  } while (0)
+  AMX_ZSTAMP();
   for (int s = 0; s < nsteps; ++s) {
     {
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
@@ -256,6 +266,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
       asm volatile("" ::: "memory");
     }
 
+    AMX_ZSTAMP();                                            // [planes landed]
     // ring slots of the four input planes zs+2s-1 .. zs+2s+2  (q = 2s + pl)
     int b1[4], bx3[4];
 #pragma unroll
@@ -332,6 +343,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
+    AMX_ZSTAMP();                                            // [sweep done]
 
     // ---- epilogue: activation + store (never waited for)
     if (p.dbg & 4) {
@@ -450,6 +462,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
                                   (unsigned)to_bits<T>(pm[2]) | ((unsigned)to_bits<T>(pm[3]) << 16));
       }
     }
+    AMX_ZSTAMP();                                            // [epilogue issued]
   }
   if (OUTMODE == 0 && RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
@@ -475,6 +488,7 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   if (dbg < 0) {
     const char* e = getenv("AMX_DBG");
     dbg = e ? atoi(e) : 0;
+    if (getenv("AMX_TRACE")) dbg |= 8;
   }
   p.dbg = dbg;
   p.nby = (p.H + TY - 1) / TY;
@@ -487,7 +501,30 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
+  static unsigned long long* trace_buf = nullptr;
+  if (p.dbg & 8) {   // debug only: per-phase cycle stamps of consumer waves 0 and 4, printed after a sync
+    if (!trace_buf && hipMalloc((void**)&trace_buf, 1024 * 128 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(trace_buf, 0, 1024 * 128 * 8, st);
+    p.stats = (float*)trace_buf;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + C::NL + NS) * 64), LDS, st, p, zseg, nseg);
+  if (p.dbg & 8) {
+    static int printed = 0;
+    (void)hipStreamSynchronize(st);
+    if (printed++ == 3) {
+      static unsigned long long hostbuf[1024 * 128];
+      (void)hipMemcpy(hostbuf, trace_buf, sizeof hostbuf, hipMemcpyDeviceToHost);
+      const int wgs[3] = {0, 77, 255};
+      for (int wi = 0; wi < 3; ++wi)
+        for (int half = 0; half < 2; ++half) {
+          const unsigned long long* tr = hostbuf + ((long long)wgs[wi] * 2 + half) * 128;
+          fprintf(stderr, "[trace %s wg %d wave %d] wait/sweep/epilogue:", g_kernel_name3, wgs[wi], half * 4);
+          for (int k = 1; k + 2 < 128 && tr[k + 2]; k += 3)
+            fprintf(stderr, " %llu/%llu/%llu", tr[k] - tr[k - 1], tr[k + 1] - tr[k], tr[k + 2] - tr[k + 1]);
+          fprintf(stderr, "\n");
+        }
+    }
+  }
   return hipGetLastError();
 }
 
@@ -514,8 +551,10 @@ static hipError_t launch_zm(const ConvParams& p, hipStream_t st) {
   // Measured (batch 4, 128^3, 16 -> 16): fp32 planar output 253 -> 177 us with storers (whole 128-byte lines, eight
   // rows per store instruction, instead of 64-byte pieces from the MFMA lanes); 16-bit NDHWC output 130 -> 155 us
   // (its direct stores are already 512-byte runs; the staging round trip only adds LDS traffic) -- so planar only.
-  if constexpr (NCK == 1 && OUTMODE == 1)
-    if (zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
+  static int stage16 = -1;
+  if (stage16 < 0) stage16 = getenv("AMX_STAGE16") ? 1 : 0;
+  if constexpr (NCK == 1)
+    if ((OUTMODE == 1 || stage16) && zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
   return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 0>(p, st);
 }
 
