@@ -11,5 +11,6 @@ from .supcon import SupPatchNCELoss
 from .patch_sample import PatchSampleF
 from .step import contrastive_step, GraphedContrastiveStep
 from .data_parallel import GradientBuckets
+from .data import H5SupCLDataset, random_crop
 
-__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep", "GradientBuckets"]
+__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep", "GradientBuckets", "H5SupCLDataset", "random_crop"]
