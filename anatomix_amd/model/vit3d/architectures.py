@@ -64,11 +64,10 @@ class LayerNormNd(nn.Module):
         self.weight, self.bias, self.eps = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c)), eps
 
     def forward(self, x):
-        u = x.mean(1, keepdim=True)
-        s = (x - u).pow(2).mean(1, keepdim=True)
-        x = (x - u) / torch.sqrt(s + self.eps)
+        # (x - mean) / sqrt(var + eps) * w + b over the channel axis, in four passes over the tensor instead of nine
+        s, u = torch.var_mean(x, dim=1, keepdim=True, unbiased=False)
         shape = (1, -1) + (1,) * (x.dim() - 2)
-        return x * self.weight.view(shape) + self.bias.view(shape)
+        return torch.addcmul(self.bias.view(shape), (x - u) * torch.rsqrt(s + self.eps), self.weight.view(shape))
 
 
 def build_out_norm(mode, num_classes, eps):

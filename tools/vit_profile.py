@@ -31,3 +31,19 @@ with torch.no_grad():
     t_dec, _ = timed(lambda: m.up_projection(vol))
     t_all, _ = timed(lambda: m(x))
 print(f"B={B}: total {t_all:.2f} ms | tokenizer {t_tok:.2f} | one block {t_blk:.3f} (x12 = {12*t_blk:.2f}): attention core {t_core:.3f} (same core as torch ops, fp32: {t_core_torch:.3f}), qkv linears {t_qkv:.3f}, mlp+norm2 {t_mlp:.3f}, one LayerNorm {t_ln:.3f} | decoder {t_dec:.2f}")
+# ---- tokenizer breakdown (stem conv / norm+act / the three residual stages / projection)
+with torch.no_grad():
+    tk = m.down_projection
+    t_c, y0 = timed(lambda: tk.stem.conv(x))
+    t_n, y1 = timed(lambda: torch.nn.functional.leaky_relu(tk.stem.norm(y0), 0.01))
+    parts = []
+    h = y1
+    for st in tk.stages:
+        t_s, h2 = timed(lambda st=st, h=h: st(h))
+        t_c1, _ = timed(lambda st=st, h=h: st.conv1(h))
+        parts.append((t_s, t_c1))
+        h = h2
+    t_p, _ = timed(lambda: tk.proj(h))
+    print(f"tokenizer: stem conv {t_c:.2f}, stem norm+act {t_n:.2f}, stages (total, conv1) {[(round(a, 2), round(b, 2)) for a, b in parts]}, proj {t_p:.2f}")
+    t_dec_old, _ = timed(lambda: m.up_projection.decode(vol))
+    print(f"decoder: GEMM path {t_dec:.2f} ms, module chain {t_dec_old:.2f} ms")
