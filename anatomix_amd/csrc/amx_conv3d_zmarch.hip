@@ -70,7 +70,9 @@ struct ZmStage {
 // memory queue is full; with the stores on the MFMA waves, math and write-out serialised (16 -> 16 @128^3, batch
 // 4: 91 us without the epilogue, 100 us without the math, 130 us together; fp32 planar output 93 / 165 / 247 us).
 // Requires full tiles and 16-byte aligned dense outputs (conv_zmarch_can_stage), else NS = 0.
-template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS>
+// POOL: the fused 2x2x2 max-pool output (p.out2) is a compile-time variant -- its own kernel symbol (own row in profiler
+// tables: it writes 1/8 more) and no run-time test in the epilogue of the plain one.
+template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL>
 __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
   typedef ZmCfg<NCK, QT, TY, TX, R> C;
   typedef ZmStage<QT, TY, TX, OUTMODE> SG;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
                                       x0 + wcx * 16 + (li & ~3)
                                 : nullptr;
   // fused 2x2x2 max-pool output (dense 16-bit NDHWC at half resolution); even lanes store
-  char* out2_l = (OUTMODE == 0 && p.out2) ? p.out2 + (long long)n * p.qn + (long long)(yl >> 1) * p.qy +
+  char* out2_l = (OUTMODE == 0 && POOL) ? p.out2 + (long long)n * p.qn + (long long)(yl >> 1) * p.qy +
                                                (long long)(xl >> 1) * p.qx + cb * 2
                                           : nullptr;
 
@@ -446,7 +448,7 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
       asm volatile("" ::: "memory");                        // LDS is in-order: the flag lands after the staged data
       flag_store(staged + wave, s + 1);
     }
-    if (OUTMODE == 0 && out2_l) {
+    if constexpr (OUTMODE == 0 && POOL) {
       // the wave's 2 x 2 x 16 block is one max-pool window per x pair: exchange with lane ^ 1, even lanes store.
       // (rounding is monotonic, so pooling the fp32 values equals pooling the stored 16-bit values.)
       float pm[4];
@@ -470,14 +472,16 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS>
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false>
 static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
+  if constexpr (OUTMODE == 0 && NS == 0 && !POOL)
+    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true>(p, st);
   constexpr int TX = 32, TZ = 2;
   typedef ZmCfg<NCK, QT, TY, TX, R> C;
   constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
   snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
            __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE, p.out2 ? ",pool" : "");
-  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS>;
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -554,7 +558,7 @@ static hipError_t launch_zm(const ConvParams& p, hipStream_t st) {
   static int stage16 = -1;
   if (stage16 < 0) stage16 = getenv("AMX_STAGE16") ? 1 : 0;
   if constexpr (NCK == 1)
-    if ((OUTMODE == 1 || stage16) && zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
+    if ((OUTMODE == 1 || (stage16 && !p.out2)) && zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
   return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 0>(p, st);
 }
 
