@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4, help="128^3 windows per step per GPU (sliding-window batch)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="128^3 windows per step per GPU (sliding-window batch); >= 8 run as chunks of 4 on two HIP streams")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "strict", "f16x2", "bf16x2"],
                     help="storage precision of the HIP path; strict (= bf16x2) / f16x2: split hi+lo 16-bit operands, three MFMAs per "
@@ -454,7 +455,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             gflop_vol *= 3.0      # forward + data gradient + weight gradient
         else:
             workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
-                          f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}")
+                          f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}" +
+                          ("; the module runs the batch as chunks of 4 on two HIP streams" if B >= 8 and not vit else ""))
             if vit:
                 workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]); attention core (QK-LayerNorm "
                               "+ rotary + softmax(qk^T)v) on the hand-written MFMA kernel with f16 operands / fp32 softmax and "

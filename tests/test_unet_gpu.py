@@ -197,3 +197,25 @@ def test_results_do_not_depend_on_memory_nobody_wrote():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "poison_check.py")], capture_output=True, text=True, timeout=300)
     tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:]
     assert out.returncode == 0 and tail == "poison check: 0 bad results", out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_concurrent_chunks_do_not_change_results(device):
+    """Batches of >= 8 volumes run as chunks of 4 on two HIP streams (network.py::_forward_chunks): same values as one launch
+    sequence, for full and ragged chunk counts, and the caller's stream sees the finished output."""
+    m, _ = _model(device, 0, 1.0)
+    x = R.synthetic_input(7, 9, (32, 32, 32)).to(device)
+    with torch.no_grad():
+        m.concurrent_chunks = 0
+        want = m(x)
+        m.concurrent_chunks = 4
+        got9 = m(x)                     # chunks 4 + 4 + 1
+        got8 = m(x[:8])                 # chunks 4 + 4
+        m.concurrent_chunks = 2
+        got_small = m(x[:5])            # chunks 2 + 2 + 1
+        s = torch.cuda.Stream(device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):      # a non-default caller stream
+            m.concurrent_chunks = 4
+            got_side = m(x)
+        torch.cuda.current_stream(device).wait_stream(s)
+    assert torch.equal(got9, want) and torch.equal(got8, want[:8]) and torch.equal(got_small, want[:5]) and torch.equal(got_side, want)
