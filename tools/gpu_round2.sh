@@ -28,7 +28,7 @@ done
 cd $REPO
 f=$(ls $OUT/${TAG}_pmc_FETCH_SIZE/*counter_collection.csv | head -1)
 w=$(ls $OUT/${TAG}_pmc_WRITE_SIZE/*counter_collection.csv | head -1)
-python tools/pmc_summary.py $f $w $OUT/${TAG}_pmc_traffic.json 8
+python tools/pmc_summary.py $f $w $OUT/${TAG}_pmc_traffic.json 4
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 mv $OUT/${TAG}_bench_headline_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 head -8 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-150
