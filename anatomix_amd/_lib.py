@@ -56,6 +56,7 @@ SYMBOLS = {
     "amx_unet_forward_taps": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, C.c_size_t, C.POINTER(_I), _I, C.POINTER(_P), _I, _P]),
     "amx_unet_forward_window": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_unet_forward_windows": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
+    "amx_unet_forward_windows_pipelined": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P, C.c_size_t, _I, _P]),
     "amx_sw_normalize": (_I, [_P, _P, _I, C.c_longlong, _P]),
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),

@@ -140,6 +140,7 @@ struct amx_unet {
   int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
   int* d_flag = nullptr;    // device: raised by any epilogue that was about to store a value outside the f16 range (or NaN)
   int* h_flag = nullptr;    // pinned host mirror, refreshed by an async copy at the end of every forward
+  hipEvent_t acc_done[2] = {nullptr, nullptr};   // amx_unet_forward_windows_pipelined: "slot s has finished accumulating"
 };
 
 namespace {
@@ -230,6 +231,9 @@ int level_channels(const amx_unet* h, int level) {
   if (level == 0 && h->cfg.output_nc > c) c = h->cfg.output_nc;
   return c;
 }
+
+// set by amx_unet_forward_windows_pipelined around its run_forward call (per host thread)
+static thread_local hipEvent_t g_acc_gate = nullptr, g_acc_done = nullptr;
 
 struct Profiler {
   std::vector<hipEvent_t> ev;
@@ -466,6 +470,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
         return amx::launch_conv(q, c.precision, L.q, st);
       };
+      // pipelined windows (two batches in flight on two streams): the accumulating launches of this batch wait for the other
+      // slot's accumulations, so that overlapping windows still add up in window order
+      if (x_offs && L.is_final && g_acc_gate) AMX_HIP(hipStreamWaitEvent(st, g_acc_gate, 0));
       if (x_offs && (p.src0_f32c1 || L.is_final)) {
         for (int wi = 0; wi < n; ++wi) {
           amx::ConvParams q = p;
@@ -484,6 +491,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       } else {
         AMX_HIP(launch_one(p));
       }
+      if (x_offs && L.is_final && g_acc_done) AMX_HIP(hipEventRecord(g_acc_done, st));
       if (prof)
         snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s",
                  p.src0_f32c1 ? amx::last_conv_stem_kernel_name()
@@ -718,6 +726,8 @@ void amx_unet_destroy(amx_unet_t* h) {
   if (!h) return;
   if (h->d_flag) (void)hipFree(h->d_flag);
   if (h->h_flag) (void)hipHostFree(h->h_flag);
+  for (int i = 0; i < 2; ++i)
+    if (h->acc_done[i]) (void)hipEventDestroy(h->acc_done[i]);
   for (ConvLayer& L : h->convs) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);
@@ -876,6 +886,21 @@ int amx_unet_forward_windows(amx_unet_t* h, const float* d_vol, int vd, int vh, 
   return run_forward(h, d_vol, vvox * 4, (long long)vh * vw * 4, (long long)vw * 4, d_acc, vvox * h->cfg.output_nc, vvox,
                      (long long)vh * vw, vw, d_wmap, n_windows, rd, rh, rw, d_workspace, workspace_bytes,
                      (hipStream_t)stream, nullptr, offs, offs);
+}
+
+int amx_unet_forward_windows_pipelined(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int n_windows,
+                                       const int* offsets_zyx, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                                       void* d_workspace, size_t workspace_bytes, int slot, void* stream) {
+  if (!h) return fail(AMX_ERR_INVALID, "null handle");
+  if (slot != 0 && slot != 1) return fail(AMX_ERR_INVALID, "slot must be 0 or 1 (got %d)", slot);
+  for (int i = 0; i < 2; ++i)
+    if (!h->acc_done[i]) AMX_HIP(hipEventCreateWithFlags(&h->acc_done[i], hipEventDisableTiming));
+  g_acc_gate = h->acc_done[slot ^ 1];       // never recorded yet: the wait is a no-op
+  g_acc_done = h->acc_done[slot];
+  const int rc = amx_unet_forward_windows(h, d_vol, vd, vh, vw, n_windows, offsets_zyx, rd, rh, rw, d_wmap, d_acc, d_workspace,
+                                          workspace_bytes, stream);
+  g_acc_gate = g_acc_done = nullptr;
+  return rc;
 }
 
 int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream) {

@@ -152,7 +152,7 @@ class Unet(nn.Module):
     # nn.DataParallel replicas (which copy __dict__) must not share them: a copy starts without a handle and builds its own on
     # its first HIP forward (sharing the raw pointer would be a use-after-free on the first re-create and a double free in
     # __del__; ctypes pointers do not pickle either).
-    _PER_OBJECT_STATE = ("_handle", "_handle_key", "_workspace", "_uploaded_sig", "_sig_tensors", "_side_streams", "_side_ws")
+    _PER_OBJECT_STATE = ("_handle", "_handle_key", "_workspace", "_uploaded_sig", "_sig_tensors", "_side_streams", "_side_ws", "_sw_streams", "_sw_ws")
 
     def __getstate__(self):
         state = self.__dict__.copy()

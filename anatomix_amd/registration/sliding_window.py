@@ -231,6 +231,7 @@ def _gather_slabs(slab, depth, world, group):
 
 
 FUSED_WINDOW_BATCH = 4     # windows per amx_unet_forward_windows call (fills the chip on the deep levels)
+PIPELINE_WINDOWS = True    # keep two window batches in flight on two HIP streams (ordered accumulation, identical results)
 
 
 def _run_fused(inputs, roi, starts, wmap, model, cnt):
@@ -251,18 +252,44 @@ def _run_fused(inputs, roi, starts, wmap, model, cnt):
             model._upload_weights(lib, dev)
         k = max(1, min(FUSED_WINDOW_BATCH, len(starts)))
         ws, need = model._get_workspace(lib, k, roi[0], roi[1], roi[2], dev)
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        cur = torch.cuda.current_stream(dev)
+        st = ctypes.c_void_p(cur.cuda_stream)
         wm = wmap.contiguous()
+        ngroups = (len(starts) + k - 1) // k
+        # two window batches in flight (amx_unet_forward_windows_pipelined): batch g + 1 runs on the other stream and only its
+        # accumulating launches wait for batch g -- same sums in the same order, the underfilled deep levels overlap
+        pipelined = PIPELINE_WINDOWS and B * ngroups >= 4 and not torch.cuda.is_current_stream_capturing()
+        if pipelined:
+            if getattr(model, "_sw_streams", None) is None or model._sw_streams[0].device != dev:
+                model._sw_streams = [torch.cuda.Stream(dev) for _ in range(2)]
+                model._sw_ws = None
+            if model._sw_ws is None or model._sw_ws.numel() < need:
+                model._sw_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            lanes = [(model._sw_streams[0], ws), (model._sw_streams[1], model._sw_ws)]
+            ready = cur.record_event()
+            for s_, _ in lanes:
+                s_.wait_event(ready)
+        call = 0
         for g0 in range(0, len(starts), k):
             grp = starts[g0:g0 + k]
             offs = (ctypes.c_int * (3 * len(grp)))(*[v for s3 in grp for v in s3])
             for b in range(B):
-                _lib.check(lib.amx_unet_forward_windows(model._handle, _lib.ptr(x[b]), size[0], size[1], size[2], len(grp),
-                                                        offs, roi[0], roi[1], roi[2], _lib.ptr(wm), _lib.ptr(acc[b]),
-                                                        _lib.ptr(ws), need, st))
-            for (z, y, xx) in grp:
+                if pipelined:
+                    s_, w_ = lanes[call & 1]
+                    _lib.check(lib.amx_unet_forward_windows_pipelined(
+                        model._handle, _lib.ptr(x[b]), size[0], size[1], size[2], len(grp), offs, roi[0], roi[1], roi[2],
+                        _lib.ptr(wm), _lib.ptr(acc[b]), _lib.ptr(w_), need, call & 1, ctypes.c_void_p(s_.cuda_stream)))
+                    call += 1
+                else:
+                    _lib.check(lib.amx_unet_forward_windows(model._handle, _lib.ptr(x[b]), size[0], size[1], size[2], len(grp),
+                                                            offs, roi[0], roi[1], roi[2], _lib.ptr(wm), _lib.ptr(acc[b]),
+                                                            _lib.ptr(ws), need, st))
+            for (z, y, xx) in grp:              # the count map is independent of the network: caller's stream
                 _lib.check(lib.amx_sw_count(_lib.ptr(cnt), size[0], size[1], size[2], z, y, xx, roi[0], roi[1], roi[2],
                                             _lib.ptr(wm), st))
+        if pipelined:
+            for s_, _ in lanes:
+                cur.wait_stream(s_)
         if model.precision in ("f16", "fp16", "float16", "f16x2") and not torch.cuda.is_current_stream_capturing():
             # the accumulation volume leaves the library here: one synchronising range check per volume (f16 storage only)
             model.check_numerics(synchronize=True)

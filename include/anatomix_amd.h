@@ -167,6 +167,16 @@ int amx_unet_forward_windows(amx_unet_t* h, const float* d_vol, int vd, int vh, 
                              const int* offsets_zyx, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
                              void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Two window batches in flight.  Same as amx_unet_forward_windows, for a caller that alternates TWO streams (and two
+ * workspaces) over consecutive window batches: slot = 0 / 1 alternately.  Everything up to the output conv of batch k+1 overlaps
+ * batch k; the accumulating launches of a batch first wait for the other slot's accumulations, so overlapping windows are still
+ * added in window order and the result is bit-identical to the single-stream sequence.  The caller joins both streams before
+ * reading d_acc.  (MONAI's sliding_window_inference runs its sw_batch groups strictly one after the other,
+ * convex_adam_utils.py:205-219 is the call.) */
+int amx_unet_forward_windows_pipelined(amx_unet_t* h, const float* d_vol, int vd, int vh, int vw, int n_windows,
+                                       const int* offsets_zyx, int rd, int rh, int rw, const float* d_wmap, float* d_acc,
+                                       void* d_workspace, size_t workspace_bytes, int slot, void* stream);
+
 /* Final step of sliding_window_inference: d_acc[c][v] /= d_cnt[v] in place. */
 int amx_sw_normalize(float* d_acc, const float* d_cnt, int channels, long long voxels, void* stream);
 

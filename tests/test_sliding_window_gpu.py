@@ -59,3 +59,22 @@ def test_extract_features_surface(device):
     f, mv = extract_features(fixed, moving, m, fixminclip=0.0, fixmaxclip=500.0)
     assert f.shape == (1, 16, 128, 144, 128) and mv.shape == (1, 16, 112, 128, 128)
     assert torch.isfinite(f).all() and torch.isfinite(mv).all() and f.is_cuda
+
+
+def test_two_window_batches_in_flight_give_identical_sums(device):
+    """amx_unet_forward_windows_pipelined: consecutive window batches alternate two streams, only the accumulating launches are
+    ordered -- the accumulated volume must be bit-identical to the single-stream sequence, repeatedly (no race on overlaps)."""
+    from anatomix_amd.registration import sliding_window as SW
+    m, _ = _model(device)
+    x = R.synthetic_input(31, 1, (96, 80, 112)).to(device)
+    kw = dict(overlap=0.8, mode="gaussian", sigma_scale=0.25)
+    assert len(window_starts((96, 80, 112), (64, 64, 64), 0.8)) >= 16
+    with torch.no_grad():
+        SW.PIPELINE_WINDOWS = False
+        try:
+            want = sliding_window_inference(x, (64, 64, 64), 2, m, **kw)
+        finally:
+            SW.PIPELINE_WINDOWS = True
+        for _ in range(3):
+            got = sliding_window_inference(x, (64, 64, 64), 2, m, **kw)
+            assert torch.equal(got, want)
