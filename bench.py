@@ -493,7 +493,7 @@ def secondary_workloads(ctx, args):
     """Short driver-timed runs of the other BASELINE configs, attached to the default N=1 line (each with its own roofline)."""
     S = args.size
     plan = [
-        ("anatomix_batch8_two_chunks_in_flight", dict(variant="anatomix", precision="f16", steps=50, warmup=5, batch=8)),
+        ("anatomix_batch8_two_chunks_in_flight", dict(variant="anatomix", precision="f16", steps=60, warmup=15, batch=8)),
         ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
         ("anatomix_dev", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=4)),
         ("anatomix_dev_strict", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),

@@ -12,11 +12,11 @@ import collections, csv, json, re, sys
 
 
 def friendly(mangled):
-    m = re.match(r"_ZN3amx23conv3d_k3_zmarch_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
-    if m:   # <T, NCK, QT, TY, TX, R, OUTMODE, NS>; same text as the launcher prints (minus the run-time ",pool" tag)
-        t, nck, qt, ty, tx, r, o, ns = m.groups()
+    m = re.match(r"_ZN3amx23conv3d_k3_zmarch_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E(?:Lb(\d)E)?", mangled)
+    if m:   # <T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL>; same text as the launcher prints
+        t, nck, qt, ty, tx, r, o, ns, pool = m.groups()
         return (f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},{16*int(nck)}->{16*int(qt)},2x{ty}x{tx},"
-                f"c8+l{2*int(nck)}+s{ns},r{r},o{o}>")
+                f"c8+l{2*int(nck)}+s{ns},r{r},o{o}{',pool' if pool == '1' else ''}>")
     m = re.match(r"_ZN3amx21conv3d_upcat16_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
     if m:
         return f"conv3d_upcat16<{'f16' if m.group(1) == 'DF16_' else 'bf16'},2x8x32,c8+l3,r10/6,o{m.group(2)}>"
