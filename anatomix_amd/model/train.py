@@ -24,6 +24,17 @@ from . import train_ops as T
 _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
 
+OVERLAP_WGRAD = True           # weight gradients on a side stream, beside the data gradient of the same block
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
+
+
 def unsupported_reason(model, x, layers):
     c = model._cfg
     if model.precision not in _DT:
@@ -252,7 +263,11 @@ class _UnetTrainFn(torch.autograd.Function):
             else:
                 n_, d_, h_, w_, c_ = low.shape
                 add_grad(low_name, gu.reshape(n_, d_, 2, h_, 2, w_, 2, c_).float().sum((2, 4, 6)).to(dt))
+        wgrad_pending = None
         for op in reversed(ctx.ops):
+            if wgrad_pending is not None:                               # the frames and the scratch are shared: one in flight
+                torch.cuda.current_stream(tensors["x"].device).wait_stream(wgrad_pending)
+                wgrad_pending = None
             if op[0] == "pool":
                 _, src, dst, avg, pid = op
                 if pid in dtap:                                         # tap at the pool id: gradient of the pooled tensor
@@ -328,7 +343,21 @@ class _UnetTrainFn(torch.autograd.Function):
                     T.interior(fr).zero_()
                 if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
                     T.import_ncdhw(dtap.pop(idx), T.interior(fr), accumulate=True)
-            pgrads[id(conv.weight)] = T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"])
+            # The weight gradient and the data gradient of a block both read `fr` and nothing else of each other: the weight
+            # gradient goes to a side stream (result and scratch preallocated / cached on this one) and is joined before the next
+            # block touches a framed buffer (they are shared per shape).  Letting it also run beside the next block's BatchNorm
+            # adjoint (second frame per shape + events) measured slower: 11.4 vs 10.7 ms per step.
+            if OVERLAP_WGRAD and x0.is_cuda:
+                dw = torch.empty((blk["cout"], blk["cin"], 3, 3, 3), dtype=torch.float32, device=x0.device)
+                T.wgrad_scratch(x0, x1, blk["cout"])                   # make sure the cached scratch exists (allocated here)
+                side = _side_stream(x0.device)
+                side.wait_stream(torch.cuda.current_stream(x0.device))
+                with torch.cuda.stream(side):
+                    T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"], out=dw)
+                pgrads[id(conv.weight)] = dw
+                wgrad_pending = side
+            else:
+                pgrads[id(conv.weight)] = T.conv_wgrad(fr, x0, x1, blk["cin"], blk["cout"])
             if conv.bias is not None:                                   # d bias = sum of the pre-norm gradient over the voxels
                 pgrads[id(conv.bias)] = T.interior(fr).float().sum((0, 1, 2, 3))[: blk["cout"]]
             if blk["in0"] == "x":
@@ -356,6 +385,8 @@ class _UnetTrainFn(torch.autograd.Function):
                     add_grad(blk["in0"], dcat[..., :c0].contiguous())
                     up = dcat[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1)
                     add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))
+        if wgrad_pending is not None:
+            torch.cuda.current_stream(tensors["x"].device).wait_stream(wgrad_pending)
         return (None, dx_in, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
 
 

@@ -138,13 +138,24 @@ def conv_dgrad(dx_framed, weight, cin_keep=None, accumulate_into=None):
     return din
 
 
-def conv_wgrad(dx_framed, x0, x1, cin_real, cout):
-    """Weight gradient: fp32 [Cout, cin_real, 3, 3, 3]."""
+def wgrad_scratch(x0, x1, cout):
+    """Allocates (once, on the current stream) the cached partial-sum scratch conv_wgrad uses for this shape."""
+    lib = _lib.load()
+    n, d, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    with torch.cuda.device(x0.device):
+        nbytes = lib.amx_conv3d_wgrad_scratch_bytes(n, d, h, w, cout, c0 + c1)
+        return _cached(("wgrad", x0.device, nbytes), lambda: torch.empty(nbytes, dtype=torch.uint8, device=x0.device))
+
+
+def conv_wgrad(dx_framed, x0, x1, cin_real, cout, out=None):
+    """Weight gradient: fp32 [Cout, cin_real, 3, 3, 3] (``out``: preallocated result, e.g. by the caller's main stream when the
+    kernel itself is enqueued on a side stream)."""
     lib = _lib.load()
     dev = x0.device
     n, d, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[-1]
-    dw = torch.empty((cout, cin_real, 3, 3, 3), dtype=torch.float32, device=dev)
+    dw = out if out is not None else torch.empty((cout, cin_real, 3, 3, 3), dtype=torch.float32, device=dev)
     view = interior(dx_framed)
     es = dx_framed.element_size()
     sn, sz, sy, sx, _ = [s * es for s in view.stride()]
