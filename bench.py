@@ -497,7 +497,7 @@ def secondary_workloads(ctx, args):
         ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
         ("anatomix_dev", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=4)),
         ("anatomix_dev_strict", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),
-        ("anatomix_dev_vit", dict(variant="anatomix-dev-vit", steps=10, warmup=3, batch=2)),
+        ("anatomix_dev_vit", dict(variant="anatomix-dev-vit", steps=8, warmup=3, batch=4)),
         ("sliding_window_256", dict(variant="anatomix", sw_volume=2 * S, steps=3, warmup=1)),
         ("contrastive_step", dict(variant="anatomix", workload="step", steps=10, warmup=1)),
     ]
