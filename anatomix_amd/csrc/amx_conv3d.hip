@@ -160,12 +160,14 @@ int conv_pick_q(int Cout, int W) {
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);
 const char* last_conv_v2_kernel_name();
 bool conv_zmarch_eligible(const ConvParams& p);
+bool conv_zmarch_eligible_split(const ConvParams& p);
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st);
 const char* last_conv_zm_kernel_name();
 
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (precision < 2 && conv_zmarch_eligible(p) && Q == p.Cout / 16) {   // narrow full/half-resolution layers: z-marching ring kernel
+  if (((precision < 2 && conv_zmarch_eligible(p)) || (precision >= 2 && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16) {
+    // narrow full/half-resolution layers: z-marching ring kernel
     hipError_t e = launch_conv_zmarch(p, precision, st);
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
     return e;

@@ -72,9 +72,15 @@ struct ZmStage {
 // Requires full tiles and 16-byte aligned dense outputs (conv_zmarch_can_stage), else NS = 0.
 // POOL: the fused 2x2x2 max-pool output (p.out2) is a compile-time variant -- its own kernel symbol (own row in profiler
 // tables: it writes 1/8 more) and no run-time test in the epilogue of the plain one.
-template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL>
-__global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
-  typedef ZmCfg<NCK, QT, TY, TX, R> C;
+// SPLIT (strict precision, 16 -> 16 only): the input voxel is [hi(16) | lo(16)] -- the ring holds four 8-channel planes like a
+// 32-channel input -- and the step is swept twice: the hi planes against Wh and Wl (two MFMAs per fragment read), the lo planes
+// against Wh (Wh / Wl are the two packed "chunks" and stay in registers like the two chunks of the 32-channel kernel); the
+// epilogue splits the fp32 result again.
+template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL, bool SPLIT = false>
+__global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+  static_assert(!SPLIT || (NCK == 1 && QT == 1 && NS == 0 && !POOL), "strict z-march: 16 -> 16, direct stores");
+  constexpr int NCKP = SPLIT ? 2 : NCK;                             // chunk planes in the ring / weight sets in registers
+  typedef ZmCfg<NCKP, QT, TY, TX, R> C;
   typedef ZmStage<QT, TY, TX, OUTMODE> SG;
   typedef typename Ops<T>::vec8 vec8;
   constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, XT = C::XT, NDMA = C::NDMA, NL = C::NL, NC = C::NC, TZ = C::TZ;
@@ -207,9 +213,9 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
   const int wrow = (wr / XT) * 2;                          // first of the wave's two rows
   const int wcx = wr % XT;                                 // the wave's x tile
   // resident weights (A fragments of tile wq) and bias
-  vec8 wreg[NCK][kSteps];
+  vec8 wreg[NCKP][kSteps];
 #pragma unroll
-  for (int k = 0; k < NCK; ++k)
+  for (int k = 0; k < NCKP; ++k)
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) wreg[k][s] = *(const vec8*)(p.wpk + ((k * kSteps + s) * QT + wq) * 1024 + lane * 16);
   const int cb = g * 4 * QT + wq * 4;                      // lane holds output channels cb .. cb+3
@@ -286,12 +292,21 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 
     if (!(p.dbg & 2)) {
 #pragma unroll
-      for (int k = 0; k < NCK; ++k) {
-        const int koff = k * 2 * PPL;                        // channel planes 2k, 2k+1
+      for (int ps = 0; ps < NCKP; ++ps) {
+        // SPLIT: pass 0 reads the hi planes and multiplies every fragment with Wh AND Wl (two MFMAs per fragment read),
+        // pass 1 reads the lo planes and multiplies with Wh.  Otherwise pass = chunk.
+        const int k = SPLIT ? 0 : ps;                        // (first) weight set of this pass
+        const bool both = SPLIT && ps == 0;                  // also the second weight set (Wl)
+        const int koff = ps * 2 * PPL;                       // channel planes 2 ps, 2 ps + 1
+        auto mm = [&](const int widx, const vec8& frag, f32x4 a) {
+          a = Ops<T>::mfma(wreg[k][widx], frag, a);
+          if (both) a = Ops<T>::mfma(wreg[NCKP - 1][widx], frag, a);
+          return a;
+        };
         // Per input plane pl: 4 row fragments of taps (kz,ky,0)|(kz,ky,1) and 2 fragments of taps
         // (kz,0,2)|(kz,1,2); plane pl is tap plane kz = pl - tz of output plane tz.  Batches are double
         // buffered one plane ahead of their MFMAs (sched_barrier pins the phases).
-        constexpr bool DB = NCK == 1;      // two chunks: 28 resident weight fragments leave no room for a 2nd buffer
+        constexpr bool DB = NCKP == 1;     // two chunks: 28 resident weight fragments leave no room for a 2nd buffer
         vec8 F[DB ? 2 : 1][4], H[DB ? 2 : 1][2];
         auto load_plane = [&](int buf, int pl) {
 #pragma unroll
@@ -307,9 +322,9 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-              for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = Ops<T>::mfma(wreg[k][kz * 3 + ky], F[buf][cy + ky], acc[tz][cy]);
+              for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(kz * 3 + ky, F[buf][cy + ky], acc[tz][cy]);
 #pragma unroll
-            for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = Ops<T>::mfma(wreg[k][9 + kz], H[buf][cy], acc[tz][cy]);
+            for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(9 + kz, H[buf][cy], acc[tz][cy]);
           }
         };
         if (DB) {
@@ -337,8 +352,8 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
           for (int cy = 0; cy < 2; ++cy) {
             const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
             const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
-            acc[tz][cy] = Ops<T>::mfma(wreg[k][12], s0, acc[tz][cy]);
-            acc[tz][cy] = Ops<T>::mfma(wreg[k][13], s1, acc[tz][cy]);
+            acc[tz][cy] = mm(12, s0, acc[tz][cy]);
+            acc[tz][cy] = mm(13, s1, acc[tz][cy]);
           }
         }
       }
@@ -361,11 +376,12 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 #pragma unroll
     for (int tz = 0; tz < 2; ++tz) {
       const int zo = zs + s * TZ + tz;
-      if (WIDE && !(p.dbg & 32)) {
+      if (WIDE && (SPLIT || !(p.dbg & 32))) {
         // Cout = 16, 16-bit channels-last output: the rows cy = 0 / 1 of a lane quartet (g, g ^ 1) are exchanged with one
         // v_permlane16_swap per dword so that every lane owns 8 consecutive channels of ONE voxel: one 16-byte store per lane
-        // (a wave instruction = two 512-byte rows) instead of two 8-byte ones.
-        unsigned pk[2][2];
+        // (a wave instruction = two 512-byte rows) instead of two 8-byte ones.  SPLIT: the same for the lo halves, which sit
+        // Cout channels further on in the voxel.
+        unsigned pk[2][2], pl[SPLIT ? 2 : 1][2];
 #pragma unroll
         for (int cy = 0; cy < 2; ++cy) {
           float v[4];
@@ -380,13 +396,27 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
           }
           pk[cy][0] = (unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
           pk[cy][1] = (unsigned)to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+          if constexpr (SPLIT) {
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = v[j] - (float)(T)v[j];
+            pl[cy][0] = (unsigned)to_bits<T>(r[0]) | ((unsigned)to_bits<T>(r[1]) << 16);
+            pl[cy][1] = (unsigned)to_bits<T>(r[2]) | ((unsigned)to_bits<T>(r[3]) << 16);
+          }
         }
         // odd rows of pk[0] <-> even rows of pk[1]: even g keeps row cy = 0 (its own 4 channels + the 4 of g + 1), odd g row cy = 1
         const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        unsigned l0a = 0, l0b = 0, l1a = 0, l1b = 0;
+        if constexpr (SPLIT) {
+          const auto t0 = __builtin_amdgcn_permlane16_swap(pl[0][0], pl[1][0], false, false);
+          const auto t1 = __builtin_amdgcn_permlane16_swap(pl[0][1], pl[1][1], false, false);
+          l0a = t0[0]; l0b = t0[1]; l1a = t1[0]; l1b = t1[1];
+        }
         if (zo >= ze) continue;
         if (!full_xy && !((yl + (g & 1) < p.H) & (xl < p.W))) continue;
         *(uint4*)(out_w + (long long)zo * p.oz) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if constexpr (SPLIT) *(uint4*)(out_w + (long long)zo * p.oz + p.Cout * 2) = make_uint4(l0a, l1a, l0b, l1b);
         continue;
       }
 #pragma unroll
@@ -472,16 +502,18 @@ __global__ __launch_bounds__((8 + 2 * NCK + NS) * 64) void conv3d_k3_zmarch_kern
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false>
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false>
 static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
-  if constexpr (OUTMODE == 0 && NS == 0 && !POOL)
+  if constexpr (OUTMODE == 0 && NS == 0 && !POOL && !SPLIT)
     if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true>(p, st);
+  if (SPLIT && p.out2) return hipErrorInvalidValue;      // the strict path pools with its own kernel
   constexpr int TX = 32, TZ = 2;
-  typedef ZmCfg<NCK, QT, TY, TX, R> C;
+  typedef ZmCfg<SPLIT ? 2 : NCK, QT, TY, TX, R> C;
   constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
-  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
-           __is_same(T, f16) ? "f16" : "bf16", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE, p.out2 ? ",pool" : "");
-  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL>;
+  snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
+           __is_same(T, f16) ? "f16" : "bf16", SPLIT ? "x2" : "", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE,
+           p.out2 ? ",pool" : "");
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL, SPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -580,8 +612,20 @@ bool conv_zmarch_can_pool(const ConvParams& p) {
   return !off && conv_zmarch_eligible(p) && !p.out32 && !(p.D & 1) && !(p.H & 1) && !(p.W & 1);
 }
 
+// Strict precision: the 16 -> 16 layers (all of level 0 in the 6M network) have a z-march variant too.
+bool conv_zmarch_eligible_split(const ConvParams& p) {
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_ZMARCH_SPLIT") ? 1 : 0;
+  return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16 && !p.out2 && !p.wmap;
+}
+
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
+  if (precision >= 2) {   // strict: 16 -> 16 only; ring of 7 planes x 4 channel planes, stores from the accumulators
+    if (p.C0 != 16 || p.Cout != 16) return hipErrorInvalidValue;
+    if (precision == 2) return planar ? launch_zm_ns<f16, 1, 1, 8, 7, 1, 0, false, true>(p, st) : launch_zm_ns<f16, 1, 1, 8, 7, 0, 0, false, true>(p, st);
+    return planar ? launch_zm_ns<bf16, 1, 1, 8, 7, 1, 0, false, true>(p, st) : launch_zm_ns<bf16, 1, 1, 8, 7, 0, 0, false, true>(p, st);
+  }
   if (p.Cout == 16) {
     if (precision == 0) return planar ? launch_zm<f16, 1, 1, 8, 10, 1>(p, st) : launch_zm<f16, 1, 1, 8, 10, 0>(p, st);
     return planar ? launch_zm<bf16, 1, 1, 8, 10, 1>(p, st) : launch_zm<bf16, 1, 1, 8, 10, 0>(p, st);
