@@ -157,6 +157,18 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   // ---- DMA lane constants: lane -> (row within instruction, x within halo row)
   const int dl = lane / HX, hxl = lane - dl * HX;
   const bool dma_lane = dl < C::RR;
+  // packed mode (RR == 1): instruction j covers halo voxels 64 j .. 64 j + 63; this wave issues j = iw, iw + INW, ...
+  constexpr int NPK = (C::HV + 63) / 64, PKS = C::RR == 1 ? (NPK + INW - 1) / INW : 1;
+  int pk_pos[PKS], pk_off0[PKS], pk_off1[PKS];           // hz | hy << 8 | hx << 16 (or -1 past the halo); byte offsets per item
+  // 32-bit offsets inside one sample: every full-resolution segment must be smaller than 2 GiB
+  const bool pk_ok = C::RR == 1 && !(p.dbg & 256) && (long long)p.D * (p.s0z > p.s1z ? p.s0z : p.s1z) < (1ll << 31);
+#pragma unroll
+  for (int m = 0; m < PKS; ++m) {
+    const int hv = (iw + m * INW) * 64 + lane;
+    const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX;
+    pk_pos[m] = hv < C::HV ? (hz | (hy << 8) | ((rem - hy * HX) << 16)) : -1;
+    pk_off0[m] = pk_off1[m] = 0;
+  }
 
   ItemCoord nx;   // next item to issue DMA for (one-time decode; afterwards increment-and-carry)
   {
@@ -178,6 +190,16 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     char* buf = smem + bsel01 * C::BUF;
     const int z0 = it.bz * C::TZ, y0 = it.by * C::TY, x0 = it.bx * C::TX;
     const int gx = reflect_clamp(x0 + hxl - 1, p.W);
+    if (C::RR == 1 && pk_ok && stage == 0) {
+#pragma unroll
+      for (int m = 0; m < PKS; ++m) {
+        const int pos = pk_pos[m];
+        const int gz = reflect_clamp(z0 + (pos & 255) - 1, p.D), gy = reflect_clamp(y0 + ((pos >> 8) & 255) - 1, p.H);
+        const int gxx = reflect_clamp(x0 + ((pos >> 16) & 255) - 1, p.W);
+        pk_off0[m] = gz * (int)p.s0z + gy * (int)p.s0y + gxx * (int)p.s0x;
+        pk_off1[m] = gz * (int)p.s1z + gy * (int)p.s1y + gxx * (int)p.s1x;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int vch = stage * NCH + k;                      // wave-uniform; SPLIT: virtual chunk in [0, 3 * nchunk)
@@ -207,6 +229,24 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
           char* dst = buf + k * HALO + j * (C::RRL * C::LXH * 16);   // uniform
           dma_count += 2;
           if (dl2 < C::RRL && r < C::NROWL) {
+            AMX_DMA16(src, dst);
+            AMX_DMA16(src + 16, dst + PLANE);
+          }
+        }
+      } else if (C::RR == 1 && sh == 0 && pk_ok) {
+        // Halo rows wider than half a wave (HX = 34): one instruction per ROW uses 34 of 64 lanes and lands at unaligned LDS
+        // addresses (22 % of the LDS cycles of these kernels were bank conflicts).  The halo image is linear, so an instruction
+        // fills 64 consecutive halo voxels = one aligned KiB instead; every lane has its own source voxel, whose byte offset
+        // inside the sample was computed once per item (pk_off).
+        const int* offs = second ? pk_off1 : pk_off0;
+#pragma unroll
+        for (int m = 0; m < PKS; ++m) {
+          const int j = iw + m * INW;                          // uniform
+          if (j >= NPK) break;
+          const char* src = base + offs[m];
+          char* dst = buf + k * HALO + j * 1024;               // uniform
+          dma_count += 2;
+          if (pk_pos[m] >= 0) {
             AMX_DMA16(src, dst);
             AMX_DMA16(src + 16, dst + PLANE);
           }
