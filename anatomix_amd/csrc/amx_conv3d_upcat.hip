@@ -268,6 +268,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
 
+    act_inplace<4>(&acc[0], p.act, p.slope);
     if (OUTMODE == 0 && zo < ze && !(p.dbg & 4) && !(p.dbg & 32)) {
       // 16-bit channels-last output: the lane groups g and g ^ 1 exchange one row each (v_permlane16_swap), so that a lane
       // stores 8 consecutive channels of ONE voxel -- one 16-byte store per lane and row pair instead of two 8-byte ones.
@@ -280,9 +281,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float f = acc[2 * cp + h][j];
-            if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-            else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
-            if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
+              if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
             v[j] = f;
           }
           pk[h][0] = (unsigned)to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
@@ -302,8 +301,6 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float f = acc[c][j];
-          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
           if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[j] = f;
         }

@@ -531,6 +531,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     cu_stage = 0;
 
     // ---- item finished: activation + pack into the pending registers (stored next iteration)
+    act_inplace<CTW * Q>(&acc[0][0], p.act, p.slope);
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
@@ -540,8 +541,6 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float f = acc[c][q][j];
-          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
           if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[q * 4 + j] = f;
         }

@@ -372,6 +372,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
         while (flag_load(stored) < s + 1 - SG::NB || flag_load(stored + 1) < s + 1 - SG::NB) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
+    act_inplace<4>(&acc[0][0], p.act, p.slope);
     float pooled[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int tz = 0; tz < 2; ++tz) {
@@ -388,9 +389,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float f = acc[tz][cy][j];
-            if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-            else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
-            if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
+              if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);
             v[j] = f;
             pooled[j] = f > pooled[j] ? f : pooled[j];
           }
@@ -425,8 +424,6 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float f = acc[tz][cy][j];
-          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
           if (OUTMODE == 0 && RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
           v[j] = f;
           pooled[j] = f > pooled[j] ? f : pooled[j];

@@ -84,6 +84,25 @@ __device__ __forceinline__ void flag_store(int* p, int v) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
+// Activation of a wave's accumulators in place, under ONE uniform branch.  `p.act` is a run-time value; testing it per output value
+// (as the epilogues did) compiled to a scalar compare-and-branch chain per value -- ~120 scalar instructions per z-march step and
+// no scheduling across the values.  (A branch-free form, (f > 0 ? f : f * k) + 0 with k = 0 / slope / 1, was measured too: it
+// helps the MFMA-heavy kernels but costs 4 VALU per value, which the VALU-bound stem and the plain 16 -> 16 layer lose again.)
+template <int N>
+__device__ __forceinline__ void act_inplace(f32x4* a, int act, float slope) {
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[i][j] = a[i][j] > 0.f ? a[i][j] : 0.f;
+  } else if (act == ACT_LRELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[i][j] = a[i][j] > 0.f ? a[i][j] : a[i][j] * slope;
+  }
+}
+
 // LDS-DMA of 16 bytes per lane, written as inline asm: lane l's 16 bytes land at lds_base + 16 l (lds_base wave-uniform).
 // Why not the builtin: with a builtin LDS-DMA pending in a wave hipcc falls back to `s_waitcnt lgkmcnt(0)` for every LDS read of
 // that wave (no counted waits), which exposes the read latency in an MFMA sweep that runs beside its own prefetch.  The caller
