@@ -148,51 +148,72 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
 #pragma unroll
     for (int e = 0; e < 3; ++e) be[e] = g < 3 ? own : sl[e] + lanepos + ((2 * HX + 2) - ((e / 3) * HX + e % 3)) * 4;
 
+    // Three phases without control flow between the tiles (the step used to be a chain of tile-after-tile basic blocks: per-value
+    // activation branches, per-tile ablation tests -- ~650 instructions per four MFMAs, nothing overlapped): gather all tiles'
+    // operands, multiply, activate every accumulator under one branch; only the stores are predicated.
+    vec8 bf[CTW], bl[SPLIT ? CTW : 1];
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
       const int cx = c % XT, cy = c / XT;
       const int toff = (cy * HX + cx * 16) * 4;
-      vec8 bf, bl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int imm = ((e / 3) * HX + e % 3) * 4 + toff;
         const float f = *(const float*)(smem + (e < 3 ? be[e] : own) + imm);
-        bf[e] = (T)f;
-        if (SPLIT) bl[e] = (T)(f - (float)bf[e]);
+        bf[c][e] = (T)f;
+        if (SPLIT) bl[SPLIT ? c : 0][e] = (T)(f - (float)bf[c][e]);
       }
-      float v[4 * Q];
+    }
+    f32x4 acc[CTW][Q];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        f32x4 acc = bias[q];
-        if (!(p.dbg & 2)) acc = Ops<T>::mfma(wreg[q], bf, acc);
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc[c][q] = bias[q];
+    if (!(p.dbg & 2)) {
+#pragma unroll
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          acc[c][q] = Ops<T>::mfma(wreg[q], bf[c], acc[c][q]);
+          if (SPLIT) {
+            acc[c][q] = Ops<T>::mfma(wreg[q], bl[SPLIT ? c : 0], acc[c][q]);
+            acc[c][q] = Ops<T>::mfma(wlo[q], bf[c], acc[c][q]);
+          }
+        }
+    }
+    act_inplace<CTW * Q>(&acc[0][0], p.act, p.slope);
+    if (RangeCheck<T>::on) {
+#pragma unroll
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bad |= RangeCheck<T>::bad(acc[c][q][j]);   // the values about to be stored
+    }
+    if (zo < ze && !(p.dbg & 4)) {
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = c / XT;
+        if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
+        char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
+        float v[4 * Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[q * 4 + j] = acc[c][q][j];
+        unsigned w[2 * Q];
+#pragma unroll
+        for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+        if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
+        else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
         if (SPLIT) {
-          acc = Ops<T>::mfma(wreg[q], bl, acc);
-          acc = Ops<T>::mfma(wlo[q], bf, acc);
+#pragma unroll
+          for (int j = 0; j < 2 * Q; ++j)
+            w[j] = (unsigned)to_bits<T>(v[2 * j] - (float)(T)v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1] - (float)(T)v[2 * j + 1]) << 16);
+          char* dlo = dst + p.Cout * 2;
+          if (Q == 1) *(uint2*)dlo = make_uint2(w[0], w[1]);
+          else *(uint4*)dlo = make_uint4(w[0], w[1], w[2], w[3]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float f = acc[j];
-          if (p.act == ACT_RELU) f = f > 0.f ? f : 0.f;
-          else if (p.act == ACT_LRELU) f = f > 0.f ? f : f * p.slope;
-          if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(f);   // the value about to be stored
-          v[q * 4 + j] = f;
-        }
-      }
-      if (zo >= ze || (p.dbg & 4)) continue;
-      if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
-      char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
-      unsigned w[2 * Q];
-#pragma unroll
-      for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
-      if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
-      else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
-      if (SPLIT) {
-#pragma unroll
-        for (int j = 0; j < 2 * Q; ++j)
-          w[j] = (unsigned)to_bits<T>(v[2 * j] - (float)(T)v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1] - (float)(T)v[2 * j + 1]) << 16);
-        char* dlo = dst + p.Cout * 2;
-        if (Q == 1) *(uint2*)dlo = make_uint2(w[0], w[1]);
-        else *(uint4*)dlo = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
