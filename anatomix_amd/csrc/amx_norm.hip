@@ -162,8 +162,7 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * q[2 * e] + q[2 * e + 1];
-      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      v = act_fwd(v, act_k(act, slope));
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
@@ -200,8 +199,7 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * a[e] + b[e];
-      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      v = act_fwd(v, act_k(act, slope));
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
@@ -313,8 +311,7 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
-      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      v = act_fwd(v, act_k(act, slope));
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }

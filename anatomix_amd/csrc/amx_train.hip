@@ -173,8 +173,7 @@ __global__ void bn_apply_kernel(const char* __restrict__ x, char* __restrict__ y
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * ab[2 * (c8 * 8 + e)] + ab[2 * (c8 * 8 + e) + 1];
-      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      v = act_fwd(v, act_k(act, slope));
       f[e] = v;
     }
     *(uint4*)(y + idx * 16) = t_pack8<T>(f);
@@ -200,8 +199,7 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const char* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * a[e] + b[e];
-      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * slope;
+      v = act_fwd(v, act_k(act, slope));
       f[e] = v;
     }
     *(uint4*)(y + idx * 16) = t_pack8<T>(f);
@@ -237,8 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restric
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float dz = g[e];
-        if (act == ACT_RELU) dz = yy[e] > 0.f ? dz : 0.f;
-        else if (act == ACT_LRELU) dz = yy[e] > 0.f ? dz : dz * slope;
+        dz = act_bwd(dz, yy[e], act_k(act, slope));
         s1[e] += dz;
         s2[e] += dz * (xx[e] - mu[e]) * rs[e];
       }
@@ -322,8 +319,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float dz = g[e];
-      if (act == ACT_RELU) dz = yv[e] > 0.f ? dz : 0.f;
-      else if (act == ACT_LRELU) dz = yv[e] > 0.f ? dz : dz * slope;
+      dz = act_bwd(dz, yv[e], act_k(act, slope));
       const float* q = coef + 3 * (c8 * 8 + e);
       g[e] = mean ? q[0] * dz + q[1] * xv[e] + q[2] : dz;
     }
