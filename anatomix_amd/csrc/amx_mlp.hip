@@ -37,10 +37,8 @@ __device__ __forceinline__ void block_sums(float (&v)[NV], float* red) {
   for (int c = 0; c < NV; ++c) v[c] = ((red[c] + red[NV + c]) + red[2 * NV + c]) + red[3 * NV + c];
 }
 
-__device__ __forceinline__ float act_grad(float y, int act, float slope) {
-  if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
-  if (act == ACT_LRELU) return y > 0.f ? 1.f : slope;
-  return 1.f;
+__device__ __forceinline__ float act_grad(float y, int act, float slope) {   // branch-free: one select on a per-kernel constant
+  return y > 0.f ? 1.f : act_k(act, slope);
 }
 
 // BatchNorm1d with batch statistics over the n rows of z [n][m] + activation; a block owns 8 columns for all rows, so the
@@ -106,9 +104,7 @@ __global__ __launch_bounds__(256) void mlp_bn_fwd_kernel(const float* __restrict
     for (int c = 0; c < MLP_CB; ++c) {
       float o = (v[i][c] - mu[c]) * q[c];
       if (gamma) o = o * gamma[j0 + c] + beta[j0 + c];
-      if (act == ACT_RELU) o = o > 0.f ? o : 0.f;
-      else if (act == ACT_LRELU) o = o > 0.f ? o : o * slope;
-      yo[c] = o;
+      yo[c] = act_fwd(o, act_k(act, slope));
     }
     float4* yp = (float4*)(y + (size_t)r * m + j0);
     yp[0] = make_float4(yo[0], yo[1], yo[2], yo[3]);
