@@ -613,7 +613,7 @@ bool conv_zmarch_can_pool(const ConvParams& p) {
 bool conv_zmarch_eligible_split(const ConvParams& p) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_ZMARCH_SPLIT") ? 1 : 0;
-  return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16 && !p.out2 && !p.wmap;
+  return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16 && !p.out2;
 }
 
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
