@@ -316,12 +316,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     t_unpack8<T>(*(const uint4*)(dy + in_off + (size_t)i * 16), g);
     t_unpack8<T>(*(const uint4*)(y + in_off + (size_t)i * 16), yv);
     if (mean) t_unpack8<T>(*(const uint4*)(x + in_off + (size_t)i * 16), xv);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = 0.f;              // bare activation adjoint: coefficients are (1, 0, 0)
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float dz = g[e];
-      dz = act_bwd(dz, yv[e], act_k(act, slope));
+      const float dz = act_bwd(g[e], yv[e], act_k(act, slope));
       const float* q = coef + 3 * (c8 * 8 + e);
-      g[e] = mean ? q[0] * dz + q[1] * xv[e] + q[2] : dz;
+      g[e] = q[0] * dz + q[1] * xv[e] + q[2];               // no per-element test of `mean`
     }
     *(uint4*)(dxf + out_off + (size_t)i * 16) = t_pack8<T>(g);     // i = x * c8n + c8: the row is contiguous in the frame too
   }
