@@ -39,7 +39,7 @@ size_t attention_scratch_bytes(int b, int heads, int n);
 hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
                             const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
                             float* out, void* scratch, hipStream_t st);
-hipError_t launch_poison_if_flag(const int* flag, float* y, long long count, hipStream_t st);
+hipError_t launch_poison_if_flag(const int* flag, int* host_flag, float* y, long long count, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
                                       hipStream_t st);
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
@@ -139,7 +139,8 @@ struct amx_unet {
   std::vector<int> mod_c, mod_level;  // per module: channels / resolution level of `feat` after it (post-concat for Upsample)
   int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
   int* d_flag = nullptr;    // device: raised by any epilogue that was about to store a value outside the f16 range (or NaN)
-  int* h_flag = nullptr;    // pinned host mirror, refreshed by an async copy at the end of every forward
+  int* h_flag = nullptr;    // pinned host mirror, written by the last kernel of a forward when the device flag is up
+  int* h_flag_dev = nullptr;   // the same memory as the device sees it
   hipEvent_t acc_done[2] = {nullptr, nullptr};   // amx_unet_forward_windows_pipelined: "slot s has finished accumulating"
 };
 
@@ -645,9 +646,10 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
   if (rc == AMX_OK && f16_storage && h->d_flag) {
     // the output tensor (plain forward: dense [n][Cout][d][hh][w]; windows: the accumulation volume is the caller's, its
     // extent is not known here -- the flag and the status call cover that path) is poisoned when the flag is up
-    if (!wmap && !x_offs && !(taps && taps->stop >= 0))
-      AMX_HIP(amx::launch_poison_if_flag(h->d_flag, y, (long long)n * h->cfg.output_nc * d * hh * w, st));
-    AMX_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    const bool poison = !wmap && !x_offs && !(taps && taps->stop >= 0);
+    AMX_HIP(amx::launch_poison_if_flag(h->d_flag, h->h_flag_dev, poison ? y : nullptr,
+                                       poison ? (long long)n * h->cfg.output_nc * d * hh * w : 0, st));
+    if (!h->h_flag_dev) AMX_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));   // unmapped host memory
   }
   return rc;
 }
@@ -718,6 +720,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     return fail(AMX_ERR_HIP, "hipMalloc (status flag): %s", hipGetErrorString(e));
   }
   *h->h_flag = 0;
+  if (hipHostGetDevicePointer((void**)&h->h_flag_dev, h->h_flag, 0) != hipSuccess) h->h_flag_dev = nullptr;
   *out = h;
   return AMX_OK;
 }

@@ -387,14 +387,20 @@ __global__ void import_ncdhw_kernel(const float* __restrict__ src, char* __restr
 
 // Last launch of a forward: if any epilogue raised the range flag, the network output is overwritten with NaN -- the
 // features a caller holds after an f16 overflow are unmistakably invalid, whatever the caller does with status codes.
-__global__ void poison_if_flag_kernel(const int* __restrict__ flag, float* __restrict__ y, long long count) {
+__global__ void poison_if_flag_kernel(const int* __restrict__ flag, int* host_flag, float* __restrict__ y, long long count) {
   if (*flag == 0) return;
+  // the host-visible mirror (pinned, mapped memory) is written from here: no device-to-host copy per forward on the stream
+  if (host_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    __atomic_store_n(host_flag, 1, __ATOMIC_RELAXED);
+    __threadfence_system();
+  }
   const float nan = __builtin_nanf("");
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) y[i] = nan;
 }
 
-hipError_t launch_poison_if_flag(const int* flag, float* y, long long count, hipStream_t st) {
-  hipLaunchKernelGGL(poison_if_flag_kernel, dim3(2048), dim3(256), 0, st, flag, y, count);
+// y == nullptr / count == 0: only mirror the flag (paths whose output extent the library does not know)
+hipError_t launch_poison_if_flag(const int* flag, int* host_flag, float* y, long long count, hipStream_t st) {
+  hipLaunchKernelGGL(poison_if_flag_kernel, dim3(count > 0 ? 512 : 1), dim3(256), 0, st, flag, host_flag, y, count);
   return hipGetLastError();
 }
 
