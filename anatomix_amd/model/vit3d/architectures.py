@@ -70,22 +70,33 @@ class LayerNormNd(nn.Module):
         return torch.addcmul(self.bias.view(shape), (x - u) * torch.rsqrt(s + self.eps), self.weight.view(shape))
 
 
+# spelling -> canonical name of the output normalisation (the strings are the reference's interface, architectures.py:55-86)
+_OUT_NORM_ALIASES = {
+    **dict.fromkeys(("none", "identity", "off"), "none"),
+    **dict.fromkeys(("instance", "instancenorm", "in"), "instance"),
+    **dict.fromkeys(("demean", "center"), "demean"),
+    **dict.fromkeys(("layernorm", "layer", "ln"), "layernorm"),
+    **dict.fromkeys(("layernorm_affine", "layernorm-affine", "ln_affine"), "layernorm_affine"),
+}
+_OUT_NORM_FACTORY = {
+    "none": lambda c, eps: nn.Identity(),
+    "instance": lambda c, eps: nn.InstanceNorm3d(c, eps=eps, affine=False),
+    "demean": lambda c, eps: ChannelDemean(),
+    "layernorm": lambda c, eps: ChannelLayerNorm(eps=eps),
+    "layernorm_affine": lambda c, eps: LayerNormNd(c, eps=eps),
+}
+
+
 def build_out_norm(mode, num_classes, eps):
-    """architectures.py:55-86."""
+    """Output normalisation selected by name; a bool means instance norm on / off, ``None`` means none (architectures.py:55-86)."""
     if isinstance(mode, bool):
-        mode = "instance" if mode else "none"
-    mode = (mode or "none").lower()
-    if mode in ("none", "identity", "off"):
-        return nn.Identity()
-    if mode in ("instance", "instancenorm", "in"):
-        return nn.InstanceNorm3d(num_classes, eps=eps, affine=False)
-    if mode in ("demean", "center"):
-        return ChannelDemean()
-    if mode in ("layernorm", "layer", "ln"):
-        return ChannelLayerNorm(eps=eps)
-    if mode in ("layernorm_affine", "layernorm-affine", "ln_affine"):
-        return LayerNormNd(num_classes, eps=eps)
-    raise ValueError(f"unsupported output normalization: {mode!r}")
+        key = "instance" if mode else "none"
+    else:
+        key = str(mode).lower() if mode else "none"          # None / "" select no normalisation
+    try:
+        return _OUT_NORM_FACTORY[_OUT_NORM_ALIASES[key]](num_classes, eps)
+    except KeyError:
+        raise ValueError(f"unsupported output normalization: {mode!r}") from None
 
 
 class _ConvNormAct(nn.Module):
