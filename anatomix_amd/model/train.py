@@ -7,7 +7,7 @@ blocks, max-pools and the upsample + concat convs through the library's single-o
 (``anatomix_amd.model.train_ops``), keeps what the adjoint needs (raw conv outputs, activations, batch statistics) in
 16-bit channels-last tensors, and the backward walks the blocks in reverse: activation/BatchNorm adjoint -> weight
 gradient (MFMA kernel) -> data gradient (forward kernel on the zero-framed gradient with flipped weights + reflect fold)
--> max-pool / upsample / concat adjoints.  Storage precision is ``model.precision`` ("bf16" mirrors the reference's
+-> max-pool / upsample / concat adjoints.  Storage precision is ``model.train_precision`` (``model.precision`` when set explicitly, else "bf16": "bf16" mirrors the reference's
 bf16 autocast); parameter gradients and BatchNorm statistics are fp32.
 
 Supported configuration: norm 'batch' (batch statistics + running-stat update; layers in eval mode use their frozen
@@ -37,9 +37,9 @@ def _side_stream(device):
 
 def unsupported_reason(model, x, layers):
     c = model._cfg
-    if model.precision not in _DT:
+    if model.train_precision not in _DT:
         return (f"the HIP training path stores activations in f16 / bf16 (the reference trains under bf16 autocast); "
-                f"precision '{model.precision}' is an inference mode")
+                f"precision '{model.train_precision}' is an inference mode")
     if c["dimension"] != 3 or c["pad_type"] != "reflect" or c["residual_connection"]:
         return "only dimension=3, pad_type='reflect', residual_connection=False are implemented"
     if c["norm"] not in ("batch", "instance", "instance_affine") or c["activation"] not in ("relu", "lrelu") or c["final_act"] != "none":
@@ -100,7 +100,7 @@ def _to_ncdhw(t):             # 16-bit NDHWC -> fp32 NCDHW
 class _UnetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, layers, *params):
-        dt = _DT[model.precision]
+        dt = _DT[model.train_precision]
         act = model._cfg["activation"]
         trilinear = model._cfg["interp"] == "trilinear"
         kinds = _module_kinds(model)

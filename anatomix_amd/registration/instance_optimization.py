@@ -23,8 +23,11 @@ def _fill_outside_mask(img, mask_vol):
     _, idx = edt((mask[0, 0, ::2, ::2, ::2] == 0).squeeze().cpu().numpy(), return_indices=True)
     idx = [torch.from_numpy(i).to(img.device).long() for i in idx]
     sub = img[..., ::2, ::2, ::2].reshape(-1)
-    filled = F.interpolate(sub[idx[0] * (d // 2) * (w // 2) + idx[1] * (d // 2) + idx[2]].unsqueeze(0).unsqueeze(0),
-                           scale_factor=2, mode="trilinear")
+    # flat index into the subsampled volume with the reference's own integer arithmetic (left to right: ((i0*D)//2*W)//2, :71);
+    # equal to i0*(D/2)*(W/2) + i1*(D/2) + i2 on even extents.  An odd extent does not survive the subsample / x2 round trip: the
+    # masked assignment below then raises IndexError, as the reference does (fixture flag `odd_dim_raises`).
+    flat = idx[0] * d // 2 * w // 2 + idx[1] * d // 2 + idx[2]
+    filled = F.interpolate(sub[flat].unsqueeze(0).unsqueeze(0), scale_factor=2, mode="trilinear")
     keep = mask.view(-1) != 0
     filled.view(-1)[keep] = img.reshape(-1)[keep]
     return filled

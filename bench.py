@@ -470,7 +470,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
                        "128^3 volumes/sec feature-extraction (%s)" % ("6M UNet" if variant == "anatomix" else
                                                                       ("26M 3D ViT" if vit else "94M dev UNet"))),
             "value": round(value, 2), "unit": "volumes/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
+            "n_gpus": world, "ranks_seen": getattr(ctx, "ranks_seen", 1), "devices": getattr(ctx, "devices", None),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong" if sw_volume else "weak", "vs_baseline": None,
             "dtype": "bf16" if workload == "step" else ("f16 attention / f32 linears" if vit else
                                                         ("bf16x2" if precision == "strict" else precision)),
@@ -532,16 +533,18 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if args.dry_run:
+        seen = 1
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
             t = torch.ones(1)
             dist.all_reduce(t)
-            assert int(t.item()) == world
+            seen = int(t.item())
+            assert seen == world
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup}))
+            print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "volumes/s", "n_gpus": world, "ranks_seen": seen,
+                              "steps": args.steps, "warmup": args.warmup}))
         return
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if world > 1 and torch.cuda.device_count() < world:
@@ -555,6 +558,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=ctx.dev)
+    # auditability of the N-rank line: every rank adds a one over RCCL (ranks_seen must equal n_gpus) and reports its device
+    ctx.ranks_seen, ctx.devices = 1, [f"cuda:{ctx.dev.index} {torch.cuda.get_device_name(ctx.dev)}"]
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int32, device=ctx.dev)
+        dist.all_reduce(ones)
+        ctx.ranks_seen = int(ones.item())
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{ctx.dev.index} {torch.cuda.get_device_name(ctx.dev)} "
+                                      f"(uuid {getattr(torch.cuda.get_device_properties(ctx.dev), 'uuid', 'n/a')})")
+        ctx.devices = names
 
     result = run_workload(ctx, variant=args.variant, workload=args.workload, sw_volume=args.sw_volume, precision=args.precision,
                           steps=args.steps, warmup=args.warmup, batch=args.batch, size=args.size, no_graph=args.no_graph,

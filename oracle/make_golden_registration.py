@@ -22,14 +22,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import registration_ref as RR                  # noqa: E402
-from oracle.registration_inputs import CASES, inputs      # noqa: E402
+from oracle.registration_inputs import CASES, MASK_CASES, inputs, mask_inputs      # noqa: E402
 
 REF = "/root/reference/anatomix/registration"
 
 
 def reference_functions():
     torch.Tensor.cuda = lambda self, *a, **k: self        # noqa: E731  generator-only shim
-    ns = {"torch": torch, "nn": nn, "F": F, "np": np}
+    nn.Module.cuda = lambda self, *a, **k: self           # noqa: E731  (merge_features builds its pooling module with .cuda())
+    from scipy.ndimage import distance_transform_edt
+    ns = {"torch": torch, "nn": nn, "F": F, "np": np, "edt": distance_transform_edt}
     wanted = {"convex_adam_utils.py": {"pdist_squared", "MINDSSC", "apply_avg_pool3d", "correlate"},
               "instance_optimization.py": {"merge_features"}}
     for fname, names in wanted.items():
@@ -44,6 +46,35 @@ def reference_functions():
 def probes(rs, arr, n=4096):
     idx = rs.randint(0, arr.size, n).astype(np.int64)
     return idx, arr.reshape(-1)[idx].astype(np.float32)
+
+
+def masked_merge_golden(ref):
+    """merge_features(use_mask=True) (instance_optimization.py:52-97) -> tests/golden/merge_masked_golden.npz: the full
+    12-channel MIND-SSC of the mask-filled images and the masked network features, for both volumes."""
+    out = {}
+    for case in MASK_CASES:
+        img_f, img_m, feat_f, feat_m, mask_f, mask_m = mask_inputs(case)
+        tf = lambda a: torch.from_numpy(a.copy())          # noqa: E731
+        with torch.no_grad():
+            mf, mm, cat_f, cat_m = ref["merge_features"](True, tf(feat_f)[None], tf(feat_m)[None], tf(mask_f), tf(mask_m),
+                                                         tf(img_f)[None, None], tf(img_m)[None, None])
+        assert cat_f.shape[1] == 12 + feat_f.shape[0]
+        out[f"{case}|mind_fixed"], out[f"{case}|mind_moving"] = mf[0].numpy(), mm[0].numpy()
+        out[f"{case}|pred_fixed"], out[f"{case}|pred_moving"] = cat_f[0, 12:].numpy(), cat_m[0, 12:].numpy()
+        print(case, "masked merge_features", tuple(cat_f.shape), "mind mean", float(mf.mean()))
+    # an odd extent does not survive the reference's subsample / x2 interpolate round trip: record that it raises
+    img = np.random.RandomState(3).rand(10, 12, 13).astype(np.float32)
+    msk = np.ones_like(img)
+    try:
+        ref["merge_features"](True, torch.zeros(1, 2, 10, 12, 13), torch.zeros(1, 2, 10, 12, 13), torch.from_numpy(msk),
+                              torch.from_numpy(msk), torch.from_numpy(img)[None, None], torch.from_numpy(img)[None, None])
+        out["odd_dim_raises"] = np.array(0)
+    except Exception as e:                                  # noqa: BLE001
+        print("odd extent:", type(e).__name__, str(e)[:80])
+        out["odd_dim_raises"] = np.array(1)
+    path = os.path.join(ROOT, "tests", "golden", "merge_masked_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 def main():
@@ -105,6 +136,7 @@ def main():
             e = float(np.abs(RR.box_filter(x, k, rep) - y).max())
             worst = max(worst, e)
             out[f"{case}|box{k}x{rep}|idx"], out[f"{case}|box{k}x{rep}|val"] = probes(rs, y, 1024)
+    masked_merge_golden(ref)
     print("worst oracle-vs-reference deviation", worst)
     assert worst < 2e-5
     path = os.path.join(ROOT, "tests", "golden", "registration_golden.npz")

@@ -36,3 +36,22 @@ def hash_name(s):
     for ch in s:
         v = (v * 131 + ord(ch)) & 0x7FFFFFFF
     return v
+
+
+# masked merge_features cases (instance_optimization.py:52-97): case -> (H, W, D, feature channels); even dims (the reference's
+# 2x subsample + trilinear x2 round trip only closes on even dims)
+MASK_CASES = {"mask_even": (20, 24, 28, 4), "mask_cube": (16, 16, 16, 2)}
+
+
+def mask_inputs(case):
+    """(img_f, img_m, feat_f, feat_m, mask_f, mask_m): float32 0/1 ellipsoid masks that leave a margin on every side."""
+    h, w, d, c = MASK_CASES[case]
+    rs = np.random.RandomState(abs(hash_name(case)) % (1 << 31))
+    img_f = _smooth(rs, (h, w, d))
+    img_m = (0.6 * np.roll(img_f, (1, 2, -1), (0, 1, 2)) + 0.4 * _smooth(rs, (h, w, d))).astype(np.float32)
+    feat_f = rs.randn(c, h, w, d).astype(np.float32)
+    feat_m = rs.randn(c, h, w, d).astype(np.float32)
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, h), np.linspace(-1, 1, w), np.linspace(-1, 1, d), indexing="ij")
+    mask_f = ((zz / 0.8) ** 2 + (yy / 0.7) ** 2 + (xx / 0.75) ** 2 < 1).astype(np.float32)
+    mask_m = (((zz - 0.1) / 0.7) ** 2 + (yy / 0.8) ** 2 + ((xx + 0.05) / 0.8) ** 2 < 1).astype(np.float32)
+    return img_f, img_m, feat_f, feat_m, mask_f, mask_m

@@ -18,7 +18,7 @@ def test_bench_self_launches_its_ranks():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["ranks_seen"] == 2
 
 
 def test_bench_under_an_external_launcher():
@@ -28,4 +28,4 @@ def test_bench_under_an_external_launcher():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2

@@ -54,3 +54,30 @@ def test_correlate_finds_a_pure_shift():
     k = 3
     want = ((-1 + 1) * k + (0 + 1)) * k + (1 + 1)         # (dx * k + dy) * k + dz with dz = +1, dy = 0, dx = -1
     assert (amin[3:-3, 3:-3, 3:-3] == want).all()
+
+
+# ---- merge_features(use_mask=True): the distance-transform fill is host logic of the mirror (anatomix_amd/registration/
+#      instance_optimization.py); MIND-SSC of the filled image through the oracle must reproduce the reference's descriptors
+GM = np.load(os.path.join(os.path.dirname(__file__), "golden", "merge_masked_golden.npz"))
+
+
+@pytest.mark.parametrize("case", ["mask_even", "mask_cube"])
+def test_masked_fill_matches_reference_fixture(case):
+    import torch
+    from anatomix_amd.registration.instance_optimization import _fill_outside_mask
+    from oracle.registration_inputs import mask_inputs
+    img_f, img_m, feat_f, feat_m, mask_f, mask_m = mask_inputs(case)
+    for img, mask, tag in ((img_f, mask_f, "fixed"), (img_m, mask_m, "moving")):
+        filled = _fill_outside_mask(torch.from_numpy(img)[None, None], torch.from_numpy(mask))
+        assert filled.shape == (1, 1) + img.shape
+        mind = RR.mindssc(filled[0, 0].numpy(), 1, 2)
+        assert np.abs(mind - GM[f"{case}|mind_{tag}"]).max() < 5e-6
+    assert int(GM["odd_dim_raises"]) == 1
+
+
+def test_masked_fill_refuses_odd_extents_like_the_reference():
+    import torch
+    from anatomix_amd.registration.instance_optimization import _fill_outside_mask
+    img = torch.rand(1, 1, 10, 12, 13)
+    with pytest.raises(IndexError):
+        _fill_outside_mask(img, torch.ones(10, 12, 13))

@@ -151,3 +151,21 @@ def test_stage1_inputs_composition():
     want_idx = ((-1 + 1) * 3 + (0 + 1)) * 3 + (1 + 1)
     inner = res["ssd_argmin"][8:-8, 8:-8, 8:-8]
     assert (inner == want_idx).float().mean().item() > 0.9
+
+
+@pytest.mark.parametrize("case", ["mask_even", "mask_cube"])
+def test_masked_merge_features_matches_reference_fixture(case):
+    """merge_features(use_mask=True) (instance_optimization.py:52-97): distance-transform fill outside the eroded mask, MIND-SSC
+    of the filled images on the HIP kernel, network features zeroed outside the mask -- against the reference's own outputs
+    (oracle/make_golden_registration.py -> tests/golden/merge_masked_golden.npz)."""
+    from anatomix_amd.registration import merge_features
+    from oracle.registration_inputs import mask_inputs
+    gm = np.load(os.path.join(os.path.dirname(__file__), "golden", "merge_masked_golden.npz"))
+    img_f, img_m, feat_f, feat_m, mask_f, mask_m = mask_inputs(case)
+    mf, mm, cat_f, cat_m = merge_features(True, cu(feat_f)[None], cu(feat_m)[None], cu(mask_f), cu(mask_m),
+                                          cu(img_f)[None, None], cu(img_m)[None, None])
+    assert cat_f.shape[1] == 12 + feat_f.shape[0] and torch.equal(cat_f[:, :12], mf) and torch.equal(cat_m[:, :12], mm)
+    assert np.abs(mf[0].cpu().numpy() - gm[f"{case}|mind_fixed"]).max() < 5e-6
+    assert np.abs(mm[0].cpu().numpy() - gm[f"{case}|mind_moving"]).max() < 5e-6
+    assert np.array_equal(cat_f[0, 12:].cpu().numpy(), gm[f"{case}|pred_fixed"])
+    assert np.array_equal(cat_m[0, 12:].cpu().numpy(), gm[f"{case}|pred_moving"])

@@ -78,3 +78,21 @@ def test_two_window_batches_in_flight_give_identical_sums(device):
         for _ in range(3):
             got = sliding_window_inference(x, (64, 64, 64), 2, m, **kw)
             assert torch.equal(got, want)
+
+
+def test_real_operating_point_roi128_overlap08_matches_cpu_oracle(device):
+    """The reference's own configuration (convex_adam_utils.py:202-219: roi 128^3, overlap 0.8 -> scan interval 25, gaussian
+    sigma_scale 0.25) on a 128 x 128 x 160 volume = 3 windows (x starts 0, 25, 32), fused HIP path vs the numpy oracle driving
+    the fp32 CPU network.  f16 storage (the default of this variant): <= 1e-3 rel-L2."""
+    m, sd = _model(device)
+    vol = np.random.RandomState(8).rand(1, 128, 128, 160).astype(np.float32)
+    starts = window_starts((128, 128, 160), (128, 128, 128), 0.8)
+    assert [tuple(s) for s in starts] == [(0, 0, 0), (0, 0, 25), (0, 0, 32)]
+    with torch.no_grad():
+        x = torch.from_numpy(vol)[None].to(device)
+        assert _fused_ok(m, x)
+        got = sliding_window_inference(x, (128, 128, 128), 2, m, overlap=0.8, mode="gaussian", sigma_scale=0.25).cpu()[0]
+        torch.set_num_threads(16)
+        ref = O.sliding_window(vol, (128, 128, 128), lambda a: R.forward(torch.from_numpy(a), sd, KW).numpy(), 0.8, "gaussian", 0.25)
+    assert got.shape == (16, 128, 128, 160) and torch.isfinite(got).all()
+    assert rel_l2(got, torch.from_numpy(ref)) <= 1e-3

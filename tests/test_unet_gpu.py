@@ -37,19 +37,25 @@ def test_forward_matches_emulated_oracle(device, size, n, gain):
         ref = R.forward_lowp(x, sd, KW, torch.float16)
     assert y.shape == ref.shape and y.dtype == torch.float32
     assert torch.isfinite(y).all()
-    assert rel_l2(y, ref) < (1e-3 if gain == 1.0 else 4e-3), (rel_l2(y, ref), max_rel(y, ref))
+    # kernel-vs-emulation distance (same rounding points; the rest is accumulation order + 1-ulp storage flips that the deeper
+    # layers amplify), NOT the precision claim: 4.6e-4 at gain 1, 1.6e-3 .. 1.8e-3 on He-scaled weights, where f16 storage itself
+    # is 1.9e-3 from fp32 -- outside the tolerance, which is why He-scaled checkpoints belong to `precision = "strict"`
+    assert rel_l2(y, ref) < (1e-3 if gain == 1.0 else 2.5e-3), (rel_l2(y, ref), max_rel(y, ref))
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_forward_f16_meets_1e3_vs_fp32_oracle(device, seed):
-    """north_star: feature maps within 1e-3 (relative) of the fp32 reference."""
+    """north_star: feature maps within 1e-3 (relative) of the fp32 reference -- held in the rel-L2 sense with f16 storage on all
+    four weight seeds (measured 5.1e-4 .. 6.7e-4, tools/tol_probe.py).  The worst single voxel relative to the largest feature
+    (max-norm) is 8e-4 .. 1.4e-3 over the same seeds: f16 storage does NOT hold 1e-3 in the max-norm on every seed -- the bound
+    below is what it does hold; `precision = "strict"` holds both norms with >= 60x margin (tests/test_strict_precision_gpu.py)."""
     m, sd = _model(device, seed, 1.0)
     x = R.synthetic_input(100 + seed, 1, (64, 64, 64))
     with torch.no_grad():
         y = m(x.to(device)).cpu()
         ref = R.forward(x, sd, KW)
     assert rel_l2(y, ref) <= 1e-3, rel_l2(y, ref)
-    assert max_rel(y, ref) <= 2e-3, max_rel(y, ref)
+    assert max_rel(y, ref) <= 1.5e-3, max_rel(y, ref)
 
 
 def test_forward_bf16_mode_runs_and_is_bf16_accurate(device):
@@ -161,7 +167,7 @@ def test_small_volumes_and_wide_outputs(device, kw, size):
         y = m(x.to(device)).cpu()
         ref = R.forward(x, sd, kw)
     assert y.shape == ref.shape
-    assert rel_l2(y, ref) < 1.5e-3, rel_l2(y, ref)
+    assert rel_l2(y, ref) <= 1e-3, rel_l2(y, ref)
 
 
 def test_forward_is_hip_graph_capturable(device):
