@@ -61,6 +61,8 @@ SYMBOLS = {
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
     "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_conv3d_upcat_merged_packed_bytes": (C.c_size_t, [_I, _I, _I]),
+    "amx_conv3d_upcat_merged": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "amx_conv3d_k3_reflect_ex": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "amx_pool2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_instance_norm_scratch_bytes": (C.c_size_t, [_I, _I]),

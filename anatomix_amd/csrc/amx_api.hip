@@ -13,7 +13,13 @@
 namespace amx {
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st);
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0);
+                               int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0);
+size_t conv_upmerge_packed_bytes(int C1, int Cout);
+bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift);
+hipError_t launch_conv_upmerge(const UpmergeParams& p, int precision, hipStream_t st);
+hipError_t launch_pack_upmerge(const float* w, const float* scale, void* wpk, int c_off, int CinTotal, int C1, int Cout, int precision,
+                               hipStream_t st);
+const char* last_conv_upmerge_kernel_name();
 hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
                             const float* conv_bias, float eps, int C, float* scale, float* shift,
                             hipStream_t st);
@@ -119,6 +125,9 @@ struct ConvLayer {
   int cin_pad = 0;
   void* wpk = nullptr;    // packed A fragments
   void* wpk_up = nullptr; // second packing for the 16+32 -> 16 merged-tap kernel (amx_conv3d_upcat.hip)
+  bool after_up = false;  // first conv of a decoder block: its input is cat(skip [cout channels], upsample(low [cin - cout]))
+  void* wpk_skip = nullptr;   // wider concat layers, nearest upsample: 27-tap packing of the skip channels only ...
+  void* wpk_merge = nullptr;  // ... and the merged-tap packing of the upsampled channels (amx_conv3d_upmerge.hip)
   float* in_gamma = nullptr;  // InstanceNorm3d(affine=True) weight / bias of the norm that follows (else null)
   float* in_beta = nullptr;
   float* scale = nullptr; // folded norm gain (applied to the weights at pack time)
@@ -189,6 +198,7 @@ void build_plan(amx_unet* h) {
     const int m = c.use_skip ? mult + mult / 2 : mult;
     const int level = c.num_downs - 1 - i;
     add_block(c.ngf * m, c.ngf * (mult / 2), level);
+    h->convs.back().after_up = c.use_skip != 0;
     if (c.doubleconv) add_block(c.ngf * (mult / 2), c.ngf * (mult / 2), level);
     mult /= 2;
   }
@@ -466,6 +476,27 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
       const bool use_upcat = !split && !p.src0_f32c1 && !raw_bn && L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p);
       if (use_upcat) p.wpk = (const char*)L.wpk_up;
+      // wider concat layers: the ordinary convolution over the skip channels first (raw partial sums into a free slot of this
+      // level), then the merged-tap convolution over the upsampled channels, which adds them, the bias and the activation
+      const bool use_merge = !use_upcat && !split && !raw_bn && L.wpk_merge && have_cur_up && have_skip && !cur_is_full_up && !L.is_final &&
+                             p.C0 == L.cout && amx::conv_upmerge_eligible(p.C0, p.C1, L.cout, dd, dh, dw, p.up_shift);
+      int p_slot = -1;
+      amx::UpmergeParams u;
+      memset(&u, 0, sizeof u);
+      if (use_merge) {
+        p_slot = grab(lv);
+        if (p_slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
+        u.src = p.src1; u.sn = p.s1n; u.sz = p.s1z; u.sy = p.s1y; u.sx = p.s1x; u.C1 = p.C1;
+        u.N = n; u.LD = dd / 2; u.LH = dh / 2; u.LW = dw / 2; u.Cout = L.cout;
+        u.wpk = (const char*)L.wpk_merge;
+        u.part = A.slot[lv][p_slot]; u.out = p.out;
+        u.bias = p.bias; u.act = p.act; u.slope = p.slope;
+        u.oflow = h->d_flag;
+        p.out = A.slot[lv][p_slot];                  // same strides as the layer's output
+        p.bias = nullptr; p.act = AMX_ACT_NONE;
+        p.src1 = nullptr; p.C1 = 0; p.up_shift = 0;
+        p.wpk = (const char*)L.wpk_skip;
+      }
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, c.precision, st);
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
@@ -493,10 +524,19 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         AMX_HIP(launch_one(p));
       }
       if (x_offs && L.is_final && g_acc_done) AMX_HIP(hipEventRecord(g_acc_done, st));
-      if (prof)
-        snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s",
-                 p.src0_f32c1 ? amx::last_conv_stem_kernel_name()
-                              : use_upcat ? amx::last_conv_upcat_kernel_name() : amx::last_conv_kernel_name());
+      if (use_merge) {
+        AMX_HIP(amx::launch_conv_upmerge(u, c.precision, st));
+        A.used[lv][p_slot] = false;                  // the partial sums are dead once their consumer is enqueued (stream order)
+      }
+      if (prof) {
+        if (use_merge)
+          snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%.34s + %.26s", amx::last_conv_kernel_name(),
+                   amx::last_conv_upmerge_kernel_name() + 7);
+        else
+          snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s",
+                   p.src0_f32c1 ? amx::last_conv_stem_kernel_name()
+                                : use_upcat ? amx::last_conv_upcat_kernel_name() : amx::last_conv_kernel_name());
+      }
       if (raw_bn) {
         AMX_HIP(export_slot(out, tap_conv));
         AMX_HIP(amx::launch_affine_act(A.slot[lv][out.slot], L.scale, L.shift, n, (long long)dd * dh * dw, L.cout,
@@ -700,6 +740,13 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     hipError_t e = hipMalloc(&L.wpk, wbytes);
     if (e == hipSuccess && !is_split(cfg->precision) && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
+    // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
+    // that are at least 32 voxels wide at the reference operating point
+    if (e == hipSuccess && !is_split(cfg->precision) && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr &&
+        amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1)) {
+      e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2);
+      if (e == hipSuccess) e = hipMalloc(&L.wpk_merge, amx::conv_upmerge_packed_bytes(L.cin - L.cout, L.cout));
+    }
     if (e == hipSuccess && cfg->norm == AMX_NORM_BATCH_EVAL && L.norm_idx >= 0) e = hipMalloc(&L.wpk_raw, wbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
@@ -735,6 +782,8 @@ void amx_unet_destroy(amx_unet_t* h) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);
     if (L.wpk_raw) (void)hipFree(L.wpk_raw);
+    if (L.wpk_skip) (void)hipFree(L.wpk_skip);
+    if (L.wpk_merge) (void)hipFree(L.wpk_merge);
     if (L.scale) (void)hipFree(L.scale);
     if (L.in_gamma) (void)hipFree(L.in_gamma);
     if (L.in_beta) (void)hipFree(L.in_beta);
@@ -782,6 +831,10 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
       AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
                                        h->cfg.precision, st));
       if (L.wpk_up) AMX_HIP(amx::launch_pack_upcat16(d_weight, L.scale, L.wpk_up, h->cfg.precision, st));
+      if (L.wpk_merge) {   // skip channels [0, cout) as an ordinary 27-tap packing, upsampled channels [cout, cin) merged
+        AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk_skip, L.cout, L.cout, L.cout, L.q, h->cfg.precision, st, 0, 0, L.cin));
+        AMX_HIP(amx::launch_pack_upmerge(d_weight, L.scale, L.wpk_merge, L.cout, L.cin, L.cin - L.cout, L.cout, h->cfg.precision, st));
+      }
     }
     L.loaded = true;
     return AMX_OK;
@@ -989,6 +1042,43 @@ int amx_conv3d_k3_reflect_ex(const void* d_x0, int c0, const void* d_x1, int c1,
                              float* d_out32, void* stream) {
   return conv3d_single(d_x0, c0, d_x1, c1, d_weight, weight_mode, cin_real, cout_real, d_scale, d_shift, cout, n, d, hh, w,
                        act, slope, precision, d_wpk, d_out16, d_out32, stream);
+}
+
+size_t amx_conv3d_upcat_merged_packed_bytes(int c0, int c1, int cout) {
+  return align_up((size_t)cout * c0 * 28 * 2, 256) + amx::conv_upmerge_packed_bytes(c1, cout);
+}
+
+int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, const float* d_scale,
+                            const float* d_shift, int cout, int n, int d, int hh, int w, int act, float slope, int precision,
+                            void* d_wpk, void* d_partial, void* d_out16, void* stream) {
+  if (!d_x0 || !d_x1 || !d_weight || !d_wpk || !d_partial || !d_out16) return fail(AMX_ERR_INVALID, "null argument");
+  if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return fail(AMX_ERR_INVALID, "merged concat conv: precision f16 / bf16 only");
+  if (c0 != cout || !amx::conv_upmerge_eligible(c0, c1, cout, d, hh, w, 1))
+    return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32, c1 %% 32 == 0, w >= 32, even dims (c0=%d c1=%d cout=%d dims %d,%d,%d)",
+                c0, c1, cout, d, hh, w);
+  hipStream_t st = (hipStream_t)stream;
+  const int q = amx::conv_pick_q(cout, w);
+  char* wmerge = (char*)d_wpk + align_up((size_t)cout * c0 * 28 * 2, 256);
+  AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, c0, c0, cout, q, precision, st, 0, 0, c0 + c1));
+  AMX_HIP(amx::launch_pack_upmerge(d_weight, d_scale, wmerge, c0, c0 + c1, c1, cout, precision, st));
+  amx::ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
+  p.src0 = (const char*)d_x0; p.C0 = c0;
+  p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
+  p.wpk = (const char*)d_wpk; p.act = AMX_ACT_NONE;
+  p.out = (char*)d_partial;
+  p.ox = (long long)cout * 2; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+  AMX_HIP(amx::launch_conv(p, precision, q, st));
+  amx::UpmergeParams u;
+  memset(&u, 0, sizeof u);
+  u.src = (const char*)d_x1; u.C1 = c1;
+  u.sx = (long long)c1 * 2; u.sy = u.sx * (w / 2); u.sz = u.sy * (hh / 2); u.sn = u.sz * (d / 2);
+  u.N = n; u.LD = d / 2; u.LH = hh / 2; u.LW = w / 2; u.Cout = cout;
+  u.wpk = wmerge; u.part = (const char*)d_partial; u.out = (char*)d_out16;
+  u.bias = d_shift; u.act = act; u.slope = slope;
+  AMX_HIP(amx::launch_conv_upmerge(u, precision, st));
+  return AMX_OK;
 }
 
 int amx_pool2(const void* d_in, void* d_out, int n, int dout, int hout, int wout, int c, int avg, int precision,

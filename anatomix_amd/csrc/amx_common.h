@@ -61,6 +61,23 @@ struct ConvParams {
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
 };
 
+// Merged-tap convolution over the upsampled segment of a concat layer (amx_conv3d_upmerge.hip).
+struct UpmergeParams {
+  const char* src;              // low-res tensor [N][LD][LH][LW][C1 (x2 when split)] 16-bit, byte strides below
+  long long sn, sz, sy, sx;
+  int C1;                       // up-channels, a multiple of 32
+  int N, LD, LH, LW, Cout;
+  const char* wpk;              // pack_upmerge: [cout group][stage][class][tap e][q][lane][8]
+  const char* part;             // partial sums of the skip-channel conv (no bias, no activation): [N][2 LD][2 LH][2 LW][Cout] 16-bit
+  char* out;                    // the layer's output, same layout: act(part + merged-tap sum + bias)
+  const float* bias;            // [Cout] fp32 or null
+  int act;
+  float slope;
+  int nbz, nby, nbx;
+  int* oflow;
+  int dbg;
+};
+
 // Weight-gradient launch (amx_wgrad.hip).
 struct WgradParams {
   const char* dy;                       // 16-bit [N][D][H][W][Cout] through byte strides (may be a framed view)

@@ -33,7 +33,7 @@ namespace amx {
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                     T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
-                                    int split) {
+                                    int split, int CinStride) {
   const int nchunk_phys = CinPad / 16 * (split ? 2 : 1);
   const long long total = (long long)(Cout / 16) * nchunk_phys * kSteps * 64 * 8;
   const int nchunk = CinPad / 16;
@@ -57,7 +57,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     float v = 0.f;
     if (tap >= 0 && cin < CinReal) {
       if (mode == 0) {
-        v = w[((long long)cout * CinReal + cin) * 27 + tap];
+        v = w[((long long)cout * CinStride + cin) * 27 + tap];   // CinStride > CinReal: the leading channels of a wider tensor
       } else if (cout < CoutReal) {
         // data-gradient weights straight from the forward tensor w[CinReal][CoutReal][27]: taps flipped, channels transposed
         v = w[((long long)cin * CoutReal + cout) * 27 + (26 - tap)];
@@ -180,16 +180,17 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 }
 
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal) {
+                               int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal, int CinStride) {
+  if (CinStride <= 0) CinStride = CinReal;
   const int split = precision >= 2;
   const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8 * (split ? 2 : 1);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if ((precision & 1) == 0)
     hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk,
-                       CinReal, CinPad, Cout, Q, mode, CoutReal, split);
+                       CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride);
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale,
-                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split);
+                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride);
   return hipGetLastError();
 }
 

@@ -244,6 +244,18 @@ int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int h
 int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int din, int hin, int win, int c, int precision,
                                      void* stream);
 
+/* The same layer as amx_conv3d_k3_reflect with c1 > 0, computed the way amx_unet_forward runs the wider nearest-upsample
+ * concat layers (network.py:403-435: nn.Upsample(2,'nearest') -> torch.cat((skip, up), 1) -> nn.Conv3d(3, reflect) -> norm ->
+ * act): (1) the ordinary 27-tap convolution over the skip channels writes raw partial sums into d_partial; (2) the merged-tap
+ * convolution over the upsampled channels at LOW resolution -- the 27 taps over a nearest-upsampled tensor collapse to 2x2x2
+ * parity-dependent taps, 3.4x fewer multiply-accumulates -- adds them, the bias and the activation.  Needs c0 == cout,
+ * c1 a multiple of 32, cout >= 32, w >= 32, even dims, precision f16 / bf16; AMX_ERR_INVALID otherwise.  d_wpk:
+ * amx_conv3d_upcat_merged_packed_bytes(c0, c1, cout) bytes of scratch for both packings; d_partial: n*d*h*w*cout*2 bytes. */
+size_t amx_conv3d_upcat_merged_packed_bytes(int c0, int c1, int cout);
+int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, const float* d_scale,
+                            const float* d_shift, int cout, int n, int d, int hh, int w, int act, float slope, int precision,
+                            void* d_wpk, void* d_partial, void* d_out16, void* stream);
+
 /* ---- Training-path operators (the UNet inside the contrastive step, pretraining/models/supcl_model.py:603-661, runs in
  * train mode and is differentiated).  All activations / gradients: dense 16-bit channels-last [n][d][h][w][c];
  * parameter gradients and statistics fp32.  d_scratch: amx_train_scratch_bytes(c) bytes. */

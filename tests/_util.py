@@ -127,7 +127,28 @@ def ref_conv_fp64(x0, x1, w, scale, shift, act, slope=0.3):
     return y.float()
 
 
-def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3):
+def run_conv_merged(device, x0, x1, w, scale, shift, act, precision, slope=0.3):
+    """Calls amx_conv3d_upcat_merged (merged-tap launch over the upsampled channels + skip conv that adds its partial sums)."""
+    lib = _lib.load()
+    tdt = TORCH_T[precision]
+    n, c0, d, h, ww = x0.shape
+    cout, c1 = w.shape[0], x1.shape[1]
+    dx0, dx1 = to_ndhwc(x0, tdt).to(device), to_ndhwc(x1, tdt).to(device)
+    dw = w.reshape(cout, c0 + c1, 27).contiguous().float().to(device)
+    dsc = None if scale is None else scale.float().to(device)
+    dsh = None if shift is None else shift.float().to(device)
+    wpk = torch.empty(lib.amx_conv3d_upcat_merged_packed_bytes(c0, c1, cout), dtype=torch.uint8, device=device)
+    part = torch.full((n * d * h * ww * cout,), float("nan"), dtype=tdt, device=device)
+    out = torch.full((n, d, h, ww, cout), float("nan"), dtype=tdt, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.amx_conv3d_upcat_merged(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dsh), cout,
+                                           n, d, h, ww, act, slope, _lib.PRECISION[precision], _lib.ptr(wpk), _lib.ptr(part),
+                                           _lib.ptr(out), st))
+    torch.cuda.synchronize(device)
+    return from_ndhwc(out.cpu().float())
+
+
+def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3, round_partial=False):
     """Reference for the merged-tap kernel (amx_conv3d_upcat.hip): the skip segment is a plain
     reflect-padded 3x3x3 convolution with rounded weights; the nearest-upsampled segment is, per
     output parity class, a 2x2x2 convolution over the REPLICATE-padded low-res tensor whose weights
@@ -139,6 +160,9 @@ def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3):
     sc = torch.ones(w.shape[0]) if scale is None else scale.float()
     xs = q(x0).double()
     y = F.conv3d(F.pad(xs, (1,) * 6, mode="reflect"), q(wf[:, :c0] * sc[:, None, None, None, None]).double())
+    if round_partial:                                   # two-launch form: the skip partial sums are stored in the 16-bit storage type
+        y = q(y.float()).double()
+    part = torch.zeros_like(y)                          # the merged-tap part (its own launch in amx_conv3d_upmerge.hip)
     lo = F.pad(q(x1).double(), (1,) * 6, mode="replicate")
     wu = wf[:, c0:]                                     # merged in fp32 first, gain applied to the sum (kernel order)
     sets = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}          # parity -> taps merged into low offset e = 0, 1
@@ -157,7 +181,8 @@ def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3):
                                         acc = acc + wu[:, :, kz, ky, kx]
                             wm[:, :, ez, ey, ex] = acc
                 sub = lo[:, :, pz:pz + d // 2 + 1, py:py + h // 2 + 1, px:px + ww // 2 + 1]
-                y[:, :, pz::2, py::2, px::2] += F.conv3d(sub, q(wm * sc[:, None, None, None, None]).double())
+                part[:, :, pz::2, py::2, px::2] = F.conv3d(sub, q(wm * sc[:, None, None, None, None]).double())
+    y = y + part
     if shift is not None:
         y = y + shift.double()[None, :, None, None, None]
     if act == 1:

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import TORCH_T, max_rel, ref_conv, ref_conv_fp64, ref_conv_upcat_merged, rel_l2, run_conv
+from _util import TORCH_T, max_rel, ref_conv, ref_conv_fp64, ref_conv_upcat_merged, rel_l2, run_conv, run_conv_merged
 
 pytestmark = pytest.mark.gpu
 
@@ -106,3 +106,46 @@ def test_conv_transpose_detecting(device):
     got = run_conv(device, x0, None, wgt, None, None, 0, "f16")
     ref = ref_conv(x0, None, wgt, None, None, 0, "f16")
     assert torch.equal(got, ref.half().float())
+
+
+MERGED_CASES = [
+    # (c0 = cout, c1, (d,h,w), n, act): the wider nearest-upsample concat layers as amx_unet_forward runs them
+    (32, 64, (8, 8, 32), 1, 1),           # 96 -> 32, one brick row
+    (32, 64, (16, 24, 64), 2, 1),         # z-march skip conv, several bricks, batch 2
+    (32, 64, (6, 10, 40), 1, 2),          # ragged: low-res 3 x 5 x 20 (partial tiles on every axis), leaky relu
+    (64, 128, (8, 16, 32), 1, 1),         # 192 -> 64: generic skip conv (Q = 4), two cout groups in the merged launch
+    (64, 128, (4, 12, 48), 1, 0),         # ragged, no activation
+    (128, 256, (4, 8, 32), 1, 1),         # 384 -> 128
+    (48, 96, (4, 8, 32), 1, 1),           # cout not a multiple of 32: 16-channel groups in the merged launch
+]
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("case", MERGED_CASES, ids=lambda c: "c%d+%d_%dx%dx%d_n%d_a%d" % (c[0], c[1], *c[2], c[3], c[4]))
+def test_merged_concat_conv_matches_cpu(device, case, precision):
+    """amx_conv3d_upcat_merged (= how amx_unet_forward runs network.py:403-435 for the wider decoder blocks): merged 2x2x2 taps
+    over the low-res tensor, partial sums rounded once to the storage type, skip conv adds them.  Reference: an independent CPU
+    formulation of the same algebra in fp64 on the same rounded operands; and the plain 27-tap reference within what the one
+    extra rounding of the partial sums can cost."""
+    c0, c1, (d, h, w), n, act = case
+    cout = c0
+    rs = np.random.RandomState(hash((c0, c1, d, h, w)) & 0xFFFF)
+    x0 = torch.from_numpy(rs.randn(n, c0, d, h, w).astype(np.float32))
+    x1 = torch.from_numpy(rs.randn(n, c1, d // 2, h // 2, w // 2).astype(np.float32))
+    wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy((rs.randn(cout) * 0.1).astype(np.float32))
+    got = run_conv_merged(device, x0, x1, wgt, scale, shift, act, precision)
+    ref = ref_conv_upcat_merged(x0, x1, wgt, scale, shift, act, precision, round_partial=True)
+    assert torch.isfinite(got).all()
+    ulp = 2.0 ** -10 if precision == "f16" else 2.0 ** -7
+    err = (got.double() - ref.double()).abs()
+    # one rounding of the result + (rarely) a partial sum that rounds the other way after fp32 accumulation-order differences
+    # (a flipped partial sum costs one ulp of a value of magnitude <= ~4)
+    tol = ulp * (ref.abs().double() + 4.0) + 2e-5
+    assert (err <= tol).all(), f"max err {err.max().item():.3e} rel_l2 {rel_l2(got, ref):.3e}"
+    flips = (err > ulp * ref.abs().double() + 1e-3 * ulp + 2e-5).double().mean().item()
+    assert flips < 2e-3, flips                                             # ... and is rare
+    assert rel_l2(got, ref) < (4e-4 if precision == "f16" else 3.2e-3)     # the result's own rounding: 2^-11 / sqrt(3), 2^-8 / sqrt(3)
+    plain = ref_conv(x0, x1, wgt, scale, shift, act, precision)          # 27 separately rounded taps, no partial rounding
+    assert rel_l2(got, plain) < (6e-4 if precision == "f16" else 5e-3), rel_l2(got, plain)
