@@ -14,8 +14,8 @@ namespace amx {
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st);
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
                                int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0);
-size_t conv_upmerge_packed_bytes(int C1, int Cout);
-bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift);
+size_t conv_upmerge_packed_bytes(int C1, int Cout, int split);
+bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split);
 hipError_t launch_conv_upmerge(const UpmergeParams& p, int precision, hipStream_t st);
 hipError_t launch_pack_upmerge(const float* w, const float* scale, void* wpk, int c_off, int CinTotal, int C1, int Cout, int precision,
                                hipStream_t st);
@@ -478,8 +478,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       if (use_upcat) p.wpk = (const char*)L.wpk_up;
       // wider concat layers: the ordinary convolution over the skip channels first (raw partial sums into a free slot of this
       // level), then the merged-tap convolution over the upsampled channels, which adds them, the bias and the activation
-      const bool use_merge = !use_upcat && !split && !raw_bn && L.wpk_merge && have_cur_up && have_skip && !cur_is_full_up && !L.is_final &&
-                             p.C0 == L.cout && amx::conv_upmerge_eligible(p.C0, p.C1, L.cout, dd, dh, dw, p.up_shift);
+      const bool use_merge = !use_upcat && !raw_bn && L.wpk_merge && have_cur_up && have_skip && !cur_is_full_up && !L.is_final &&
+                             p.C0 == L.cout && amx::conv_upmerge_eligible(p.C0, p.C1, L.cout, dd, dh, dw, p.up_shift, split);
       int p_slot = -1;
       amx::UpmergeParams u;
       memset(&u, 0, sizeof u);
@@ -742,10 +742,10 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
     // that are at least 32 voxels wide at the reference operating point
-    if (e == hipSuccess && !is_split(cfg->precision) && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr &&
-        amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1)) {
-      e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2);
-      if (e == hipSuccess) e = hipMalloc(&L.wpk_merge, amx::conv_upmerge_packed_bytes(L.cin - L.cout, L.cout));
+    if (e == hipSuccess && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr &&
+        amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1, is_split(cfg->precision))) {
+      e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2 * (is_split(cfg->precision) ? 2 : 1));
+      if (e == hipSuccess) e = hipMalloc(&L.wpk_merge, amx::conv_upmerge_packed_bytes(L.cin - L.cout, L.cout, is_split(cfg->precision)));
     }
     if (e == hipSuccess && cfg->norm == AMX_NORM_BATCH_EVAL && L.norm_idx >= 0) e = hipMalloc(&L.wpk_raw, wbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
@@ -1045,35 +1045,37 @@ int amx_conv3d_k3_reflect_ex(const void* d_x0, int c0, const void* d_x1, int c1,
 }
 
 size_t amx_conv3d_upcat_merged_packed_bytes(int c0, int c1, int cout) {
-  return align_up((size_t)cout * c0 * 28 * 2, 256) + amx::conv_upmerge_packed_bytes(c1, cout);
+  return 2 * (align_up((size_t)cout * c0 * 28 * 2, 256) + amx::conv_upmerge_packed_bytes(c1, cout, 0));   // room for [Wh | Wl]
 }
 
 int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, const float* d_scale,
                             const float* d_shift, int cout, int n, int d, int hh, int w, int act, float slope, int precision,
                             void* d_wpk, void* d_partial, void* d_out16, void* stream) {
   if (!d_x0 || !d_x1 || !d_weight || !d_wpk || !d_partial || !d_out16) return fail(AMX_ERR_INVALID, "null argument");
-  if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return fail(AMX_ERR_INVALID, "merged concat conv: precision f16 / bf16 only");
-  if (c0 != cout || !amx::conv_upmerge_eligible(c0, c1, cout, d, hh, w, 1))
-    return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32, c1 %% 32 == 0, w >= 32, even dims (c0=%d c1=%d cout=%d dims %d,%d,%d)",
-                c0, c1, cout, d, hh, w);
+  if (precision < AMX_PREC_F16 || precision > AMX_PREC_BF16X2) return fail(AMX_ERR_INVALID, "unsupported precision %d", precision);
+  const bool split = is_split(precision);
+  const long long eb = split ? 4 : 2;
+  if (c0 != cout || !amx::conv_upmerge_eligible(c0, c1, cout, d, hh, w, 1, split))
+    return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32 (16 in the strict precisions), c1 %% 32 == 0, w >= 32, even dims "
+                "(c0=%d c1=%d cout=%d dims %d,%d,%d)", c0, c1, cout, d, hh, w);
   hipStream_t st = (hipStream_t)stream;
   const int q = amx::conv_pick_q(cout, w);
-  char* wmerge = (char*)d_wpk + align_up((size_t)cout * c0 * 28 * 2, 256);
+  char* wmerge = (char*)d_wpk + align_up((size_t)cout * c0 * 28 * 2 * (split ? 2 : 1), 256);
   AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, c0, c0, cout, q, precision, st, 0, 0, c0 + c1));
   AMX_HIP(amx::launch_pack_upmerge(d_weight, d_scale, wmerge, c0, c0 + c1, c1, cout, precision, st));
   amx::ConvParams p;
   memset(&p, 0, sizeof p);
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
   p.src0 = (const char*)d_x0; p.C0 = c0;
-  p.s0x = (long long)c0 * 2; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
+  p.s0x = (long long)c0 * eb; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
   p.wpk = (const char*)d_wpk; p.act = AMX_ACT_NONE;
   p.out = (char*)d_partial;
-  p.ox = (long long)cout * 2; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+  p.ox = (long long)cout * eb; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
   AMX_HIP(amx::launch_conv(p, precision, q, st));
   amx::UpmergeParams u;
   memset(&u, 0, sizeof u);
   u.src = (const char*)d_x1; u.C1 = c1;
-  u.sx = (long long)c1 * 2; u.sy = u.sx * (w / 2); u.sz = u.sy * (hh / 2); u.sn = u.sz * (d / 2);
+  u.sx = (long long)c1 * eb; u.sy = u.sx * (w / 2); u.sz = u.sy * (hh / 2); u.sn = u.sz * (d / 2);
   u.N = n; u.LD = d / 2; u.LH = hh / 2; u.LW = w / 2; u.Cout = cout;
   u.wpk = wmerge; u.part = (const char*)d_partial; u.out = (char*)d_out16;
   u.bias = d_shift; u.act = act; u.slope = slope;

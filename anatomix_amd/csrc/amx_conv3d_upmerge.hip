@@ -32,22 +32,28 @@
 namespace amx {
 
 
-template <int Q, int TZ, int TY, int NBUF, int KS>
+template <int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false>
 struct UpmCfg {
+  static constexpr int NP = SPLIT ? 2 : 1;                // strict precision: hi and lo halves of every operand
+  static_assert(!SPLIT || KS == 1, "strict precision: 32-channel stages");
   static constexpr int T = TZ * TY;                       // tiles per wave (= per class)
   static constexpr int HZ = TZ + 2, HY = TY + 2, HX = 18, HV = HZ * HY * HX;
   static constexpr int PL = ((HV * 16 + 255) / 256) * 256;   // one 8-channel plane of the halo
-  static constexpr int BUF = 4 * KS * PL;                 // KS x 32 channels per stage
+  static constexpr int BUF = 4 * KS * NP * PL;            // KS x 32 channels per stage (strict: hi planes, then lo planes)
   static constexpr int NJ = (HV + 63) / 64;               // DMA instructions per plane
-  static constexpr int NDMA = 4 * KS * NJ;
+  static constexpr int NDMA = 4 * KS * NP * NJ;
   static constexpr int PER_WAVE = (NDMA + 7) / 8;
   static constexpr int LDS_BYTES = NBUF * BUF;
   static_assert(LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
 };
 
-template <typename T_, int Q, int TZ, int TY, int NBUF, int KS>
+// SPLIT (strict precision): every tensor holds [hi(C) | lo(C)] 16-bit channels per voxel (value = hi + lo), the packing holds Wh
+// and Wl fragments per tap; the sweep multiplies Wh*xh + Wh*xl + Wl*xh into the same fp32 accumulators (amx_conv3d_v2.hip), the
+// epilogue adds hi + lo of the skip partial sums and splits the result again.
+template <typename T_, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT>
 __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams p) {
-  typedef UpmCfg<Q, TZ, TY, NBUF, KS> C;
+  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT> C;
+  constexpr int NP = C::NP;
   typedef typename Ops<T_>::vec8 vec8;
   constexpr int HY = C::HY, HX = C::HX, PL = C::PL, NT = C::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +115,8 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
       if (id < C::NDMA) {
         const int plane = id / C::NJ, j = id - plane * C::NJ;
         if (off[m] >= 0)
-          dma16_asm(base + off[m] + plane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(buf + plane * PL + j * 1024)));
+          dma16_asm(base + off[m] + (SPLIT && plane >= 4 ? p.C1 * 2 + (plane - 4) * 16 : plane * 16),
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(buf + plane * PL + j * 1024)));
       }
     }
   };
@@ -117,16 +124,16 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   // ---- this class's A fragments of one (item, stage)
   auto wptr = [&](int it, int stage) -> const char* {
     const int cg = it / nbricks;
-    return p.wpk + ((((long long)cg * nstage * KS + stage * KS) * 8 + wave) * 8 * Q) * 1024 + lane * 16;
+    return p.wpk + ((((long long)cg * nstage * KS + stage * KS) * 8 + wave) * 8 * NP * Q) * 1024 + lane * 16;
   };
   // tap index e' = ks * 8 + e of a stage -> byte offset from wptr (the packing is [32-channel block][class][tap][q])
-  auto woff = [](const int e2) { return ((e2 >> 3) * 64 + (e2 & 7)) * Q * 1024; };
+  auto woff = [](const int e2) { return ((e2 >> 3) * 64 + (e2 & 7)) * NP * Q * 1024; };
   constexpr int NTAP = 8 * KS;
   // A fragments stream through a window of 4 taps: tap e of a stage sits in wq[e % WIN]; after its last use the slot is refilled
   // with tap e + WIN (of this stage or the next one) -- WIN taps (>= ~1000 cycles of MFMAs) of cover for an L2 round trip.
   // Nothing is reused across stages, so holding all eight taps would only cost accumulator registers.
   constexpr int WIN = 4;
-  vec8 wq[WIN][Q];
+  vec8 wq[WIN][NP][Q];
   // ---- lane-constant LDS base: halo voxel (lz + pz + ez, ly + py + ey, li + px + ex), plane g
   const int lbase = g * PL + ((pz * HY + py) * HX + px + li) * 16;
 
@@ -143,35 +150,41 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
 #pragma unroll
     for (int e = 0; e < WIN; ++e)
 #pragma unroll
-      for (int q = 0; q < Q; ++q) wq[e][q] = *(const vec8*)(w0 + woff(e) + q * 1024);
+      for (int h = 0; h < NP; ++h)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) wq[e][h][q] = *(const vec8*)(w0 + woff(e) + (h * Q + q) * 1024);
   }
 
   int cu_it = it0, cu_stage = 0;
   bool bad = false;
   // deferred store of a finished item (full-resolution channels-last output, this class's voxels are every second one per axis): issued after the next stage's DMA, drains under its sweep
-  unsigned pend[NT][2 * Q];
+  unsigned pend[NT][2 * Q * NP];
   int pend_it = -1;
   // the skip conv's partial sums of the item being multiplied: requested in the item's last stage, after the previous item's
   // stores (whose registers they may take), so that the latency hides under the sweep
-  unsigned padd[NT][2 * Q];
+  unsigned padd[NT][2 * Q * NP];
   auto load_part = [&](const int it) {
     const Item I = decode(it);
     const int lx = I.bx * 16 + li;
-    const long long sx = (long long)p.Cout * 2, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
+    const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
     const char* pb = p.part + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int lz = I.bz * TZ + i / TY, ly = I.by * TY + i % TY;
       const bool in = (lz < p.LD) & (ly < p.LH) & (lx < p.LW);
-      const char* src = pb + 2 * lz * sz + 2 * ly * sy;
-      if (Q == 1) {
-        const uint2 v = in ? *(const uint2*)src : make_uint2(0u, 0u);
-        padd[i][0] = v.x; padd[i][1] = v.y;
-      } else {
 #pragma unroll
-        for (int h = 0; h < Q / 2; ++h) {
-          const uint4 v = in ? *(const uint4*)(src + h * 16) : make_uint4(0u, 0u, 0u, 0u);
-          padd[i][4 * h] = v.x; padd[i][4 * h + 1] = v.y; padd[i][4 * h + 2] = v.z; padd[i][4 * h + 3] = v.w;
+      for (int hl = 0; hl < NP; ++hl) {                     // strict: the lo channels follow Cout channels further on in the voxel
+        const char* src = pb + 2 * lz * sz + 2 * ly * sy + hl * p.Cout * 2;
+        unsigned* dst = &padd[i][hl * 2 * Q];
+        if (Q == 1) {
+          const uint2 v = in ? *(const uint2*)src : make_uint2(0u, 0u);
+          dst[0] = v.x; dst[1] = v.y;
+        } else {
+#pragma unroll
+          for (int h = 0; h < Q / 2; ++h) {
+            const uint4 v = in ? *(const uint4*)(src + h * 16) : make_uint4(0u, 0u, 0u, 0u);
+            dst[4 * h] = v.x; dst[4 * h + 1] = v.y; dst[4 * h + 2] = v.z; dst[4 * h + 3] = v.w;
+          }
         }
       }
     }
@@ -180,17 +193,21 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
     const Item I = decode(pend_it);
     pend_it = -1;
     const int lx = I.bx * 16 + li;
-    const long long sx = (long long)p.Cout * 2, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
+    const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
     char* pb = p.out + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int lz = I.bz * TZ + i / TY, ly = I.by * TY + i % TY;
       if (lz >= p.LD || ly >= p.LH || lx >= p.LW) continue;
-      char* dst = pb + 2 * lz * sz + 2 * ly * sy;         // output voxel (2 lz + pz, 2 ly + py, 2 lx + px)
-      if (Q == 1) *(uint2*)dst = make_uint2(pend[i][0], pend[i][1]);
-      else {
 #pragma unroll
-        for (int h = 0; h < Q / 2; ++h) *(uint4*)(dst + h * 16) = make_uint4(pend[i][4 * h], pend[i][4 * h + 1], pend[i][4 * h + 2], pend[i][4 * h + 3]);
+      for (int hl = 0; hl < NP; ++hl) {
+        char* dst = pb + 2 * lz * sz + 2 * ly * sy + hl * p.Cout * 2;     // output voxel (2 lz + pz, 2 ly + py, 2 lx + px)
+        const unsigned* v = &pend[i][hl * 2 * Q];
+        if (Q == 1) *(uint2*)dst = make_uint2(v[0], v[1]);
+        else {
+#pragma unroll
+          for (int h = 0; h < Q / 2; ++h) *(uint4*)(dst + h * 16) = make_uint4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+        }
       }
     }
   };
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
     // tap 0's fragment was requested (during stage t - 1) AFTER those pieces: touching it makes hipcc place exactly the counted
     // wait that covers them, while the requests of taps 1-3 and of stage t + 1's halo stay in flight.
     if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("" ::"v"(wq[0][0]) : "memory");
+    else asm volatile("" ::"v"(wq[0][0][0]) : "memory");
     __syncthreads();                                       // everyone's pieces of stage t landed; buffer (t + 2) % NBUF is free
     if (t + NBUF - 1 < T_total && !(p.dbg & 1)) {
       issue(nx_it, nx_stage, (t + NBUF - 1) % NBUF);
@@ -222,15 +239,17 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
     if (!(p.dbg & 2)) {
       // B fragments in groups of GT tiles, one group ahead of the MFMAs (scheduling fences keep the order: left alone, hipcc
       // hoists every read of a tap -- 64 registers of fragments next to 128 of accumulators -- and spills)
-      constexpr int GT = NT < 4 ? NT : 4, NGT = NT / GT, NG = NTAP * NGT;
-      vec8 fb[2][GT];
+      constexpr int GT = SPLIT ? 2 : (NT < 4 ? NT : 4), NGT = NT / GT, NG = NTAP * NGT;   // strict: two fragments (hi, lo) per tile
+      vec8 fb[2][GT][NP];
       auto load_group = [&](const int gi, const int set) {
         const int e2 = gi / NGT, i0 = (gi % NGT) * GT;
         const int ks = e2 >> 3, ez = (e2 >> 2) & 1, ey = (e2 >> 1) & 1, ex = e2 & 1;
 #pragma unroll
         for (int k = 0; k < GT; ++k) {
           const int lz = (i0 + k) / TY, ly = (i0 + k) % TY;
-          fb[set][k] = *(const vec8*)(buf + ks * 4 * PL + (((lz + ez) * HY + ly + ey) * HX + ex) * 16);
+#pragma unroll
+          for (int h = 0; h < NP; ++h)
+            fb[set][k][h] = *(const vec8*)(buf + (ks + h) * 4 * PL + (((lz + ez) * HY + ly + ey) * HX + ex) * 16);
         }
       };
       load_group(0, 0);
@@ -242,12 +261,20 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
 #pragma unroll
         for (int k = 0; k < GT; ++k)
 #pragma unroll
-          for (int q = 0; q < Q; ++q) acc[i0 + k][q] = Ops<T_>::mfma(wq[e % WIN][q], fb[gi & 1][k], acc[i0 + k][q]);
+          for (int q = 0; q < Q; ++q) {
+            acc[i0 + k][q] = Ops<T_>::mfma(wq[e % WIN][0][q], fb[gi & 1][k][0], acc[i0 + k][q]);
+            if (SPLIT) {
+              acc[i0 + k][q] = Ops<T_>::mfma(wq[e % WIN][0][q], fb[gi & 1][k][NP - 1], acc[i0 + k][q]);     // Wh * xl
+              acc[i0 + k][q] = Ops<T_>::mfma(wq[e % WIN][NP - 1][q], fb[gi & 1][k][0], acc[i0 + k][q]);     // Wl * xh
+            }
+          }
         __builtin_amdgcn_sched_barrier(0);
         if ((gi % NGT) == NGT - 1 && (e + WIN < NTAP || more)) {   // last use of tap e: its slot takes tap e + WIN (next stage: - NTAP)
           const char* src = e + WIN < NTAP ? wc + woff(e + WIN) : wn + woff(e + WIN - NTAP);
 #pragma unroll
-          for (int q = 0; q < Q; ++q) wq[e % WIN][q] = *(const vec8*)(src + q * 1024);
+          for (int h = 0; h < NP; ++h)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) wq[e % WIN][h][q] = *(const vec8*)(src + (h * Q + q) * 1024);
         }
       }
     }
@@ -257,17 +284,18 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
     // ---- item finished: + skip partial sums + bias, activation, pack; stored under the NEXT stage's sweep (flush)
     {
       const int cgb = (cu_it / nbricks) * 16 * Q + g * 4 * Q;
+      auto cvt = [](const unsigned w, const int half) { return (float)__builtin_bit_cast(T_, (unsigned short)(half ? w >> 16 : w & 0xffffu)); };
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const f32x4 bv = p.bias ? *(const f32x4*)(p.bias + cgb + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const unsigned lo = padd[i][2 * q], hi2 = padd[i][2 * q + 1];
-          acc[i][q][0] += bv[0] + (float)__builtin_bit_cast(T_, (unsigned short)(lo & 0xffffu));
-          acc[i][q][1] += bv[1] + (float)__builtin_bit_cast(T_, (unsigned short)(lo >> 16));
-          acc[i][q][2] += bv[2] + (float)__builtin_bit_cast(T_, (unsigned short)(hi2 & 0xffffu));
-          acc[i][q][3] += bv[3] + (float)__builtin_bit_cast(T_, (unsigned short)(hi2 >> 16));
-        }
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = cvt(padd[i][2 * q + (j >> 1)], j & 1);
+            if (SPLIT) a += cvt(padd[i][2 * Q + 2 * q + (j >> 1)], j & 1);
+            acc[i][q][j] += bv[j] + a;
+          }
       }
       act_inplace<NT * Q>(&acc[0][0], p.act, p.slope);
     }
@@ -280,6 +308,13 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
           if (RangeCheck<T_>::on) bad |= RangeCheck<T_>::bad(acc[i][q][j]);
         pend[i][2 * q] = (unsigned)to_bits<T_>(acc[i][q][0]) | ((unsigned)to_bits<T_>(acc[i][q][1]) << 16);
         pend[i][2 * q + 1] = (unsigned)to_bits<T_>(acc[i][q][2]) | ((unsigned)to_bits<T_>(acc[i][q][3]) << 16);
+        if (SPLIT) {
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = acc[i][q][j] - (float)(T_)acc[i][q][j];
+          pend[i][2 * Q + 2 * q] = (unsigned)to_bits<T_>(r[0]) | ((unsigned)to_bits<T_>(r[1]) << 16);
+          pend[i][2 * Q + 2 * q + 1] = (unsigned)to_bits<T_>(r[2]) | ((unsigned)to_bits<T_>(r[3]) << 16);
+        }
       }
     pend_it = cu_it;
     ++cu_it;
@@ -295,13 +330,14 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
 //   per axis, formed in fp32 and rounded ONCE.
 template <typename T>
 __global__ void pack_upmerge_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk, int c_off,
-                                    int CinTotal, int C1, int Cout, int Q) {
-  const int nstage = C1 / 32;
-  const long long total = (long long)(Cout / (16 * Q)) * nstage * 64 * Q * 512;
+                                    int CinTotal, int C1, int Cout, int Q, int split) {
+  const int nstage = C1 / 32, NP = split ? 2 : 1;           // strict: [.. tap e][part: hi, lo][q]
+  const long long total = (long long)(Cout / (16 * Q)) * nstage * 64 * NP * Q * 512;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int j = idx & 7, lane = (idx >> 3) & 63;
     long long r = idx >> 9;
     const int q = r % Q; r /= Q;
+    const int part = r % NP; r /= NP;
     const int e = r % 8; r /= 8;
     const int cls = r % 8; r /= 8;
     const int stage = r % nstage;
@@ -320,32 +356,36 @@ __global__ void pack_upmerge_kernel(const float* __restrict__ w, const float* __
     for (int kz = lo[0]; kz <= hi[0]; ++kz)
       for (int ky = lo[1]; ky <= hi[1]; ++ky)
         for (int kx = lo[2]; kx <= hi[2]; ++kx) sum += w[((long long)cout * CinTotal + cin) * 27 + (kz * 3 + ky) * 3 + kx];
-    wpk[idx] = (T)(sum * (scale ? scale[cout] : 1.f));
+    const float v = sum * (scale ? scale[cout] : 1.f);
+    const T vh = (T)v;
+    wpk[idx] = part ? (T)(v - (float)vh) : vh;
   }
 }
 
 static thread_local char g_kernel_name6[64] = "";
 const char* last_conv_upmerge_kernel_name() { return g_kernel_name6; }
 
-size_t conv_upmerge_packed_bytes(int C1, int Cout) { return (size_t)Cout * C1 * 64 * 2; }        // 8 classes x 8 taps per (cout, cin)
+size_t conv_upmerge_packed_bytes(int C1, int Cout, int split) { return (size_t)Cout * C1 * 64 * 2 * (split ? 2 : 1); }   // 8 classes x 8 taps per (cout, cin)
 size_t conv_upmerge_partial_bytes(int N, int D, int H, int W, int Cout) { return (size_t)N * D * H * W * Cout * 2; }
-int conv_upmerge_q(int Cout) { return Cout % 32 == 0 ? 2 : 1; }
+int conv_upmerge_q(int Cout, int split) { return (!split && Cout % 32 == 0) ? 2 : 1; }
 
 // the low-res tensor must be at least one tile wide; 32-channel stages
-bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift) {
+// (the 48 -> 16 layer has its own fused kernel in the 16-bit precisions, amx_conv3d_upcat.hip; in strict precision it comes here)
+bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_UPMERGE") ? 1 : 0;
-  return !off && up_shift == 1 && C0 >= 16 && C1 >= 32 && C1 % 32 == 0 && Cout >= 32 && Cout % 16 == 0 && W >= 32 && !(D & 1) && !(H & 1) &&
+  return !off && up_shift == 1 && C0 >= 16 && C1 >= 32 && C1 % 32 == 0 && Cout >= (split ? 16 : 32) && Cout % 16 == 0 && W >= 32 && !(D & 1) && !(H & 1) &&
          !(W & 1) && D >= 4 && H >= 4;
 }
 
 static int g_num_cus6 = 0;
 
-template <typename T, int Q, int TZ, int TY, int NBUF, int KS>
+template <typename T, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false>
 static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
-  typedef UpmCfg<Q, TZ, TY, NBUF, KS> C;
-  snprintf(g_kernel_name6, sizeof g_kernel_name6, "conv3d_upmerge<%s,q%d,%dx%dx16,b%d,k%d>", __is_same(T, f16) ? "f16" : "bf16", Q, TZ, TY, NBUF, 32 * KS);
-  auto kern = conv3d_upmerge_kernel<T, Q, TZ, TY, NBUF, KS>;
+  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT> C;
+  snprintf(g_kernel_name6, sizeof g_kernel_name6, "conv3d_upmerge<%s,q%d,%dx%dx16,b%d,k%d>", __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q,
+           TZ, TY, NBUF, 32 * KS);
+  auto kern = conv3d_upmerge_kernel<T, Q, TZ, TY, NBUF, KS, SPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -374,8 +414,15 @@ static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
 }
 
 template <typename T>
+static hipError_t launch_upm_split(const UpmergeParams& p, hipStream_t st) {
+  const long long cells = (long long)p.N * p.LD * p.LH * ((p.LW + 15) / 16);
+  if (cells / 8 * (p.Cout / 16) >= 256) return launch_upm<T, 1, 2, 4, 2, 1, true>(p, st);   // two buffers: hi + lo planes are 55 KB
+  return launch_upm<T, 1, 2, 2, 3, 1, true>(p, st);
+}
+
+template <typename T>
 static hipError_t launch_upm_t(const UpmergeParams& p, hipStream_t st) {
-  const int Q = conv_upmerge_q(p.Cout);
+  const int Q = conv_upmerge_q(p.Cout, 0);
   const long long cells = (long long)p.N * p.LD * p.LH * ((p.LW + 15) / 16);       // tiles of 16 cells
   const long long groups = p.Cout / (16 * Q);
   // bricks of 8 / 4 tiles at Q = 2 (16 tiles = 128 accumulator registers spill next to the fragment buffers), 16 / 8 at Q = 1: the
@@ -393,20 +440,21 @@ static hipError_t launch_upm_t(const UpmergeParams& p, hipStream_t st) {
 hipError_t launch_conv_upmerge(const UpmergeParams& p, int precision, hipStream_t st) {
   if (precision == 0) return launch_upm_t<f16>(p, st);
   if (precision == 1) return launch_upm_t<bf16>(p, st);
+  if (precision == 2) return launch_upm_split<f16>(p, st);
+  if (precision == 3) return launch_upm_split<bf16>(p, st);
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_pack_upmerge(const float* w, const float* scale, void* wpk, int c_off, int CinTotal, int C1, int Cout, int precision,
                                hipStream_t st) {
-  const int Q = conv_upmerge_q(Cout);
-  const long long total = (long long)Cout * C1 * 64;
+  const int split = precision >= 2;
+  const int Q = conv_upmerge_q(Cout, split);
+  const long long total = (long long)Cout * C1 * 64 * (split ? 2 : 1);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  if (precision == 0)
-    hipLaunchKernelGGL(pack_upmerge_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk, c_off, CinTotal, C1, Cout, Q);
-  else if (precision == 1)
-    hipLaunchKernelGGL(pack_upmerge_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale, (bf16*)wpk, c_off, CinTotal, C1, Cout, Q);
+  if ((precision & 1) == 0)
+    hipLaunchKernelGGL(pack_upmerge_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk, c_off, CinTotal, C1, Cout, Q, split);
   else
-    return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_upmerge_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale, (bf16*)wpk, c_off, CinTotal, C1, Cout, Q, split);
   return hipGetLastError();
 }
 

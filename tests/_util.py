@@ -128,24 +128,28 @@ def ref_conv_fp64(x0, x1, w, scale, shift, act, slope=0.3):
 
 
 def run_conv_merged(device, x0, x1, w, scale, shift, act, precision, slope=0.3):
-    """Calls amx_conv3d_upcat_merged (merged-tap launch over the upsampled channels + skip conv that adds its partial sums)."""
+    """Calls amx_conv3d_upcat_merged (skip conv into a scratch tensor + merged-tap launch over the upsampled channels that adds it)."""
     lib = _lib.load()
     tdt = TORCH_T[precision]
+    split = precision in SPLIT
     n, c0, d, h, ww = x0.shape
     cout, c1 = w.shape[0], x1.shape[1]
-    dx0, dx1 = to_ndhwc(x0, tdt).to(device), to_ndhwc(x1, tdt).to(device)
+    pack = (lambda t: to_ndhwc_split(t, tdt)) if split else (lambda t: to_ndhwc(t, tdt))
+    dx0, dx1 = pack(x0).to(device), pack(x1).to(device)
     dw = w.reshape(cout, c0 + c1, 27).contiguous().float().to(device)
     dsc = None if scale is None else scale.float().to(device)
     dsh = None if shift is None else shift.float().to(device)
     wpk = torch.empty(lib.amx_conv3d_upcat_merged_packed_bytes(c0, c1, cout), dtype=torch.uint8, device=device)
-    part = torch.full((n * d * h * ww * cout,), float("nan"), dtype=tdt, device=device)
-    out = torch.full((n, d, h, ww, cout), float("nan"), dtype=tdt, device=device)
+    k = 2 if split else 1
+    part = torch.full((n * d * h * ww * cout * k,), float("nan"), dtype=tdt, device=device)
+    out = torch.full((n, d, h, ww, cout * k), float("nan"), dtype=tdt, device=device)
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _lib.check(lib.amx_conv3d_upcat_merged(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dsh), cout,
                                            n, d, h, ww, act, slope, _lib.PRECISION[precision], _lib.ptr(wpk), _lib.ptr(part),
                                            _lib.ptr(out), st))
     torch.cuda.synchronize(device)
-    return from_ndhwc(out.cpu().float())
+    out = out.cpu()
+    return from_ndhwc_split(out) if split else from_ndhwc(out.float())
 
 
 def ref_conv_upcat_merged(x0, x1, w, scale, shift, act, precision, slope=0.3, round_partial=False):

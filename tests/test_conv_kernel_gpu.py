@@ -149,3 +149,25 @@ def test_merged_concat_conv_matches_cpu(device, case, precision):
     assert rel_l2(got, ref) < (4e-4 if precision == "f16" else 3.2e-3)     # the result's own rounding: 2^-11 / sqrt(3), 2^-8 / sqrt(3)
     plain = ref_conv(x0, x1, wgt, scale, shift, act, precision)          # 27 separately rounded taps, no partial rounding
     assert rel_l2(got, plain) < (6e-4 if precision == "f16" else 5e-3), rel_l2(got, plain)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x2"])
+@pytest.mark.parametrize("case", MERGED_CASES + [(16, 32, (8, 16, 32), 1, 1), (16, 32, (12, 24, 64), 2, 1)],
+                         ids=lambda c: "c%d+%d_%dx%dx%d_n%d_a%d" % (c[0], c[1], *c[2], c[3], c[4]))
+def test_merged_concat_conv_strict_precision_matches_fp64(device, case, precision):
+    """The same two-launch form in the strict precisions (hi + lo operands, three MFMAs per product, split partial sums and
+    outputs), incl. the 48 -> 16 layer, which has no fused kernel there.  Reference: fp64 convolution of the un-rounded fp32
+    operands -- the whole point of the mode; the merged weights are sums formed in fp32 and split once."""
+    c0, c1, (d, h, w), n, act = case
+    cout = c0
+    rs = np.random.RandomState(hash((c0, c1, d, h, w)) & 0xFFFF)
+    x0 = torch.from_numpy(rs.randn(n, c0, d, h, w).astype(np.float32))
+    x1 = torch.from_numpy(rs.randn(n, c1, d // 2, h // 2, w // 2).astype(np.float32))
+    wgt = torch.from_numpy((rs.randn(cout, c0 + c1, 3, 3, 3) / np.sqrt(27.0 * (c0 + c1))).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy((rs.randn(cout) * 0.1).astype(np.float32))
+    got = run_conv_merged(device, x0, x1, wgt, scale, shift, act, precision)
+    assert torch.isfinite(got).all()
+    full = ref_conv_fp64(x0, x1, wgt, scale, shift, act)
+    tol = 3e-5 if precision == "bf16x2" else 4e-6
+    assert rel_l2(got, full) < tol and max_rel(got, full) < 4 * tol, (rel_l2(got, full), max_rel(got, full))
