@@ -147,7 +147,14 @@ struct amx_unet {
   std::vector<int> encoder_idx, decoder_idx;
   std::vector<int> mod_c, mod_level;  // per module: channels / resolution level of `feat` after it (post-concat for Upsample)
   int pack_w = 0;  // spatial W the packing heuristic assumed (reference window: 128)
-  int* d_flag = nullptr;    // device: raised by any epilogue that was about to store a value outside the f16 range (or NaN)
+  // device flags raised by any epilogue that was about to store a value outside the f16 range (or NaN): a ring of kFlagSlots,
+  // ONE PER FORWARD.  A forward clears its slot on its own stream before its first kernel and its last kernel mirrors the slot
+  // into the (sticky) host flag -- so forwards of one handle that overlap on different streams (chunks in flight, pipelined window
+  // batches) neither erase nor inherit each other's flag, and nothing is ever reset from another stream.
+  static constexpr int kFlagSlots = 16;
+  int* d_flags = nullptr;
+  int* d_flag = nullptr;    // the slot of the forward being enqueued
+  unsigned flag_next = 0;
   int* h_flag = nullptr;    // pinned host mirror, written by the last kernel of a forward when the device flag is up
   int* h_flag_dev = nullptr;   // the same memory as the device sees it
   hipEvent_t acc_done[2] = {nullptr, nullptr};   // amx_unet_forward_windows_pipelined: "slot s has finished accumulating"
@@ -665,8 +672,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
 // produced it has already had its output overwritten with NaN on the device (poison_if_flag).
 int pending_numerics_error(amx_unet* h) {
   if (h->h_flag && *(volatile int*)h->h_flag) {
-    *(volatile int*)h->h_flag = 0;
-    (void)hipMemsetAsync(h->d_flag, 0, sizeof(int), nullptr);
+    *(volatile int*)h->h_flag = 0;      // the device slots are per forward and cleared by their own forwards
     return fail(AMX_ERR_OVERFLOW, "a previous forward of this network produced values outside the f16 range (or NaN) in %s storage; "
                 "its output was overwritten with NaN.  Use precision bf16 or strict (bf16x2), which keep fp32's exponent range",
                 h->cfg.precision == AMX_PREC_F16X2 ? "f16x2" : "f16");
@@ -680,6 +686,11 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
                 hipStream_t st, Profiler* prof = nullptr, const long long* x_offs = nullptr,
                 const long long* y_offs = nullptr, const TapReq* taps = nullptr) {
   if (int e = pending_numerics_error(h)) return e;
+  const bool f16_store = h->cfg.precision == AMX_PREC_F16 || h->cfg.precision == AMX_PREC_F16X2;
+  if (h->d_flags) {
+    h->d_flag = h->d_flags + (h->flag_next++ % amx_unet::kFlagSlots);
+    if (f16_store) AMX_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+  }
   int rc = run_forward_impl(h, x, xs_n, xs_z, xs_y, y, ys_n, ys_c, ys_z, ys_y, wmap, n, d, hh, w, ws, ws_bytes, st, prof, x_offs,
                             y_offs, taps);
   const bool f16_storage = h->cfg.precision == AMX_PREC_F16 || h->cfg.precision == AMX_PREC_F16X2;
@@ -759,8 +770,9 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
       return fail(AMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
     }
   }
-  hipError_t e = hipMalloc((void**)&h->d_flag, sizeof(int));
-  if (e == hipSuccess) e = hipMemset(h->d_flag, 0, sizeof(int));
+  hipError_t e = hipMalloc((void**)&h->d_flags, amx_unet::kFlagSlots * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(h->d_flags, 0, amx_unet::kFlagSlots * sizeof(int));
+  h->d_flag = h->d_flags;
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flag, sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) {
     amx_unet_destroy(h);
@@ -774,7 +786,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
 
 void amx_unet_destroy(amx_unet_t* h) {
   if (!h) return;
-  if (h->d_flag) (void)hipFree(h->d_flag);
+  if (h->d_flags) (void)hipFree(h->d_flags);
   if (h->h_flag) (void)hipHostFree(h->h_flag);
   for (int i = 0; i < 2; ++i)
     if (h->acc_done[i]) (void)hipEventDestroy(h->acc_done[i]);

@@ -7,6 +7,8 @@ The Hub download itself needs network access; everything after it (variant -> co
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 from .network import Unet
@@ -58,6 +60,13 @@ def load_from_hf(variant, repo_id=DEFAULT_REPO, revision=None, map_location="cpu
     """load_from_hf.py:52-79.  ``weights_path`` (extension) loads a local ``<variant>.pth`` instead of
     downloading it."""
     model = build_variant(variant)
+    if "vit_kwargs" in ANATOMIX_VARIANTS[variant]:
+        # The reference builds this variant on `dynamic-network-architectures==0.4.4` + timm, neither of which was available to
+        # compare against: module names / state_dict keys, token order and the rotary table of anatomix_amd.model.vit3d restate the
+        # published architecture and are NOT pinned against the upstream package.
+        warnings.warn(f"{variant}: the PrimusV2 body of anatomix_amd is an UNPINNED restatement of the upstream package "
+                      "(dynamic-network-architectures 0.4.4 / timm were unavailable); a published checkpoint may not load "
+                      "(strict key match) and, if it loads, its features are not verified against the reference", stacklevel=2)
     if weights_path is None:
         from huggingface_hub import hf_hub_download   # needs network access
         weights_path = hf_hub_download(repo_id, f"{variant}.pth", revision=revision)

@@ -66,6 +66,11 @@ def _bn_momentum(bn):
     """torch: momentum=None means a cumulative moving average, factor 1 / num_batches_tracked (counted including this batch)."""
     if bn.momentum is not None:
         return bn.momentum
+    if torch.cuda.is_current_stream_capturing():
+        # the factor 1 / (n + 1) is read back from the device (a host synchronisation, illegal during capture) and would be frozen
+        # into the graph for every replay; the reference never builds its norms this way (network.py:148-152: default momentum)
+        raise NotImplementedError("BatchNorm3d(momentum=None) (cumulative moving average) cannot be captured in a HIP graph: "
+                                  "run the step eagerly or give the layer a momentum")
     if bn.num_batches_tracked is None:
         raise NotImplementedError("BatchNorm3d(momentum=None) without num_batches_tracked in the HIP training path")
     return 1.0 / (int(bn.num_batches_tracked.item()) + 1)

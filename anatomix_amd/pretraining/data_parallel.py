@@ -26,11 +26,22 @@ import torch
 
 
 class GradientBuckets:
-    def __init__(self, nets: Iterable[torch.nn.Module], group=None, bucket_mb: float = 16.0, overlap: bool = False):
+    """Replica policy: at construction every parameter AND buffer is broadcast from the group's first rank (``broadcast=True``),
+    so the replicas start identical whatever each rank's seed was.  Parameters then stay in step because every rank applies the
+    same averaged gradient.  BatchNorm running statistics are per-rank afterwards (each rank sees its own pair of views; the
+    reference updates them sequentially pair by pair, supcl_model.py:618-661) -- they only matter for eval-mode use, for which
+    rank 0's are the ones a checkpoint would hold; ``sync_buffers()`` re-broadcasts them on demand."""
+
+    def __init__(self, nets: Iterable[torch.nn.Module], group=None, bucket_mb: float = 16.0, overlap: bool = False,
+                 broadcast: bool = True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nets = list(nets)
+        self.nets = nets
+        if broadcast and self.world > 1:
+            self._broadcast([t for net in nets for t in list(net.parameters()) + list(net.buffers())])
         self.buckets: List[torch.Tensor] = []
         self.params: List[List[torch.nn.Parameter]] = []      # per bucket
         self.views: List[List[torch.Tensor]] = []
@@ -76,6 +87,17 @@ class GradientBuckets:
                             self._launch(b)
                     for p in grp:
                         p.register_post_accumulate_grad_hook(hook)
+
+    def _broadcast(self, tensors):
+        src = self.dist.get_global_rank(self.group, 0) if self.group is not None and self.group is not self.dist.group.WORLD else 0
+        with torch.no_grad():
+            for t in tensors:
+                self.dist.broadcast(t.data, src=src, group=self.group)
+
+    def sync_buffers(self):
+        """Re-broadcast every buffer (BatchNorm running statistics, counters) from the group's first rank."""
+        if self.world > 1:
+            self._broadcast([b for net in self.nets for b in net.buffers()])
 
     @property
     def nbytes(self):

@@ -23,7 +23,7 @@ def _layer_streams(device, n):
 
 
 def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights, num_patches, lambda_nce,
-                      sample_ids, grad_accum_iters):
+                      sample_ids, grad_accum_iters, scaler=None):
     """forward with taps -> sampler + heads -> per-layer losses -> backward.  Nothing here synchronises with the host."""
     if nce_weights is None:
         nce_weights = [1.0 / len(nce_layers)] * len(nce_layers)
@@ -52,7 +52,8 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     total = 0.0
     for part in parts:
         total = total + part
-    (total / grad_accum_iters).backward()
+    loss = total / grad_accum_iters
+    (scaler.scale(loss) if scaler is not None else loss).backward()      # supcl_model.py:624-626
     return total, layer_losses, ids, out
 
 
@@ -65,7 +66,7 @@ def _grad_norms(netG, netF):
 
 def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights=None, num_patches=512,
                      lambda_nce=1.0, optimizers=None, sample_ids=None, grad_accum_iters=1, grad_sync=None, do_step=None,
-                     iters=None, grad_buckets=None):
+                     iters=None, grad_buckets=None, scaler=None):
     """Two aligned views through the shared network with feature taps, same-coordinate patch sampling, per-layer
     SupPatchNCELoss, weighted sum, backward and (optionally) the optimizer steps.
 
@@ -79,8 +80,15 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
     optimizers step (and are zeroed) only on calls where ``do_step`` is true -- pass it directly, or pass the reference's
     running ``iters`` counter and it is ``iters % grad_accum_iters == 0``.  With optimizers and grad_accum_iters > 1 one of
     the two must be given: stepping on every call would shrink the gradients instead of accumulating them.
+    scaler: a ``torch.amp.GradScaler`` -- the reference's loss-scaling protocol (supcl_model.py:523-525, 624-661): the loss is
+    scaled before the backward; on a stepping call every optimizer is unscaled (so the recorded norms are those of the true
+    gradients), ``scaler.step`` SKIPS an optimizer whose gradients hold an inf / NaN, and ``scaler.update()`` then lowers the
+    scale.  With finite gradients the scale is a power of two and the step is bit-identical to the unscaled one.  (Eager steps
+    only: GradScaler reads its found-inf flag on the host.)
     Returns an OrderedDict(loss, per_layer, grad_norm_G, grad_norm_F, sample_ids, out).
     """
+    if scaler is not None and optimizers is None:
+        raise ValueError("contrastive_step: scaler= needs the optimizers it unscales and steps")
     if grad_buckets is not None and grad_buckets.overlap and grad_accum_iters > 1:
         raise ValueError("GradientBuckets(overlap=True) reduces a bucket as soon as one backward filled it: not with grad_accum_iters > 1")
     if do_step is None:
@@ -92,16 +100,24 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
         else:
             do_step = True
     total, layer_losses, ids, out = _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights,
-                                                     num_patches, lambda_nce, sample_ids, grad_accum_iters)
+                                                     num_patches, lambda_nce, sample_ids, grad_accum_iters, scaler)
     if do_step:
         if grad_sync is not None:
             grad_sync()
         if grad_buckets is not None:
             grad_buckets.sync()
+        if scaler is not None:
+            for opt in optimizers:                   # unscale first: the norms below are those of the true gradients
+                scaler.unscale_(opt)
     gG, gF = _grad_norms(netG, netF)
     if optimizers is not None and do_step:
         for opt in optimizers:
-            opt.step()
+            if scaler is not None:
+                scaler.step(opt)                     # skipped when this optimizer's gradients hold an inf / NaN
+            else:
+                opt.step()
+        if scaler is not None:
+            scaler.update()
         if grad_buckets is not None:
             grad_buckets.release()
         else:
@@ -134,6 +150,10 @@ class GraphedContrastiveStep:
         self.netG, self.netF, self.criterions, self.nce_layers = netG, netF, criterions, list(nce_layers)
         self.optimizers, self.nce_weights, self.num_patches, self.lambda_nce = optimizers, nce_weights, num_patches, lambda_nce
         self.grad_buckets = grad_buckets
+        if grad_buckets is not None and getattr(grad_buckets, "overlap", False):
+            # the post-accumulate hooks of overlap mode would launch RCCL all-reduces and mutate Python bookkeeping DURING the capture;
+            # neither re-runs on replay, so sync() would skip those buckets
+            raise ValueError("GraphedContrastiveStep needs GradientBuckets(overlap=False): hooks that launch collectives cannot be captured")
         if grad_buckets is not None and grad_sync is None and grad_buckets.world > 1:
             grad_sync = grad_buckets.sync
         self.grad_sync, self.warmup = grad_sync, warmup

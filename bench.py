@@ -99,6 +99,7 @@ def cpu_baseline(size, forwards, variant="anatomix"):
             if time.perf_counter() - t_start > 20.0:
                 break
     best = min(ts)
+    cpu_baseline.last_output = R.forward(x, sd, kw) if forwards else None      # checker: the headline's parity figure
     return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{len(ts)} forwards of one 1x1x{size}^3 volume, fp32 eval, torch CPU (oneDNN) with {cores} of "
                       f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
@@ -251,6 +252,20 @@ def step_roofline(torch, dev, S):
             "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
             "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
+
+
+def parity_vs_split(torch, ctx, variant, precision, x, y):
+    """rel-L2 of this run's features (first volume) against the SAME network in f16x2 storage on the GPU -- the product's own
+    highest-precision mode, itself pinned against the fp32 CPU oracle by tests/test_strict_precision_gpu.py (6 M 1.3e-6, dev
+    2.3e-5 at 128^3).  Cheap enough to run inside the bench for every forward secondary."""
+    ref_model = build_model(ctx, variant, "f16x2")
+    with torch.no_grad():
+        ref = ref_model(x[:1]).double()
+    rel = float(((y[:1].double() - ref).norm() / ref.norm()).item())
+    del ref_model, ref
+    torch.cuda.empty_cache()
+    return {"rel_l2": float("%.3e" % rel), "against": "the same network in f16x2 storage (1.3e-6 / 2.3e-5 from the fp32 oracle)",
+            "tolerance": 1e-3, "compliant": bool(rel <= 1e-3)}
 
 
 def self_launch(args):
@@ -485,6 +500,14 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         if world == 1 and with_cpu:
             result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else \
                 (cpu_baseline_vit() if vit else cpu_baseline(S, cpu_forwards, variant))
+        if workload == "forward" and not sw_volume and not vit:
+            result["parity"] = parity_vs_split(torch, ctx, variant, precision, x, y)
+            ref_cpu = getattr(cpu_baseline, "last_output", None) if (world == 1 and with_cpu) else None
+            if ref_cpu is not None and rank == 0:     # rank 0's first volume is the oracle's input (seed 100)
+                d = (y[:1].cpu().double() - ref_cpu.double()).norm() / ref_cpu.double().norm()
+                result["parity"]["rel_l2_vs_fp32_cpu_oracle"] = float("%.3e" % float(d))
+                result["parity"]["compliant"] = bool(float(d) <= 1e-3)
+                cpu_baseline.last_output = None
     del model, x, y
     torch.cuda.empty_cache()
     return result
@@ -496,8 +519,10 @@ def secondary_workloads(ctx, args):
     plan = [
         ("anatomix_batch8_two_chunks_in_flight", dict(variant="anatomix", precision="f16", steps=60, warmup=15, batch=8)),
         ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
-        ("anatomix_dev", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=4)),
-        ("anatomix_dev_strict", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),
+        # anatomix-dev (BASELINE configs[3]): `strict` is the module's default for InstanceNorm networks and the compliant number;
+        # single f16 storage is an explicit opt-in that misses the 1e-3 tolerance (reported with its measured error, not credited)
+        ("anatomix_dev", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),
+        ("anatomix_dev_f16_noncompliant", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=4)),
         ("anatomix_dev_vit", dict(variant="anatomix-dev-vit", steps=8, warmup=3, batch=4)),
         ("sliding_window_256", dict(variant="anatomix", sw_volume=2 * S, steps=3, warmup=1)),
         ("contrastive_step", dict(variant="anatomix", workload="step", steps=10, warmup=1)),
@@ -508,7 +533,7 @@ def secondary_workloads(ctx, args):
         try:
             r = run_workload(ctx, size=S, with_cpu=False, **kw)
             keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "end_to_end_TFLOPs",
-                                      "end_to_end_mfma_frac", "roofline")}
+                                      "end_to_end_mfma_frac", "roofline", "parity") if k in r}
             keep["workload"] = r["config"]["workload"]
             keep["batch_per_gpu"] = r["config"]["batch_per_gpu"]
             keep["roofline"].pop("per_kernel", None)
