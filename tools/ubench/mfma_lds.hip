@@ -4,6 +4,7 @@
 // v_mfma_f32_32x32x16_f16 (32 cycles) and v_mfma_f32_16x16x32_f16 (16 cycles) -- at 1 and 2 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -16,12 +17,18 @@ template <> struct Acc<0> { typedef f32x4 t; static __device__ __forceinline__ t
 
 // NW MFMA waves (+ LW loader waves).  AREG: A fragments stay in registers (no A reads).
 template <int BIG, int NA, int NB, int NW, int LW, int AREG, int RD>
-__global__ __launch_bounds__((NW + LW) * 64) void k(const char* src, int steps, unsigned long long* out, float* sink) {
+__global__ __launch_bounds__((NW + LW) * 64) void k(const char* src, int steps, unsigned long long* out, float* sink, int data) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Acc<BIG>::t acc_t;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) ((unsigned*)smem)[i] = ((i * 2654435761u) >> 3 & 0x3fff3fffu) | 0x20002000u;   // pseudo-random finite f16 pairs
+  for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) {
+    unsigned v = ((i * 2654435761u) >> 3 & 0x3fff3fffu) | 0x20002000u;   // pseudo-random finite f16 pairs
+    const unsigned h = i * 0x9E3779B1u;
+    if (data == 1 && i < 32768 / 4) v &= ((h & 0x10000u) ? 0xffffu : 0u) | ((h & 0x20000u) ? 0xffff0000u : 0u);   // B operands: ~half zeros (post-ReLU)
+    if (data == 2) v = 0u;
+    ((unsigned*)smem)[i] = v;
+  }
   __syncthreads();
   if (wave >= NW) {   // loader: stream LDS-DMA into the upper 64 KiB for the whole run
     const char* base = src + (long long)blockIdx.x * 65536;
@@ -90,17 +97,18 @@ __global__ __launch_bounds__((NW + LW) * 64) void k(const char* src, int steps, 
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
 
+static int g_data = 0, g_reps = 2, g_steps = 4096;
 template <int BIG, int NA, int NB, int NW, int LW, int AREG, int RD = 0>
 static void run(const char* src, unsigned long long* out, float* sink, int grid = 256) {
-  const int steps = 4096;
+  const int steps = g_steps;
   unsigned long long h[256];
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto kern = k<BIG, NA, NB, NW, LW, AREG, RD>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < g_reps; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3((NW + LW) * 64), 131072, 0, src, steps, out, sink);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((NW + LW) * 64), 131072, 0, src, steps, out, sink, g_data);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
   }
@@ -109,23 +117,31 @@ static void run(const char* src, unsigned long long* out, float* sink, int grid 
   (void)hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
   const double flop = (double)steps * NA * NB * NW * (BIG ? 32768.0 : 16384.0) * grid;
   const double mfma_cycles = (double)steps * NA * NB * (BIG ? 32 : 16) * (NW / 4.0);   // per SIMD
-  printf("grid %3d %s NA %d NB %d waves %d%s%s: reads/MFMA %.2f  %7.1f us  %6.0f TFLOP/s  MFMA-busy %.2f (wg0: %.2f)\n", grid, BIG ? "32x32x16" : "16x16x32", NA, NB, NW,
+  printf("data %s grid %3d %s NA %d NB %d waves %d%s%s: reads/MFMA %.2f  %7.1f us  %6.0f TFLOP/s  MFMA-busy %.2f (wg0: %.2f)\n", g_data == 0 ? "random" : (g_data == 1 ? "relu-like" : "zeros"), grid, BIG ? "32x32x16" : "16x16x32", NA, NB, NW,
          LW ? "+loader" : "", AREG ? " A-in-regs" : (RD == 1 ? " asm-waits" : (RD == 2 ? " NO-READS" : (RD == 3 ? " NO-READS/2 sets" : (RD == 4 ? " asm wait0" : "")))), (double)((AREG ? 0 : NA) + NB) / (NA * NB), ms * 1e3, flop / (ms * 1e-3) / 1e12,
          flop / (ms * 1e-3) / (2.5e15 * grid / 256.0), mfma_cycles / (double)h[0]);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // usage: mfma_lds [data: 0 random | 1 relu-like | 2 zeros] [reps] [sustain: 1 = only the generic-kernel tile shape, long]
+  g_data = argc > 1 ? atoi(argv[1]) : 0;
+  g_reps = argc > 2 ? atoi(argv[2]) : 2;
+  const int sustain = argc > 3 ? atoi(argv[3]) : 0;
   char* src; unsigned long long* out; float* sink;
   (void)hipMalloc(&src, 256 * 65536); (void)hipMemset(src, 0, 256 * 65536); (void)hipMalloc(&out, 256 * 8); (void)hipMalloc(&sink, 4096);
+  if (sustain) {
+    run<0, 2, 4, 8, 0, 0, 1>(src, out, sink, 256);      // the generic conv kernel's wave tile, operands from LDS, counted waits
+    return 0;
+  }
   for (int grid : {256, 64, 8}) {
     run<1, 2, 4, 8, 0, 0, 2>(src, out, sink, grid);
     run<1, 2, 4, 8, 0, 0, 3>(src, out, sink, grid);
     run<1, 2, 4, 8, 0, 0, 1>(src, out, sink, grid);
-    run<1, 2, 4, 8, 0, 0, 4>(src, out, sink, grid);
     run<1, 4, 4, 4, 0, 0, 1>(src, out, sink, grid);
     run<1, 1, 8, 8, 0, 0, 1>(src, out, sink, grid);
     run<0, 2, 4, 8, 0, 0, 3>(src, out, sink, grid);
     run<0, 2, 4, 8, 0, 0, 1>(src, out, sink, grid);
+    run<0, 4, 4, 8, 0, 0, 1>(src, out, sink, grid);
   }
   return 0;
 }
