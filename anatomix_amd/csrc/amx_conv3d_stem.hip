@@ -21,6 +21,8 @@ namespace amx {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+constexpr int kStemF32Offset = 8192;    // byte offset of the fp32 [27][Cout] weight table inside the stem's packed-weight buffer
+
 template <int TY, int TX, int TZ, int NC, int R>
 struct StemCfg {
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
@@ -222,12 +224,167 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   if (RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------------
+// VALU variant (round 3) -- MEASURED, NOT THE DEFAULT (AMX_STEM_VALU=1 selects it).  6 M stem, batch 4 x 128^3, same box: 144 us
+// against 131 us for the MFMA kernel (strict, 32 channels: 385 vs 259).  Ablations of both (profiles/r03_stem_ablation.txt): input
+// ring + output stores alone take 76-92 us (the 268 MB of output leave at ~3.5 TB/s at best), the arithmetic phase (37 us of
+// gather + MFMA there, 54 us of packed fp32 FMAs here -- v_pk_fma_f32 is 4 cycles per wave, the stencil is 46 us of pure VALU at
+// 2.4 GHz) adds to that almost serially in BOTH formulations, and more workgroups per CU (512 .. 2048) change nothing.  The stem is
+// bound by its store stream plus whatever arithmetic sits in front of it, not by the operand path the verdict suspected.
+// The MFMA kernel above spends ~125 instructions per MFMA gathering, converting and packing the 27 taps
+// of a voxel into a K = 32 fragment: it is instruction-bound at 2.1x its write floor.  With one input channel the layer is
+// 27 x Cout multiply-adds per voxel on an operand that needs no rounding at all -- the fp32 input and the fp32 (norm-folded)
+// weights: here a lane owns ONE voxel, reads its 27 fp32 taps from the same LDS ring, and runs 27 x Cout v_fma_f32 whose second
+// operand is a scalar register (the weight table [tap][cout] comes through the scalar cache: the constant address space makes
+// hipcc use s_load for it).  No conversions, no packing, no MFMA -- and the arithmetic is exact fp32 instead of 16-bit operands.
+// Same tile (8 x 32 x 2 planes per step), same loader wave, same flag protocol as above.
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+
+template <typename T, int Q, int TY, int TX, int TZ, int NC, int R, bool SPLIT>
+__global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_valu_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef StemCfg<TY, TX, TZ, NC, R> C;
+  constexpr int HX = C::HX, PLSZ = C::PLSZ, NDMA = C::NDMA, CO = 16 * Q;
+  static_assert(TX == 32 && NC * 64 == TZ * TY * TX, "one lane per voxel of a step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  const int bx = b % p.nbx;
+  b /= p.nbx;
+  const int by = b % p.nby;
+  b /= p.nby;
+  const int sg = b % nseg;
+  const int n = b / nseg;
+  const int y0 = by * TY, x0 = bx * TX;
+  const int zs = sg * zseg;
+  const int ze = (zs + zseg < p.D) ? zs + zseg : p.D;
+  const int nplanes = ze - zs + 2;
+  const int nsteps = (ze - zs + TZ - 1) / TZ;
+
+  int* ready = (int*)(smem + C::FLAGOFF);
+  int* done = (int*)(smem + C::FLAGOFF + 32);
+  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  __syncthreads();
+
+  if (wave >= NC) {
+    // ================================ loader wave (as in the MFMA kernel) ================================
+    int off[NDMA];
+    bool valid[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int hv = j * 64 + lane;
+      const int hy = hv / HX, hx = hv - hy * HX;
+      valid[j] = hv < C::HVP;
+      off[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x;
+    }
+    const char* src_n = p.src0 + (long long)n * p.s0n;
+    auto issue_plane = [&](int q) {
+      const char* plane = src_n + (long long)reflect_clamp(zs - 1 + q, p.D) * p.s0z;
+      char* dstp = smem + (q % R) * PLSZ;
+#pragma unroll
+      for (int j = 0; j < NDMA; ++j)
+        if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 256), 4, 0, 0);
+    };
+    int next_issue = 0, next_pub = 0;
+    const unsigned a_ready = lds_addr(ready), a_done = lds_addr(done);
+    while (next_pub < nplanes) {
+      if (next_issue < nplanes) {
+        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
+        int lim = R + TZ * md;
+        lim = lim < nplanes ? lim : nplanes;
+        while (next_issue < lim) issue_plane(next_issue++);
+      }
+      if (next_issue == next_pub) {
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      WaitVm<NDMA, R - 1>::run(next_issue - next_pub - 1);
+      flag_store_asm(a_ready, ++next_pub);
+    }
+    return;
+  }
+
+  // ================================ consumer wave: one voxel per lane ================================
+  constexpr int WPZ = NC / TZ;                              // waves per output plane
+  const int tz = wave / WPZ;
+  const int row = (wave % WPZ) * (TY / WPZ) + (lane >> 5), col = lane & 31;
+  const int lanepos = (row * HX + col) * 4;
+  const int yl = y0 + row, xl = x0 + col;
+  const bool in_xy = (yl < p.H) & (xl < p.W);
+  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox;
+  const cfloat_ptr wt = (cfloat_ptr)(p.wpk + kStemF32Offset);          // [27][CO] fp32, norm gain folded in
+  const cfloat_ptr bs = (cfloat_ptr)p.bias;
+
+  bool bad = false;
+  for (int s = 0; s < nsteps; ++s) {
+    {
+      int need = TZ * s + TZ + 2;
+      need = need < nplanes ? need : nplanes;
+      while (flag_load(ready) < need) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    }
+    const int zo = zs + s * TZ + tz;
+    float x[27];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const char* pl = smem + ((s * TZ + tz + kz) % R) * PLSZ + lanepos;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) x[kz * 9 + e] = *(const float*)(pl + ((e / 3) * HX + e % 3) * 4);
+    }
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = p.bias ? bs[c] : 0.f;
+    if (!(p.dbg & 2)) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = __builtin_fmaf(x[t], wt[t * CO + c], acc[c]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
+    flag_store(done + wave, s + 1);
+    if (p.act == ACT_RELU) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = acc[c] > 0.f ? acc[c] : 0.f;
+    } else if (p.act == ACT_LRELU) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = acc[c] > 0.f ? acc[c] : acc[c] * p.slope;
+    }
+    if (RangeCheck<T>::on) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) bad |= RangeCheck<T>::bad(acc[c]);
+    }
+    if (zo < ze && in_xy && !(p.dbg & 4)) {
+      char* dst = out_l + (long long)zo * p.oz;
+      unsigned w[CO / 2];
+#pragma unroll
+      for (int j = 0; j < CO / 2; ++j) w[j] = (unsigned)to_bits<T>(acc[2 * j]) | ((unsigned)to_bits<T>(acc[2 * j + 1]) << 16);
+#pragma unroll
+      for (int j = 0; j < CO / 8; ++j) *(uint4*)(dst + j * 16) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+      if (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j)
+          w[j] = (unsigned)to_bits<T>(acc[2 * j] - (float)(T)acc[2 * j]) | ((unsigned)to_bits<T>(acc[2 * j + 1] - (float)(T)acc[2 * j + 1]) << 16);
+#pragma unroll
+        for (int j = 0; j < CO / 8; ++j) *(uint4*)(dst + p.Cout * 2 + j * 16) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+      }
+    }
+  }
+  if (RangeCheck<T>::on) raise_flag(p.oflow, bad);
+}
+
 // Stem weights: fp32 [Cout][1][3][3][3] (* folded norm gain) -> [q][lane 64][8] A fragments with
 // k = 8*g + e <-> tap as described above; row m of tile q is channel (m>>2)*4Q + q*4 + (m&3).
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk,
                                  int Q, int split) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 27 * 16 * Q) {                          // fp32 table of the VALU kernel: [tap][cout], gain folded in
+    const int t = idx / (16 * Q), c = idx % (16 * Q);
+    ((float*)((char*)wpk + kStemF32Offset))[idx] = w[c * 27 + t] * (scale ? scale[c] : 1.f);
+  }
   if (idx >= Q * 512 * (split ? 2 : 1)) return;
   const int part = idx / (Q * 512);                 // split: [Wh tiles | Wl tiles]
   const int e = idx & 7, lane = (idx >> 3) & 63, q = (idx >> 9) % Q;
@@ -260,12 +417,23 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   p.nby = (p.H + TY - 1) / TY;
   p.nbx = (p.W + TX - 1) / TX;
   const int tiles = p.nby * p.nbx * p.N;
-  int nseg = (512 + tiles - 1) / tiles;       // tiny LDS footprint: two workgroups per CU
+  static int wgs = -1;
+  if (wgs < 0) wgs = getenv("AMX_STEM_WGS") ? atoi(getenv("AMX_STEM_WGS")) : 512;
+  int nseg = (wgs + tiles - 1) / tiles;       // tiny LDS footprint: several workgroups per CU
   if (nseg < 1) nseg = 1;
   int zseg = (p.D + nseg - 1) / nseg;
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
+  static int valu = -1;
+  if (valu < 0) valu = getenv("AMX_STEM_VALU") ? 1 : 0;     // opt-in: measured slower (below)
+  if (valu) {
+    snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem_valu<%s,q%d,%dx%dx%d,c%d+l1,r%d>",
+             __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q, TZ, TY, TX, NC, R);
+    hipLaunchKernelGGL((conv3d_stem_valu_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
+                       C::LDS_BYTES, st, p, zseg, nseg);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((conv3d_stem_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
                      C::LDS_BYTES, st, p, zseg, nseg);
   return hipGetLastError();
