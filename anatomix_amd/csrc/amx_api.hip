@@ -1068,7 +1068,7 @@ int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, 
   const bool split = is_split(precision);
   const long long eb = split ? 4 : 2;
   if (c0 != cout || !amx::conv_upmerge_eligible(c0, c1, cout, d, hh, w, 1, split))
-    return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32 (16 in the strict precisions), c1 %% 32 == 0, w >= 32, even dims "
+    return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32 (16 in the strict precisions), c1 %% 32 == 0, w >= 16, even dims "
                 "(c0=%d c1=%d cout=%d dims %d,%d,%d)", c0, c1, cout, d, hh, w);
   hipStream_t st = (hipStream_t)stream;
   const int q = amx::conv_pick_q(cout, w);

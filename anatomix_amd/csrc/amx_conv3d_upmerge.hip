@@ -32,12 +32,15 @@
 namespace amx {
 
 
-template <int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false>
+template <int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false, int LXT = 16>
 struct UpmCfg {
+  static_assert(LXT == 16 || LXT == 8, "a tile is 16 cells of one low-res row, or 8 cells of two rows (rows shorter than 16)");
+  static constexpr int RPT = 16 / LXT;                   // rows per tile
+  static constexpr int BY = TY * RPT;                    // brick rows
   static constexpr int NP = SPLIT ? 2 : 1;                // strict precision: hi and lo halves of every operand
   static_assert(!SPLIT || KS == 1, "strict precision: 32-channel stages");
   static constexpr int T = TZ * TY;                       // tiles per wave (= per class)
-  static constexpr int HZ = TZ + 2, HY = TY + 2, HX = 18, HV = HZ * HY * HX;
+  static constexpr int HZ = TZ + 2, HY = BY + 2, HX = LXT + 2, HV = HZ * HY * HX;
   static constexpr int PL = ((HV * 16 + 255) / 256) * 256;   // one 8-channel plane of the halo
   static constexpr int BUF = 4 * KS * NP * PL;            // KS x 32 channels per stage (strict: hi planes, then lo planes)
   static constexpr int NJ = (HV + 63) / 64;               // DMA instructions per plane
@@ -50,9 +53,10 @@ struct UpmCfg {
 // SPLIT (strict precision): every tensor holds [hi(C) | lo(C)] 16-bit channels per voxel (value = hi + lo), the packing holds Wh
 // and Wl fragments per tap; the sweep multiplies Wh*xh + Wh*xl + Wl*xh into the same fp32 accumulators (amx_conv3d_v2.hip), the
 // epilogue adds hi + lo of the skip partial sums and splits the result again.
-template <typename T_, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT>
+template <typename T_, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT, int LXT>
 __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams p) {
-  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT> C;
+  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT, LXT> C;
+  constexpr int RPT = C::RPT, BY = C::BY;
   constexpr int NP = C::NP;
   typedef typename Ops<T_>::vec8 vec8;
   constexpr int HY = C::HY, HX = C::HX, PL = C::PL, NT = C::T;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
+  const int lix = li & (LXT - 1), liy = LXT == 8 ? li >> 3 : 0;     // cell of the tile this lane multiplies
   const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
 
   // ---- this workgroup's contiguous run of items (brick, cout group); XCD b % 8 gets a contiguous span
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
         const int j = id % C::NJ;
         const int hv = j * 64 + lane;
         const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-        int gz = I.bz * TZ - 1 + hz, gy = I.by * TY - 1 + hy, gx = I.bx * 16 - 1 + hx;
+        int gz = I.bz * TZ - 1 + hz, gy = I.by * BY - 1 + hy, gx = I.bx * LXT - 1 + hx;
         gz = gz < 0 ? 0 : (gz >= p.LD ? p.LD - 1 : gz);
         gy = gy < 0 ? 0 : (gy >= p.LH ? p.LH - 1 : gy);
         gx = gx < 0 ? 0 : (gx >= p.LW ? p.LW - 1 : gx);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   constexpr int WIN = 4;
   vec8 wq[WIN][NP][Q];
   // ---- lane-constant LDS base: halo voxel (lz + pz + ez, ly + py + ey, li + px + ex), plane g
-  const int lbase = g * PL + ((pz * HY + py) * HX + px + li) * 16;
+  const int lbase = g * PL + ((pz * HY + py + liy) * HX + px + lix) * 16;
 
   f32x4 acc[NT][Q];
   int nx_it = it0, nx_stage = 0;                           // next (item, stage) to fetch
@@ -165,12 +170,12 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   unsigned padd[NT][2 * Q * NP];
   auto load_part = [&](const int it) {
     const Item I = decode(it);
-    const int lx = I.bx * 16 + li;
+    const int lx = I.bx * LXT + lix;
     const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
     const char* pb = p.part + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int lz = I.bz * TZ + i / TY, ly = I.by * TY + i % TY;
+      const int lz = I.bz * TZ + i / TY, ly = I.by * BY + (i % TY) * RPT + liy;
       const bool in = (lz < p.LD) & (ly < p.LH) & (lx < p.LW);
 #pragma unroll
       for (int hl = 0; hl < NP; ++hl) {                     // strict: the lo channels follow Cout channels further on in the voxel
@@ -192,12 +197,12 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   auto flush = [&]() {
     const Item I = decode(pend_it);
     pend_it = -1;
-    const int lx = I.bx * 16 + li;
+    const int lx = I.bx * LXT + lix;
     const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
     char* pb = p.out + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int lz = I.bz * TZ + i / TY, ly = I.by * TY + i % TY;
+      const int lz = I.bz * TZ + i / TY, ly = I.by * BY + (i % TY) * RPT + liy;
       if (lz >= p.LD || ly >= p.LH || lx >= p.LW) continue;
 #pragma unroll
       for (int hl = 0; hl < NP; ++hl) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
           const int lz = (i0 + k) / TY, ly = (i0 + k) % TY;
 #pragma unroll
           for (int h = 0; h < NP; ++h)
-            fb[set][k][h] = *(const vec8*)(buf + (ks + h) * 4 * PL + (((lz + ez) * HY + ly + ey) * HX + ex) * 16);
+            fb[set][k][h] = *(const vec8*)(buf + (ks + h) * 4 * PL + (((lz + ez) * HY + ly * RPT + ey) * HX + ex) * 16);
         }
       };
       load_group(0, 0);
@@ -374,18 +379,18 @@ int conv_upmerge_q(int Cout, int split) { return (!split && Cout % 32 == 0) ? 2 
 bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_UPMERGE") ? 1 : 0;
-  return !off && up_shift == 1 && C0 >= 16 && C1 >= 32 && C1 % 32 == 0 && Cout >= (split ? 16 : 32) && Cout % 16 == 0 && W >= 32 && !(D & 1) && !(H & 1) &&
+  return !off && up_shift == 1 && C0 >= 16 && C1 >= 32 && C1 % 32 == 0 && Cout >= (split ? 16 : 32) && Cout % 16 == 0 && W >= 16 && !(D & 1) && !(H & 1) &&
          !(W & 1) && D >= 4 && H >= 4;
 }
 
 static int g_num_cus6 = 0;
 
-template <typename T, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false>
+template <typename T, int Q, int TZ, int TY, int NBUF, int KS, bool SPLIT = false, int LXT = 16>
 static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
-  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT> C;
-  snprintf(g_kernel_name6, sizeof g_kernel_name6, "conv3d_upmerge<%s,q%d,%dx%dx16,b%d,k%d>", __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q,
-           TZ, TY, NBUF, 32 * KS);
-  auto kern = conv3d_upmerge_kernel<T, Q, TZ, TY, NBUF, KS, SPLIT>;
+  typedef UpmCfg<Q, TZ, TY, NBUF, KS, SPLIT, LXT> C;
+  snprintf(g_kernel_name6, sizeof g_kernel_name6, "conv3d_upmerge<%s,q%d,%dx%dx%d,b%d,k%d>", __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q,
+           TZ, C::BY, LXT, NBUF, 32 * KS);
+  auto kern = conv3d_upmerge_kernel<T, Q, TZ, TY, NBUF, KS, SPLIT, LXT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -399,8 +404,8 @@ static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
     g_num_cus6 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   p.nbz = (p.LD + TZ - 1) / TZ;
-  p.nby = (p.LH + TY - 1) / TY;
-  p.nbx = (p.LW + 15) / 16;
+  p.nby = (p.LH + C::BY - 1) / C::BY;
+  p.nbx = (p.LW + LXT - 1) / LXT;
   static int dbg = -1;
   if (dbg < 0) {
     const char* e = getenv("AMX_DBG");
@@ -415,6 +420,7 @@ static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
 
 template <typename T>
 static hipError_t launch_upm_split(const UpmergeParams& p, hipStream_t st) {
+  if (p.LW < 16) return launch_upm<T, 1, 2, 2, 3, 1, true, 8>(p, st);        // rows shorter than a 16-cell tile: 8 cells x 2 rows
   const long long cells = (long long)p.N * p.LD * p.LH * ((p.LW + 15) / 16);
   if (cells / 8 * (p.Cout / 16) >= 256) return launch_upm<T, 1, 2, 4, 2, 1, true>(p, st);   // two buffers: hi + lo planes are 55 KB
   return launch_upm<T, 1, 2, 2, 3, 1, true>(p, st);
@@ -423,6 +429,10 @@ static hipError_t launch_upm_split(const UpmergeParams& p, hipStream_t st) {
 template <typename T>
 static hipError_t launch_upm_t(const UpmergeParams& p, hipStream_t st) {
   const int Q = conv_upmerge_q(p.Cout, 0);
+  if (p.LW < 16) {                                                             // rows shorter than a 16-cell tile: 8 cells x 2 rows
+    if (Q == 2) return p.C1 % 64 == 0 ? launch_upm<T, 2, 2, 2, 2, 2, false, 8>(p, st) : launch_upm<T, 2, 2, 2, 3, 1, false, 8>(p, st);
+    return launch_upm<T, 1, 2, 2, 3, 1, false, 8>(p, st);
+  }
   const long long cells = (long long)p.N * p.LD * p.LH * ((p.LW + 15) / 16);       // tiles of 16 cells
   const long long groups = p.Cout / (16 * Q);
   // bricks of 8 / 4 tiles at Q = 2 (16 tiles = 128 accumulator registers spill next to the fragment buffers), 16 / 8 at Q = 1: the

@@ -249,7 +249,7 @@ int amx_upsample2_trilinear_backward(const void* d_gout, void* d_gin, int n, int
  * act): (1) the ordinary 27-tap convolution over the skip channels writes raw partial sums into d_partial; (2) the merged-tap
  * convolution over the upsampled channels at LOW resolution -- the 27 taps over a nearest-upsampled tensor collapse to 2x2x2
  * parity-dependent taps, 3.4x fewer multiply-accumulates -- adds them, the bias and the activation.  Needs c0 == cout,
- * c1 a multiple of 32, cout >= 32, w >= 32, even dims, precision f16 / bf16; AMX_ERR_INVALID otherwise.  d_wpk:
+ * c1 a multiple of 32, cout >= 32 (>= 16 in the strict precisions), w >= 16, even dims; AMX_ERR_INVALID otherwise.  d_wpk:
  * amx_conv3d_upcat_merged_packed_bytes(c0, c1, cout) bytes of scratch for both packings; d_partial: n*d*h*w*cout*2 bytes. */
 size_t amx_conv3d_upcat_merged_packed_bytes(int c0, int c1, int cout);
 int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, const float* d_scale,

@@ -117,6 +117,9 @@ MERGED_CASES = [
     (64, 128, (4, 12, 48), 1, 0),         # ragged, no activation
     (128, 256, (4, 8, 32), 1, 1),         # 384 -> 128
     (48, 96, (4, 8, 32), 1, 1),           # cout not a multiple of 32: 16-channel groups in the merged launch
+    (128, 256, (8, 8, 16), 2, 1),         # 384 -> 128 @16: low-res rows of 8 cells -> tiles of 8 cells x 2 rows
+    (64, 128, (4, 12, 24), 1, 2),         # low-res rows of 12 cells: two 8-cell tiles, the second half empty; odd row count (6)
+    (32, 32, (6, 6, 20), 1, 1),           # a single 32-channel stage, low-res 3 x 3 x 10
 ]
 
 
@@ -152,7 +155,7 @@ def test_merged_concat_conv_matches_cpu(device, case, precision):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16x2"])
-@pytest.mark.parametrize("case", MERGED_CASES + [(16, 32, (8, 16, 32), 1, 1), (16, 32, (12, 24, 64), 2, 1)],
+@pytest.mark.parametrize("case", MERGED_CASES + [(16, 32, (8, 16, 32), 1, 1), (16, 32, (12, 24, 64), 2, 1), (16, 32, (4, 4, 16), 1, 1)],
                          ids=lambda c: "c%d+%d_%dx%dx%d_n%d_a%d" % (c[0], c[1], *c[2], c[3], c[4]))
 def test_merged_concat_conv_strict_precision_matches_fp64(device, case, precision):
     """The same two-launch form in the strict precisions (hi + lo operands, three MFMAs per product, split partial sums and

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import anatomix_amd
-from _util import run_conv, ref_conv, ref_conv_upcat_merged, rel_l2
+from _util import run_conv, run_conv_merged, ref_conv, ref_conv_fp64, ref_conv_upcat_merged, rel_l2
 from oracle import unet_ref as R
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -156,6 +156,29 @@ while time.time() < t_end:
             if not ok:
                 nfail += 1
                 print("BWD FAIL", dict(dt=str(dt), c0=c0, c1=c1, cin=cin, cout=cout, size=size, n=n), "e_w", e_w, "e_x", e_x)
+        elif pick < 0.38:
+            # ---- the two-launch merged concat conv (amx_conv3d_upcat_merged), 16-bit and strict precisions, ragged sizes
+            prec = rng.choice(["f16", "bf16", "f16x2", "bf16x2"])
+            strict = prec.endswith("x2")
+            c0 = rng.choice([16, 32, 48, 64] if strict else [32, 48, 64, 128]); c1 = 32 * rng.randint(1, 4)
+            size = (2 * rng.randint(2, 6), 2 * rng.randint(2, 9), 2 * rng.randint(16, 36))
+            n, act = rng.randint(1, 2), rng.choice([0, 1, 2])
+            g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+            x0 = torch.randn(n, c0, *size, generator=g)
+            x1 = torch.randn(n, c1, *[s // 2 for s in size], generator=g)
+            w = torch.randn(c0, c0 + c1, 3, 3, 3, generator=g) / (27 * (c0 + c1)) ** 0.5
+            scale = (0.5 + torch.rand(c0, generator=g)) if rng.random() < 0.5 else None
+            shift = torch.randn(c0, generator=g) * 0.1 if rng.random() < 0.7 else None
+            y = run_conv_merged(dev, x0, x1, w, scale, shift, act, prec)
+            if strict:
+                r, tol = ref_conv_fp64(x0, x1, w, scale, shift, act), (4e-5 if prec == "bf16x2" else 6e-6)
+            else:
+                r, tol = ref_conv_upcat_merged(x0, x1, w, scale, shift, act, prec, round_partial=True), (4e-4 if prec == "f16" else 3.2e-3)
+            e = rel_l2(y, r)
+            nconv += 1
+            if not (e < tol) or torch.isnan(y).any():
+                nfail += 1
+                print("MERGED CONV FAIL", dict(prec=prec, c0=c0, c1=c1, size=size, n=n, act=act), "rel_l2", e)
         elif pick < 0.7:
             prec = rng.choice(["f16", "bf16"])
             up = rng.random() < 0.35
