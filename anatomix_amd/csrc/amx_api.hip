@@ -38,9 +38,13 @@ hipError_t launch_conv_upcat16(const ConvParams& p, int precision, hipStream_t s
 hipError_t launch_pack_upcat16(const float* w, const float* scale, void* wpk, int precision, hipStream_t st);
 const char* last_conv_upcat_kernel_name();
 bool conv_zmarch_can_pool(const ConvParams& p);
-size_t instnorm_scratch_bytes(int N, int C);
+size_t instnorm_scratch_bytes(int N, int C, long long max_slots_x_C);
+int conv_v2_stats_slots(int D, int H, int W, int Q);
+bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
+int last_conv_stats_slots();
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
-                           float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr);
+                           float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
+                           const float* kshift = nullptr);
 size_t attention_scratch_bytes(int b, int heads, int n);
 hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
                             const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
@@ -281,6 +285,19 @@ size_t level_bytes(const amx_unet* h, int level, int n, int d, int hh, int w) {
   return align_up((size_t)n * vox * level_channels(h, level) * 2 * (is_split(h->cfg.precision) ? 2 : 1), 256);
 }
 
+// InstanceNorm scratch of a forward: the separate statistics pass needs 65536 entries per sample; a conv epilogue that writes the
+// partial sums itself needs one slot per (brick, wave) of that layer
+size_t in_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
+  long long worst = 0;
+  if (h->cfg.norm == AMX_NORM_INSTANCE || h->cfg.norm == AMX_NORM_INSTANCE_AFFINE)
+    for (const ConvLayer& L : h->convs) {
+      if (L.norm_idx < 0) continue;
+      const long long s = (long long)amx::conv_v2_stats_slots(d >> L.level, hh >> L.level, w >> L.level, L.q) * L.cout;
+      worst = s > worst ? s : worst;
+    }
+  return align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs, worst), 256);
+}
+
 int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
   const int L = h->cfg.num_downs;
   if (n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
@@ -321,7 +338,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
   size_t need = 0;
   for (int l = 0; l < NL; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
   void* in_scratch = (char*)ws + need;                 // instance-norm partial sums + (a, b) pairs
-  need += align_up(amx::instnorm_scratch_bytes(n, c.ngf << c.num_downs), 256);
+  need += in_scratch_bytes(h, n, d, hh, w);
   if (ws_bytes < need || ((uintptr_t)ws & 255))
     return fail(AMX_ERR_WORKSPACE, "workspace needs %zu bytes, 256-byte aligned (got %zu)", need, ws_bytes);
 
@@ -504,6 +521,10 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         p.src1 = nullptr; p.C1 = 0; p.up_shift = 0;
         p.wpk = (const char*)L.wpk_skip;
       }
+      // InstanceNorm layers on the generic kernel: the conv epilogue writes the partial sums of the statistics pass itself
+      const bool fuse_stats = inorm && !use_merge && !use_upcat && !p.src0_f32c1 && !L.is_final && !x_offs &&
+                              amx::conv_fuses_stats(p, c.precision, L.q);
+      if (fuse_stats) p.stats = (float*)in_scratch;
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, c.precision, st);
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
@@ -562,7 +583,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
-                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag));
+                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
+                                     fuse_stats ? amx::last_conv_stats_slots() : 0, fuse_stats ? L.shift : nullptr));
       }
       if (final_via_export)
         AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st));
@@ -858,7 +880,7 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int hh, int w
   if (!h) return 0;
   size_t need = 0;
   for (int l = 0; l <= h->cfg.num_downs; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
-  need += align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs), 256);
+  need += in_scratch_bytes(h, n, d, hh, w);
   return need;
 }
 
@@ -1201,7 +1223,7 @@ int amx_supcon_loss(const float* d_feat, const int* d_labels, int n, int c, floa
   return AMX_OK;
 }
 
-size_t amx_instance_norm_scratch_bytes(int n, int c) { return amx::instnorm_scratch_bytes(n, c); }
+size_t amx_instance_norm_scratch_bytes(int n, int c) { return amx::instnorm_scratch_bytes(n, c, 0); }
 
 int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, float eps, int n, long long voxels, int c,
                       int act, float slope, void* d_scratch, int precision, void* stream) {

@@ -159,10 +159,20 @@ int conv_pick_q(int Cout, int W) {
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);
 const char* last_conv_v2_kernel_name();
+int last_conv_v2_stats_slots();
 bool conv_zmarch_eligible(const ConvParams& p);
 bool conv_zmarch_eligible_split(const ConvParams& p);
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st);
 const char* last_conv_zm_kernel_name();
+
+// true when launch_conv runs the generic kernel for this layer -- the one whose epilogue can write InstanceNorm partial sums
+bool conv_fuses_stats(const ConvParams& p, int precision, int Q) {
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_FUSED_STATS") ? 1 : 0;
+  if (off || p.src0_f32c1 || p.out32) return false;
+  return !((((precision < 2 && conv_zmarch_eligible(p)) || (precision >= 2 && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16));
+}
+int last_conv_stats_slots() { return last_conv_v2_stats_slots(); }
 
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;

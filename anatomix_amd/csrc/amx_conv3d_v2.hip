@@ -383,6 +383,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   };
 
   f32x4 acc[CTW][Q];
+  f32x4 kshift[Q];                 // InstanceNorm statistics: the conv bias of this lane's channels, reloaded only when the cout group changes
+  int kshift_cg = -1;
 
   // optional cycle trace (AMX_TRACE=1): wave 0 of each workgroup stamps s_memtime per phase
   unsigned long long* trace = (p.dbg & 8) ? (unsigned long long*)p.stats + (long long)blockIdx.x * 128 : nullptr;
@@ -530,6 +532,62 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     if (++cu_stage < nstage) continue;
     cu_stage = 0;
 
+    // ---- InstanceNorm statistics of this item (ConvParams::stats, not with the cycle trace): shifted sums S1 = sum(x - K),
+    //      S2 = sum((x - K)^2) of the values ABOUT TO BE STORED (rounded like the store; strict: hi + lo = the fp32 value), K = the
+    //      conv bias of the channel.  Reduced over the 16 voxel lanes of a lane group with DPP row shifts, ONE slot per
+    //      (brick, wave) and sample: partial[n][brick * NW + wave][channel][2] -- every entry written exactly once, summed in a
+    //      fixed order by in_finalize (deterministic, no atomics).  Saves the separate statistics pass over the tensor.
+    if (OUTMODE == 0 && p.stats && !(p.dbg & 8)) {
+      const int z0s = cu.bz * C::TZ, y0s = cu.by * C::TY, x0s = cu.bx * C::TX;
+      const int zls = z0s + wz * WZ, yls = y0s + wy * WY + dy, xls = x0s + dx;
+      const int cbs = cu.cg * 16 * Q + g * 4 * Q;
+      if (cu.cg != kshift_cg) {        // (a global load per item stalled the epilogue: +7 % on the 32 -> 32 @128^3 layers)
+        kshift_cg = cu.cg;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) kshift[q] = p.bias ? *(const f32x4*)(p.bias + cbs + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float s1[4 * Q], s2[4 * Q];
+#pragma unroll
+      for (int k = 0; k < 4 * Q; ++k) s1[k] = s2[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+        const bool in = (zls + cz < p.D) & (yls + cy * LY < p.H) & (xls + cx * LX < p.W);
+        if (in) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = SPLIT ? acc[c][q][j] : (float)(T)acc[c][q][j];
+              const float d = v - kshift[q][j];
+              s1[q * 4 + j] += d;
+              s2[q * 4 + j] += d * d;
+            }
+          }
+        }
+      }
+      // sum over the 16 lanes of the lane group: row_shr 1, 2, 4, 8 (out-of-row lanes contribute 0); lane 15 of the row holds it
+#pragma unroll
+      for (int k = 0; k < 4 * Q; ++k) {
+        s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x111, 0xF, 0xF, true));
+        s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x111, 0xF, 0xF, true));
+        s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x112, 0xF, 0xF, true));
+        s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x112, 0xF, 0xF, true));
+        s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x114, 0xF, 0xF, true));
+        s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x114, 0xF, 0xF, true));
+        s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x118, 0xF, 0xF, true));
+        s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x118, 0xF, 0xF, true));
+      }
+      if (li == 15) {
+        const long long brick = ((long long)cu.bz * p.nby + cu.by) * p.nbx + cu.bx;
+        const long long nslots = (long long)p.nbz * p.nby * p.nbx * NW;
+        float* o = p.stats + (((long long)cu.n * nslots + brick * NW + wave) * p.Cout + cbs) * 2;
+#pragma unroll
+        for (int k = 0; k < 4 * Q; k += 2)               // (S1, S2) pairs of two channels per 16-byte store
+          *(float4*)(o + 2 * k) = make_float4(s1[k], s2[k], s1[k + 1], s2[k + 1]);
+      }
+    }
+
     // ---- item finished: activation + pack into the pending registers (stored next iteration)
     act_inplace<CTW * Q>(&acc[0][0], p.act, p.slope);
     bool bad = false;
@@ -573,6 +631,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
 // -------------------------------------------------------------------------------------------
 static thread_local char g_kernel_name2[64] = "";
 const char* last_conv_v2_kernel_name() { return g_kernel_name2; }
+static thread_local int g_stats_slots = 0;
+int last_conv_v2_stats_slots() { return g_stats_slots; }       // partial-statistics slots per sample written by the last launch
 
 static int g_num_cus = 0;
 
@@ -602,6 +662,7 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
   p.nbz = (p.D + C::TZ - 1) / C::TZ;
   p.nby = (p.H + C::TY - 1) / C::TY;
   p.nbx = (p.W + C::TX - 1) / C::TX;
+  g_stats_slots = p.nbz * p.nby * p.nbx * C::NW;
   static int dbg = -1;
   static unsigned long long* trace_buf = nullptr;
   if (dbg < 0) {
@@ -682,6 +743,24 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
   if (Q == 4) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
+}
+
+// Partial-statistics slots per sample a launch of this layer writes (ConvParams::stats): bricks x MFMA waves of the brick shape
+// launch_conv2_t picks for (W, Q) -- keep in step with the dispatch above.
+int conv_v2_stats_slots(int D, int H, int W, int Q) {
+  int tz = 4, ty, tx, nw;
+  if (W >= 32) {
+    if (Q == 1) { ty = 8; tx = 32; nw = 8; }
+    else if (Q == 2) { ty = 4; tx = getenv("AMX_V2_NARROW") ? 16 : 32; nw = 8; }
+    else { ty = 4; tx = 16; nw = 8; }
+  } else if (W >= 16) {
+    if (Q == 1) { ty = 2; tx = 16; nw = 4; }
+    else { ty = 4; tx = 16; nw = 8; }
+  } else {
+    if (Q == 2) { ty = 4; tx = 8; nw = 8; }
+    else { ty = 2; tx = 8; nw = 4; }
+  }
+  return ((D + tz - 1) / tz) * ((H + ty - 1) / ty) * ((W + tx - 1) / tx) * nw;
 }
 
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st) {

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ 
 template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
                                                          const float* gamma, const float* beta, float eps, long long vox,
-                                                         int C, int nblk, float* __restrict__ ab) {
+                                                         int C, int nblk, float* __restrict__ ab, const float* kshift, int use_kshift) {
   __shared__ double red[2][8][32];
   const int n = blockIdx.y, c = blockIdx.x * 8 + (threadIdx.x & 7), l = threadIdx.x >> 3;
   double s1 = 0.0, s2 = 0.0;
@@ -132,8 +132,14 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
       s1 += red[0][threadIdx.x][k];
       s2 += red[1][threadIdx.x][k];
     }
-    const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C * (SPLIT ? 2 : 1) + cc) * 2);
-    const float K = (float)__builtin_bit_cast(T, kb);
+    // the shift the partial sums were taken about: the channel's first voxel (in_stats), or -- sums written by a conv epilogue --
+    // the conv bias (zero without one)
+    float K;
+    if (use_kshift) K = kshift ? kshift[cc] : 0.f;
+    else {
+      const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C * (SPLIT ? 2 : 1) + cc) * 2);
+      K = (float)__builtin_bit_cast(T, kb);
+    }
     const double m1 = s1 / (double)vox;
     double var = s2 / (double)vox - m1 * m1;              // biased variance, shift invariant
     var = var < 0.0 ? 0.0 : var;
@@ -142,6 +148,35 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
     const float g = gamma ? gamma[cc] : 1.f;
     ab[((long long)n * C + cc) * 2] = rstd * g;
     ab[((long long)n * C + cc) * 2 + 1] = (beta ? beta[cc] : 0.f) - mean * rstd * g;
+  }
+}
+
+// Many slots (a conv epilogue writes one per brick and wave: 32768 per sample on a 128^3 level): grid (C/8, N, kPreChunks) folds
+// the slots of one chunk, in order, into partial2[n][chunk][c][2]; in_finalize then adds the kPreChunks chunks.  Fixed order.
+constexpr int kPreChunks = 64;
+__global__ __launch_bounds__(256) void in_prereduce_kernel(const float* __restrict__ partial, float* __restrict__ partial2, int C,
+                                                          int nblk) {
+  __shared__ float red[2][8][32];
+  const int n = blockIdx.y, c = blockIdx.x * 8 + (threadIdx.x & 7), l = threadIdx.x >> 3, ch = blockIdx.z;
+  const int per = (nblk + kPreChunks - 1) / kPreChunks, b0 = ch * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = b0 + l; b < b1; b += 32) {
+    const float* q = partial + (((long long)n * nblk + b) * C + c) * 2;
+    s1 += q[0];
+    s2 += q[1];
+  }
+  red[0][threadIdx.x & 7][l] = s1;
+  red[1][threadIdx.x & 7][l] = s2;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    s1 = 0.f; s2 = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      s1 += red[0][threadIdx.x][k];
+      s2 += red[1][threadIdx.x][k];
+    }
+    float* o = partial2 + (((long long)n * kPreChunks + ch) * C + blockIdx.x * 8 + threadIdx.x) * 2;
+    o[0] = s1;
+    o[1] = s2;
   }
 }
 
@@ -405,14 +440,35 @@ hipError_t launch_poison_if_flag(const int* flag, int* host_flag, float* y, long
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-size_t instnorm_scratch_bytes(int N, int C) { return ((size_t)N * 65536 * 2 + (size_t)N * C * 2) * sizeof(float); }
+// scratch: [N][slots][C][2] partial sums + [N][C][2] coefficients.  slots * C <= 65536 for the separate statistics pass; a conv
+// epilogue writes one slot per (brick, wave): the caller passes the largest slots * C of its layers (conv_v2_stats_slots)
+size_t instnorm_scratch_bytes(int N, int C, long long max_slots_x_C) {
+  const size_t per = (size_t)max_slots_x_C > 65536 ? (size_t)max_slots_x_C : 65536;
+  return ((size_t)N * per * 2 + (size_t)N * C * 2 + (size_t)N * 64 * C * 2) * sizeof(float);      // + chunk sums of in_prereduce
+}
+static size_t in_coeff_offset(int N, long long vox, int C, int fused_slots) {      // floats
+  (void)vox;
+  const size_t per = (size_t)fused_slots * C > 65536 ? (size_t)fused_slots * C : 65536;
+  return (size_t)N * per * 2;
+}
 
+// fused_slots > 0: the partial sums [N][fused_slots][C][2] were written by the producing conv's epilogue (shift = kshift, the conv
+// bias, or 0): only finalize + apply run here.
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
-                           float slope, void* scratch, int precision, hipStream_t st, int* oflow) {
+                           float slope, void* scratch, int precision, hipStream_t st, int* oflow, int fused_slots = 0,
+                           const float* kshift = nullptr) {
   if (C % 8) return hipErrorInvalidValue;
   float* partial = (float*)scratch;
-  float* ab = partial + (size_t)N * 65536 * 2;
-  const int nblk = in_num_blocks(vox, C);
+  float* ab = partial + in_coeff_offset(N, vox, C, fused_slots);
+  int nblk = fused_slots > 0 ? fused_slots : in_num_blocks(vox, C);
+  if (fused_slots > 4096) {
+    // fold the slots into kPreChunks chunks first (the chunk sums live behind the coefficients: N * kPreChunks * C * 2 floats, which
+    // fit the 65536-entry floor of the scratch of the separate statistics pass only when C * 64 <= 65536 -- true for C <= 1024)
+    float* partial2 = ab + (size_t)N * C * 2;
+    hipLaunchKernelGGL(in_prereduce_kernel, dim3(C / 8, N, kPreChunks), dim3(256), 0, st, partial, partial2, C, nblk);
+    partial = partial2;
+    nblk = kPreChunks;
+  }
   const int c8n = C / 8;
   if (c8n > 256) return hipErrorInvalidValue;          // C <= 2048
   const int nrow = 256 / c8n;
@@ -420,9 +476,10 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   const long long total = (long long)N * vox * c8n;
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define AMX_IN(T, S)                                                                                                   \
-  hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
+  if (fused_slots <= 0)                                                                                                \
+    hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
   hipLaunchKernelGGL((in_finalize_kernel<T, S>), dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
-                     nblk, ab);                                                                                 \
+                     nblk, ab, kshift, fused_slots > 0 ? 1 : 0);                                                  \
   if (256 % c8n == 0) {                                                                                          \
     const long long per = vox * c8n;                                                                             \
     const int bx = (int)((per + 255) / 256 > 4096 ? 4096 : (per + 255) / 256);                                   \

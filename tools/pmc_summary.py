@@ -28,6 +28,11 @@ def friendly(mangled):
         t, wz, wy, wx, nwz, nwy, q, nch, o = m.groups()
         return (f"conv3d_k3_v2<{'f16' if t == 'DF16_' else 'bf16'},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},"
                 f"w{int(nwz)*int(nwy)},q{q},nch{nch},o{o}>")
+    m = re.match(r"_ZN3amx21conv3d_upmerge_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E", mangled)
+    if m:   # <T, Q, TZ, TY, NBUF, KS, SPLIT, LXT>
+        t, q, tz, ty, nbuf, ks, split, lxt = m.groups()
+        name = ("f16" if t == "DF16_" else "bf16") + ("x2" if split == "1" else "")
+        return f"conv3d_upmerge<{name},q{q},{tz}x{int(ty) * 16 // int(lxt)}x{lxt},b{nbuf},k{32 * int(ks)}>"
     if "pool2_kernel" in mangled:
         return "pool2<max>" if "Li0EEE" in mangled else "pool2<avg>"
     return None
