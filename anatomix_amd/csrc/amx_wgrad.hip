@@ -23,6 +23,8 @@
 // written to LDS after it (software prefetch; one barrier per item).  Its 8 waves split the item's K-blocks, keep 27
 // accumulators each for the whole chunk, and are summed through LDS at the end.  Partials [chunk][pair][27][16][16]
 // fp32 are then added by wgrad_reduce_kernel with a fixed summation tree: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "amx_device.h"
 
 namespace amx {
@@ -291,7 +293,13 @@ static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* ni
   *nyt = (H + ty - 1) / ty;
   *nitems = N * D * *nyt;
   const int npairs = (Cout / 16) * (CinPad / 16);
-  int nc = (1024 + npairs - 1) / npairs;
+  // One workgroup per compute unit (139 KB of LDS each), so the grid should be ONE round of at most 256 workgroups with as many
+  // items each as that allows: 1024 workgroups (four rounds, each with its own ring fill, cross-wave reduction and 27 KB of
+  // partial sums) measured 135 us on 16 -> 16 @128^3 x 2 views against 99 us for 256, 99 -> 58 us on 32 -> 32 @64^3, 68 -> 38 us
+  // on 64 -> 64 @32^3; 257 .. 320 workgroups (a second, nearly empty round) are the worst case (tools/wgrad_time.py).
+  static int target = -1;
+  if (target < 0) target = getenv("AMX_WGRAD_WGS") ? atoi(getenv("AMX_WGRAD_WGS")) : 256;
+  int nc = target / npairs;                    // floor: never spill into a second round
   if (nc > *nitems) nc = *nitems;
   if (nc < 1) nc = 1;
   *ipc = (*nitems + nc - 1) / nc;
