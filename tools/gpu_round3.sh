@@ -32,3 +32,6 @@ python tools/pmc_summary.py $f $w $OUT/${TAG}_pmc_traffic.json 4
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 mv $OUT/${TAG}_bench_headline_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 head -8 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-150
+# SQ-side counters of the headline (separate pass, counters only)
+tools/gpu_pmc_sq.sh ${TAG} > $OUT/${TAG}_pmc_sq.txt 2>&1
+tail -16 $OUT/${TAG}_pmc_sq.txt
