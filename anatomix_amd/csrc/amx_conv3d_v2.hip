@@ -633,6 +633,7 @@ static thread_local char g_kernel_name2[64] = "";
 const char* last_conv_v2_kernel_name() { return g_kernel_name2; }
 static thread_local int g_stats_slots = 0;
 int last_conv_v2_stats_slots() { return g_stats_slots; }       // partial-statistics slots per sample written by the last launch
+int conv_v2_stats_slots(int D, int H, int W, int Q);
 
 static int g_num_cus = 0;
 
@@ -663,6 +664,8 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
   p.nby = (p.H + C::TY - 1) / C::TY;
   p.nbx = (p.W + C::TX - 1) / C::TX;
   g_stats_slots = p.nbz * p.nby * p.nbx * C::NW;
+  // the forward sizes its statistics scratch with conv_v2_stats_slots(): the two must agree, or the epilogue would write past it
+  if (p.stats && !(p.dbg & 8) && g_stats_slots != conv_v2_stats_slots(p.D, p.H, p.W, Q)) return hipErrorInvalidConfiguration;
   static int dbg = -1;
   static unsigned long long* trace_buf = nullptr;
   if (dbg < 0) {
