@@ -290,6 +290,9 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = bias;
 
+    // TIMING-ONLY experiment (AMX_DBG bits 10..12 = extra sweeps per step; results are garbage): what a layer costs when its matrix
+    // work is doubled / tripled at unchanged traffic -- the lower bound of a conv -> conv chain through the ring
+    for (int rep = (p.dbg >> 10) & 7; rep >= 0; --rep)
     if (!(p.dbg & 2)) {
 #pragma unroll
       for (int ps = 0; ps < NCKP; ++ps) {
