@@ -13,7 +13,8 @@
 namespace amx {
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st);
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0);
+                               int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0,
+                               int C0Real = 0, int C0Phys = 0);
 size_t conv_upmerge_packed_bytes(int C1, int Cout, int split);
 bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split);
 hipError_t launch_conv_upmerge(const UpmergeParams& p, int precision, hipStream_t st);
@@ -30,7 +31,7 @@ hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, i
                            int rw, const float* wmap, hipStream_t st);
 int conv_pick_q(int Cout, int W);
 hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st);
-hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st);
+hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st, int CoutReal = 0);
 const char* last_conv_stem_kernel_name();
 size_t conv_upcat16_packed_bytes();
 bool conv_upcat16_eligible(const ConvParams& p);
@@ -55,7 +56,7 @@ hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, i
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
                              float slope, int precision, hipStream_t st, int* oflow = nullptr);
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
-                               float* out, int precision, hipStream_t st);
+                               float* out, int precision, hipStream_t st, int S0 = 0, int S1 = 0);
 const char* last_conv_kernel_name();
 size_t train_scratch_bytes(int C);
 hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, const float* beta, float eps, long long rows, int C,
@@ -126,7 +127,9 @@ struct ConvLayer {
   bool has_act = false, is_final = false;
   int level = 0;          // resolution level the conv runs at (0 = full)
   int q = 1;              // MFMA tiles per workgroup the weights are packed for
-  int cin_pad = 0;
+  int cin_pad = 0;        // STORED input channels: every segment padded to a multiple of 16 (ngf = 24: 24 -> 32)
+  int cout_p = 0;         // stored output channels (cout rounded up to 16; the extra channels are exact zeros)
+  int c0_real = 0, c0_p = 0;   // first conv of a decoder block: real / stored channels of the skip segment
   void* wpk = nullptr;    // packed A fragments
   void* wpk_up = nullptr; // second packing for the 16+32 -> 16 merged-tap kernel (amx_conv3d_upcat.hip)
   bool after_up = false;  // first conv of a decoder block: its input is cat(skip [cout channels], upsample(low [cin - cout]))
@@ -210,6 +213,7 @@ void build_plan(amx_unet* h) {
     const int level = c.num_downs - 1 - i;
     add_block(c.ngf * m, c.ngf * (mult / 2), level);
     h->convs.back().after_up = c.use_skip != 0;
+    if (c.use_skip) h->convs.back().c0_real = c.ngf * (mult / 2);
     if (c.doubleconv) add_block(c.ngf * (mult / 2), c.ngf * (mult / 2), level);
     mult /= 2;
   }
@@ -245,7 +249,7 @@ void build_plan(amx_unet* h) {
 
 // widest tensor materialised at a level: its own width, or (trilinear) the upsampled image of the level below it
 int level_channels(const amx_unet* h, int level) {
-  const int own = h->cfg.ngf << level;
+  const int own = ((h->cfg.ngf + 15) / 16 * 16) << level;      // stored width: ngf padded to 16 channels
   int c = (h->cfg.interp == AMX_INTERP_TRILINEAR && level < h->cfg.num_downs) ? 2 * own : own;
   // the output conv's result is staged in a level-0 slot when it leaves through the export pass (W < 32 or output_nc > 32):
   // output_nc may exceed ngf.  (Sizing this by ngf alone overran the slot for output_nc = 64 -- silent while the bytes behind
@@ -292,7 +296,7 @@ size_t in_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
   if (h->cfg.norm == AMX_NORM_INSTANCE || h->cfg.norm == AMX_NORM_INSTANCE_AFFINE)
     for (const ConvLayer& L : h->convs) {
       if (L.norm_idx < 0) continue;
-      const long long s = (long long)amx::conv_v2_stats_slots(d >> L.level, hh >> L.level, w >> L.level, L.q) * L.cout;
+      const long long s = (long long)amx::conv_v2_stats_slots(d >> L.level, hh >> L.level, w >> L.level, L.q) * L.cout_p;
       worst = s > worst ? s : worst;
     }
   return align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs, worst), 256);
@@ -363,7 +367,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     return -1;
   };
 
-  struct Tensor { int level = 0, slot = -1, C = 0; };
+  struct Tensor { int level = 0, slot = -1, C = 0, Cr = 0; };     // C: stored channels per voxel, Cr: the reference's channel count
   Tensor cur;              // current activation (slot -1: the fp32 network input)
   bool have_cur_up = false;  // cur is to be read through a x2 upsample by the next conv
   std::vector<Tensor> skips;
@@ -382,8 +386,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
   const int stop = taps ? taps->stop : -1;
   // tap = fp32 NCDHW copy of a stored 16-bit tensor
   auto export_slot = [&](const Tensor& t, float* dst) -> hipError_t {
-    return amx::launch_export_ncdhw(A.slot[t.level][t.slot], t.C, nullptr, 0, 0, n, d >> t.level, hh >> t.level, w >> t.level,
-                                    dst, c.precision, st);
+    return amx::launch_export_ncdhw(A.slot[t.level][t.slot], t.Cr, nullptr, 0, 0, n, d >> t.level, hh >> t.level, w >> t.level,
+                                    dst, c.precision, st, t.C, 0);
   };
 
   for (size_t i = 0; i < h->kinds.size(); ++i) {
@@ -394,7 +398,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       const int dd = d >> lv, dh = hh >> lv, dw = w >> lv;
       amx::ConvParams p;
       memset(&p, 0, sizeof p);
-      p.N = n; p.D = dd; p.H = dh; p.W = dw; p.Cout = L.cout;
+      p.N = n; p.D = dd; p.H = dh; p.W = dw; p.Cout = L.cout_p;
       if (cur.slot < 0) {  // stem: fp32 single-channel input
         p.src0 = (const char*)x;
         p.s0n = xs_n; p.s0z = xs_z; p.s0y = xs_y; p.s0x = 4;
@@ -455,10 +459,10 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         p.act = AMX_ACT_NONE;
       }
       Tensor out;
-      out.level = lv; out.C = L.cout;
+      out.level = lv; out.C = L.cout_p; out.Cr = L.cout;
       // the fp32 planar epilogues need W >= 32 and <= 32 output channels; outside that the output conv stores 16-bit
       // channels-last like any other layer and one export pass produces the fp32 NCDHW tensor
-      const bool final_via_export = L.is_final && (dw < 32 || L.cout > 32);
+      const bool final_via_export = L.is_final && (dw < 32 || L.cout_p > 32);
       if (final_via_export && (wmap || x_offs))
         return fail(AMX_ERR_SHAPE, "sliding-window accumulation needs roi width >= 32 and output_nc <= 32");
       if (L.is_final && c.final_act != AMX_ACT_NONE && stop_at != L.module_idx) p.act = c.final_act;
@@ -470,7 +474,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         out.slot = grab(lv);
         if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
         p.out = A.slot[lv][out.slot];
-        p.ox = (long long)L.cout * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
+        p.ox = (long long)L.cout_p * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
       }
       if (prof) {
         amx_launch_record r;
@@ -488,22 +492,22 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       {
         size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
         if (!split && !L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
-            cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout / 16) {
-          fused_pool.level = lv + 1; fused_pool.C = L.cout; fused_pool.slot = grab(lv + 1);
+            cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout_p / 16) {
+          fused_pool.level = lv + 1; fused_pool.C = L.cout_p; fused_pool.Cr = L.cout; fused_pool.slot = grab(lv + 1);
           if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
           p.out2 = A.slot[lv + 1][fused_pool.slot];
-          p.qx = (long long)L.cout * 2; p.qy = p.qx * (dw / 2); p.qz = p.qy * (dh / 2); p.qn = p.qz * (dd / 2);
+          p.qx = (long long)L.cout_p * 2; p.qy = p.qx * (dw / 2); p.qz = p.qy * (dh / 2); p.qn = p.qz * (dd / 2);
           have_fused_pool = true;
         }
       }
-      if (p.src0_f32c1 && (L.is_final || L.cout > 32))
+      if (p.src0_f32c1 && (L.is_final || L.cout_p > 32))
         return fail(AMX_ERR_INVALID, "stem kernel supports ngf in {16, 32} and a following layer (ngf=%d)", L.cout);
       const bool use_upcat = !split && !p.src0_f32c1 && !raw_bn && L.wpk_up && have_cur_up && have_skip && amx::conv_upcat16_eligible(p);
       if (use_upcat) p.wpk = (const char*)L.wpk_up;
       // wider concat layers: the ordinary convolution over the skip channels first (raw partial sums into a free slot of this
       // level), then the merged-tap convolution over the upsampled channels, which adds them, the bias and the activation
       const bool use_merge = !use_upcat && !raw_bn && L.wpk_merge && have_cur_up && have_skip && !cur_is_full_up && !L.is_final &&
-                             p.C0 == L.cout && amx::conv_upmerge_eligible(p.C0, p.C1, L.cout, dd, dh, dw, p.up_shift, split);
+                             L.cout_p == L.cout && p.C0 == L.cout && amx::conv_upmerge_eligible(p.C0, p.C1, L.cout, dd, dh, dw, p.up_shift, split);
       int p_slot = -1;
       amx::UpmergeParams u;
       memset(&u, 0, sizeof u);
@@ -567,7 +571,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       }
       if (raw_bn) {
         AMX_HIP(export_slot(out, tap_conv));
-        AMX_HIP(amx::launch_affine_act(A.slot[lv][out.slot], L.scale, L.shift, n, (long long)dd * dh * dw, L.cout,
+        AMX_HIP(amx::launch_affine_act(A.slot[lv][out.slot], L.scale, L.shift, n, (long long)dd * dh * dw, L.cout_p,
                                        act_on ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st, h->d_flag));
       } else if (tap_conv && !L.is_final && inorm) {
         AMX_HIP(export_slot(out, tap_conv));     // the stored raw convolution output, before the instance norm below
@@ -583,11 +587,11 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
-                                     L.cout, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
+                                     L.cout_p, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
                                      fuse_stats ? amx::last_conv_stats_slots() : 0, fuse_stats ? L.shift : nullptr));
       }
       if (final_via_export)
-        AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st));
+        AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st, L.cout_p, 0));
       if (L.is_final) {
         if (tap_conv)   // contiguous [n][Cout][d][h][w] output (taps are only offered by the plain forward)
           AMX_HIP(hipMemcpyAsync(tap_conv, y, (size_t)n * L.cout * dd * dh * dw * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -626,7 +630,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     } else if (kind == K_POOL) {
       const int lv = cur.level + 1;
       Tensor out;
-      out.level = lv; out.C = cur.C; out.slot = grab(lv);
+      out.level = lv; out.C = cur.C; out.Cr = cur.Cr; out.slot = grab(lv);
       if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
       if (prof) {
         amx_launch_record r;
@@ -652,7 +656,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         // then reads two full-resolution segments (up_shift = 0)
         const int lv = cur.level - 1;
         Tensor up;
-        up.level = lv; up.C = cur.C; up.slot = grab(lv);
+        up.level = lv; up.C = cur.C; up.Cr = cur.Cr; up.slot = grab(lv);
         if (up.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
         if (prof) {
           amx_launch_record r;
@@ -677,8 +681,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       if (float* t = tap_of((int)i)) {   // taken after torch.cat((skip, up), 1) -- network.py:500-502
         const int lv = cur_is_full_up ? cur.level : cur.level - 1;
         AMX_HIP(amx::launch_export_ncdhw(have_skip ? A.slot[pend_skip.level][pend_skip.slot] : nullptr,
-                                         have_skip ? pend_skip.C : 0, A.slot[cur.level][cur.slot], cur.C,
-                                         cur_is_full_up ? 0 : 1, n, d >> lv, hh >> lv, w >> lv, t, c.precision, st));
+                                         have_skip ? pend_skip.Cr : 0, A.slot[cur.level][cur.slot], cur.Cr,
+                                         cur_is_full_up ? 0 : 1, n, d >> lv, hh >> lv, w >> lv, t, c.precision, st,
+                                         have_skip ? pend_skip.C : 0, cur.C));
       }
       if (stop == (int)i) return AMX_OK;
     } else if (kind == K_FINAL_ACT) {
@@ -743,9 +748,10 @@ const char* amx_last_error(void) { return g_err.c_str(); }
 int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   if (!out || !cfg) return fail(AMX_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (cfg->num_downs < 1 || cfg->num_downs > 7 || cfg->ngf < 16 || cfg->ngf % 16)
-    return fail(AMX_ERR_INVALID, "ngf must be a positive multiple of 16 and 1 <= num_downs <= 7 (got ngf=%d num_downs=%d)",
-                cfg->ngf, cfg->num_downs);
+  // ngf = 8 mod 16 (the reference's default width 24, network.py:268): the ngf-wide tensors are stored with 16-channel padding
+  if (cfg->num_downs < 1 || cfg->num_downs > 7 || cfg->ngf < 8 || cfg->ngf % 8 || (cfg->ngf + 15) / 16 * 16 > 32)
+    return fail(AMX_ERR_INVALID, "ngf must be 8, 16, 24 or 32 (the stem kernel stores 16 or 32 channels) and 1 <= num_downs <= 7 (got ngf=%d "
+                "num_downs=%d)", cfg->ngf, cfg->num_downs);
   if (cfg->input_nc != 1) return fail(AMX_ERR_INVALID, "HIP path supports input_nc == 1 (got %d)", cfg->input_nc);
   if (cfg->output_nc < 16 || cfg->output_nc % 16)
     return fail(AMX_ERR_INVALID, "output_nc must be a multiple of 16 (got %d)", cfg->output_nc);
@@ -765,27 +771,37 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   build_plan(h);
   h->pack_w = 128;
   for (ConvLayer& L : h->convs) {
-    L.cin_pad = (L.cin + 15) / 16 * 16;
+    L.cout_p = (L.cout + 15) / 16 * 16;
+    if (L.after_up && L.c0_real) {            // cat(skip, up): each segment padded on its own
+      L.c0_p = (L.c0_real + 15) / 16 * 16;
+      L.cin_pad = L.c0_p + (L.cin - L.c0_real + 15) / 16 * 16;
+    } else {
+      L.cin_pad = (L.cin + 15) / 16 * 16;
+    }
     // Q is chosen for the reference operating point (128^3 windows): level l runs at W = 128>>l.
     const int w_at = h->pack_w >> L.level;
-    L.q = amx::conv_pick_q(L.cout, w_at > 0 ? w_at : 1);
-    const size_t wbytes = (size_t)L.cout * L.cin_pad * 28 * 2 * (is_split(cfg->precision) ? 2 : 1);   // strict: [Wh | Wl]
+    L.q = amx::conv_pick_q(L.cout_p, w_at > 0 ? w_at : 1);
+    const size_t wbytes = (size_t)L.cout_p * L.cin_pad * 28 * 2 * (is_split(cfg->precision) ? 2 : 1);   // strict: [Wh | Wl]
     hipError_t e = hipMalloc(&L.wpk, wbytes);
     if (e == hipSuccess && !is_split(cfg->precision) && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
     // that are at least 32 voxels wide at the reference operating point
-    if (e == hipSuccess && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr &&
+    if (e == hipSuccess && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr && L.cout_p == L.cout &&
         amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1, is_split(cfg->precision))) {
       e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2 * (is_split(cfg->precision) ? 2 : 1));
       if (e == hipSuccess) e = hipMalloc(&L.wpk_merge, amx::conv_upmerge_packed_bytes(L.cin - L.cout, L.cout, is_split(cfg->precision)));
     }
     if (e == hipSuccess && cfg->norm == AMX_NORM_BATCH_EVAL && L.norm_idx >= 0) e = hipMalloc(&L.wpk_raw, wbytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.scale, L.cout_p * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.shift, L.cout_p * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(L.scale, 0, L.cout_p * sizeof(float));      // padded channels: gain 0, shift 0 -> exact zeros
+    if (e == hipSuccess) e = hipMemset(L.shift, 0, L.cout_p * sizeof(float));
     if (e == hipSuccess && cfg->norm == AMX_NORM_INSTANCE_AFFINE && L.norm_idx >= 0) {
-      e = hipMalloc((void**)&L.in_gamma, L.cout * sizeof(float));
-      if (e == hipSuccess) e = hipMalloc((void**)&L.in_beta, L.cout * sizeof(float));
+      e = hipMalloc((void**)&L.in_gamma, L.cout_p * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void**)&L.in_beta, L.cout_p * sizeof(float));
+      if (e == hipSuccess) e = hipMemset(L.in_gamma, 0, L.cout_p * sizeof(float));
+      if (e == hipSuccess) e = hipMemset(L.in_beta, 0, L.cout_p * sizeof(float));
     }
     if (e != hipSuccess) {
       amx_unet_destroy(h);
@@ -857,13 +873,14 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
       AMX_HIP(hipMemcpyAsync(L.in_beta, d_beta, L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     if (L.cin == 1 && &L == &h->convs[0]) {   // stem: 27 taps packed into one K = 32 MFMA step
-      AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout, h->cfg.precision, st));
-      if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout, h->cfg.precision, st));
+      AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout_p, h->cfg.precision, st, L.cout));
+      if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout_p, h->cfg.precision, st, L.cout));
     } else {
       if (L.wpk_raw)
-        AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, L.wpk_raw, L.cin, L.cin_pad, L.cout, L.q, h->cfg.precision, st));
-      AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout, L.q,
-                                       h->cfg.precision, st));
+        AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, L.wpk_raw, L.cin, L.cin_pad, L.cout_p, L.q, h->cfg.precision, st, 0, L.cout,
+                                         0, L.c0_real, L.c0_p));
+      AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk, L.cin, L.cin_pad, L.cout_p, L.q,
+                                       h->cfg.precision, st, 0, L.cout, 0, L.c0_real, L.c0_p));
       if (L.wpk_up) AMX_HIP(amx::launch_pack_upcat16(d_weight, L.scale, L.wpk_up, h->cfg.precision, st));
       if (L.wpk_merge) {   // skip channels [0, cout) as an ordinary 27-tap packing, upsampled channels [cout, cin) merged
         AMX_HIP(amx::launch_pack_weights(d_weight, L.scale, L.wpk_skip, L.cout, L.cout, L.cout, L.q, h->cfg.precision, st, 0, 0, L.cin));

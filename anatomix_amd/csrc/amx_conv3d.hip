@@ -33,7 +33,7 @@ namespace amx {
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                     T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
-                                    int split, int CinStride) {
+                                    int split, int CinStride, int C0Real, int C0Phys) {
   const int nchunk_phys = CinPad / 16 * (split ? 2 : 1);
   const long long total = (long long)(Cout / 16) * nchunk_phys * kSteps * 64 * 8;
   const int nchunk = CinPad / 16;
@@ -53,9 +53,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     const int m = lane & 15, g = lane >> 4;
     const int cout = cg * 16 * Q + (m >> 2) * 4 * Q + q * 4 + (m & 3);
     const int tap = (g >> 1) ? tapB_index(s) : tapA_index(s);
-    const int cin = chunk * 16 + (g & 1) * 8 + e;
+    // physical input channel -> channel of the weight tensor.  C0Phys > C0Real: the first (skip) segment of a concat input is
+    // stored padded to a multiple of 16 channels (ngf = 24: 24 -> 32), the second segment starts behind the padding.
+    const int cphys = chunk * 16 + (g & 1) * 8 + e;
+    int cin = cphys;
+    if (C0Phys > C0Real) cin = cphys < C0Phys ? (cphys < C0Real ? cphys : CinReal) : C0Real + (cphys - C0Phys);
     float v = 0.f;
-    if (tap >= 0 && cin < CinReal) {
+    if (tap >= 0 && cin < CinReal && (mode != 0 || CoutReal <= 0 || cout < CoutReal)) {    // (padded output channels: zero rows)
       if (mode == 0) {
         v = w[((long long)cout * CinStride + cin) * 27 + tap];   // CinStride > CinReal: the leading channels of a wider tensor
       } else if (cout < CoutReal) {
@@ -190,17 +194,18 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 }
 
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
-                               int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal, int CinStride) {
+                               int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal, int CinStride, int C0Real,
+                               int C0Phys) {
   if (CinStride <= 0) CinStride = CinReal;
   const int split = precision >= 2;
   const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8 * (split ? 2 : 1);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if ((precision & 1) == 0)
     hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, scale, (f16*)wpk,
-                       CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride);
+                       CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride, C0Real, C0Phys);
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale,
-                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride);
+                       (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride, C0Real, C0Phys);
   return hipGetLastError();
 }
 

@@ -379,11 +379,11 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_valu_kernel(const C
 // k = 8*g + e <-> tap as described above; row m of tile q is channel (m>>2)*4Q + q*4 + (m&3).
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk,
-                                 int Q, int split) {
+                                 int Q, int split, int CoutReal) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < 27 * 16 * Q) {                          // fp32 table of the VALU kernel: [tap][cout], gain folded in
     const int t = idx / (16 * Q), c = idx % (16 * Q);
-    ((float*)((char*)wpk + kStemF32Offset))[idx] = w[c * 27 + t] * (scale ? scale[c] : 1.f);
+    ((float*)((char*)wpk + kStemF32Offset))[idx] = c < CoutReal ? w[c * 27 + t] * (scale ? scale[c] : 1.f) : 0.f;
   }
   if (idx >= Q * 512 * (split ? 2 : 1)) return;
   const int part = idx / (Q * 512);                 // split: [Wh tiles | Wl tiles]
@@ -394,7 +394,7 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __res
   if (g < 3) tap = g * 9 + e;
   else if (e < 3) tap = e * 9 + 8;
   float v = 0.f;
-  if (tap >= 0) v = w[cout * 27 + tap] * (scale ? scale[cout] : 1.f);
+  if (tap >= 0 && cout < CoutReal) v = w[cout * 27 + tap] * (scale ? scale[cout] : 1.f);      // padded output channels: zero rows
   wpk[idx] = part ? (T)(v - (float)(T)v) : (T)v;
 }
 
@@ -451,13 +451,14 @@ hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st) 
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st) {
+hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st, int CoutReal) {
+  if (CoutReal <= 0) CoutReal = Cout;
   const int Q = Cout / 16, split = precision >= 2;
   const int n = Q * 512 * (split ? 2 : 1);
   if ((precision & 1) == 0)
-    hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q, split);
+    hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q, split, CoutReal);
   else
-    hipLaunchKernelGGL(pack_stem_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (bf16*)wpk, Q, split);
+    hipLaunchKernelGGL(pack_stem_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (bf16*)wpk, Q, split, CoutReal);
   return hipGetLastError();
 }
 

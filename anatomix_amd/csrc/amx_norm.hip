@@ -361,7 +361,7 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
 // One thread = one voxel x 8 channels; a wavefront writes 64 consecutive floats of each of its 8 planes.
 template <typename T, bool SPLIT>
 __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const char* __restrict__ src1, int C1, int up_shift,
-                                    int N, int D, int H, int W, float* __restrict__ out) {
+                                    int N, int D, int H, int W, float* __restrict__ out, int S0, int S1) {     // S: stored channels per voxel (>= C)
   constexpr int M = SPLIT ? 2 : 1;
   const int C = C0 + C1, c8n = C >> 3;
   const long long vox = (long long)D * H * W;
@@ -373,14 +373,14 @@ __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const
     const int c8 = r % c8n, n = r / c8n;
     const int c = c8 * 8;
     const char* sp;
-    int lo_off = C0 * 2;
+    int lo_off = S0 * 2;
     if (c < C0) {
-      sp = src0 + (((long long)n * vox + v) * C0 * M + c) * 2;
+      sp = src0 + (((long long)n * vox + v) * S0 * M + c) * 2;
     } else {
-      lo_off = C1 * 2;
+      lo_off = S1 * 2;
       const int x = v % W, y = (v / W) % H, z = v / ((long long)W * H);
       const long long lv = (((long long)n * ld + (z >> up_shift)) * lh + (y >> up_shift)) * lw + (x >> up_shift);
-      sp = src1 + (lv * C1 * M + (c - C0)) * 2;
+      sp = src1 + (lv * S1 * M + (c - C0)) * 2;
     }
     float f[8];
     load8<T, SPLIT>(sp, lo_off, f);
@@ -542,11 +542,13 @@ hipError_t launch_affine_act(void* x, const float* scale, const float* shift, in
 }
 
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
-                               float* out, int precision, hipStream_t st) {
+                               float* out, int precision, hipStream_t st, int S0, int S1) {
+  if (S0 <= 0) S0 = C0;
+  if (S1 <= 0) S1 = C1;
   if (C0 % 8 || C1 % 8 || C0 + C1 < 8) return hipErrorInvalidValue;
   const long long total = (long long)N * ((C0 + C1) / 8) * D * H * W;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-#define AMX_EX(T, S) hipLaunchKernelGGL((export_ncdhw_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1, up_shift, N, D, H, W, out)
+#define AMX_EX(T, S) hipLaunchKernelGGL((export_ncdhw_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1, up_shift, N, D, H, W, out, S0, S1)
   switch (precision) {
     case 0: AMX_EX(f16, false); break;
     case 1: AMX_EX(bf16, false); break;

@@ -225,3 +225,35 @@ def test_concurrent_chunks_do_not_change_results(device):
             got_side = m(x)
         torch.cuda.current_stream(device).wait_stream(s)
     assert torch.equal(got9, want) and torch.equal(got8, want[:8]) and torch.equal(got_small, want[:5]) and torch.equal(got_side, want)
+
+
+@pytest.mark.parametrize("kw,size,layers", [
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=4), (32, 32, 64), []),                       # the reference's DEFAULT width ngf = 24
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2), (16, 32, 64), [1, 8, 9, 16, 23, 27, 30]),     # taps incl. a padded 24-channel tensor,
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=8), (16, 16, 32), [2, 9, 23]),            # the pool and the post-concat Upsample id
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=24, norm="instance", pooling="Avg", interp="trilinear",
+          norm_eps=1e-2), (16, 16, 32), [5, 23]),
+    (dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=24, use_skip_connection=False), (16, 16, 32), []),
+])
+def test_widths_that_are_not_multiples_of_16(device, kw, size, layers):
+    """network.py:268: `ngf=24` is the constructor's default.  The ngf-wide tensors are stored padded to 32 (8 -> 16) channels with
+    exact zeros; weights, norms, concat offsets and the feature taps see the reference's channel counts."""
+    m = anatomix_amd.Unet(**kw)
+    sd = R.synthetic_state_dict({**dict(ngf=24), **kw}, 6)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    x = R.synthetic_input(33, 2, size)
+    full = {**dict(ngf=24), **kw}
+    with torch.no_grad():
+        if layers:
+            y, feats = m(x.to(device), layers)
+            ref, rfeats = R.forward(x, sd, full, layers=layers)
+        else:
+            y, feats, rfeats = m(x.to(device)), [], []
+            ref = R.forward(x, sd, full)
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    strict = kw.get("norm") == "instance"                 # InstanceNorm networks default to strict precision
+    assert rel_l2(y.cpu(), ref) <= (2e-4 if strict else 1.2e-3), rel_l2(y.cpu(), ref)
+    assert len(feats) == len(rfeats)
+    for a, b in zip(feats, rfeats):
+        assert a.shape == b.shape and rel_l2(a.cpu(), b) <= (2e-4 if strict else 2e-3), (a.shape, rel_l2(a.cpu(), b))

@@ -208,7 +208,7 @@ while time.time() < t_end:
                 print("CONV FAIL", dict(prec=prec, c0=c0, c1=c1, cout=cout, size=size, n=n, act=act, planar=planar, scale=scale is not None), "rel_l2", e)
         else:
             nd = rng.randint(1, 3)
-            kw = dict(dimension=3, input_nc=1, output_nc=rng.choice([16, 32]), num_downs=nd, ngf=rng.choice([16, 32]),
+            kw = dict(dimension=3, input_nc=1, output_nc=rng.choice([16, 32]), num_downs=nd, ngf=rng.choice([8, 16, 24, 32]),
                       norm=rng.choice(["batch", "batch", "instance", "instance_affine", "none"]), activation=rng.choice(["relu", "lrelu"]),
                       pooling=rng.choice(["Max", "Avg"]), interp=rng.choice(["nearest", "trilinear"]),
                       doubleconv=rng.random() < 0.8, use_skip_connection=rng.random() < 0.85)
