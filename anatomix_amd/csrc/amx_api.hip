@@ -84,6 +84,7 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
 hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
                               int acc_skip, int precision, hipStream_t st);
+hipError_t launch_import_input(const float* src, void* dst, int N, int Cin, long long vox, int precision, hipStream_t st);
 hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D, int H, int W, long long dn, long long dz,
                                long long dy, long long dx, int accumulate, int precision, hipStream_t st);
 hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
@@ -254,7 +255,7 @@ int level_channels(const amx_unet* h, int level) {
   // the output conv's result is staged in a level-0 slot when it leaves through the export pass (W < 32 or output_nc > 32):
   // output_nc may exceed ngf.  (Sizing this by ngf alone overran the slot for output_nc = 64 -- silent while the bytes behind
   // the workspace were unused, wrong results / faults once the allocator had neighbours there.)
-  if (level == 0 && h->cfg.output_nc > c) c = h->cfg.output_nc;
+  if (level == 0 && (h->cfg.output_nc + 15) / 16 * 16 > c) c = (h->cfg.output_nc + 15) / 16 * 16;
   return c;
 }
 
@@ -390,6 +391,12 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
                                     dst, c.precision, st, t.C, 0);
   };
 
+  if (c.input_nc > 1) {
+    if (x_offs || wmap) return fail(AMX_ERR_INVALID, "the fused sliding-window path needs input_nc == 1");
+    cur.level = 0; cur.C = 16; cur.Cr = c.input_nc; cur.slot = grab(0);
+    if (cur.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level 0");
+    AMX_HIP(amx::launch_import_input(x, A.slot[0][cur.slot], n, c.input_nc, (long long)d * hh * w, c.precision, st));
+  }
   for (size_t i = 0; i < h->kinds.size(); ++i) {
     const int kind = h->kinds[i];
     if (kind == K_CONV) {
@@ -462,7 +469,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       out.level = lv; out.C = L.cout_p; out.Cr = L.cout;
       // the fp32 planar epilogues need W >= 32 and <= 32 output channels; outside that the output conv stores 16-bit
       // channels-last like any other layer and one export pass produces the fp32 NCDHW tensor
-      const bool final_via_export = L.is_final && (dw < 32 || L.cout_p > 32);
+      const bool final_via_export = L.is_final && (dw < 32 || L.cout_p > 32 || L.cout_p != L.cout);
       if (final_via_export && (wmap || x_offs))
         return fail(AMX_ERR_SHAPE, "sliding-window accumulation needs roi width >= 32 and output_nc <= 32");
       if (L.is_final && c.final_act != AMX_ACT_NONE && stop_at != L.module_idx) p.act = c.final_act;
@@ -752,9 +759,10 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   if (cfg->num_downs < 1 || cfg->num_downs > 7 || cfg->ngf < 8 || cfg->ngf % 8 || (cfg->ngf + 15) / 16 * 16 > 32)
     return fail(AMX_ERR_INVALID, "ngf must be 8, 16, 24 or 32 (the stem kernel stores 16 or 32 channels) and 1 <= num_downs <= 7 (got ngf=%d "
                 "num_downs=%d)", cfg->ngf, cfg->num_downs);
-  if (cfg->input_nc != 1) return fail(AMX_ERR_INVALID, "HIP path supports input_nc == 1 (got %d)", cfg->input_nc);
-  if (cfg->output_nc < 16 || cfg->output_nc % 16)
-    return fail(AMX_ERR_INVALID, "output_nc must be a multiple of 16 (got %d)", cfg->output_nc);
+  // input_nc > 1: the input is imported into a 16-channel tensor and the first conv is an ordinary layer; output_nc that is not a
+  // multiple of 16: the output conv stores padded channels and an export pass writes the fp32 NCDHW tensor
+  if (cfg->input_nc < 1 || cfg->input_nc > 16) return fail(AMX_ERR_INVALID, "HIP path supports 1 <= input_nc <= 16 (got %d)", cfg->input_nc);
+  if (cfg->output_nc < 1 || cfg->output_nc > 2048) return fail(AMX_ERR_INVALID, "output_nc out of range (got %d)", cfg->output_nc);
   if (cfg->norm < AMX_NORM_NONE || cfg->norm > AMX_NORM_INSTANCE_AFFINE)
     return fail(AMX_ERR_INVALID, "unknown norm mode %d", cfg->norm);
   if (cfg->interp != AMX_INTERP_NEAREST && cfg->interp != AMX_INTERP_TRILINEAR)

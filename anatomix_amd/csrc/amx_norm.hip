@@ -363,7 +363,7 @@ template <typename T, bool SPLIT>
 __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const char* __restrict__ src1, int C1, int up_shift,
                                     int N, int D, int H, int W, float* __restrict__ out, int S0, int S1) {     // S: stored channels per voxel (>= C)
   constexpr int M = SPLIT ? 2 : 1;
-  const int C = C0 + C1, c8n = C >> 3;
+  const int C = C0 + C1, c8n = (C + 7) >> 3;         // C1 == 0 may leave a ragged last group (stored channels cover it)
   const long long vox = (long long)D * H * W;
   const long long total = (long long)N * c8n * vox;
   const int lw = W >> up_shift, lh = H >> up_shift, ld = D >> up_shift;
@@ -386,7 +386,8 @@ __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const
     load8<T, SPLIT>(sp, lo_off, f);
     float* o = out + ((long long)n * C + c) * vox + v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e * vox] = f[e];
+    for (int e = 0; e < 8; ++e)
+      if (c + e < C) o[e * vox] = f[e];
   }
 }
 
@@ -418,6 +419,43 @@ __global__ void import_ncdhw_kernel(const float* __restrict__ src, char* __restr
     }
     *(uint4*)o = pack8<T>(f);
   }
+}
+
+// Network input with MORE THAN ONE channel (the reference's constructor takes any input_nc; its pretraining options default to 2,
+// pretraining/options/base_options.py:69-73): fp32 [N][Cin][D][H][W] -> 16-bit channels-last with 16 stored channels (Cin real, the
+// rest zero), after which the first conv is an ordinary 16 -> ngf layer (the single-channel stem kernel is not involved).
+// One thread per voxel; SPLIT: [hi(16) | lo(16)].
+template <typename T, bool SPLIT>
+__global__ void import_input_kernel(const float* __restrict__ src, char* __restrict__ dst, int N, int Cin, long long vox) {
+  const long long total = (long long)N * vox;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long n = idx / vox, v = idx - n * vox;
+    float f0[8], f1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      f0[c] = c < Cin ? src[(n * Cin + c) * vox + v] : 0.f;
+      f1[c] = c + 8 < Cin ? src[(n * Cin + c + 8) * vox + v] : 0.f;
+    }
+    char* o = dst + idx * (SPLIT ? 64 : 32);
+    store8<T, SPLIT>(o, 32, f0);
+    store8<T, SPLIT>(o + 16, 32, f1);
+  }
+}
+
+hipError_t launch_import_input(const float* src, void* dst, int N, int Cin, long long vox, int precision, hipStream_t st) {
+  if (Cin < 1 || Cin > 16) return hipErrorInvalidValue;
+  const long long total = (long long)N * vox;
+  const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+#define AMX_II(T, S) hipLaunchKernelGGL((import_input_kernel<T, S>), dim3(blocks), dim3(256), 0, st, src, (char*)dst, N, Cin, vox)
+  switch (precision) {
+    case 0: AMX_II(f16, false); break;
+    case 1: AMX_II(bf16, false); break;
+    case 2: AMX_II(f16, true); break;
+    case 3: AMX_II(bf16, true); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef AMX_II
+  return hipGetLastError();
 }
 
 // Last launch of a forward: if any epilogue raised the range flag, the network output is overwritten with NaN -- the
@@ -545,8 +583,10 @@ hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C
                                float* out, int precision, hipStream_t st, int S0, int S1) {
   if (S0 <= 0) S0 = C0;
   if (S1 <= 0) S1 = C1;
-  if (C0 % 8 || C1 % 8 || C0 + C1 < 8) return hipErrorInvalidValue;
-  const long long total = (long long)N * ((C0 + C1) / 8) * D * H * W;
+  // a ragged channel count is only possible for a single segment whose storage is padded (the output conv of a network whose
+  // output_nc is not a multiple of 16)
+  if (C0 + C1 < 1 || (C1 > 0 && (C0 % 8 || C1 % 8)) || (C1 == 0 && S0 < (C0 + 7) / 8 * 8)) return hipErrorInvalidValue;
+  const long long total = (long long)N * ((C0 + C1 + 7) / 8) * D * H * W;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
 #define AMX_EX(T, S) hipLaunchKernelGGL((export_ncdhw_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1, up_shift, N, D, H, W, out, S0, S1)
   switch (precision) {

@@ -277,13 +277,13 @@ class Unet(nn.Module):
             return "activation not implemented in the HIP path"
         if c["interp"] not in _lib.INTERP or c["pooling"] not in _lib.POOL:
             return f"interp='{c['interp']}' / pooling='{c['pooling']}' is not implemented in the HIP path"
-        if c["input_nc"] != 1 or c["ngf"] not in (8, 16, 24, 32) or c["output_nc"] % 16 or c["output_nc"] < 16:
-            return ("HIP path needs input_nc == 1, ngf in {8, 16, 24, 32} (the stem kernel stores 16 or 32 channels; 8 and 24 -- the "
-                    "reference's default width -- run with the ngf-wide tensors padded to 16 / 32) and output_nc a positive multiple of 16")
+        if not 1 <= c["input_nc"] <= 16 or c["ngf"] not in (8, 16, 24, 32) or c["output_nc"] < 1:
+            return ("HIP path needs 1 <= input_nc <= 16 and ngf in {8, 16, 24, 32} (the first layer stores 16 or 32 channels; 8 and 24 -- the "
+                    "reference's default width -- run with the ngf-wide tensors padded to 16 / 32)")
         if c["num_downs"] < 1 or c["num_downs"] > 7 or (c["ngf"] << c["num_downs"]) > 2048:
             return "HIP path needs 1 <= num_downs <= 7 and at most 2048 channels at the bottleneck"
-        if x.dim() != 5 or x.shape[1] != 1:
-            return "expected input of shape [N, 1, D, H, W]"
+        if x.dim() != 5 or x.shape[1] != c["input_nc"]:
+            return f"expected input of shape [N, {c['input_nc']}, D, H, W]"
         return None
 
     def _ensure_handle(self, device):

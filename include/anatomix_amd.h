@@ -52,10 +52,10 @@ enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1, AMX_PREC_F16X2 = 2, AMX_PREC_BF16X2 
 /* Constructor arguments of anatomix/model/network.py:262-279 (Unet.__init__) that shape the
  * arithmetic.  dimension is fixed at 3, pad_type at 'reflect', residual_connection at False. */
 typedef struct amx_unet_cfg {
-  int32_t input_nc;       /* network.py:265 */
-  int32_t output_nc;      /* network.py:266 */
+  int32_t input_nc;       /* network.py:265; 1 .. 16 (the fused sliding-window entries need 1) */
+  int32_t output_nc;      /* network.py:266; any positive count (the sliding-window accumulation needs <= 32) */
   int32_t num_downs;      /* network.py:267 */
-  int32_t ngf;            /* network.py:268 */
+  int32_t ngf;            /* network.py:268; 8, 16, 24 (the reference default) or 32 */
   int32_t norm;           /* AMX_NORM_*   <- norm=      network.py:269,127-168 */
   float norm_eps;         /*              <- norm_eps=  network.py:278 */
   int32_t activation;     /* AMX_ACT_*    <- activation= network.py:271,171-204 */

@@ -257,3 +257,34 @@ def test_widths_that_are_not_multiples_of_16(device, kw, size, layers):
     assert len(feats) == len(rfeats)
     for a, b in zip(feats, rfeats):
         assert a.shape == b.shape and rel_l2(a.cpu(), b) <= (2e-4 if strict else 2e-3), (a.shape, rel_l2(a.cpu(), b))
+
+
+@pytest.mark.parametrize("kw,size,layers", [
+    # the argparse defaults of the reference's pretraining options (base_options.py:69-84): two input channels, 33 output channels
+    (dict(dimension=3, input_nc=2, output_nc=33, num_downs=2, ngf=16), (16, 32, 64), []),
+    (dict(dimension=3, input_nc=3, output_nc=5, num_downs=2, ngf=24), (16, 16, 32), [0, 2, 9, 23, 37]),
+    (dict(dimension=3, input_nc=4, output_nc=16, num_downs=1, ngf=32, norm="instance", norm_eps=1e-2), (8, 16, 32), [1]),
+])
+def test_input_and_output_channel_counts_of_the_constructor_envelope(device, kw, size, layers):
+    """input_nc > 1: the fp32 NCDHW input is imported into a 16-channel tensor and the first conv is an ordinary layer; output_nc
+    not a multiple of 16: the output conv stores padded channels and one export pass writes the fp32 NCDHW result."""
+    m = anatomix_amd.Unet(**kw)
+    sd = R.synthetic_state_dict(kw, 8)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    x = torch.cat([R.synthetic_input(50 + c, 2, size) for c in range(kw["input_nc"])], dim=1)
+    with torch.no_grad():
+        if layers:
+            y, feats = m(x.to(device), layers)
+            ref, rfeats = R.forward(x, sd, kw, layers=layers)
+        else:
+            y, feats, rfeats = m(x.to(device)), [], []
+            ref = R.forward(x, sd, kw)
+    assert y.shape == ref.shape == (2, kw["output_nc"]) + size and torch.isfinite(y).all()
+    strict = kw.get("norm") == "instance"
+    assert rel_l2(y.cpu(), ref) <= (2e-4 if strict else 1.5e-3), rel_l2(y.cpu(), ref)
+    for a, b in zip(feats, rfeats):
+        assert a.shape == b.shape and rel_l2(a.cpu(), b) <= (2e-4 if strict else 2e-3), (a.shape, rel_l2(a.cpu(), b))
+    # the fused sliding-window entry is single-channel only: the generic path serves these networks
+    from anatomix_amd.registration.sliding_window import _fused_ok
+    assert not _fused_ok(m, x.to(device)) or kw["input_nc"] == 1

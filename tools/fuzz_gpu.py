@@ -208,7 +208,7 @@ while time.time() < t_end:
                 print("CONV FAIL", dict(prec=prec, c0=c0, c1=c1, cout=cout, size=size, n=n, act=act, planar=planar, scale=scale is not None), "rel_l2", e)
         else:
             nd = rng.randint(1, 3)
-            kw = dict(dimension=3, input_nc=1, output_nc=rng.choice([16, 32]), num_downs=nd, ngf=rng.choice([8, 16, 24, 32]),
+            kw = dict(dimension=3, input_nc=rng.choice([1, 1, 1, 2, 3]), output_nc=rng.choice([16, 32, 16, 32, 5, 33]), num_downs=nd, ngf=rng.choice([8, 16, 24, 32]),
                       norm=rng.choice(["batch", "batch", "instance", "instance_affine", "none"]), activation=rng.choice(["relu", "lrelu"]),
                       pooling=rng.choice(["Max", "Avg"]), interp=rng.choice(["nearest", "trilinear"]),
                       doubleconv=rng.random() < 0.8, use_skip_connection=rng.random() < 0.85)
@@ -222,7 +222,8 @@ while time.time() < t_end:
             sd = R.synthetic_state_dict(kw, rng.randint(0, 99))
             m.load_state_dict(sd, strict=True)
             m = m.to(dev).eval()
-            x = R.synthetic_input(rng.randint(0, 999), rng.randint(1, 2), size)
+            nb = rng.randint(1, 2)
+            x = torch.cat([R.synthetic_input(rng.randint(0, 999), nb, size) for _ in range(kw["input_nc"])], dim=1)
             nmod = len(m.model)
             layers = sorted(rng.sample(range(nmod), rng.randint(0, 4)))
             with torch.no_grad():
