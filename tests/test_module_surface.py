@@ -131,12 +131,12 @@ def test_copies_do_not_share_the_native_handle():
 def test_hip_gate_mirrors_the_library_limits():
     """Configurations the C side would refuse are refused by the Python gate with a reason (so allow_torch_path applies)."""
     dev_like = torch.zeros(1, 1, 32, 32, 32)
-    for kwargs in (dict(ngf=48), dict(ngf=64), dict(ngf=16, output_nc=8)):
+    for kwargs in (dict(ngf=48), dict(ngf=64), dict(ngf=12), dict(ngf=16, input_nc=17)):     # (ngf 8 / 24, any output_nc, input_nc <= 16 run)
         kw = dict(dimension=3, input_nc=1, output_nc=16, num_downs=2, ngf=16)
         kw.update(kwargs)
         m = anatomix_amd.Unet(**kw).eval()
         class _X:                                         # is_cuda is checked first: a stand-in for a GPU tensor
-            is_cuda = True; requires_grad = False; shape = dev_like.shape
+            is_cuda = True; requires_grad = False; shape = (1, kw["input_nc"], 32, 32, 32)
             def dim(self): return 5
         with torch.no_grad():
             assert m.hip_unsupported_reason(_X()) is not None, kwargs
