@@ -39,6 +39,7 @@ hipError_t launch_conv_upcat16(const ConvParams& p, int precision, hipStream_t s
 hipError_t launch_pack_upcat16(const float* w, const float* scale, void* wpk, int precision, hipStream_t st);
 const char* last_conv_upcat_kernel_name();
 bool conv_zmarch_can_pool(const ConvParams& p);
+bool conv_zmarch_can_pool_split(const ConvParams& p);
 size_t instnorm_scratch_bytes(int N, int C, long long max_slots_x_C);
 int conv_v2_stats_slots(int D, int H, int W, int Q);
 bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
@@ -498,12 +499,13 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue
       {
         size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
-        if (!split && !L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
-            cur.slot >= 0 && !have_cur_up && amx::conv_zmarch_can_pool(p) && L.q == L.cout_p / 16) {
+        if (!L.is_final && !inorm && !raw_bn && nxt < h->kinds.size() && h->kinds[nxt] == K_POOL && c.pooling == AMX_POOL_MAX &&
+            cur.slot >= 0 && !have_cur_up && (split ? amx::conv_zmarch_can_pool_split(p) : amx::conv_zmarch_can_pool(p)) &&
+            L.q == L.cout_p / 16) {
           fused_pool.level = lv + 1; fused_pool.C = L.cout_p; fused_pool.Cr = L.cout; fused_pool.slot = grab(lv + 1);
           if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
           p.out2 = A.slot[lv + 1][fused_pool.slot];
-          p.qx = (long long)L.cout_p * 2; p.qy = p.qx * (dw / 2); p.qz = p.qy * (dh / 2); p.qn = p.qz * (dd / 2);
+          p.qx = (long long)L.cout_p * eb; p.qy = p.qx * (dw / 2); p.qz = p.qy * (dh / 2); p.qn = p.qz * (dd / 2);
           have_fused_pool = true;
         }
       }

@@ -78,7 +78,7 @@ struct ZmStage {
 // epilogue splits the fp32 result again.
 template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
-  static_assert(!SPLIT || (NCK == 1 && QT == 1 && NS == 0 && !POOL), "strict z-march: 16 -> 16, direct stores");
+  static_assert(!SPLIT || (NCK == 1 && QT == 1 && NS == 0), "strict z-march: 16 -> 16, direct stores");
   constexpr int NCKP = SPLIT ? 2 : NCK;                             // chunk planes in the ring / weight sets in registers
   typedef ZmCfg<NCKP, QT, TY, TX, R> C;
   typedef ZmStage<QT, TY, TX, OUTMODE> SG;
@@ -492,6 +492,13 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
         char* dst = out2_l + (long long)zp * p.qz;
         *(uint2*)dst = make_uint2((unsigned)to_bits<T>(pm[0]) | ((unsigned)to_bits<T>(pm[1]) << 16),
                                   (unsigned)to_bits<T>(pm[2]) | ((unsigned)to_bits<T>(pm[3]) << 16));
+        if constexpr (SPLIT) {    // hi + lo is monotonic in the fp32 value: the split of the maximum IS the stored maximum
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = pm[j] - (float)(T)pm[j];
+          *(uint2*)(dst + p.Cout * 2) = make_uint2((unsigned)to_bits<T>(r[0]) | ((unsigned)to_bits<T>(r[1]) << 16),
+                                                   (unsigned)to_bits<T>(r[2]) | ((unsigned)to_bits<T>(r[3]) << 16));
+        }
       }
     }
     AMX_ZSTAMP();                                            // [epilogue issued]
@@ -504,9 +511,8 @@ const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
 template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false>
 static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
-  if constexpr (OUTMODE == 0 && NS == 0 && !POOL && !SPLIT)
-    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true>(p, st);
-  if (SPLIT && p.out2) return hipErrorInvalidValue;      // the strict path pools with its own kernel
+  if constexpr (OUTMODE == 0 && NS == 0 && !POOL)
+    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true, SPLIT>(p, st);
   constexpr int TX = 32, TZ = 2;
   typedef ZmCfg<SPLIT ? 2 : NCK, QT, TY, TX, R> C;
   constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
@@ -616,8 +622,9 @@ bool conv_zmarch_can_pool(const ConvParams& p) {
 bool conv_zmarch_eligible_split(const ConvParams& p) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_ZMARCH_SPLIT") ? 1 : 0;
-  return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16 && !p.out2;
+  return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16;
 }
+bool conv_zmarch_can_pool_split(const ConvParams& p) { return conv_zmarch_can_pool(p) && conv_zmarch_eligible_split(p); }
 
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
