@@ -26,6 +26,16 @@ class UnetCfg(C.Structure):
     ]
 
 
+class VitCfg(C.Structure):
+    _fields_ = [
+        ("input_channels", C.c_int32), ("num_classes", C.c_int32), ("embed_dim", C.c_int32), ("depth", C.c_int32),
+        ("heads", C.c_int32), ("num_register_tokens", C.c_int32), ("grid_d", C.c_int32), ("grid_h", C.c_int32),
+        ("grid_w", C.c_int32), ("hidden", C.c_int32), ("dec1", C.c_int32), ("dec2", C.c_int32), ("qk_norm", C.c_int32),
+        ("scale_attn_inner", C.c_int32), ("layer_scale", C.c_int32), ("in_eps", C.c_float), ("out_norm", C.c_int32),
+        ("decoder_split", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 
@@ -83,6 +93,15 @@ SYMBOLS = {
                               _I, _P, _I, _P, C.c_size_t, _I, _P]),
     "amx_attention_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "amx_attention_qknorm_rope": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
+    "amx_vit_create": (_I, [C.POINTER(_P), C.POINTER(VitCfg)]),
+    "amx_vit_destroy": (None, [_P]),
+    "amx_vit_num_params": (_I, [_P]),
+    "amx_vit_param_name": (C.c_char_p, [_P, _I]),
+    "amx_vit_load": (_I, [_P, C.POINTER(_P), _I, _P, _P]),
+    "amx_vit_workspace_bytes": (C.c_size_t, [_P, _I]),
+    "amx_vit_forward": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _I, _P]),
+    "amx_vit_debug_read": (_I, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_size_t), _P]),
+    "amx_linear": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "amx_supcon_scratch_bytes": (C.c_size_t, [_I, _I]),
     "amx_supcon_loss": (_I, [_P, _P, _I, _I, C.c_float, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_mlp_head_forward": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _I, C.c_float, _P, _P, _P, _P, _P]),

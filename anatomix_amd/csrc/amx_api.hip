@@ -122,6 +122,15 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(AMX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+}  // namespace
+namespace amx {
+int set_error(int code, const char* msg) {      // for the other translation units of the C ABI (amx_vit.hip)
+  g_err = msg;
+  return code;
+}
+}  // namespace amx
+namespace {
+
 enum Kind { K_CONV, K_NORM, K_ACT, K_POOL, K_UP, K_FINAL_ACT };
 
 struct ConvLayer {

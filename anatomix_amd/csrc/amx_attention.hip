@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
                                                         const float* __restrict__ v, const float* __restrict__ qn_w,
                                                         const float* __restrict__ qn_b, const float* __restrict__ kn_w,
                                                         const float* __restrict__ kn_b, float eps, const float* __restrict__ rope,
-                                                        int n_prefix, int n, int heads, int hd, f16* __restrict__ Qp,
+                                                        int n_prefix, int n, int heads, int hd, int ld, f16* __restrict__ Qp,
                                                         f16* __restrict__ Kp, f16* __restrict__ Vt) {
   const int lane = threadIdx.x & 63, tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int h = blockIdx.y, b = blockIdx.z, npad = att_npad(n);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
     for (int d = lane; d < kAttDV; d += 64) vo[d * kAttVRow] = (f16)0.f;
     return;
   }
-  const long long src = ((long long)b * n + tok) * heads * hd + (long long)h * hd;
+  const long long src = ((long long)b * n + tok) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
   // lane l holds channels l and l + 64 (head_dim <= 96); a rotation pair (2i, 2i+1) sits in neighbouring lanes of one slot
   const bool a0 = lane < hd, a1 = lane + 64 < hd;
   auto wave_sum = [](float x) {
@@ -289,15 +289,15 @@ size_t attention_scratch_bytes(int b, int heads, int n) {
   return (size_t)b * heads * npad * (2 * kAttKRow + kAttDV * kAttVRow / kAttBN) * sizeof(f16);
 }
 
-hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
-                            const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
-                            float* out, void* scratch, hipStream_t st) {
+hipError_t launch_attention_ld(const float* q, const float* k, const float* v, int ld, const float* qn_w, const float* qn_b, const float* kn_w,
+                               const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
+                               float* out, void* scratch, hipStream_t st) {
   const int npad = att_npad(n);
   f16* Qp = (f16*)scratch;
   f16* Kp = Qp + (size_t)b * heads * npad * kAttKRow;
   f16* Vt = Kp + (size_t)b * heads * npad * kAttKRow;
   hipLaunchKernelGGL(attn_prep_kernel, dim3((npad + 3) / 4, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
-                     n_prefix, n, heads, hd, Qp, Kp, Vt);
+                     n_prefix, n, heads, hd, ld, Qp, Kp, Vt);
   constexpr int LDS = kAttNBUF * (kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2) + 64;
   static bool attr_done = false;
   if (!attr_done) {
@@ -307,6 +307,12 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, cons
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
   return hipGetLastError();
+}
+
+hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
+                            const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
+                            float* out, void* scratch, hipStream_t st) {
+  return launch_attention_ld(q, k, v, heads * hd, qn_w, qn_b, kn_w, kn_b, eps, rope, n_prefix, b, n, heads, hd, out, scratch, st);
 }
 
 }  // namespace amx

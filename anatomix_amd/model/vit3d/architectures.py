@@ -10,11 +10,14 @@ oracle/vit_ref.py for every assumption) -- **parity with the upstream package is
 ``ChannelDemean`` output norm, tokenizer ``in_eps``) and the arithmetic of the published blocks are reproduced; upstream
 state_dict key names and a few hyper-parameters of the tokenizer / decoder could not be checked.
 
-What runs where: for CUDA inputs under ``torch.no_grad()`` the attention core of every block -- QK-LayerNorm, rotary
-embedding and softmax(q k^T) v for 4104 tokens x 6 heads x head_dim 66, 63 % of the model's FLOPs -- is ONE call into
-libanatomix_amd.so (``amx_attention_qknorm_rope``: MFMA flash attention, csrc/amx_attention.hip).  The plain linears and the
-small convolutional tokenizer / decoder are stock torch modules (vendor GEMM / MIOpen).  Under autograd or on the CPU the same
-attention math runs as torch ops (training the ViT is not part of the accelerated path).
+What runs where: for CUDA inputs under ``torch.no_grad()`` the WHOLE forward -- conv tokenizer, position embedding / register
+tokens, every EVA block (LayerNorms, q / k / v, QK-LayerNorm + rotary embedding + softmax attention, output projection,
+LayerScale residuals, SwiGLU MLP), final norm, transposed-conv decoder, ChannelDemean -- is ONE call into libanatomix_amd.so
+(``amx_vit_forward``, csrc/amx_vit.hip: own MFMA kernels for the convolutions, the token-matrix products and the attention;
+no vendor GEMM / conv library).  Output norms other than none / demean are applied on the engine's output by their torch module.
+Under autograd or on the CPU the torch modules below compute the same network (training the ViT is not part of the accelerated
+path); ``PrimusV2.use_engine = False`` forces that composition on the GPU too (its attention core then still runs through
+``amx_attention_qknorm_rope``).
 """
 from __future__ import annotations
 
@@ -294,6 +297,83 @@ class PrimusV2(nn.Module):
         # (Measured: torch.autocast(float16) around them costs 2.6e-3 rel-L2 against the fp32 result -- beyond the 1e-3 target --
         # for 10 % at batch 2, so no such mode is offered.)
         self.register_buffer("rope_table", build_rope_table(self.grid, embed_dim // eva_numheads), persistent=False)
+        self._vit_cfg = dict(input_channels=int(input_channels), num_classes=int(num_classes), embed_dim=int(embed_dim), depth=int(eva_depth),
+                             heads=int(eva_numheads), num_register_tokens=self.num_register_tokens, grid_d=self.grid[0], grid_h=self.grid[1],
+                             grid_w=self.grid[2], hidden=int(embed_dim * mlp_ratio), dec1=0, dec2=0, qk_norm=int(bool(qk_norm)),
+                             scale_attn_inner=int(bool(scale_attn_inner)), layer_scale=int(init_values is not None), in_eps=float(in_eps),
+                             out_norm=int(isinstance(self.out_norm, ChannelDemean)), decoder_split=1)
+        dec = [m for m in self.up_projection.decode.modules() if isinstance(m, nn.ConvTranspose3d)]
+        self._vit_cfg["dec1"], self._vit_cfg["dec2"] = (dec[0].out_channels, dec[1].out_channels) if len(dec) == 3 else (0, 0)
+        self.use_engine = True
+        self._handle = None
+        self._engine_sig = None
+        self._engine_ws = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # HIP engine (one C-ABI call per forward)
+    def _engine_tensors(self, lib):
+        sd = dict(self.named_parameters())
+        n = lib.amx_vit_num_params(self._handle)
+        return [sd[lib.amx_vit_param_name(self._handle, i).decode()] for i in range(n)]
+
+    def forward_hip(self, x, n_blocks=-1):
+        """[N, 1, D, H, W] fp32 on the GPU -> [N, num_classes, D, H, W]: ``amx_vit_forward`` + (for output norms other than none /
+        demean) the torch output norm.  Raises when the configuration is outside the engine's envelope -- there is no fallback."""
+        lib = _lib.load()
+        dev = x.device
+        if tuple(x.shape[2:]) != tuple(8 * g for g in self.grid) or x.shape[1] != self._vit_cfg["input_channels"]:
+            raise ValueError(f"PrimusV2 was built for inputs of {tuple(8 * g for g in self.grid)} (got {tuple(x.shape[1:])})")
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if self._handle is None:
+                cfg = _lib.VitCfg(**self._vit_cfg)
+                hnd = ctypes.c_void_p()
+                _lib.check(lib.amx_vit_create(ctypes.byref(hnd), ctypes.byref(cfg)))
+                self._handle = hnd
+            tensors = self._engine_tensors(lib)
+            sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(dev),)
+            if sig != self._engine_sig:
+                held = [t.detach().float().contiguous() for t in tensors]
+                arr = (ctypes.c_void_p * len(held))(*[t.data_ptr() for t in held])
+                rope = self.rope_table.detach().float().contiguous()
+                _lib.check(lib.amx_vit_load(self._handle, arr, len(held), _lib.ptr(rope), stream))
+                torch.cuda.current_stream(dev).synchronize()          # the staging copies in `held` may be temporaries
+                self._engine_sig = sig
+            n = x.shape[0]
+            need = lib.amx_vit_workspace_bytes(self._handle, n)
+            ws = self._engine_ws
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._engine_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            xin = x.detach().float().contiguous()
+            y = torch.empty((n, self._vit_cfg["num_classes"]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
+            _lib.check(lib.amx_vit_forward(self._handle, _lib.ptr(xin), _lib.ptr(y), n, _lib.ptr(ws), need, int(n_blocks), stream))
+        if not isinstance(self.out_norm, (ChannelDemean, nn.Identity)):
+            y = self.out_norm(y)
+        return y
+
+    def debug_read(self, name, dtype=torch.float32):
+        """A workspace buffer of the last ``forward_hip`` (tests): flat tensor of ``dtype``."""
+        lib = _lib.load()
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.amx_vit_debug_read(self._handle, name.encode(), None, 0, ctypes.byref(nbytes), None))
+        out = torch.empty(nbytes.value, dtype=torch.uint8, device=self._engine_ws.device)
+        with torch.cuda.device(out.device):
+            _lib.check(lib.amx_vit_debug_read(self._handle, name.encode(), _lib.ptr(out), nbytes.value, None,
+                                              ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
+        return out.view(dtype)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._engine_sig = None
+        self._engine_ws = None
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().amx_vit_destroy(self._handle)
+        except Exception:
+            pass
 
     def _body(self, x):
         feat = self.down_projection(x)
@@ -314,7 +394,10 @@ class PrimusV2(nn.Module):
         the upstream positional ``ret_mask`` (no patch dropout here: the mask is all ones)."""
         if isinstance(layers, bool):
             ret_mask, layers = layers, None
-        output = self.out_norm(self._body(x))
+        if x.is_cuda and not torch.is_grad_enabled() and self.use_engine:
+            output = self.forward_hip(x)
+        else:
+            output = self.out_norm(self._body(x))
         if ret_mask:
             return output, torch.ones((x.shape[0], 1) + self.grid, dtype=torch.bool, device=x.device)
         if layers:

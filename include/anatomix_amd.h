@@ -311,6 +311,51 @@ int amx_attention_qknorm_rope(const float* d_q, const float* d_k, const float* d
                               const float* d_kn_w, const float* d_kn_b, float norm_eps, const float* d_rope, int n_prefix, int b,
                               int n, int heads, int head_dim, float* d_out, void* d_scratch, size_t scratch_bytes, void* stream);
 
+/* ---- The whole 3D ViT variant `anatomix-dev-vit` (PrimusV2-S) as one forward ------------------------------------------------
+ * Replaces PrimusV2.forward (anatomix/model/vit3d/architectures.py:231-260 with the wrapper's extensions :89-165, tokenizer
+ * deep_tokenizer.py:12-68, registry entry load_from_hf.py:25-35): conv tokenizer (stem + three stride-2 residual stages + 1x1x1
+ * projection), position embedding + register tokens, `depth` EVA blocks (LayerNorm, q/k/v, per-head QK LayerNorm + rotary
+ * embedding + softmax attention, inner LayerNorm, output projection, LayerScale; SwiGLU MLP with sub-LayerNorm), final LayerNorm,
+ * patch decoder (three ConvTranspose3d(k = 2, s = 2) with channel LayerNorm + GELU between them), ChannelDemean.  Every kernel is
+ * this library's (amx_tokenizer.hip, amx_gemm.hip, amx_attention.hip); none of it calls a vendor GEMM / conv library.
+ * The blocks themselves live in third-party packages absent from this image: arithmetic follows oracle/vit_ref.py's restatement
+ * (PARITY WITH THE UPSTREAM PACKAGE UNPINNED). */
+typedef struct amx_vit_cfg {
+  int32_t input_channels;       /* 1 */
+  int32_t num_classes;          /* output channels, a multiple of 4 */
+  int32_t embed_dim;            /* architectures.py:20-25 (PRIMUS_CONFIGS), a multiple of 4, <= 448 */
+  int32_t depth;                /* eva_depth */
+  int32_t heads;                /* eva_numheads; head_dim = embed_dim / heads even, <= 80 */
+  int32_t num_register_tokens;  /* architectures.py:117-120 */
+  int32_t grid_d, grid_h, grid_w; /* token grid = input_shape / 8 */
+  int32_t hidden;               /* SwiGLU hidden width (int(embed_dim * 4 * 2 / 3)), a multiple of 16 */
+  int32_t dec1, dec2;           /* channel widths after the first / second transposed conv (oracle/vit_ref.py::vit_plan) */
+  int32_t qk_norm;              /* architectures.py:108-115 */
+  int32_t scale_attn_inner;     /* LayerNorm between attention and its output projection */
+  int32_t layer_scale;          /* gamma_1 / gamma_2 present (init_values is not None) */
+  float in_eps;                 /* tokenizer InstanceNorm epsilon (deep_tokenizer.py:66-68) */
+  int32_t out_norm;             /* 0 none, 1 ChannelDemean (architectures.py:28-33); other modes are applied by the caller */
+  int32_t decoder_split;        /* 1: hi + lo f16 operands in the decoder (fp32-grade), 0: plain f16 */
+} amx_vit_cfg;
+typedef struct amx_vit amx_vit_t;
+
+int amx_vit_create(amx_vit_t** out, const amx_vit_cfg* cfg);
+void amx_vit_destroy(amx_vit_t* h);
+/* Parameter slots: amx_vit_param_name(h, i) is the state_dict key (anatomix_amd.model.vit3d.PrimusV2) of slot i. */
+int amx_vit_num_params(const amx_vit_t* h);
+const char* amx_vit_param_name(const amx_vit_t* h, int idx);
+/* d_params[i]: contiguous fp32 device tensor of slot i; d_rope: fp32 [grid tokens][2 * head_dim] = per token [sin | cos].
+ * Packs / copies everything into library-owned memory (call again after the parameters change). */
+int amx_vit_load(amx_vit_t* h, const float* const* d_params, int count, const float* d_rope, void* stream);
+size_t amx_vit_workspace_bytes(const amx_vit_t* h, int n);
+/* d_x: fp32 [n][1][8 grid_d][8 grid_h][8 grid_w]; d_y: fp32 [n][num_classes][same volume].  d_ws: amx_vit_workspace_bytes(h, n)
+ * bytes, 256-byte aligned.  n_blocks < 0: all blocks (a smaller count is a debugging aid). */
+int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_ws, size_t ws_bytes, int n_blocks, void* stream);
+int amx_vit_debug_read(amx_vit_t* h, const char* name, void* d_dst, size_t max_bytes, size_t* bytes, void* stream);
+/* y[m][n] = sum_k x[m][k] w[n][k] + b[n] through the ViT's MFMA product kernel (f16 operands, or hi + lo pairs when split != 0):
+ * a test entry for nn.Linear-shaped products; synchronous (allocates and frees its operand buffers). */
+int amx_linear(const float* d_x, const float* d_w, const float* d_b, int m, int k, int n, int split, float* d_y, void* stream);
+
 /* SupPatchNCELoss.forward + its backward (pretraining/models/supcl_model.py:73-226) for one nce layer.
  * d_feat: fp32 [n][c], n = views * patches anchors in (view, patch) order (features.view(ntps * num_patches, nc),
  * supcl_model.py:134); d_labels: int32 [n], the segmentation class of every anchor (the label gather of :100-112,
