@@ -40,7 +40,7 @@ hipError_t launch_ln_rows(const void* in, int in_f16, long long ldi, int C, cons
                           int rows_in, int skip, int gelu, void* hi, void* lo, int ldo, hipStream_t st);
 hipError_t launch_place_registers(const float* reg, int nreg, int E, int rows_per_b, int nb, float* tok, hipStream_t st);
 hipError_t launch_colsum(const void* hi, const void* lo, int ld, int C, int nb, int rows_per_b, int nchunk, float* out, hipStream_t st);
-hipError_t launch_demean(const float* colsum, int nchunk, int K, long long rows_per_b, const float* W, int Creal, const float* bias, int nb,
+hipError_t launch_demean(const float* colsum, int nchunk, int ld, int K, long long rows_per_b, const float* W, int Creal, const float* bias, int nb,
                          float* mean, hipStream_t st);
 hipError_t launch_export_planar(const float* in, int C, long long vox, int nb, const float* sub, float* out, hipStream_t st);
 

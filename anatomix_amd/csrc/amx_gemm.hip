@@ -332,45 +332,70 @@ hipError_t launch_place_registers(const float* reg, int nreg, int E, int rows_pe
 
 // Column sums of an f16 (hi [+ lo]) operand matrix per sample: out[b][chunk][c] = sum over the chunk's rows (fp32; the
 // caller adds the chunks).  Feeds ChannelDemean (architectures.py:28-33) through the linearity of the last transposed conv.
-__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, int ld, int C, int rows_per_b,
+// One thread = 8 columns (16-byte loads), ld / 8 threads per row, 256 / (ld / 8) rows per pass; LDS reduction over the rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const char* __restrict__ hi, const char* __restrict__ lo, int ld, int rows_per_b,
                                                      int rows_per_chunk, float* __restrict__ out) {
+  __shared__ float red[256][9];
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  const int tpr = ld / 8, rpp = 256 / tpr;                         // threads per row, rows per pass
+  const int cg = threadIdx.x % tpr, rr = threadIdx.x / tpr;
   const long long r0 = (long long)b * rows_per_b + (long long)chunk * rows_per_chunk;
-  float s = 0.f;
-  for (int r = 0; r < rows_per_chunk; ++r) {
-    const long long o = (r0 + r) * ld + c;
-    s += (float)hi[o] + (lo ? (float)lo[o] : 0.f);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rr < rpp)
+    for (int r = rr; r < rows_per_chunk; r += rpp) {
+      const long long o = ((r0 + r) * ld + cg * 8) * 2;
+      const f16x8 h = *(const f16x8*)(hi + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+      if (lo) {
+        const f16x8 l = *(const f16x8*)(lo + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)l[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < tpr) {                                          // thread cg adds the rpp partial rows of its column group
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < rpp; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += red[q * tpr + cg][e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[((long long)b * nch + chunk) * ld + cg * 8 + e] = t[e];
   }
-  out[((long long)b * nch + chunk) * C + c] = s;
 }
 hipError_t launch_colsum(const void* hi, const void* lo, int ld, int C, int nb, int rows_per_b, int nchunk, float* out, hipStream_t st) {
-  if (C > 256 || rows_per_b % nchunk) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nb), dim3(256), 0, st, (const f16*)hi, (const f16*)lo, ld, C, rows_per_b, rows_per_b / nchunk, out);
+  if (ld > 256 || ld % 8 || C > ld || rows_per_b % nchunk) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nb), dim3(256), 0, st, (const char*)hi, (const char*)lo, ld, rows_per_b, rows_per_b / nchunk, out);
   return hipGetLastError();
 }
 
 // mean of output channel c of sample b after the last transposed conv: (1/8) sum_par sum_k W[k][c][par] xbar[b][k] + bias[c],
-// xbar = column sums / rows (double accumulation; a few thousand terms)
-__global__ void demean_kernel(const float* __restrict__ colsum, int nchunk, int K, long long rows_per_b, const float* __restrict__ W, int Creal,
-                              const float* __restrict__ bias, float* __restrict__ mean) {
-  const int b = blockIdx.x, c = threadIdx.x;
+// xbar = column sums / rows.  One workgroup per sample: the chunk sums are combined into LDS, then one thread per channel.
+__global__ __launch_bounds__(256) void demean_kernel(const float* __restrict__ colsum, int nchunk, int ld, int K, double inv_rows,
+                                                     const float* __restrict__ W, int Creal, const float* __restrict__ bias, float* __restrict__ mean) {
+  __shared__ double xbar[256];
+  const int b = blockIdx.x;
+  if ((int)threadIdx.x < K) {
+    double xs = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) xs += colsum[((long long)b * nchunk + ch) * ld + threadIdx.x];
+    xbar[threadIdx.x] = xs * inv_rows;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
   if (c >= Creal) return;
   double acc = 0.0;
   for (int k = 0; k < K; ++k) {
-    double xs = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) xs += colsum[((long long)b * nchunk + ch) * K + k];
-    double ws = 0.0;
-    for (int par = 0; par < 8; ++par) ws += W[((long long)k * Creal + c) * 8 + par];
-    acc += xs / (double)rows_per_b * ws * 0.125;
+    const float4 w0 = *(const float4*)(W + ((long long)k * Creal + c) * 8), w1 = *(const float4*)(W + ((long long)k * Creal + c) * 8 + 4);
+    acc += xbar[k] * (double)(w0.x + w0.y + w0.z + w0.w + w1.x + w1.y + w1.z + w1.w) * 0.125;
   }
   mean[b * Creal + c] = (float)(acc + (bias ? bias[c] : 0.f));
 }
-hipError_t launch_demean(const float* colsum, int nchunk, int K, long long rows_per_b, const float* W, int Creal, const float* bias, int nb,
+hipError_t launch_demean(const float* colsum, int nchunk, int ld, int K, long long rows_per_b, const float* W, int Creal, const float* bias, int nb,
                          float* mean, hipStream_t st) {
-  if (Creal > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(demean_kernel, dim3(nb), dim3(256), 0, st, colsum, nchunk, K, rows_per_b, W, Creal, bias, mean);
+  if (Creal > 256 || K > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(demean_kernel, dim3(nb), dim3(256), 0, st, colsum, nchunk, ld, K, 1.0 / (double)rows_per_b, W, Creal, bias, mean);
   return hipGetLastError();
 }
 

@@ -361,7 +361,7 @@ struct Plan {
   size_t total;
 };
 
-constexpr int kColChunks = 512;
+constexpr int kColChunks = 128;
 
 Plan make_plan(const amx_vit* h, int n, char* base) {
   Plan P{};
@@ -532,7 +532,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     g.out = P.rawd[k]; g.ldo = d.cout; g.gd = gd; g.gh = gh; g.gw = gw; g.Cp = d.cp; g.Creal = d.cout;
     if (k == 2 && c.out_norm == 1) {      // ChannelDemean: the mean of every output channel follows from the column means of this stage's input
       VIT_HIP(amx::launch_colsum(P.Ad_hi[2], P.Ad_lo[2], up(d.cin, 32), d.cin, n, (int)(rows / n), kColChunks, P.colsum, st));
-      VIT_HIP(amx::launch_demean(P.colsum, kColChunks, d.cin, rows / n, d.w_raw, d.cout, d.bias, n, P.mean, st));
+      VIT_HIP(amx::launch_demean(P.colsum, kColChunks, up(d.cin, 32), d.cin, rows / n, d.w_raw, d.cout, d.bias, n, P.mean, st));
     }
     VIT_HIP(amx::launch_gemm(g, amx::EPI_SCATTER, st));
     rows *= 8; gd *= 2; gh *= 2; gw *= 2;

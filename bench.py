@@ -475,10 +475,12 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
                           f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}" +
                           ("; the module runs the batch as chunks of 4 on two HIP streams" if B >= 8 and not vit else ""))
             if vit:
-                workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]); attention core (QK-LayerNorm "
-                              "+ rotary + softmax(qk^T)v) on the hand-written MFMA kernel with f16 operands / fp32 softmax and "
-                              "accumulate, linears and tokenizer / decoder convolutions on the vendor libraries in fp32; the network "
-                              "body restates published algorithms (parity with the upstream package unpinned)")
+                workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]), one amx_vit_forward call: "
+                              "conv tokenizer and transposed-conv decoder on own MFMA kernels with hi+lo f16 operands (fp32-grade), "
+                              "block linears on the own f16 MFMA product kernel (fp32 residual stream, fused bias / SwiGLU / LayerScale "
+                              "epilogues), attention core (QK-LayerNorm + rotary + softmax(qk^T)v) on the flash kernel with f16 operands / "
+                              "fp32 softmax; no vendor GEMM / conv library; the network body restates published algorithms (parity with "
+                              "the upstream package unpinned)")
             par = f"replicas x{world} (no data-path collective)"
         result = {
             "metric": ("128^3 volumes/sec through the contrastive pretraining step (6M UNet)" if workload == "step" else
@@ -488,7 +490,7 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             "n_gpus": world, "ranks_seen": getattr(ctx, "ranks_seen", 1), "devices": getattr(ctx, "devices", None),
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong" if sw_volume else "weak", "vs_baseline": None,
-            "dtype": "bf16" if workload == "step" else ("f16 attention / f32 linears" if vit else
+            "dtype": "bf16" if workload == "step" else ("f16 (blocks) / f16x2 (tokenizer, decoder)" if vit else
                                                         ("bf16x2" if precision == "strict" else precision)),
             "data": f"synthetic (uniform [0,1) volumes, seeded random weights of the {variant} architecture)",
             "config": {"workload": workload_s, "batch_per_gpu": 1 if sw_volume else (2 if workload == "step" else B), "window": S,
