@@ -10,7 +10,9 @@ enum GemmEpi {
   EPI_RESID = 2,    // out32[m][n] += gamma[n] * (acc + bias[n])
   EPI_SWIGLU = 3,   // tile pairs (gate, value): out16[m][h] = silu(gate + bg) * (value + bx)
   EPI_SCATTER = 4,  // ConvTranspose3d(k = 2, s = 2): n = parity * Cp + c -> out32[voxel(2 z + dz, 2 y + dy, 2 x + dx)][c]
-  EPI_TOKENS = 5    // out32[b][nreg + v][n] = acc + bias + pos[v][n]   (m = b * V + v)
+  EPI_TOKENS = 5,   // out32[b][nreg + v][n] = acc + bias + pos[v][n]   (m = b * V + v)
+  EPI_PLANAR = 6,   // last ConvTranspose3d: features ordered ((dz, dy), c, dx); planar fp32 out[b][c][2 z + dz][2 y + dy][2 x + dx] - sub[b][c]
+  EPI_SCATTER_LN = 7  // ConvTranspose3d + channel LayerNorm + GELU: hi / lo operand rows of the next stage (Cp == 128)
 };
 
 struct GemmParams {
@@ -29,6 +31,11 @@ struct GemmParams {
   int gd, gh, gw, Cp, Creal;    // EPI_SCATTER: input grid, padded / real channels per parity
   int V, nreg;                  // EPI_TOKENS: patch tokens per sample, register tokens in front
   const float* pos;             // EPI_TOKENS: [V][ldo]
+  const float* sub;             // EPI_PLANAR: per (sample, channel) constant subtracted from the output (ChannelDemean), or null
+  const float* lnw;             // EPI_SCATTER_LN: LayerNorm weight / bias [Creal], eps; output planes out (hi) / out_lo, ldo halves per row
+  const float* lnb;
+  float eps;
+  void* out_lo;
 };
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);

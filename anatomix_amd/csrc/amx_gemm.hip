@@ -18,76 +18,111 @@
 //   SPLIT     hi + lo f16 pairs for both operands, three MFMAs per product (fp32-grade; the tokenizer / decoder ends of the
 //             network need it, the blocks do not -- measured in DESIGN.md section 8).
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "amx_device.h"
 #include "amx_gemm.h"
 
 namespace amx {
 
-template <int MT, int NT, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, g = lane >> 4;
-  const int ncb = (p.ntiles + NT - 1) / NT;                      // column blocks; consecutive workgroups share the token rows
-  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
-  const int m0 = (rb * 4 + wave) * MT * 16, nt0 = cb * NT;
-  if (m0 >= p.M) return;
-  const int KS = p.KS;
+// erf with |error| < 1.5e-7 (Abramowitz-Stegun 7.1.26): one rcp, one exp, a degree-5 polynomial -- GELU in a product kernel's epilogue
+// must not cost more VALU time than the MFMAs it follows (libm's erff: ~70 instructions with both branches taken per wave)
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = __builtin_fabsf(x), t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.f - poly * __expf(-ax * ax);
+  return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_exact(float y) { return 0.5f * y * (1.f + erf_fast(y * 0.70710678118654752f)); }
 
-  const char* wp[NT];
-  const char* ap[MT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int nt = nt0 + t < p.ntiles ? nt0 + t : p.ntiles - 1;
-    wp[t] = p.w_hi + ((long long)nt * KS * 64 + lane) * 16;
-  }
-#pragma unroll
-  for (int u = 0; u < MT; ++u) {
-    int m = m0 + u * 16 + li;
-    m = m < p.M ? m : p.M - 1;
-    ap[u] = p.a_hi + (long long)m * p.lda * 2 + g * 16;
-  }
-  const long long wlo = SPLIT ? p.w_lo - p.w_hi : 0, alo = SPLIT ? p.a_lo - p.a_hi : 0;
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  f16x8 wh[2][NT], ah[2][MT], wl[2][SPLIT ? NT : 1], al[2][SPLIT ? MT : 1];
-  auto load = [&](int ks, const int buf) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wh[buf][t] = *(const f16x8*)(wp[t] + (long long)ks * 1024);
-      if (SPLIT) wl[buf][t] = *(const f16x8*)(wp[t] + wlo + (long long)ks * 1024);
-    }
+// Epilogues of the product kernels: `acc[t][u]` = tile (feature tile nt0 + t, row tile at m0 + 16 u) of this wave.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], const int m0, const int nt0, const int li, const int g) {
+  if (EPI == EPI_PLANAR) {
+    // lane (li, g) holds feature n = 16 tile + li of voxels m .. m + 3 (one x run); features are ordered ((dz, dy), c, dx), so the
+    // neighbouring lane holds the other x parity of the same channel: one quad exchange turns 2 x 4 strided values into two float4
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
-      ah[buf][u] = *(const f16x8*)(ap[u] + ks * 64);
-      if (SPLIT) al[buf][u] = *(const f16x8*)(ap[u] + alo + ks * 64);
-    }
-  };
-  auto compute = [&](const int buf) {
+      const int m = m0 + u * 16 + 4 * g;
+      if (m >= p.M) continue;
+      const int x = m % p.gw, r1 = m / p.gw, y = r1 % p.gh, r2 = r1 / p.gh, z = r2 % p.gd, b = r2 / p.gd;
+      const bool even = !(li & 1);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int u = 0; u < MT; ++u) {
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], ah[buf][u], acc[t][u], 0, 0, 0);
-        if (SPLIT) {
-          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], al[buf][u], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[buf][t], ah[buf][u], acc[t][u], 0, 0, 0);
-        }
+      for (int t = 0; t < NT; ++t) {
+        if (nt0 + t >= p.ntiles) continue;
+        const int n = (nt0 + t) * 16 + li, q = n >> 1, c = q % p.Cp, zy = q / p.Cp;
+        const float add = c < p.Creal ? p.bias[c] - (p.sub ? p.sub[b * p.Creal + c] : 0.f) : 0.f;
+        const float v0 = acc[t][u][0] + add, v1 = acc[t][u][1] + add, v2 = acc[t][u][2] + add, v3 = acc[t][u][3] + add;
+        const float o0 = dpp_quad<0xB1>(even ? v2 : v0), o1 = dpp_quad<0xB1>(even ? v3 : v1);
+        if (c >= p.Creal) continue;
+        const long long row = (((long long)b * p.Creal + c) * 2 * p.gd + 2 * z + (zy >> 1)) * 2 * p.gh + 2 * y + (zy & 1);
+        float* o = (float*)p.out + row * 2 * p.gw + 2 * x + (even ? 0 : 4);
+        *(float4*)o = even ? make_float4(v0, o0, v1, o1) : make_float4(o0, v2, o1, v3);
       }
-  };
-  load(0, 0);
-  for (int ks = 0; ks < KS; ks += 2) {
-    if (ks + 1 < KS) load(ks + 1, 1);
-    compute(0);
-    if (ks + 2 < KS) load(ks + 2, 0);
-    if (ks + 1 < KS) compute(1);
+    }
+    return;
   }
-
+  if (EPI == EPI_SCATTER_LN) {
+    // NT == Cp / 16: the wave holds every channel of its rows for one parity: channel LayerNorm + GELU in registers, the hi / lo
+    // operand rows of the next transposed conv are stored directly (the fp32 tensor between the two never exists)
+    const int par = nt0 / NT;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int m = m0 + u * 16 + li;
+      const bool live = m < p.M;
+      const int mm = live ? m : p.M - 1;
+      const int x = mm % p.gw, r1 = mm / p.gw, y = r1 % p.gh, r2 = r1 / p.gh, z = r2 % p.gd, b = r2 / p.gd;
+      const long long vox = ((((long long)b * 2 * p.gd + 2 * z + (par >> 2)) * 2 * p.gh + 2 * y + ((par >> 1) & 1)) * 2 * p.gw + 2 * x + (par & 1));
+      float v[NT][4];
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = t * 16 + 4 * g;
+        const float4 b4 = *(const float4*)(p.bias + c);
+        v[t][0] = acc[t][u][0] + b4.x; v[t][1] = acc[t][u][1] + b4.y; v[t][2] = acc[t][u][2] + b4.z; v[t][3] = acc[t][u][3] + b4.w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += c + r < p.Creal ? v[t][r] : 0.f;
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / p.Creal;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = t * 16 + 4 * g + r < p.Creal ? v[t][r] - mean : 0.f;
+          v[t][r] = d;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q / p.Creal + p.eps);
+      if (!live) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = t * 16 + 4 * g;
+        if (c >= p.ldo) continue;
+        unsigned short hb[4], lb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float yv = 0.f;
+          if (c + r < p.Creal) {
+            yv = v[t][r] * rstd * p.lnw[c + r] + p.lnb[c + r];
+            yv = gelu_exact(yv);
+          }
+          const f16 yh = (f16)yv;
+          hb[r] = __builtin_bit_cast(unsigned short, yh);
+          lb[r] = to_bits<f16>(yv - (float)yh);
+        }
+        *(uint2*)((f16*)p.out + vox * p.ldo + c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+        if (p.out_lo) *(uint2*)((f16*)p.out_lo + vox * p.ldo + c) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+      }
+    }
+    return;
+  }
   // ------------------------------------------------ epilogues: lane (li, g) holds features n .. n + 3 of token row m
 #pragma unroll
   for (int u = 0; u < MT; ++u) {
@@ -151,21 +186,289 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <int MT, int NT, int EPI, bool SPLIT>
+template <int MT, int NT, int EPI, bool SPLIT, int PF>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int ncb = (p.ntiles + NT - 1) / NT;                      // column blocks; consecutive workgroups share the token rows
+  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+  const int m0 = (rb * 4 + wave) * MT * 16, nt0 = cb * NT;
+  if (m0 >= p.M) return;
+  const int KS = p.KS;
+
+  const char* wp[NT];
+  const char* ap[MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nt = nt0 + t < p.ntiles ? nt0 + t : p.ntiles - 1;
+    wp[t] = p.w_hi + ((long long)nt * KS * 64 + lane) * 16;
+  }
+#pragma unroll
+  for (int u = 0; u < MT; ++u) {
+    int m = m0 + u * 16 + li;
+    m = m < p.M ? m : p.M - 1;
+    ap[u] = p.a_hi + (long long)m * p.lda * 2 + g * 16;
+  }
+  const long long wlo = SPLIT ? p.w_lo - p.w_hi : 0, alo = SPLIT ? p.a_lo - p.a_hi : 0;
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NB = PF + 1;                                      // operand buffers: PF K steps in flight beside the one being multiplied
+  f16x8 wh[NB][NT], ah[NB][MT], wl[NB][SPLIT ? NT : 1], al[NB][SPLIT ? MT : 1];
+  auto load = [&](int ks, const int buf) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wh[buf][t] = *(const f16x8*)(wp[t] + (long long)ks * 1024);
+      if (SPLIT) wl[buf][t] = *(const f16x8*)(wp[t] + wlo + (long long)ks * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      ah[buf][u] = *(const f16x8*)(ap[u] + ks * 64);
+      if (SPLIT) al[buf][u] = *(const f16x8*)(ap[u] + alo + ks * 64);
+    }
+  };
+  auto compute = [&](const int buf) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        if (EPI == EPI_PLANAR) {     // token rows as the A operand: a lane then owns 4 consecutive VOXELS of one feature
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[buf][u], wh[buf][t], acc[t][u], 0, 0, 0);
+          if (SPLIT) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[buf][u], wh[buf][t], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[buf][u], wl[buf][t], acc[t][u], 0, 0, 0);
+          }
+          continue;
+        }
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], ah[buf][u], acc[t][u], 0, 0, 0);
+        if (SPLIT) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], al[buf][u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[buf][t], ah[buf][u], acc[t][u], 0, 0, 0);
+        }
+      }
+  };
+  // Prefetches are UNCONDITIONAL (the K index is clamped, the tail re-fetches the last step): a conditional load block makes the
+  // waitcnt pass assume the shorter queue at the join and drain it with vmcnt(0) before every buffer -- no overlap left.
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load(i < KS ? i : KS - 1, i);
+  int ks = 0;
+  for (; ks + NB <= KS; ks += NB) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int nx = ks + j + PF;
+      load(nx < KS ? nx : KS - 1, (j + PF) % NB);
+      __builtin_amdgcn_sched_barrier(0);      // and the scheduler must not sink the loads below the MFMAs either
+      compute(j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB - 1; ++j) {          // tail: < NB steps, their operands are already in flight
+    if (ks + j < KS) compute(j);
+  }
+
+  gemm_epilogue<MT, NT, EPI>(p, acc, m0, nt0, li, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary variant.  The direct kernel above streams BOTH operands from L2 for every tile: on the blocks' shapes
+// (16416 x 396..1056 by 396..2112) it is bound by L2 / texture-path bandwidth, not by the matrix pipe (profiles/r03_vit_*).
+// Here a workgroup owns NT feature tiles with the WHOLE K extent resident in LDS (fragment order, conflict-free ds_read_b128:
+// 65 KiB for 80 features x 416), and its four waves stream row groups past it: per K step a wave loads MT row fragments from
+// global memory and reads NT weight fragments from LDS for MT * NT MFMAs.  The row fragments of the next unit (row group x
+// K chunk of KC steps) are requested before the current unit is multiplied, so a wave always has KC * MT (x2 when split)
+// 1-KiB loads in flight; accumulators stay in registers across the chunks of a row group.
+static int gemm_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int MT, int NT, int KC, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [hi | lo][NT][KS][64 lanes][16 B]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int ncb = (p.ntiles + NT - 1) / NT;
+  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;              // neighbouring workgroups share the rows (L2), not the weights
+  const int nt0 = cb * NT, KS = p.KS;
+  const int plane = NT * KS * 64;                                       // 16-byte units per plane
+  // Fill: LDS-DMA, 1 KiB (one fragment) per instruction, every wave queues its whole share before the single wait.  (A load ->
+  // ds_write loop is serialised on the memory latency by its data dependence: measured 35-50 us of a 60 us launch.)
+  {
+    const int nfrag = NT * KS * (SPLIT ? 2 : 1);
+    for (int j = wave; j < nfrag; j += 4) {
+      const int pl = j / (NT * KS), r = j - pl * NT * KS, t = r / KS, ks = r - t * KS;
+      const int nt = nt0 + t < p.ntiles ? nt0 + t : p.ntiles - 1;
+      const char* src = (pl ? p.w_lo : p.w_hi) + (((long long)nt * KS + ks) * 64 + lane) * 16;
+      dma16_asm(src, lds_addr(smem) + (unsigned)j * 1024u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const int row0 = rb * rows_per_wg;
+  const int row1 = row0 + rows_per_wg < p.M ? row0 + rows_per_wg : p.M;
+  const int groups = (row1 - row0 + MT * 16 - 1) / (MT * 16), nchunk = (KS + KC - 1) / KC;
+  const long long alo = SPLIT ? p.a_lo - p.a_hi : 0;
+
+  f16x8 ah[2][MT][KC], al[2][SPLIT ? MT : 1][SPLIT ? KC : 1];
+  f32x4 acc[NT][MT];
+  auto issue = [&](auto BUF, int grp, int c) {
+    constexpr int B = decltype(BUF)::value;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      int m = row0 + (grp * MT + u) * 16 + li;
+      m = m < p.M ? m : p.M - 1;
+      const char* ap = p.a_hi + (long long)m * p.lda * 2 + g * 16;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) {          // unconditional (clamped) loads: see the direct kernel
+        const int ks = c * KC + i < KS ? c * KC + i : KS - 1;
+        ah[B][u][i] = *(const f16x8*)(ap + ks * 64);
+        if (SPLIT) al[B][u][i] = *(const f16x8*)(ap + alo + ks * 64);
+      }
+    }
+  };
+  auto step = [&](auto BUF, int grp, int c) {
+    constexpr int B = decltype(BUF)::value;
+    if (c == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int ks = c * KC + i;
+      if (ks >= KS) break;
+      f16x8 wh[NT], wl[SPLIT ? NT : 1];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        wh[t] = *(const f16x8*)(smem + ((long long)(t * KS + ks) * 64 + lane) * 16);
+        if (SPLIT) wl[t] = *(const f16x8*)(smem + ((long long)plane + (t * KS + ks) * 64 + lane) * 16);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+          if (EPI == EPI_PLANAR) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[B][u][i], wh[t], acc[t][u], 0, 0, 0);
+            if (SPLIT) {
+              acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[B][u][i], wh[t], acc[t][u], 0, 0, 0);
+              acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[B][u][i], wl[t], acc[t][u], 0, 0, 0);
+            }
+          } else {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah[B][u][i], acc[t][u], 0, 0, 0);
+            if (SPLIT) {
+              acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al[B][u][i], acc[t][u], 0, 0, 0);
+              acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah[B][u][i], acc[t][u], 0, 0, 0);
+            }
+          }
+        }
+    }
+    if (c == nchunk - 1) gemm_epilogue<MT, NT, EPI>(p, acc, row0 + grp * MT * 16, nt0, li, g);
+  };
+  auto next = [&](int& gq, int& cq) {
+    if (++cq == nchunk) { cq = 0; gq += 4; }
+  };
+  int g0 = wave, c0 = 0, g1 = wave, c1 = 0;
+  next(g1, c1);
+  if (g0 >= groups) return;
+  issue(IC<0>{}, g0, c0);
+  while (true) {                               // the unit after the last one re-fetches rows of the last group (clamped), nothing uses it
+    issue(IC<1>{}, g1 < groups ? g1 : g0, g1 < groups ? c1 : c0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(IC<0>{}, g0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    g0 = g1; c0 = c1; next(g1, c1);
+    if (g0 >= groups) break;
+    issue(IC<0>{}, g1 < groups ? g1 : g0, g1 < groups ? c1 : c0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(IC<1>{}, g0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    g0 = g1; c0 = c1; next(g1, c1);
+    if (g0 >= groups) break;
+  }
+}
+
+template <int MT, int NT, int KC, int EPI, bool SPLIT>
+static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
+  const int ncb = (p.ntiles + NT - 1) / NT;
+  const size_t lds = (size_t)NT * p.KS * 1024 * (SPLIT ? 2 : 1);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attr = 0;                                          // per instantiation
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)wsgemm_kernel<MT, NT, KC, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  // row blocks: whole groups of 4 waves x MT tiles; ~3 workgroups per CU in total, never less than one group per wave
+  const int unit = MT * 64, G = (p.M + unit - 1) / unit;
+  int nrb = 768 / ncb;
+  nrb = nrb < 1 ? 1 : (nrb > G ? G : nrb);
+  const int rows_per_wg = (G + nrb - 1) / nrb * unit;
+  nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), lds, st, p, rows_per_wg);
+  return hipGetLastError();
+}
+
+template <int MT, int NT, int EPI, bool SPLIT, int PF>
 static hipError_t launch_one(const GemmParams& p, hipStream_t st) {
   const int ncb = (p.ntiles + NT - 1) / NT, nrb = (p.M + MT * 64 - 1) / (MT * 64);
-  hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, SPLIT, PF>), dim3((unsigned)ncb * nrb), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 
 template <int EPI, bool SPLIT>
+static hipError_t launch_epi(const GemmParams& p, hipStream_t st);
+
+// weight-stationary dispatch; returns hipErrorNotSupported when the slice does not fit LDS (the caller falls back to the direct kernel)
+template <int EPI, bool SPLIT>
+static hipError_t launch_ws_epi(const GemmParams& p, hipStream_t st) {
+  const bool five = EPI != EPI_SWIGLU && p.ntiles % 5 == 0;
+  const size_t per_tile = (size_t)p.KS * 1024 * (SPLIT ? 2 : 1);
+  if (SPLIT) {
+    if (five && 5 * per_tile <= 160 * 1024) return launch_ws<2, 5, 2, EPI, true>(p, st);
+    if (!five && 4 * per_tile <= 160 * 1024) return launch_ws<2, 4, 2, EPI, true>(p, st);
+    return hipErrorNotSupported;
+  }
+  // measured in the ViT forward (tools/vit_gemm_sweep.sh): 4 row tiles per wave win for the wide fp32-output product (q | k | v),
+  // 2 row tiles (3 waves per SIMD) for the residual / SwiGLU epilogues
+  static const int wsmt_env = gemm_env("AMX_GEMM_WSMT", 0);
+  const int wsmt = wsmt_env ? wsmt_env : (EPI == EPI_F32 ? 4 : 2);
+  if (wsmt == 2) {
+    if (five && 5 * per_tile <= 160 * 1024) return launch_ws<2, 5, 4, EPI, false>(p, st);
+    if (!five && 4 * per_tile <= 160 * 1024) return launch_ws<2, 4, 4, EPI, false>(p, st);
+    return hipErrorNotSupported;
+  }
+  if (five && 5 * per_tile <= 160 * 1024) return launch_ws<4, 5, 3, EPI, false>(p, st);
+  if (!five && 4 * per_tile <= 160 * 1024) return launch_ws<4, 4, 4, EPI, false>(p, st);
+  return hipErrorNotSupported;
+}
+
+template <int EPI, bool SPLIT>
 static hipError_t launch_epi(const GemmParams& p, hipStream_t st) {
+  static const int use_ws = gemm_env("AMX_GEMM_WS", 1);
+  if (use_ws) {
+    const hipError_t e = launch_ws_epi<EPI, SPLIT>(p, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   // NT = 5 where the tile count is a multiple of 5 (396 -> 25 tiles, 3 x 396 -> 75): no idle column tiles.  SwiGLU pairs need an even NT.
   const bool five = EPI != EPI_SWIGLU && p.ntiles % 5 == 0;
-  const bool small = (long long)((p.M + 255) / 256) * ((p.ntiles + (five ? 4 : 3)) / (five ? 5 : 4)) < 512;   // < 2 workgroups per CU: halve the row block
-  if (SPLIT) return five ? launch_one<2, 5, EPI, true>(p, st) : launch_one<2, 4, EPI, true>(p, st);
-  if (five) return small ? launch_one<2, 5, EPI, false>(p, st) : launch_one<4, 5, EPI, false>(p, st);
-  return small ? launch_one<2, 4, EPI, false>(p, st) : launch_one<4, 4, EPI, false>(p, st);
+  static const int force_mt = gemm_env("AMX_GEMM_MT", 0), pf = gemm_env("AMX_GEMM_PF", 2);
+  bool small = (long long)((p.M + 255) / 256) * ((p.ntiles + (five ? 4 : 3)) / (five ? 5 : 4)) < 512;   // < 2 workgroups per CU: halve the row block
+  if (force_mt) small = force_mt == 2;
+  if (SPLIT) return five ? launch_one<2, 5, EPI, true, 1>(p, st) : launch_one<2, 4, EPI, true, 1>(p, st);
+  if (pf == 1) {
+    if (five) return small ? launch_one<2, 5, EPI, false, 1>(p, st) : launch_one<4, 5, EPI, false, 1>(p, st);
+    return small ? launch_one<2, 4, EPI, false, 1>(p, st) : launch_one<4, 4, EPI, false, 1>(p, st);
+  }
+  if (five) return small ? launch_one<2, 5, EPI, false, 2>(p, st) : launch_one<4, 5, EPI, false, 2>(p, st);
+  return small ? launch_one<2, 4, EPI, false, 2>(p, st) : launch_one<4, 4, EPI, false, 2>(p, st);
 }
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
@@ -178,6 +481,14 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
     case EPI_SWIGLU: return split ? hipErrorInvalidValue : launch_epi<EPI_SWIGLU, false>(p, st);
     case EPI_SCATTER: return split ? launch_epi<EPI_SCATTER, true>(p, st) : launch_epi<EPI_SCATTER, false>(p, st);
     case EPI_TOKENS: return split ? launch_epi<EPI_TOKENS, true>(p, st) : launch_epi<EPI_TOKENS, false>(p, st);
+    case EPI_PLANAR:
+      if (p.gw % 4) return hipErrorInvalidValue;
+      return split ? launch_epi<EPI_PLANAR, true>(p, st) : launch_epi<EPI_PLANAR, false>(p, st);
+    case EPI_SCATTER_LN:
+      if (p.Cp != 128 || p.ntiles != 64 || p.ldo > 128) return hipErrorInvalidValue;
+      if ((size_t)8 * p.KS * 1024 * (split ? 2 : 1) <= 160 * 1024)
+        return split ? launch_ws<2, 8, 2, EPI_SCATTER_LN, true>(p, st) : launch_ws<2, 8, 4, EPI_SCATTER_LN, false>(p, st);
+      return split ? launch_one<2, 8, EPI_SCATTER_LN, true, 1>(p, st) : launch_one<2, 8, EPI_SCATTER_LN, false, 1>(p, st);
   }
   return hipErrorInvalidValue;
 }
@@ -187,6 +498,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
 //   mode 0  rows of up to three [rows_i][K] matrices stacked (q | k | v; a single Linear; a 1x1x1 conv weight [N][K])
 //   mode 1  SwiGLU: tile 2 s = rows 16 s .. of src0 (gate), tile 2 s + 1 = the same rows of src1 (value)
 //   mode 2  ConvTranspose3d weight [K = Cin][Cout][2][2][2]: n = parity * Cp + c
+//   mode 3  the same weight with n = ((dz, dy) * Cp + c) * 2 + dx (EPI_PLANAR)
 __global__ void pack_gemm_kernel(const float* s0, const float* s1, const float* s2, int r0, int r1, int r2, int K, int mode, int Cp,
                                  int Creal, int ntiles, int KS, f16* hi, f16* lo) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (tile, step, lane) = 8 halves
@@ -207,9 +519,12 @@ __global__ void pack_gemm_kernel(const float* s0, const float* s1, const float* 
       } else if (mode == 1) {
         const int n = (nt >> 1) * 16 + i;
         if (n < r0) w = ((nt & 1) ? s1 : s0)[(long long)n * K + k];
-      } else {
+      } else if (mode == 2) {
         const int n = nt * 16 + i, par = n / Cp, c = n % Cp;
         if (par < 8 && c < Creal) w = s0[((long long)k * Creal + c) * 8 + par];
+      } else {                        // mode 3: n = ((dz dy) * Cp + c) * 2 + dx
+        const int n = nt * 16 + i, q = n >> 1, c = q % Cp, zy = q / Cp;
+        if (zy < 4 && c < Creal) w = s0[((long long)k * Creal + c) * 8 + zy * 2 + (n & 1)];
       }
     }
     const f16 wh = (f16)w;
@@ -292,7 +607,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const TIN* __restrict__ in
     float y = 0.f;
     if (c < C) {
       y = w ? v[i] * rstd * w[c] + b[c] : v[i] + mean;              // w == null: plain conversion (no norm)
-      if (GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+      if (GELU) y = gelu_exact(y);
     }
     const f16 yh = (f16)y;
     hi[(long long)r * ldo + c] = yh;

@@ -90,13 +90,14 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
     for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
-  int tap_n = 0, ch_n = 0, ks_n = 0;                                    // the K step the next load() fetches
+  int ks_n = 0;                                                         // the K step the next load() fetches (clamped: the tail re-fetches the last)
   auto load = [&](const int buf) {
+    const int ksl = ks_n < KS ? ks_n : KS - 1, tap_n = ksl / nch, ch_n = ksl - tap_n * nch;
     const int kz = TAPS == 1 ? 1 : tap_n / 9, ky = TAPS == 1 ? 1 : (tap_n / 3) % 3, kx = TAPS == 1 ? 1 : tap_n % 3;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      wh[buf][t] = *(const f16x8*)(wp[t] + (long long)ks_n * 1024);
-      wl[buf][t] = *(const f16x8*)(wp[t] + wlo_off + (long long)ks_n * 1024);
+      wh[buf][t] = *(const f16x8*)(wp[t] + (long long)ksl * 1024);
+      wl[buf][t] = *(const f16x8*)(wp[t] + wlo_off + (long long)ksl * 1024);
     }
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
       xl[buf][u] = ok ? *(const f16x8*)(src + lo_off) : z;
     }
     ++ks_n;
-    if (++ch_n == nch) { ch_n = 0; ++tap_n; }
   };
   auto compute = [&](const int buf) {
 #pragma unroll
@@ -121,13 +121,20 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[buf][t], xh[buf][u], acc[t][u], 0, 0, 0);
       }
   };
+  // unconditional prefetch (a conditional load block makes the waitcnt pass drain the queue with vmcnt(0) at the join)
   load(0);
-  for (int ks = 0; ks < KS; ks += 2) {
-    if (ks + 1 < KS) load(1);
+  int ks = 0;
+  for (; ks + 2 <= KS; ks += 2) {
+    load(1);
+    __builtin_amdgcn_sched_barrier(0);        // and the loads stay in front of the MFMAs they overlap
     compute(0);
-    if (ks + 2 < KS) load(0);
-    if (ks + 1 < KS) compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (ks < KS) compute(0);
 
   // epilogue: lane (li, g) holds channels n .. n + 3 of output voxel (tile u, li)
 #pragma unroll

@@ -326,7 +326,7 @@ int amx_vit_load(amx_vit_t* h, const float* const* d_params, int count, const fl
   for (int k = 0; k < 3; ++k) {
     DecStage& d = h->dec[k];
     const float* w = next();
-    VIT_HIP(amx::launch_pack_gemm(w, nullptr, nullptr, 0, 0, 0, d.cin, 2, d.cp, d.cout, d.w.ntiles, d.w.KS, d.w.hi, d.w.lo, st));
+    VIT_HIP(amx::launch_pack_gemm(w, nullptr, nullptr, 0, 0, 0, d.cin, k == 2 ? 3 : 2, d.cp, d.cout, d.w.ntiles, d.w.KS, d.w.hi, d.w.lo, st));
     if (d.w_raw) VIT_HIP(vec((float*)d.w_raw, w, d.cin * d.cout * 8));
     VIT_HIP(vec(d.bias, next(), d.cout, d.cp));
     if (k < 2) {
@@ -411,7 +411,7 @@ Plan make_plan(const amx_vit* h, int n, char* base) {
     P.Ad_hi[k] = a.take((size_t)rows * dk[k] * 2);
     P.Ad_lo[k] = c.decoder_split ? a.take((size_t)rows * dk[k] * 2) : nullptr;
     rows *= 8;
-    P.rawd[k] = a.take<float>((size_t)rows * h->dec[k].cout * 4);
+    P.rawd[k] = k < 2 ? a.take<float>((size_t)rows * h->dec[k].cout * 4) : nullptr;     // the last stage writes the planar output itself
   }
   P.colsum = a.take<float>((size_t)n * kColChunks * 256 * 4);
   P.mean = a.take<float>((size_t)n * 128 * 4);
@@ -534,12 +534,19 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
       VIT_HIP(amx::launch_colsum(P.Ad_hi[2], P.Ad_lo[2], up(d.cin, 32), d.cin, n, (int)(rows / n), kColChunks, P.colsum, st));
       VIT_HIP(amx::launch_demean(P.colsum, kColChunks, up(d.cin, 32), d.cin, rows / n, d.w_raw, d.cout, d.bias, n, P.mean, st));
     }
-    VIT_HIP(amx::launch_gemm(g, amx::EPI_SCATTER, st));
+    if (k == 2) {                         // planar fp32 output written by the product kernel itself
+      g.out = d_y; g.sub = c.out_norm == 1 ? P.mean : nullptr;
+      VIT_HIP(amx::launch_gemm(g, amx::EPI_PLANAR, st));
+    } else if (d.cp == 128 && up(d.cout, 32) <= 128) {   // channel LayerNorm + GELU fused: the next stage's operand rows come straight out
+      g.out = P.Ad_hi[k + 1]; g.out_lo = P.Ad_lo[k + 1]; g.ldo = up(d.cout, 32); g.lnw = d.lnw; g.lnb = d.lnb; g.eps = 1e-6f;
+      VIT_HIP(amx::launch_gemm(g, amx::EPI_SCATTER_LN, st));
+    } else {
+      VIT_HIP(amx::launch_gemm(g, amx::EPI_SCATTER, st));
+      VIT_HIP(amx::launch_ln_rows(P.rawd[k], 0, d.cout, d.cout, d.lnw, d.lnb, 1e-6f, (int)(rows * 8), (int)(rows * 8), (int)(rows * 8), 0, 1, P.Ad_hi[k + 1],
+                                  P.Ad_lo[k + 1], up(d.cout, 32), st));
+    }
     rows *= 8; gd *= 2; gh *= 2; gw *= 2;
-    if (k < 2) VIT_HIP(amx::launch_ln_rows(P.rawd[k], 0, d.cout, d.cout, d.lnw, d.lnb, 1e-6f, (int)rows, (int)rows, (int)rows, 0, 1, P.Ad_hi[k + 1],
-                                           P.Ad_lo[k + 1], up(d.cout, 32), st));
   }
-  VIT_HIP(amx::launch_export_planar(P.rawd[2], c.num_classes, rows / n, n, c.out_norm == 1 ? P.mean : nullptr, d_y, st));
   return AMX_OK;
 }
 
