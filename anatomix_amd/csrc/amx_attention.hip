@@ -36,64 +36,77 @@ constexpr int kAttVRow = 72;          // halves per V^T row in LDS (144 B)
 
 __host__ __device__ inline int att_npad(int n) { return (n + kAttPad - 1) / kAttPad * kAttPad; }
 
-// grid (ceil(n_pad / 4), heads, b), block 256 = 4 tokens x 64 lanes.  One wave = one token of one head: lane d < hd holds channel d.
+// grid (n_pad / 64, heads, b), block 256 = 4 waves x 16 tokens: one workgroup = one key block of one head.  One wave handles a
+// token at a time, lane d < hd holds channel d (and d + 64).  q / k rows go straight to global memory (a row is contiguous); the
+// V^T tile [dv 80][72 halves] of the block is assembled in LDS and written out as the contiguous 11.25 KiB it is in global
+// memory (the per-token 2-byte stores at a 144-byte stride of the first version were 2/3 of this kernel's time).
+// Row `hd` of the V^T tile is set to ONE for real tokens: the PV product then accumulates the softmax row sum in output row hd
+// for free (attn_fwd, ONES) -- head_dim 80 has no spare row and keeps the VALU sum.
 __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ qn_w,
                                                         const float* __restrict__ qn_b, const float* __restrict__ kn_w,
                                                         const float* __restrict__ kn_b, float eps, const float* __restrict__ rope,
                                                         int n_prefix, int n, int heads, int hd, int ld, f16* __restrict__ Qp,
                                                         f16* __restrict__ Kp, f16* __restrict__ Vt) {
-  const int lane = threadIdx.x & 63, tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) f16 vt[kAttDV * kAttVRow];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y, b = blockIdx.z, npad = att_npad(n);
-  if (tok >= npad) return;
-  const long long row = ((long long)b * heads + h) * npad + tok;
-  f16* qo = Qp + row * kAttKRow;
-  f16* ko = Kp + row * kAttKRow;
-  // V^T block-major: [b][h][key block][dv 80][72 halves] (a block's tile is contiguous, rows already padded for the LDS banks)
-  f16* vo = Vt + (((long long)b * heads + h) * (npad / kAttBN) + tok / kAttBN) * (kAttDV * kAttVRow) + (tok % kAttBN);
-  if (tok >= n) {                      // padding rows: zeros (their scores are masked, their V columns add nothing)
-    for (int d = lane; d < kAttKRow; d += 64) { qo[d] = (f16)0.f; ko[d] = (f16)0.f; }
-    for (int d = lane; d < kAttDV; d += 64) vo[d * kAttVRow] = (f16)0.f;
-    return;
-  }
-  const long long src = ((long long)b * n + tok) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
-  // lane l holds channels l and l + 64 (head_dim <= 96); a rotation pair (2i, 2i+1) sits in neighbouring lanes of one slot
+  for (int i = threadIdx.x; i < kAttDV * kAttVRow / 8; i += 256) ((uint4*)vt)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
   const bool a0 = lane < hd, a1 = lane + 64 < hd;
   auto wave_sum = [](float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
   };
-  auto norm_rot = [&](const float* x, const float* w, const float* bb, float post, float& r0, float& r1) {
-    float v0 = a0 ? x[src + lane] : 0.f, v1 = a1 ? x[src + lane + 64] : 0.f;
-    if (w) {                           // nn.LayerNorm(head_dim): biased variance, eps inside the root
-      const float mean = wave_sum(v0 + v1) / hd;
-      const float d0 = a0 ? v0 - mean : 0.f, d1 = a1 ? v1 - mean : 0.f;
-      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / hd + eps);
-      v0 = a0 ? d0 * rstd * w[lane] + bb[lane] : 0.f;
-      v1 = a1 ? d1 * rstd * w[lane + 64] + bb[lane + 64] : 0.f;
+  const float qpost = 1.4426950408889634f / sqrtf((float)hd);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int tib = wave * 16 + i, tok = blockIdx.x * kAttBN + tib;          // token in block, token
+    const long long row = ((long long)b * heads + h) * npad + tok;
+    f16* qo = Qp + row * kAttKRow;
+    f16* ko = Kp + row * kAttKRow;
+    if (tok >= n) {                      // padding rows: zeros (their scores are masked, their V columns -- incl. the ones row -- add nothing)
+      for (int d = lane; d < kAttKRow; d += 64) { qo[d] = (f16)0.f; ko[d] = (f16)0.f; }
+      continue;
     }
-    if (rope && tok >= n_prefix) {     // x * cos + rot(x) * sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i]
-      const float o0 = __shfl_xor(v0, 1, 64), o1 = __shfl_xor(v1, 1, 64);
-      const float* tb = rope + (long long)(tok - n_prefix) * 2 * hd;
-      const float sgn = (lane & 1) ? 1.f : -1.f;
-      if (a0) v0 = v0 * tb[hd + lane] + sgn * o0 * tb[lane];
-      if (a1) v1 = v1 * tb[hd + lane + 64] + sgn * o1 * tb[lane + 64];
+    const long long src = ((long long)b * n + tok) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
+    float x[2][2];
+    x[0][0] = a0 ? q[src + lane] : 0.f; x[0][1] = a1 ? q[src + lane + 64] : 0.f;
+    x[1][0] = a0 ? k[src + lane] : 0.f; x[1][1] = a1 ? k[src + lane + 64] : 0.f;
+    const float v0 = a0 ? v[src + lane] : 0.f, v1 = a1 ? v[src + lane + 64] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {        // s = 0: query, 1: key.  nn.LayerNorm(head_dim): biased variance, eps inside the root
+      const float* w = s ? kn_w : qn_w;
+      const float* bb = s ? kn_b : qn_b;
+      float y0 = x[s][0], y1 = x[s][1];
+      if (w) {
+        const float mean = wave_sum(y0 + y1) / hd;
+        const float d0 = a0 ? y0 - mean : 0.f, d1 = a1 ? y1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / hd + eps);
+        y0 = a0 ? d0 * rstd * w[lane] + bb[lane] : 0.f;
+        y1 = a1 ? d1 * rstd * w[lane + 64] + bb[lane + 64] : 0.f;
+      }
+      if (rope && tok >= n_prefix) {     // x * cos + rot(x) * sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i]
+        const float o0 = __shfl_xor(y0, 1, 64), o1 = __shfl_xor(y1, 1, 64);
+        const float* tb = rope + (long long)(tok - n_prefix) * 2 * hd;
+        const float sgn = (lane & 1) ? 1.f : -1.f;
+        if (a0) y0 = y0 * tb[hd + lane] + sgn * o0 * tb[lane];
+        if (a1) y1 = y1 * tb[hd + lane + 64] + sgn * o1 * tb[lane + 64];
+      }
+      const float post = s ? 1.f : qpost;
+      f16* o = s ? ko : qo;
+      o[lane] = (f16)(y0 * post);
+      if (lane + 64 < kAttKRow) o[lane + 64] = (f16)(a1 ? y1 * post : 0.f);
     }
-    r0 = v0 * post;
-    r1 = v1 * post;
-  };
-  float q0v, q1v, k0v, k1v;
-  norm_rot(q, qn_w, qn_b, 1.4426950408889634f / sqrtf((float)hd), q0v, q1v);
-  norm_rot(k, kn_w, kn_b, 1.f, k0v, k1v);
-  qo[lane] = (f16)q0v;
-  ko[lane] = (f16)k0v;
-  if (lane + 64 < kAttKRow) {
-    qo[lane + 64] = (f16)(a1 ? q1v : 0.f);
-    ko[lane + 64] = (f16)(a1 ? k1v : 0.f);
+    if (a0) vt[lane * kAttVRow + tib] = (f16)v0;
+    if (a1) vt[(lane + 64) * kAttVRow + tib] = (f16)v1;
+    if (lane == 0 && hd < kAttDV) vt[hd * kAttVRow + tib] = (f16)1.f;
   }
-  vo[lane * kAttVRow] = (f16)(a0 ? v[src + lane] : 0.f);
-  if (lane + 64 < kAttDV) vo[(lane + 64) * kAttVRow] = (f16)(a1 ? v[src + lane + 64] : 0.f);
+  __syncthreads();
+  // V^T block-major: [b][h][key block][dv 80][72 halves] (a block's tile is contiguous, rows already padded for the LDS banks)
+  uint4* dst = (uint4*)(Vt + (((long long)b * heads + h) * (npad / kAttBN) + blockIdx.x) * (kAttDV * kAttVRow));
+  for (int i = threadIdx.x; i < kAttDV * kAttVRow / 8; i += 256) dst[i] = ((const uint4*)vt)[i];
 }
 
 typedef __attribute__((address_space(1))) const void* att_gptr_t;
@@ -104,6 +117,7 @@ typedef __attribute__((address_space(3))) void* att_lptr_t;
 // contiguous chunk of global memory: the loader wave moves them with LDS-DMA (1 KiB per instruction, no VGPR round trip) into a
 // ring of three buffers, runs up to two key blocks ahead with counted vmcnt waits and meets the MFMA waves through LDS counters
 // (amx_device.h) -- no workgroup barrier in the loop.
+template <bool ONES>
 __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16* __restrict__ Qp, const f16* __restrict__ Kp,
                                                        const f16* __restrict__ Vt, int n, int heads, int hd, float* __restrict__ out) {
   constexpr int QT = kAttQT, KB = kAttBN * kAttKRow * 2, VB = kAttDV * kAttVRow * 2, BUF = KB + VB, NBUF = kAttNBUF;
@@ -170,9 +184,15 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
   for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) acc_o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[QT], l_run[QT];
+  // Softmax reference point m_ref per query (exp2 domain), LAZY: the scores leave the MFMA already shifted (the first K step
+  // accumulates onto -m_ref), and m_ref only moves when a score exceeds it by more than kLag (then p <= 2^kLag stays far inside
+  // f16) -- after the first key blocks that is rare, and the common path has no subtraction, no rescale of the output
+  // accumulators and no cross-lane traffic.  ONES: the row sum comes out of the PV product (V^T row hd is all ones).
+  constexpr float kLag = 8.f;
+  float m_ref[QT], l_run[QT];
+  f32x4 negm[QT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -3.0e38f; l_run[qt] = 0.f; }
+  for (int qt = 0; qt < QT; ++qt) { m_ref[qt] = 0.f; l_run[qt] = 0.f; negm[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   // max over the four lanes that share a query (lane, lane ^ 16, lane ^ 32): row swaps, VALU only
   auto max4 = [](float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -201,16 +221,13 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
     // ---- S^T = K Q^T : acc_s[qt][kt], lane (i, g) holds scores of query i for keys 16 kt + 4 g + j
     f32x4 acc_s[QT][4];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) acc_s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         const f16x8 kf = *(const f16x8*)(sK + (kt * 16 + li) * (kAttKRow * 2) + kk * 64 + g * 16);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][kk], acc_s[qt][kt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt)
+          acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][kk], kk == 0 ? negm[qt] : acc_s[qt][kt], 0, 0, 0);
       }
     if ((blk + 1) * kAttBN > n) {      // keys beyond the sequence (last block only)
 #pragma unroll
@@ -222,32 +239,50 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
             for (int qt = 0; qt < QT; ++qt) acc_s[qt][kt][j] = -3.0e38f;
           }
     }
-    // ---- online softmax (exp2 domain), probabilities straight into the B fragments of O^T += V^T P^T
-    f16x8 pf[QT][2];
+    // ---- softmax (exp2 domain), probabilities straight into the B fragments of O^T += V^T P^T
+    float mx[QT];
+    bool over = blk == 0;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float mx = acc_s[qt][0][0];
+      mx[qt] = acc_s[qt][0][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, acc_s[qt][kt][j]);
-      const float m_new = fmaxf(m_run[qt], max4(mx));
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-      m_run[qt] = m_new;
+        for (int j = 0; j < 4; ++j) mx[qt] = fmaxf(mx[qt], acc_s[qt][kt][j]);
+      over |= mx[qt] > kLag;
+    }
+    if (__builtin_amdgcn_ballot_w64(over) != 0) {          // wave-uniform; rare after the first blocks
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float mq = max4(mx[qt]);                      // the four lanes of a query move together
+        const float delta = (blk == 0 || mq > kLag) ? mq : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_ref[qt] += delta;
+        negm[qt] = f32x4{-m_ref[qt], -m_ref[qt], -m_ref[qt], -m_ref[qt]};
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc_s[qt][kt][j] -= delta;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc_o[qt][dt][j] *= alpha;
+      }
+    }
+    f16x8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float pr = __builtin_amdgcn_exp2f(acc_s[qt][kt][j] - m_new);
-          ps += pr;
+          const float pr = __builtin_amdgcn_exp2f(acc_s[qt][kt][j]);
+          if (!ONES) ps += pr;
           pf[qt][kt >> 1][(kt & 1) * 4 + j] = (f16)pr;
         }
-      l_run[qt] = l_run[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < 5; ++dt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc_o[qt][dt][j] *= alpha;
+      if (!ONES) l_run[qt] += ps;
     }
     // ---- O^T += V^T P^T : A = V^T rows (dv) with the keys of a K-step in the order {tile 2s: 4g..4g+3, tile 2s+1: 4g..4g+3}
 #pragma unroll
@@ -268,8 +303,18 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    if (ONES) {                          // output row hd of this query = sum of its (f16-rounded) probabilities: held by lane group (hd % 16) / 4
+      float cand = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (dt == (hd >> 4) && j == (hd & 3)) cand = acc_o[qt][dt][j];
+      l = __shfl(cand, li + 16 * ((hd & 15) >> 2), 64);
+    } else {
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.f / l;
     const int qi = q0 + qt * 16 + li;
     if (qi >= n) continue;
@@ -296,16 +341,20 @@ hipError_t launch_attention_ld(const float* q, const float* k, const float* v, i
   f16* Qp = (f16*)scratch;
   f16* Kp = Qp + (size_t)b * heads * npad * kAttKRow;
   f16* Vt = Kp + (size_t)b * heads * npad * kAttKRow;
-  hipLaunchKernelGGL(attn_prep_kernel, dim3((npad + 3) / 4, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
+  hipLaunchKernelGGL(attn_prep_kernel, dim3(npad / kAttBN, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
                      n_prefix, n, heads, hd, ld, Qp, Kp, Vt);
   constexpr int LDS = kAttNBUF * (kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2) + 64;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
+  if (hd < kAttDV)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
   return hipGetLastError();
 }
 
