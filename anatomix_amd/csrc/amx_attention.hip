@@ -6,8 +6,10 @@
 // vendor GEMM (torch -> hipBLASLt), as the brief allows for plain library GEMMs.
 //
 // Two kernels:
-//   attn_prep   fp32 [b][n][heads*hd] q / k / v -> f16 operands: Qp, Kp [b][h][n_pad][104] (rows padded to 208 B: the 16 lanes of
-//               an MFMA fragment then read 16 different bank quads), q pre-multiplied by log2(e) / sqrt(hd); V^T [b][h][80][n_pad].
+//   attn_prep   fp32 [b][n][heads*hd] q / k / v -> f16 operands: Qp [b][h][n_pad][104], q pre-multiplied by log2(e) / sqrt(hd);
+//               K and V^T per key block of 64 in MFMA FRAGMENT order [b][h][block][fragment][lane][8 halves] (12 + 10 fragments
+//               of 1 KiB): attn_fwd reads a fragment with one ds_read_b128 at lane * 16 -- conflict-free.  (Row-major tiles
+//               with padded rows, the first layout, measured 46 % of the LDS cycles as bank conflicts: profiles/r03_vit_pmc_sq.)
 //               LayerNorm and rotation in fp32, ONE rounding to f16.
 //   attn_fwd    one workgroup = 128 queries of one (b, h), 4 waves x 32 queries.  Everything is computed TRANSPOSED so that a
 //               lane owns ONE query: S^T = K Q^T (A = K rows from LDS, B = Q^T fragments resident in registers), then each lane
@@ -18,6 +20,8 @@
 //               v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32 softmax in the exp2 domain.
 #include <math.h>
 #include <stdio.h>
+
+#include <type_traits>
 
 #include "amx_device.h"
 
@@ -32,14 +36,15 @@ constexpr int kAttBM = 4 * 16 * kAttQT;  // queries per workgroup (4 waves)
 constexpr int kAttPad = 128;          // token padding of the operand buffers
 constexpr int kAttNLW = 2;            // loader waves
 constexpr int kAttNBUF = 3;           // ring depth (key blocks in flight); 5 measured the same: the MFMA waves, not the loaders, set the pace
-constexpr int kAttVRow = 72;          // halves per V^T row in LDS (144 B)
+constexpr int kAttKFrag = 12;         // K fragments per key block: 4 key tiles x 3 K steps (96 padded dims), 1 KiB each
+constexpr int kAttVFrag = 10;         // V^T fragments per key block: 5 output tiles x 2 K steps (64 keys)
 
 __host__ __device__ inline int att_npad(int n) { return (n + kAttPad - 1) / kAttPad * kAttPad; }
 
 // grid (n_pad / 64, heads, b), block 256 = 4 waves x 16 tokens: one workgroup = one key block of one head.  One wave handles a
-// token at a time, lane d < hd holds channel d (and d + 64).  q / k rows go straight to global memory (a row is contiguous); the
-// V^T tile [dv 80][72 halves] of the block is assembled in LDS and written out as the contiguous 11.25 KiB it is in global
-// memory (the per-token 2-byte stores at a 144-byte stride of the first version were 2/3 of this kernel's time).
+// token at a time, lane d < hd holds channel d (and d + 64).  q rows go straight to global memory (a row is contiguous); the K
+// tile (12 KiB) and the V^T tile (10 KiB) of the block are assembled in LDS in fragment order and written out linearly (the
+// per-token 2-byte stores at a 144-byte stride of the first version were 2/3 of this kernel's time).
 // Row `hd` of the V^T tile is set to ONE for real tokens: the PV product then accumulates the softmax row sum in output row hd
 // for free (attn_fwd, ONES) -- head_dim 80 has no spare row and keeps the VALU sum.
 __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -48,16 +53,29 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
                                                         const float* __restrict__ kn_b, float eps, const float* __restrict__ rope,
                                                         int n_prefix, int n, int heads, int hd, int ld, f16* __restrict__ Qp,
                                                         f16* __restrict__ Kp, f16* __restrict__ Vt) {
-  __shared__ __attribute__((aligned(16))) f16 vt[kAttDV * kAttVRow];
+  // K and V^T tiles of the block in MFMA FRAGMENT order ([fragment][lane][8 halves], the order attn_fwd reads them with one
+  // conflict-free ds_read_b128 per fragment): assembled here, written out linearly.
+  __shared__ __attribute__((aligned(16))) f16 ktile[kAttKFrag * 512];
+  __shared__ __attribute__((aligned(16))) f16 vt[kAttVFrag * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y, b = blockIdx.z, npad = att_npad(n);
-  for (int i = threadIdx.x; i < kAttDV * kAttVRow / 8; i += 256) ((uint4*)vt)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < kAttKFrag * 64; i += 256) ((uint4*)ktile)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < kAttVFrag * 64; i += 256) ((uint4*)vt)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const bool a0 = lane < hd, a1 = lane + 64 < hd;
+  // wave-wide sum on the VALU (DPP row shifts + row broadcasts, total read from lane 63): the ds_bpermute butterflies of
+  // __shfl_xor went through the LDS crossbar, 24 per token, and set this kernel's pace
   auto wave_sum = [](float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    auto dpp = [](float v, auto CTRL, auto ROWS) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(CTRL)::value, decltype(ROWS)::value, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{});   // row_shr:1
+    x += dpp(x, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{});   // row_shr:2
+    x += dpp(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{});   // row_shr:4
+    x += dpp(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{});   // row_shr:8 -> lane 15 of a row = row sum
+    x += dpp(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast:15 into rows 1, 3
+    x += dpp(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast:31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
   };
   const float qpost = 1.4426950408889634f / sqrtf((float)hd);
 #pragma unroll 4
@@ -65,9 +83,8 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
     const int tib = wave * 16 + i, tok = blockIdx.x * kAttBN + tib;          // token in block, token
     const long long row = ((long long)b * heads + h) * npad + tok;
     f16* qo = Qp + row * kAttKRow;
-    f16* ko = Kp + row * kAttKRow;
     if (tok >= n) {                      // padding rows: zeros (their scores are masked, their V columns -- incl. the ones row -- add nothing)
-      for (int d = lane; d < kAttKRow; d += 64) { qo[d] = (f16)0.f; ko[d] = (f16)0.f; }
+      for (int d = lane; d < kAttKRow; d += 64) qo[d] = (f16)0.f;
       continue;
     }
     const long long src = ((long long)b * n + tok) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
@@ -88,25 +105,37 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
         y1 = a1 ? d1 * rstd * w[lane + 64] + bb[lane + 64] : 0.f;
       }
       if (rope && tok >= n_prefix) {     // x * cos + rot(x) * sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i]
-        const float o0 = __shfl_xor(y0, 1, 64), o1 = __shfl_xor(y1, 1, 64);
+        const float o0 = dpp_quad<0xB1>(y0), o1 = dpp_quad<0xB1>(y1);          // the rotation partner sits in the neighbouring lane
         const float* tb = rope + (long long)(tok - n_prefix) * 2 * hd;
         const float sgn = (lane & 1) ? 1.f : -1.f;
         if (a0) y0 = y0 * tb[hd + lane] + sgn * o0 * tb[lane];
         if (a1) y1 = y1 * tb[hd + lane + 64] + sgn * o1 * tb[lane + 64];
       }
-      const float post = s ? 1.f : qpost;
-      f16* o = s ? ko : qo;
-      o[lane] = (f16)(y0 * post);
-      if (lane + 64 < kAttKRow) o[lane + 64] = (f16)(a1 ? y1 * post : 0.f);
+      if (s == 0) {
+        qo[lane] = (f16)(y0 * qpost);
+        if (lane + 64 < kAttKRow) qo[lane + 64] = (f16)(a1 ? y1 * qpost : 0.f);
+      } else {                           // key (tile tib / 16, row tib % 16): dim d -> fragment (tile, d / 32), lane ((d % 32) / 8, row), element d % 8
+        auto kidx = [&](int d) { return (((tib >> 4) * 3 + (d >> 5)) * 64 + ((d & 31) >> 3) * 16 + (tib & 15)) * 8 + (d & 7); };
+        if (a0) ktile[kidx(lane)] = (f16)y0;
+        if (a1) ktile[kidx(lane + 64)] = (f16)y1;
+      }
     }
-    if (a0) vt[lane * kAttVRow + tib] = (f16)v0;
-    if (a1) vt[(lane + 64) * kAttVRow + tib] = (f16)v1;
-    if (lane == 0 && hd < kAttDV) vt[hd * kAttVRow + tib] = (f16)1.f;
+    // V^T: dv row d, key tib -> fragment (d / 16, tib / 32), lane (g, d % 16); the 32 keys of a K step are taken in the order
+    // {tile 2s keys 4g..4g+3, tile 2s+1 keys 4g..4g+3} (the order the probabilities leave the softmax in, see attn_fwd)
+    auto vidx = [&](int d) {
+      const int kq = tib & 31, gq = (kq & 15) >> 2, e = (kq >> 4) * 4 + (kq & 3);
+      return (((d >> 4) * 2 + (tib >> 5)) * 64 + gq * 16 + (d & 15)) * 8 + e;
+    };
+    if (a0) vt[vidx(lane)] = (f16)v0;
+    if (a1) vt[vidx(lane + 64)] = (f16)v1;
+    if (lane == 0 && hd < kAttDV) vt[vidx(hd)] = (f16)1.f;
   }
   __syncthreads();
-  // V^T block-major: [b][h][key block][dv 80][72 halves] (a block's tile is contiguous, rows already padded for the LDS banks)
-  uint4* dst = (uint4*)(Vt + (((long long)b * heads + h) * (npad / kAttBN) + blockIdx.x) * (kAttDV * kAttVRow));
-  for (int i = threadIdx.x; i < kAttDV * kAttVRow / 8; i += 256) dst[i] = ((const uint4*)vt)[i];
+  const long long blk = ((long long)b * heads + h) * (npad / kAttBN) + blockIdx.x;     // [b][h][key block][fragment][lane][8 halves]
+  uint4* kd = (uint4*)(Kp + blk * (kAttKFrag * 512));
+  uint4* vd = (uint4*)(Vt + blk * (kAttVFrag * 512));
+  for (int i = threadIdx.x; i < kAttKFrag * 64; i += 256) kd[i] = ((const uint4*)ktile)[i];
+  for (int i = threadIdx.x; i < kAttVFrag * 64; i += 256) vd[i] = ((const uint4*)vt)[i];
 }
 
 typedef __attribute__((address_space(1))) const void* att_gptr_t;
@@ -120,7 +149,7 @@ typedef __attribute__((address_space(3))) void* att_lptr_t;
 template <bool ONES>
 __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16* __restrict__ Qp, const f16* __restrict__ Kp,
                                                        const f16* __restrict__ Vt, int n, int heads, int hd, float* __restrict__ out) {
-  constexpr int QT = kAttQT, KB = kAttBN * kAttKRow * 2, VB = kAttDV * kAttVRow * 2, BUF = KB + VB, NBUF = kAttNBUF;
+  constexpr int QT = kAttQT, KB = kAttKFrag * 1024, VB = kAttVFrag * 1024, BUF = KB + VB, NBUF = kAttNBUF;
   constexpr int NDMA = (BUF + 1023) / 1024, NLW = kAttNLW;  // 1 KiB pieces per key block (the last one partial)
   constexpr int PER = (NDMA + NLW - 1) / NLW;               // pieces per loader wave and block (waves without a last piece pad the count)
   static_assert(BUF % 16 == 0 && PER * 2 <= 60 && NLW <= 8, "tile size / vmcnt range");
@@ -139,8 +168,8 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
   if (wave >= 4) {
     // =============================== loader wave lw: pieces j = lw, lw + NLW, ... ===============================
     const int lw = wave - 4;
-    const char* kbase = (const char*)(Kp + bh * npad * kAttKRow);
-    const char* vbase = (const char*)(Vt + bh * nblk_pad * (kAttDV * kAttVRow));
+    const char* kbase = (const char*)(Kp + bh * nblk_pad * (kAttKFrag * 512));
+    const char* vbase = (const char*)(Vt + bh * nblk_pad * (kAttVFrag * 512));
     const unsigned a_ready = lds_addr(ready + lw), a_done = lds_addr(done);
     for (int blk = 0; blk < nblk; ++blk) {
       if (blk >= NBUF)                                    // buffer blk % NBUF is free once every MFMA wave finished block blk - NBUF
@@ -220,16 +249,30 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
 
     // ---- S^T = K Q^T : acc_s[qt][kt], lane (i, g) holds scores of query i for keys 16 kt + 4 g + j
     f32x4 acc_s[QT][4];
+    f16x8 kfr[4][3];                   // every K fragment of the block is requested before the first MFMA (12 reads in flight, counted waits)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) kfr[kt][kk] = *(const f16x8*)(sK + ((kt * 3 + kk) * 64 + lane) * 16);
+    __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise re-interleaves them two at a time with a full wait before each MFMA pair
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
-        const f16x8 kf = *(const f16x8*)(sK + (kt * 16 + li) * (kAttKRow * 2) + kk * 64 + g * 16);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][kk], kk == 0 ? negm[qt] : acc_s[qt][kt], 0, 0, 0);
+          acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kt][kk], qf[qt][kk], kk == 0 ? negm[qt] : acc_s[qt][kt], 0, 0, 0);
+      }
+    // V^T fragments of the block: requested now, needed after the softmax arithmetic
+    f16x8 vfr[5][2];
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        vfr[dt][ks] = *(const f16x8*)(sV + ((dt * 2 + ks) * 64 + lane) * 16);
       }
     if ((blk + 1) * kAttBN > n) {      // keys beyond the sequence (last block only)
+      asm volatile("" ::: "memory");     // keeps this a BRANCH: if-converted it was 80 select / compare instructions in every block
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -289,12 +332,8 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
     for (int dt = 0; dt < 5; ++dt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const char* vr = sV + (dt * 16 + li) * (kAttVRow * 2) + (ks * 32 + 4 * g) * 2;
-        const uint2 lo = *(const uint2*)vr, hi = *(const uint2*)(vr + 32);
-        const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const f16x8 vf = __builtin_bit_cast(f16x8, raw);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[dt][ks], pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of this block's tiles has returned: the buffer may be refilled
     flag_store(done + wave, blk + 1);
@@ -331,7 +370,7 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
 
 size_t attention_scratch_bytes(int b, int heads, int n) {
   const size_t npad = att_npad(n);
-  return (size_t)b * heads * npad * (2 * kAttKRow + kAttDV * kAttVRow / kAttBN) * sizeof(f16);
+  return (size_t)b * heads * (npad * kAttKRow + (npad / kAttBN) * (kAttKFrag + kAttVFrag) * 512) * sizeof(f16);
 }
 
 hipError_t launch_attention_ld(const float* q, const float* k, const float* v, int ld, const float* qn_w, const float* qn_b, const float* kn_w,
@@ -340,10 +379,10 @@ hipError_t launch_attention_ld(const float* q, const float* k, const float* v, i
   const int npad = att_npad(n);
   f16* Qp = (f16*)scratch;
   f16* Kp = Qp + (size_t)b * heads * npad * kAttKRow;
-  f16* Vt = Kp + (size_t)b * heads * npad * kAttKRow;
+  f16* Vt = Kp + (size_t)b * heads * (npad / kAttBN) * (kAttKFrag * 512);
   hipLaunchKernelGGL(attn_prep_kernel, dim3(npad / kAttBN, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
                      n_prefix, n, heads, hd, ld, Qp, Kp, Vt);
-  constexpr int LDS = kAttNBUF * (kAttBN * kAttKRow * 2 + kAttDV * kAttVRow * 2) + 64;
+  constexpr int LDS = kAttNBUF * (kAttKFrag + kAttVFrag) * 1024 + 64;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

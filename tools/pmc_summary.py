@@ -35,6 +35,10 @@ def friendly(mangled):
         return f"conv3d_upmerge<{name},q{q},{tz}x{int(ty) * 16 // int(lxt)}x{lxt},b{nbuf},k{32 * int(ks)}>"
     if "pool2_kernel" in mangled:
         return "pool2<max>" if "Li0EEE" in mangled else "pool2<avg>"
+    # ViT engine kernels: keep the (demangled or mangled) name up to the argument list
+    m = re.search(r"(attn_fwd_kernel|attn_prep_kernel|wsgemm_kernel|gemm_kernel|tokconv_kernel|tokstem_kernel|ln_rows_kernel)(<[^>]*>|I[A-Za-z0-9_]*?E(?=Ev|v))?", mangled)
+    if m:
+        return m.group(0)
     return None
 
 
