@@ -78,8 +78,37 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
   };
   const float qpost = 1.4426950408889634f / sqrtf((float)hd);
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
+  float lnw[2][2] = {{1.f, 1.f}, {1.f, 1.f}}, lnb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // [q | k][channel lane | lane + 64]: loop invariants
+  const bool has_norm[2] = {qn_w != nullptr, kn_w != nullptr};
+  if (qn_w) {
+    if (a0) { lnw[0][0] = qn_w[lane]; lnb[0][0] = qn_b[lane]; }
+    if (a1) { lnw[0][1] = qn_w[lane + 64]; lnb[0][1] = qn_b[lane + 64]; }
+  }
+  if (kn_w) {
+    if (a0) { lnw[1][0] = kn_w[lane]; lnb[1][0] = kn_b[lane]; }
+    if (a1) { lnw[1][1] = kn_w[lane + 64]; lnb[1][1] = kn_b[lane + 64]; }
+  }
+  for (int i0 = 0; i0 < 16; i0 += 4) {
+  // four tokens' operands are requested together (24 loads in flight per lane; one at a time exposed the latency 16 times)
+  float xin[4][6], rin[4][4];            // rin: rotary table entries {sin, cos} of channels lane, lane + 64 (shared by q and k)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tok = blockIdx.x * kAttBN + wave * 16 + i0 + j;
+    const int tc = tok < n ? tok : n - 1;
+    const long long src = ((long long)b * n + tc) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
+    xin[j][0] = a0 ? q[src + lane] : 0.f; xin[j][1] = a1 ? q[src + lane + 64] : 0.f;
+    xin[j][2] = a0 ? k[src + lane] : 0.f; xin[j][3] = a1 ? k[src + lane + 64] : 0.f;
+    xin[j][4] = a0 ? v[src + lane] : 0.f; xin[j][5] = a1 ? v[src + lane + 64] : 0.f;
+    rin[j][0] = rin[j][1] = rin[j][2] = rin[j][3] = 0.f;
+    if (rope && tc >= n_prefix) {
+      const float* tb = rope + (long long)(tc - n_prefix) * 2 * hd;
+      if (a0) { rin[j][0] = tb[lane]; rin[j][1] = tb[hd + lane]; }
+      if (a1) { rin[j][2] = tb[lane + 64]; rin[j][3] = tb[hd + lane + 64]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = i0 + j;
     const int tib = wave * 16 + i, tok = blockIdx.x * kAttBN + tib;          // token in block, token
     const long long row = ((long long)b * heads + h) * npad + tok;
     f16* qo = Qp + row * kAttKRow;
@@ -87,29 +116,23 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
       for (int d = lane; d < kAttKRow; d += 64) qo[d] = (f16)0.f;
       continue;
     }
-    const long long src = ((long long)b * n + tok) * ld + (long long)h * hd;     // ld: floats per token row of q / k / v
-    float x[2][2];
-    x[0][0] = a0 ? q[src + lane] : 0.f; x[0][1] = a1 ? q[src + lane + 64] : 0.f;
-    x[1][0] = a0 ? k[src + lane] : 0.f; x[1][1] = a1 ? k[src + lane + 64] : 0.f;
-    const float v0 = a0 ? v[src + lane] : 0.f, v1 = a1 ? v[src + lane + 64] : 0.f;
+    const float x[2][2] = {{xin[j][0], xin[j][1]}, {xin[j][2], xin[j][3]}};
+    const float v0 = xin[j][4], v1 = xin[j][5];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {        // s = 0: query, 1: key.  nn.LayerNorm(head_dim): biased variance, eps inside the root
-      const float* w = s ? kn_w : qn_w;
-      const float* bb = s ? kn_b : qn_b;
       float y0 = x[s][0], y1 = x[s][1];
-      if (w) {
+      if (has_norm[s]) {
         const float mean = wave_sum(y0 + y1) / hd;
         const float d0 = a0 ? y0 - mean : 0.f, d1 = a1 ? y1 - mean : 0.f;
         const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / hd + eps);
-        y0 = a0 ? d0 * rstd * w[lane] + bb[lane] : 0.f;
-        y1 = a1 ? d1 * rstd * w[lane + 64] + bb[lane + 64] : 0.f;
+        y0 = a0 ? d0 * rstd * lnw[s][0] + lnb[s][0] : 0.f;
+        y1 = a1 ? d1 * rstd * lnw[s][1] + lnb[s][1] : 0.f;
       }
       if (rope && tok >= n_prefix) {     // x * cos + rot(x) * sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i]
         const float o0 = dpp_quad<0xB1>(y0), o1 = dpp_quad<0xB1>(y1);          // the rotation partner sits in the neighbouring lane
-        const float* tb = rope + (long long)(tok - n_prefix) * 2 * hd;
         const float sgn = (lane & 1) ? 1.f : -1.f;
-        if (a0) y0 = y0 * tb[hd + lane] + sgn * o0 * tb[lane];
-        if (a1) y1 = y1 * tb[hd + lane + 64] + sgn * o1 * tb[lane + 64];
+        if (a0) y0 = y0 * rin[j][1] + sgn * o0 * rin[j][0];
+        if (a1) y1 = y1 * rin[j][3] + sgn * o1 * rin[j][2];
       }
       if (s == 0) {
         qo[lane] = (f16)(y0 * qpost);
@@ -129,6 +152,7 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict_
     if (a0) vt[vidx(lane)] = (f16)v0;
     if (a1) vt[vidx(lane + 64)] = (f16)v1;
     if (lane == 0 && hd < kAttDV) vt[vidx(hd)] = (f16)1.f;
+  }
   }
   __syncthreads();
   const long long blk = ((long long)b * heads + h) * (npad / kAttBN) + blockIdx.x;     // [b][h][key block][fragment][lane][8 halves]

@@ -66,24 +66,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
   if (EPI == EPI_SCATTER_LN) {
     // NT == Cp / 16: the wave holds every channel of its rows for one parity: channel LayerNorm + GELU in registers, the hi / lo
-    // operand rows of the next transposed conv are stored directly (the fp32 tensor between the two never exists)
+    // operand rows of the next transposed conv are stored directly (the fp32 tensor between the two never exists).
+    // Pass 1 (per row tile): bias, mean, deviations in place, rstd.  Pass 2 (per channel tile): the LayerNorm parameters are
+    // loaded ONCE per tile as float4 and applied to every row tile (per-value loads were 128 load instructions per wave and tile).
     const int par = nt0 / NT;
+    float rstd[MT];
+    long long vox[MT];
+    bool live[MT];
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
       const int m = m0 + u * 16 + li;
-      const bool live = m < p.M;
-      const int mm = live ? m : p.M - 1;
+      live[u] = m < p.M;
+      const int mm = live[u] ? m : p.M - 1;
       const int x = mm % p.gw, r1 = mm / p.gw, y = r1 % p.gh, r2 = r1 / p.gh, z = r2 % p.gd, b = r2 / p.gd;
-      const long long vox = ((((long long)b * 2 * p.gd + 2 * z + (par >> 2)) * 2 * p.gh + 2 * y + ((par >> 1) & 1)) * 2 * p.gw + 2 * x + (par & 1));
-      float v[NT][4];
+      vox[u] = ((((long long)b * 2 * p.gd + 2 * z + (par >> 2)) * 2 * p.gh + 2 * y + ((par >> 1) & 1)) * 2 * p.gw + 2 * x + (par & 1));
       float s = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int c = t * 16 + 4 * g;
         const float4 b4 = *(const float4*)(p.bias + c);
-        v[t][0] = acc[t][u][0] + b4.x; v[t][1] = acc[t][u][1] + b4.y; v[t][2] = acc[t][u][2] + b4.z; v[t][3] = acc[t][u][3] + b4.w;
+        acc[t][u][0] += b4.x; acc[t][u][1] += b4.y; acc[t][u][2] += b4.z; acc[t][u][3] += b4.w;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += c + r < p.Creal ? v[t][r] : 0.f;
+        for (int r = 0; r < 4; ++r) s += c + r < p.Creal ? acc[t][u][r] : 0.f;
       }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
@@ -93,37 +97,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float d = t * 16 + 4 * g + r < p.Creal ? v[t][r] - mean : 0.f;
-          v[t][r] = d;
+          const float d = t * 16 + 4 * g + r < p.Creal ? acc[t][u][r] - mean : 0.f;
+          acc[t][u][r] = d;
           q += d * d;
         }
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
-      const float rstd = rsqrtf(q / p.Creal + p.eps);
-      if (!live) continue;
+      rstd[u] = rsqrtf(q / p.Creal + p.eps);
+    }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int c = t * 16 + 4 * g;
-        if (c >= p.ldo) continue;
+    for (int t = 0; t < NT; ++t) {
+      const int c = t * 16 + 4 * g;
+      if (c >= p.ldo) continue;
+      float w4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c + 3 < p.Creal) {
+        const float4 a4 = *(const float4*)(p.lnw + c), c4 = *(const float4*)(p.lnb + c);
+        w4[0] = a4.x; w4[1] = a4.y; w4[2] = a4.z; w4[3] = a4.w;
+        o4[0] = c4.x; o4[1] = c4.y; o4[2] = c4.z; o4[3] = c4.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < p.Creal) { w4[r] = p.lnw[c + r]; o4[r] = p.lnb[c + r]; }
+      }
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        if (!live[u]) continue;
         unsigned short hb[4], lb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float yv = 0.f;
-          if (c + r < p.Creal) {
-            yv = v[t][r] * rstd * p.lnw[c + r] + p.lnb[c + r];
-            yv = gelu_exact(yv);
-          }
+          const float yv = c + r < p.Creal ? gelu_exact(acc[t][u][r] * rstd[u] * w4[r] + o4[r]) : 0.f;
           const f16 yh = (f16)yv;
           hb[r] = __builtin_bit_cast(unsigned short, yh);
           lb[r] = to_bits<f16>(yv - (float)yh);
         }
-        *(uint2*)((f16*)p.out + vox * p.ldo + c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
-        if (p.out_lo) *(uint2*)((f16*)p.out_lo + vox * p.ldo + c) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+        *(uint2*)((f16*)p.out + vox[u] * p.ldo + c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+        if (p.out_lo) *(uint2*)((f16*)p.out_lo + vox[u] * p.ldo + c) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
       }
     }
     return;
   }
-  // ------------------------------------------------ epilogues: lane (li, g) holds features n .. n + 3 of token row m
 #pragma unroll
   for (int u = 0; u < MT; ++u) {
     const int m = m0 + u * 16 + li;
@@ -615,10 +627,86 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const TIN* __restrict__ in
   }
 }
 
+// The same with 4 elements per lane and chunk (16-byte fp32 / 8-byte f16 loads, 8-byte stores): C, ldi and ldo multiples of 4.
+template <typename TIN, int PERV, bool GELU>
+__global__ __launch_bounds__(256) void ln_rows_vec_kernel(const TIN* __restrict__ in, long long ldi, int C, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float eps, int M, int rows_out, int rows_in, int skip,
+                                                          f16* __restrict__ hi, f16* __restrict__ lo, int ldo) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const long long ri = (long long)(r / rows_out) * rows_in + skip + r % rows_out;
+  const TIN* x = in + ri * ldi;
+  float v[PERV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PERV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      if (sizeof(TIN) == 4) {
+        const float4 t = *(const float4*)((const float*)x + c);
+        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+      } else {
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+        const f16x4 t = *(const f16x4*)((const f16*)x + c);
+        v[i][0] = (float)t[0]; v[i][1] = (float)t[1]; v[i][2] = (float)t[2]; v[i][3] = (float)t[3];
+      }
+    } else {
+      v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+    }
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PERV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = (i * 64 + lane) * 4 < C ? v[i][e] - mean : 0.f;
+      v[i][e] = d;
+      q += d * d;
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+  for (int i = 0; i < PERV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= ldo) continue;
+    unsigned short hb[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
+    if (c < C) {
+      float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w) { w4 = *(const float4*)(w + c); b4 = *(const float4*)(b + c); }
+      const float ww[4] = {w4.x, w4.y, w4.z, w4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = w ? v[i][e] * rstd * ww[e] + bb[e] : v[i][e] + mean;
+        if (GELU) y = gelu_exact(y);
+        const f16 yh = (f16)y;
+        hb[e] = __builtin_bit_cast(unsigned short, yh);
+        lb[e] = to_bits<f16>(y - (float)yh);
+      }
+    }
+    *(uint2*)(hi + (long long)r * ldo + c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+    if (lo) *(uint2*)(lo + (long long)r * ldo + c) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+  }
+}
+
 hipError_t launch_ln_rows(const void* in, int in_f16, long long ldi, int C, const float* w, const float* b, float eps, int M, int rows_out,
                           int rows_in, int skip, int gelu, void* hi, void* lo, int ldo, hipStream_t st) {
   if (C > 64 * 17 || ldo > 64 * 17 || ldo < C) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
+  if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && (ldo + 255) / 256 <= 5 && !(in_f16 && gelu)) {
+#define AMX_LNV(TIN, PERV, G) \
+  hipLaunchKernelGGL((ln_rows_vec_kernel<TIN, PERV, G>), grid, block, 0, st, (const TIN*)in, ldi, C, w, b, eps, M, rows_out, rows_in, skip, (f16*)hi, (f16*)lo, ldo)
+    const int perv = (ldo + 255) / 256;
+    if (in_f16) { if (perv <= 2) AMX_LNV(f16, 2, false); else AMX_LNV(f16, 5, false); }
+    else if (gelu) { if (perv <= 1) AMX_LNV(float, 1, true); else AMX_LNV(float, 2, true); }
+    else { if (perv <= 2) AMX_LNV(float, 2, false); else AMX_LNV(float, 5, false); }
+#undef AMX_LNV
+    return hipGetLastError();
+  }
 #define AMX_LN(TIN, PER, G) \
   hipLaunchKernelGGL((ln_rows_kernel<TIN, PER, G>), grid, block, 0, st, (const TIN*)in, ldi, C, w, b, eps, M, rows_out, rows_in, skip, (f16*)hi, (f16*)lo, ldo)
   const int per = (ldo + 63) / 64;
@@ -690,12 +778,20 @@ hipError_t launch_colsum(const void* hi, const void* lo, int ld, int C, int nb, 
 // xbar = column sums / rows.  One workgroup per sample: the chunk sums are combined into LDS, then one thread per channel.
 __global__ __launch_bounds__(256) void demean_kernel(const float* __restrict__ colsum, int nchunk, int ld, int K, double inv_rows,
                                                      const float* __restrict__ W, int Creal, const float* __restrict__ bias, float* __restrict__ mean) {
-  __shared__ double xbar[256];
+  __shared__ double xbar[256], part[256];
   const int b = blockIdx.x;
-  if ((int)threadIdx.x < K) {
+  {                                             // 256 / K threads per input channel share the chunks (independent loads, short chains)
+    const int tpk = 256 / K, k = threadIdx.x % K, sub = threadIdx.x / K;
     double xs = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) xs += colsum[((long long)b * nchunk + ch) * ld + threadIdx.x];
-    xbar[threadIdx.x] = xs * inv_rows;
+    if (sub < tpk)
+      for (int ch = sub; ch < nchunk; ch += tpk) xs += colsum[((long long)b * nchunk + ch) * ld + k];
+    part[threadIdx.x] = sub < tpk ? xs : 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+      double t = 0.0;
+      for (int q = 0; q < tpk; ++q) t += part[q * K + threadIdx.x];
+      xbar[threadIdx.x] = t * inv_rows;
+    }
   }
   __syncthreads();
   const int c = threadIdx.x;
