@@ -279,10 +279,12 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) kfr[kt][kk] = *(const f16x8*)(sK + ((kt * 3 + kk) * 64 + lane) * 16);
     __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise re-interleaves them two at a time with a full wait before each MFMA pair
+    // K step outermost: 8 independent accumulators between two MFMAs on the same one (kt-major order left ONE, and a dependent
+    // MFMA cannot issue before its predecessor's passes are through)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
+      for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           acc_s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kt][kk], qf[qt][kk], kk == 0 ? negm[qt] : acc_s[qt][kt], 0, 0, 0);
@@ -353,9 +355,9 @@ __global__ __launch_bounds__((4 + kAttNLW) * 64) void attn_fwd_kernel(const f16*
     }
     // ---- O^T += V^T P^T : A = V^T rows (dv) with the keys of a K-step in the order {tile 2s: 4g..4g+3, tile 2s+1: 4g..4g+3}
 #pragma unroll
-    for (int dt = 0; dt < 5; ++dt)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int dt = 0; dt < 5; ++dt) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[dt][ks], pf[qt][ks], acc_o[qt][dt], 0, 0, 0);
       }

@@ -202,8 +202,8 @@ template <int MT, int NT, int EPI, bool SPLIT, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
-  const int ncb = (p.ntiles + NT - 1) / NT;                      // column blocks; consecutive workgroups share the token rows
-  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+  const int ncb = (p.ntiles + NT - 1) / NT;                      // column blocks of one row block: ids 8 apart = one XCD, one L2 (see wsgemm_kernel)
+  const int xcd = blockIdx.x & 7, cb = (blockIdx.x >> 3) % ncb, rb = (blockIdx.x / (8 * ncb)) * 8 + xcd;
   const int m0 = (rb * 4 + wave) * MT * 16, nt0 = cb * NT;
   if (m0 >= p.M) return;
   const int KS = p.KS;
@@ -302,12 +302,19 @@ static int gemm_env(const char* name, int dflt) {
 template <int V> using IC = std::integral_constant<int, V>;
 
 template <int MT, int NT, int KC, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_wg) {
+__global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_wg, int xcd_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [hi | lo][NT][KS][64 lanes][16 B]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int ncb = (p.ntiles + NT - 1) / NT;
-  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;              // neighbouring workgroups share the rows (L2), not the weights
+  // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the ncb column blocks that
+  // share a row block are given ids 8 apart -- they land on ONE XCD and the rows are fetched into one L2 instead of up to 8
+  // (the last transposed conv re-read its 0.5 GB operand through 4 L2s: 633 -> ? us, profiles/r03_vit_*).
+  // With many column blocks (SwiGLU: 33) the per-XCD workgroup count overshoots the XCD's slots and a second round starts: plain order there.
+  const int xcd = blockIdx.x & 7;
+  const int cb = xcd_order ? (blockIdx.x >> 3) % ncb : blockIdx.x % ncb;
+  const int rb = xcd_order ? (blockIdx.x / (8 * ncb)) * 8 + xcd : blockIdx.x / ncb;
+  if (rb * rows_per_wg >= p.M) return;
   const int nt0 = cb * NT, KS = p.KS;
   const int plane = NT * KS * 64;                                       // 16-byte units per plane
   // Fill: LDS-DMA, 1 KiB (one fragment) per instruction, every wave queues its whole share before the single wait.  (A load ->
@@ -424,13 +431,15 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   nrb = nrb < 1 ? 1 : (nrb > G ? G : nrb);
   const int rows_per_wg = (G + nrb - 1) / nrb * unit;
   nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
-  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), lds, st, p, rows_per_wg);
+  const int xcd_order = ncb <= 16;
+  if (xcd_order) nrb = (nrb + 7) / 8 * 8;                          // whole groups of 8 row blocks (XCD-aware order in the kernel)
+  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), lds, st, p, rows_per_wg, xcd_order);
   return hipGetLastError();
 }
 
 template <int MT, int NT, int EPI, bool SPLIT, int PF>
 static hipError_t launch_one(const GemmParams& p, hipStream_t st) {
-  const int ncb = (p.ntiles + NT - 1) / NT, nrb = (p.M + MT * 64 - 1) / (MT * 64);
+  const int ncb = (p.ntiles + NT - 1) / NT, nrb = ((p.M + MT * 64 - 1) / (MT * 64) + 7) / 8 * 8;
   hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, SPLIT, PF>), dim3((unsigned)ncb * nrb), dim3(256), 0, st, p);
   return hipGetLastError();
 }
