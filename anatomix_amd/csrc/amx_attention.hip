@@ -399,15 +399,20 @@ size_t attention_scratch_bytes(int b, int heads, int n) {
   return (size_t)b * heads * (npad * kAttKRow + (npad / kAttBN) * (kAttKFrag + kAttVFrag) * 512) * sizeof(f16);
 }
 
-hipError_t launch_attention_ld(const float* q, const float* k, const float* v, int ld, const float* qn_w, const float* qn_b, const float* kn_w,
-                               const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
-                               float* out, void* scratch, hipStream_t st) {
+// operand buffers inside the scratch allocation (the ViT engine's q | k and v projections write them directly, amx_gemm.hip EPI_QK / EPI_VT)
+void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void** Kp, void** Vt, int* npad_out, int* nblk_pad_out) {
   const int npad = att_npad(n);
-  f16* Qp = (f16*)scratch;
-  f16* Kp = Qp + (size_t)b * heads * npad * kAttKRow;
-  f16* Vt = Kp + (size_t)b * heads * (npad / kAttBN) * (kAttKFrag * 512);
-  hipLaunchKernelGGL(attn_prep_kernel, dim3(npad / kAttBN, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
-                     n_prefix, n, heads, hd, ld, Qp, Kp, Vt);
+  f16* q = (f16*)scratch;
+  f16* k = q + (size_t)b * heads * npad * kAttKRow;
+  f16* v = k + (size_t)b * heads * (npad / kAttBN) * (kAttKFrag * 512);
+  *Qp = q; *Kp = k; *Vt = v;
+  if (npad_out) *npad_out = npad;
+  if (nblk_pad_out) *nblk_pad_out = npad / kAttBN;
+}
+
+// softmax(q k^T) v on prepared operands
+hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st) {
+  const int npad = att_npad(n);
   constexpr int LDS = kAttNBUF * (kAttKFrag + kAttVFrag) * 1024 + 64;
   static bool attr_done = false;
   if (!attr_done) {
@@ -417,10 +422,23 @@ hipError_t launch_attention_ld(const float* q, const float* k, const float* v, i
     attr_done = true;
   }
   if (hd < kAttDV)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, (const f16*)Qp, (const f16*)Kp,
+                       (const f16*)Vt, n, heads, hd, out);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, Qp, Kp, Vt, n, heads, hd, out);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, (const f16*)Qp, (const f16*)Kp,
+                       (const f16*)Vt, n, heads, hd, out);
   return hipGetLastError();
+}
+
+hipError_t launch_attention_ld(const float* q, const float* k, const float* v, int ld, const float* qn_w, const float* qn_b, const float* kn_w,
+                               const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
+                               float* out, void* scratch, hipStream_t st) {
+  void *Qp, *Kp, *Vt;
+  int npad;
+  attention_operands(scratch, b, heads, n, &Qp, &Kp, &Vt, &npad, nullptr);
+  hipLaunchKernelGGL(attn_prep_kernel, dim3(npad / kAttBN, heads, b), dim3(256), 0, st, q, k, v, qn_w, qn_b, kn_w, kn_b, eps, rope,
+                     n_prefix, n, heads, hd, ld, (f16*)Qp, (f16*)Kp, (f16*)Vt);
+  return launch_attention_fwd(Qp, Kp, Vt, b, n, heads, hd, out, st);
 }
 
 hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,

@@ -12,7 +12,10 @@ enum GemmEpi {
   EPI_SCATTER = 4,  // ConvTranspose3d(k = 2, s = 2): n = parity * Cp + c -> out32[voxel(2 z + dz, 2 y + dy, 2 x + dx)][c]
   EPI_TOKENS = 5,   // out32[b][nreg + v][n] = acc + bias + pos[v][n]   (m = b * V + v)
   EPI_PLANAR = 6,   // last ConvTranspose3d: features ordered ((dz, dy), c, dx); planar fp32 out[b][c][2 z + dz][2 y + dy][2 x + dx] - sub[b][c]
-  EPI_SCATTER_LN = 7  // ConvTranspose3d + channel LayerNorm + GELU: hi / lo operand rows of the next stage (Cp == 128)
+  EPI_SCATTER_LN = 7, // ConvTranspose3d + channel LayerNorm + GELU: hi / lo operand rows of the next stage (Cp == 128)
+  EPI_QK = 8,         // q | k projection with head-padded features (5 tiles per head): bias, per-head LayerNorm, rotary embedding,
+                      // f16 operands of the attention kernel (Qp rows / K fragment tiles) -- replaces the fp32 q, k tensors + attn_prep
+  EPI_VT = 9          // v projection, token rows as the A operand: V^T fragment tiles (+ the ones row) of the attention kernel
 };
 
 struct GemmParams {
@@ -36,12 +39,20 @@ struct GemmParams {
   const float* lnb;
   float eps;
   void* out_lo;
+  // EPI_QK / EPI_VT (attention operands; layouts in amx_attention.hip)
+  const float* rope;            // [T - n_prefix][hd / 2][4] = per token and rotation pair {sin 2i, sin 2i+1, cos 2i, cos 2i+1}, or null
+  const float *qnw, *qnb, *knw, *knb;   // per-head LayerNorm of q / k, padded to Cp floats, or null
+  float att_eps, qscale;        // LayerNorm epsilon; log2(e) / sqrt(hd)
+  int T, n_prefix, heads, hd, npad, nblk_pad;   // tokens per sample, register tokens, heads, head_dim, padded tokens, key blocks
+  void *Qp, *Kp, *Vt;
 };
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_pack_gemm(const float* s0, const float* s1, const float* s2, int r0, int r1, int r2, int K, int mode, int Cp, int Creal,
                             int ntiles, int KS, void* hi, void* lo, hipStream_t st);
 hipError_t launch_vec_place(float* dst, const float* src, int n, float fill, hipStream_t st);
+hipError_t launch_rope_pairs(float* dst, const float* src, int tokens, int hd, hipStream_t st);
+hipError_t launch_headpad_vec(float* dst, const float* src, int heads, int hd, int hd_pad, hipStream_t st);   // [heads][hd] -> [heads][hd_pad], zero fill
 hipError_t launch_swiglu_bias(float* dst, const float* bg, const float* bx, int hidden, hipStream_t st);
 hipError_t launch_ln_rows(const void* in, int in_f16, long long ldi, int C, const float* w, const float* b, float eps, int M, int rows_out,
                           int rows_in, int skip, int gelu, void* hi, void* lo, int ldo, hipStream_t st);

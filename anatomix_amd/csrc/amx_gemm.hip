@@ -64,6 +64,143 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     return;
   }
+  if (EPI == EPI_QK) {
+    // One column block = one (q | k, head): NT = 5 tiles = the head's 80 padded features.  Lane (li, g) holds features
+    // d = 16 t + 4 g .. + 3 of token row li: bias, per-head LayerNorm (sum over the lane's 20 values + the 4 lane groups),
+    // rotary embedding (the pair (2 i, 2 i + 1) sits in ONE lane), then the f16 operand layouts of attn_fwd directly.
+    const int sel = nt0 / (p.heads * NT), h = (nt0 / NT) % p.heads;
+    const float* nw = sel ? p.knw : p.qnw;
+    const float* nb = sel ? p.knb : p.qnb;
+    // every load of the epilogue first, unconditionally (see the generic epilogue): bias, norm parameters, rotary entries
+    float4 bias4[NT], w4a[NT], o4a[NT], sc[MT][NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bias4[t] = *(const float4*)(p.bias + (nt0 + t) * 16 + 4 * g);
+      w4a[t] = nw ? *(const float4*)(nw + t * 16 + 4 * g) : make_float4(1.f, 1.f, 1.f, 1.f);       // padded to Cp floats, zeros behind hd
+      o4a[t] = nw ? *(const float4*)(nb + t * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.rope) {
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        int m = m0 + u * 16 + li;
+        m = m < p.M ? m : p.M - 1;
+        int rt = m % p.T - p.n_prefix;
+        rt = rt > 0 ? rt : 0;
+        const float4* tb = (const float4*)p.rope + (long long)rt * (p.hd / 2);     // per pair {sin, sin, cos, cos}
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int pr = (t * 16 + 4 * g) / 2 + r;
+            sc[u][t][r] = tb[pr < p.hd / 2 ? pr : p.hd / 2 - 1];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int m = m0 + u * 16 + li;
+      const bool live = m < p.M;
+      const int mm = live ? m : p.M - 1, b = mm / p.T, tok = mm % p.T;
+      float v[NT][4];
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = t * 16 + 4 * g;
+        const float4 b4 = bias4[t];
+        v[t][0] = acc[t][u][0] + b4.x; v[t][1] = acc[t][u][1] + b4.y; v[t][2] = acc[t][u][2] + b4.z; v[t][3] = acc[t][u][3] + b4.w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += c + r < p.hd ? v[t][r] : 0.f;
+      }
+      if (nw) {                          // nn.LayerNorm(head_dim): biased variance, eps inside the root
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / p.hd;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = t * 16 + 4 * g + r < p.hd ? v[t][r] - mean : 0.f;
+            v[t][r] = d;
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q / p.hd + p.att_eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 w4 = w4a[t], o4 = o4a[t];
+          v[t][0] = v[t][0] * rstd * w4.x + o4.x; v[t][1] = v[t][1] * rstd * w4.y + o4.y;
+          v[t][2] = v[t][2] * rstd * w4.z + o4.z; v[t][3] = v[t][3] * rstd * w4.w + o4.w;
+        }
+      }
+      if (p.rope && tok >= p.n_prefix) {   // x * cos + rot(x) * sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i]
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const float4 q4 = sc[u][t][r >> 1];
+            const float x0 = v[t][r], x1 = v[t][r + 1];          // features behind hd are zero and are written as zero below
+            v[t][r] = x0 * q4.z - x1 * q4.x;
+            v[t][r + 1] = x1 * q4.w + x0 * q4.y;
+          }
+      }
+      if (!live) continue;
+      const float post = sel ? 1.f : p.qscale;
+      const long long bh = (long long)b * p.heads + h;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = t * 16 + 4 * g;
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = to_bits<f16>(c + r < p.hd ? v[t][r] * post : 0.f);
+        const uint2 pk = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+        if (sel == 0) {                  // Qp [b][h][n_pad][104 halves]
+          *(uint2*)((f16*)p.Qp + (bh * p.npad + tok) * 104 + c) = pk;
+        } else {                         // K fragment tile of key block tok / 64: dim d -> fragment (tile, d / 32), lane ((d % 32) / 8, row), element d % 8
+          const int kb = tok >> 6, tib = tok & 63;
+          const long long idx = (((bh * p.nblk_pad + kb) * 12 + (tib >> 4) * 3 + (c >> 5)) * 64 + ((c & 31) >> 3) * 16 + (tib & 15)) * 8 + (c & 7);
+          *(uint2*)((f16*)p.Kp + idx) = pk;
+        }
+      }
+    }
+    return;
+  }
+  if (EPI == EPI_VT) {
+    // Token rows are the A operand: lane (li, g) holds feature n = 16 tile + li (head n / Cp, V^T row d = n % Cp) of tokens m .. m + 3.
+    // V^T fragment (d / 16, key / 32): lane ((key % 16) / 4, d % 16), element (key % 32 / 16) * 4 + key % 4 -- four consecutive keys
+    // of one lane group are 8 contiguous bytes.  Row d == hd is the ONES row (softmax row sum through the PV product).
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int mb = m0 + u * 16 + 4 * g;
+      if (mb >= p.M) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (nt0 + t >= p.ntiles) continue;
+        const int n = (nt0 + t) * 16 + li, h = n / p.Cp, d = n % p.Cp;
+        if (d > p.hd || h >= p.heads) continue;           // rows behind the ones row stay zero (cleared once per forward)
+        const float bn = p.bias[n];
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = to_bits<f16>(d == p.hd ? 1.f : acc[t][u][r] + bn);
+        if ((p.T & 3) == 0) {            // the four tokens share sample, key block and lane group
+          const int b = mb / p.T, tok = mb % p.T, kb = tok >> 6, tib = tok & 63, kq = tib & 31;
+          const long long idx = (((((long long)b * p.heads + h) * p.nblk_pad + kb) * 10 + (d >> 4) * 2 + (tib >> 5)) * 64 + ((kq & 15) >> 2) * 16 + (d & 15)) * 8 + (kq >> 4) * 4;
+          *(uint2*)((f16*)p.Vt + idx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mb + r;
+            if (m >= p.M) continue;
+            const int b = m / p.T, tok = m % p.T, kb = tok >> 6, tib = tok & 63, kq = tib & 31;
+            const long long idx = (((((long long)b * p.heads + h) * p.nblk_pad + kb) * 10 + (d >> 4) * 2 + (tib >> 5)) * 64 + ((kq & 15) >> 2) * 16 + (d & 15)) * 8 + (kq >> 4) * 4 + (kq & 3);
+            ((unsigned short*)p.Vt)[idx] = o[r];
+          }
+        }
+      }
+    }
+    return;
+  }
   if (EPI == EPI_SCATTER_LN) {
     // NT == Cp / 16: the wave holds every channel of its rows for one parity: channel LayerNorm + GELU in registers, the hi / lo
     // operand rows of the next transposed conv are stored directly (the fp32 tensor between the two never exists).
@@ -73,6 +210,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     float rstd[MT];
     long long vox[MT];
     bool live[MT];
+    float4 bias4[NT], w4a[NT], o4a[NT];    // every load of the epilogue first (see the generic epilogue)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = t * 16 + 4 * g, cc = c + 3 < p.Creal ? c : 0;      // tiles that straddle Creal take the scalar path below
+      bias4[t] = *(const float4*)(p.bias + c);
+      w4a[t] = *(const float4*)(p.lnw + cc);
+      o4a[t] = *(const float4*)(p.lnb + cc);
+    }
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
       const int m = m0 + u * 16 + li;
@@ -84,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int c = t * 16 + 4 * g;
-        const float4 b4 = *(const float4*)(p.bias + c);
+        const float4 b4 = bias4[t];
         acc[t][u][0] += b4.x; acc[t][u][1] += b4.y; acc[t][u][2] += b4.z; acc[t][u][3] += b4.w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += c + r < p.Creal ? acc[t][u][r] : 0.f;
@@ -111,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       if (c >= p.ldo) continue;
       float w4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
       if (c + 3 < p.Creal) {
-        const float4 a4 = *(const float4*)(p.lnw + c), c4 = *(const float4*)(p.lnb + c);
+        const float4 a4 = w4a[t], c4 = o4a[t];
         w4[0] = a4.x; w4[1] = a4.y; w4[2] = a4.z; w4[3] = a4.w;
         o4[0] = c4.x; o4[1] = c4.y; o4[2] = c4.z; o4[3] = c4.w;
       } else {
@@ -136,6 +281,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     return;
   }
+  // EVERY global load of the epilogue is issued first, unconditionally (clamped indices), into registers: loads placed under the
+  // per-tile conditions below were each followed by a full wait -- ten to twenty exposed memory latencies per row group.
+  float4 bias4[NT], gam4[NT], extra[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nt = nt0 + t < p.ntiles ? nt0 + t : p.ntiles - 1, n = nt * 16 + 4 * g;
+    bias4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gam4[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_SCATTER) bias4[t] = *(const float4*)(p.bias + n % p.Cp);
+    else if (p.bias) bias4[t] = *(const float4*)(p.bias + n);
+    if (EPI == EPI_RESID && p.gamma) gam4[t] = *(const float4*)(p.gamma + n);
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      int m = m0 + u * 16 + li;
+      m = m < p.M ? m : p.M - 1;
+      const int nn = n < p.Nreal ? n : 0;
+      if (EPI == EPI_RESID) extra[t][u] = *(const float4*)((const float*)p.out + (long long)m * p.ldo + nn);
+      else if (EPI == EPI_TOKENS) extra[t][u] = *(const float4*)(p.pos + (long long)(m % p.V) * p.ldo + nn);
+      else extra[t][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 #pragma unroll
   for (int u = 0; u < MT; ++u) {
     const int m = m0 + u * 16 + li;
@@ -153,13 +319,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       if (nt0 + t >= p.ntiles) continue;
       const int n = (nt0 + t) * 16 + 4 * g;
       f32x4 v = acc[t][u];
+      const float4 b4 = bias4[t];
       if (EPI == EPI_SWIGLU) {
         if (t & 1) continue;                                        // tile pair (2s, 2s + 1) = (gate, value) of hidden columns 16 s ..
         if (t + 1 < NT) {
           const f32x4 x = acc[t + 1 < NT ? t + 1 : t][u];
-          const float4 bg = *(const float4*)(p.bias + n), bx = *(const float4*)(p.bias + n + 16);
+          const float4 bx = bias4[t + 1 < NT ? t + 1 : t];
           const int hcol = (nt0 + t) / 2 * 16 + 4 * g;
-          const float gv[4] = {v[0] + bg.x, v[1] + bg.y, v[2] + bg.z, v[3] + bg.w};
+          const float gv[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
           const float xv[4] = {x[0] + bx.x, x[1] + bx.y, x[2] + bx.z, x[3] + bx.w};
           unsigned short o[4];
 #pragma unroll
@@ -171,13 +338,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       if (EPI == EPI_SCATTER) {
         const int par = n / p.Cp, c = n % p.Cp;
         if (c >= p.Creal) continue;
-        const float4 b4 = *(const float4*)(p.bias + c);
         const long long vox = row_off + ((long long)(par >> 2) * 2 * p.gh + ((par >> 1) & 1)) * 2 * p.gw + (par & 1);
         *(float4*)((float*)p.out + vox * p.Creal + c) = make_float4(v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w);
         continue;
       }
       if (n >= p.Nreal) continue;
-      float4 b4 = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       float r[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
       if (EPI == EPI_F32) {
         *(float4*)((float*)p.out + (long long)m * p.ldo + n) = make_float4(r[0], r[1], r[2], r[3]);
@@ -185,13 +350,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         *(uint2*)((f16*)p.out + (long long)m * p.ldo + n) =
             make_uint2(to_bits<f16>(r[0]) | ((unsigned)to_bits<f16>(r[1]) << 16), to_bits<f16>(r[2]) | ((unsigned)to_bits<f16>(r[3]) << 16));
       } else if (EPI == EPI_RESID) {                                // x += gamma * (W h + b): LayerScale residual, fp32 stream
-        float* o = (float*)p.out + (long long)m * p.ldo + n;
-        const float4 g4 = p.gamma ? *(const float4*)(p.gamma + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 cur = *(const float4*)o;
+        const float4 g4 = gam4[t];
+        float4 cur = extra[t][u];
         cur.x += g4.x * r[0]; cur.y += g4.y * r[1]; cur.z += g4.z * r[2]; cur.w += g4.w * r[3];
-        *(float4*)o = cur;
+        *(float4*)((float*)p.out + (long long)m * p.ldo + n) = cur;
       } else if (EPI == EPI_TOKENS) {                               // token = projection + bias + position embedding, behind the registers
-        const float4 pe = *(const float4*)(p.pos + (long long)(m % p.V) * p.ldo + n);
+        const float4 pe = extra[t][u];
         *(float4*)((float*)p.out + row_off * p.ldo + n) = make_float4(r[0] + pe.x, r[1] + pe.y, r[2] + pe.z, r[3] + pe.w);
       }
     }
@@ -248,7 +412,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
-        if (EPI == EPI_PLANAR) {     // token rows as the A operand: a lane then owns 4 consecutive VOXELS of one feature
+        if (EPI == EPI_PLANAR || EPI == EPI_VT) {     // token rows as the A operand: a lane then owns 4 consecutive VOXELS / TOKENS of one feature
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[buf][u], wh[buf][t], acc[t][u], 0, 0, 0);
           if (SPLIT) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[buf][u], wh[buf][t], acc[t][u], 0, 0, 0);
@@ -374,7 +538,7 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-          if (EPI == EPI_PLANAR) {
+          if (EPI == EPI_PLANAR || EPI == EPI_VT) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[B][u][i], wh[t], acc[t][u], 0, 0, 0);
             if (SPLIT) {
               acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[B][u][i], wh[t], acc[t][u], 0, 0, 0);
@@ -425,13 +589,16 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr = lds;
   }
-  // row blocks: whole groups of 4 waves x MT tiles; ~3 workgroups per CU in total, never less than one group per wave
+  // Row blocks: whole groups of 4 waves x MT tiles, sized so that ALL workgroups are resident at once (LDS decides how many fit
+  // on a CU; a few workgroups more than slots cost a whole second round), in XCD order a multiple of 8 row blocks.
   const int unit = MT * 64, G = (p.M + unit - 1) / unit;
-  int nrb = 768 / ncb;
+  const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  const int xcd_order = ncb <= 16;
+  int nrb = 256 * per_cu / ncb;
+  if (xcd_order) nrb = nrb / 8 * 8;
   nrb = nrb < 1 ? 1 : (nrb > G ? G : nrb);
   const int rows_per_wg = (G + nrb - 1) / nrb * unit;
   nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
-  const int xcd_order = ncb <= 16;
   if (xcd_order) nrb = (nrb + 7) / 8 * 8;                          // whole groups of 8 row blocks (XCD-aware order in the kernel)
   hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), lds, st, p, rows_per_wg, xcd_order);
   return hipGetLastError();
@@ -505,6 +672,12 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
     case EPI_PLANAR:
       if (p.gw % 4) return hipErrorInvalidValue;
       return split ? launch_epi<EPI_PLANAR, true>(p, st) : launch_epi<EPI_PLANAR, false>(p, st);
+    case EPI_QK:
+      if (split || p.Cp != 80 || p.ntiles != 2 * p.heads * 5 || (size_t)5 * p.KS * 1024 > 160 * 1024) return hipErrorInvalidValue;
+      return launch_ws<2, 5, 4, EPI_QK, false>(p, st);
+    case EPI_VT:
+      if (split || p.Cp != 80 || p.ntiles != p.heads * 5 || (size_t)5 * p.KS * 1024 > 160 * 1024) return hipErrorInvalidValue;
+      return launch_ws<2, 5, 4, EPI_VT, false>(p, st);
     case EPI_SCATTER_LN:
       if (p.Cp != 128 || p.ntiles != 64 || p.ldo > 128) return hipErrorInvalidValue;
       if ((size_t)8 * p.KS * 1024 * (split ? 2 : 1) <= 160 * 1024)
@@ -520,6 +693,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
 //   mode 1  SwiGLU: tile 2 s = rows 16 s .. of src0 (gate), tile 2 s + 1 = the same rows of src1 (value)
 //   mode 2  ConvTranspose3d weight [K = Cin][Cout][2][2][2]: n = parity * Cp + c
 //   mode 3  the same weight with n = ((dz, dy) * Cp + c) * 2 + dx (EPI_PLANAR)
+//   mode 4  q | k (or v alone): every head's Creal rows padded to Cp (EPI_QK / EPI_VT)
 __global__ void pack_gemm_kernel(const float* s0, const float* s1, const float* s2, int r0, int r1, int r2, int K, int mode, int Cp,
                                  int Creal, int ntiles, int KS, f16* hi, f16* lo) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (tile, step, lane) = 8 halves
@@ -543,6 +717,10 @@ __global__ void pack_gemm_kernel(const float* s0, const float* s1, const float* 
       } else if (mode == 2) {
         const int n = nt * 16 + i, par = n / Cp, c = n % Cp;
         if (par < 8 && c < Creal) w = s0[((long long)k * Creal + c) * 8 + par];
+      } else if (mode == 4) {         // head-padded rows of up to two [heads * Creal][K] matrices: n = (matrix, head, d < Cp)
+        const int n = nt * 16 + i, span = r0 / Creal * Cp, src = n / span, within = n % span, head = within / Cp, d = within % Cp;
+        const float* S = src == 0 ? s0 : (src == 1 ? s1 : nullptr);
+        if (S && d < Creal) w = S[((long long)head * Creal + d) * K + k];
       } else {                        // mode 3: n = ((dz dy) * Cp + c) * 2 + dx
         const int n = nt * 16 + i, q = n >> 1, c = q % Cp, zy = q / Cp;
         if (zy < 4 && c < Creal) w = s0[((long long)k * Creal + c) * 8 + zy * 2 + (n & 1)];
@@ -572,6 +750,30 @@ __global__ void vec_place_kernel(float* dst, const float* src, int n, float fill
 hipError_t launch_vec_place(float* dst, const float* src, int n, float fill, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(vec_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n, fill);
+  return hipGetLastError();
+}
+
+// rotary table [tokens][2 hd] = [sin | cos] -> [tokens][hd / 2][{sin 2i, sin 2i+1, cos 2i, cos 2i+1}] (one 16-byte load per pair)
+__global__ void rope_pairs_kernel(float* dst, const float* src, int tokens, int hd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tokens * hd / 2) return;
+  const int tk = i / (hd / 2), pr = i % (hd / 2);
+  const float* s = src + (long long)tk * 2 * hd;
+  ((float4*)dst)[i] = make_float4(s[2 * pr], s[2 * pr + 1], s[hd + 2 * pr], s[hd + 2 * pr + 1]);
+}
+hipError_t launch_rope_pairs(float* dst, const float* src, int tokens, int hd, hipStream_t st) {
+  hipLaunchKernelGGL(rope_pairs_kernel, dim3((tokens * hd / 2 + 255) / 256), dim3(256), 0, st, dst, src, tokens, hd);
+  return hipGetLastError();
+}
+
+__global__ void headpad_vec_kernel(float* dst, const float* src, int heads, int hd, int hd_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= heads * hd_pad) return;
+  const int d = i % hd_pad;
+  dst[i] = (src && d < hd) ? src[(i / hd_pad) * hd + d] : 0.f;
+}
+hipError_t launch_headpad_vec(float* dst, const float* src, int heads, int hd, int hd_pad, hipStream_t st) {
+  hipLaunchKernelGGL(headpad_vec_kernel, dim3((heads * hd_pad + 255) / 256), dim3(256), 0, st, dst, src, heads, hd, hd_pad);
   return hipGetLastError();
 }
 

@@ -23,6 +23,8 @@
 namespace amx {
 int set_error(int code, const char* msg);                                     // amx_api.hip (thread-local message)
 size_t attention_scratch_bytes(int b, int heads, int n);
+void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void** Kp, void** Vt, int* npad_out, int* nblk_pad_out);
+hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st);
 hipError_t launch_attention_ld(const float* q, const float* k, const float* v, int ld, const float* qn_w, const float* qn_b, const float* kn_w,
                                const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd, float* out,
                                void* scratch, hipStream_t st);
@@ -65,8 +67,8 @@ struct Arena {
 };
 
 struct Block {
-  float *n1w, *n1b, *qkvb, *qnw, *qnb, *knw, *knb, *anw, *anb, *projb, *g1, *n2w, *n2b, *fc1b, *mnw, *mnb, *fc2b, *g2;
-  Packed qkv, proj, fc1, fc2;
+  float *n1w, *n1b, *qkb, *vb, *qnw, *qnb, *knw, *knb, *anw, *anb, *projb, *g1, *n2w, *n2b, *fc1b, *mnw, *mnb, *fc2b, *g2;
+  Packed qk, v, proj, fc1, fc2;       // q | k and v projections with every head padded to 80 features (5 tiles)
 };
 struct Stage {
   Packed c1, c2, sk;
@@ -181,11 +183,12 @@ void layout_params(amx_vit* h, Arena& a) {
   h->blk.resize(c.depth);
   const int KSe = h->Ep / 32, KSh = up(hid, 32) / 32;
   for (auto& b : h->blk) {
-    b.qkv = take_packed(a, up(3 * E, 16) / 16, KSe, false);
+    b.qk = take_packed(a, 2 * c.heads * 5, KSe, false);
+    b.v = take_packed(a, c.heads * 5, KSe, false);
     b.proj = take_packed(a, up(E, 16) / 16, KSe, false);
     b.fc1 = take_packed(a, 2 * hid / 16, KSe, false);
     b.fc2 = take_packed(a, up(E, 16) / 16, KSh, false);
-    b.n1w = f(E); b.n1b = f(E); b.qkvb = f(up(3 * E, 16)); b.qnw = f(h->hd); b.qnb = f(h->hd); b.knw = f(h->hd); b.knb = f(h->hd);
+    b.n1w = f(E); b.n1b = f(E); b.qkb = f(2 * c.heads * 80); b.vb = f(c.heads * 80); b.qnw = f(80); b.qnb = f(80); b.knw = f(80); b.knb = f(80);
     b.anw = f(E); b.anb = f(E); b.projb = f(up(E, 16)); b.g1 = f(up(E, 16)); b.n2w = f(E); b.n2b = f(E); b.fc1b = f(2 * hid);
     b.mnw = f(hid); b.mnb = f(hid); b.fc2b = f(up(E, 16)); b.g2 = f(up(E, 16));
   }
@@ -286,22 +289,23 @@ int amx_vit_load(amx_vit_t* h, const float* const* d_params, int count, const fl
   VIT_HIP(vec(h->tokproj_b, next(), E, up(E, 16)));
   if (c.num_register_tokens > 0) VIT_HIP(vec(h->regs, next(), c.num_register_tokens * E));
   VIT_HIP(vec(h->pos, next(), h->V * E));
-  VIT_HIP(vec(h->rope, d_rope, h->V * 2 * h->hd));
+  VIT_HIP(amx::launch_rope_pairs(h->rope, d_rope, h->V, h->hd, st));
   for (auto& b : h->blk) {
     VIT_HIP(vec(b.n1w, next(), E));
     VIT_HIP(vec(b.n1b, next(), E));
     const float *qw = next(), *qb = next(), *kw = next(), *vw = next(), *vb = next();
-    VIT_HIP(amx::launch_pack_gemm(qw, kw, vw, E, E, E, E, 0, 0, 0, b.qkv.ntiles, b.qkv.KS, b.qkv.hi, nullptr, st));
-    VIT_HIP(vec(b.qkvb, qb, E));
-    VIT_HIP(amx::launch_vec_place(b.qkvb + E, nullptr, E, 0.f, st));                 // EVA: the key projection has no bias
-    VIT_HIP(vec(b.qkvb + 2 * E, vb, E, up(3 * E, 16) - 2 * E));
+    VIT_HIP(amx::launch_pack_gemm(qw, kw, nullptr, E, 0, 0, E, 4, 80, h->hd, b.qk.ntiles, b.qk.KS, b.qk.hi, nullptr, st));
+    VIT_HIP(amx::launch_pack_gemm(vw, nullptr, nullptr, E, 0, 0, E, 4, 80, h->hd, b.v.ntiles, b.v.KS, b.v.hi, nullptr, st));
+    VIT_HIP(amx::launch_headpad_vec(b.qkb, qb, c.heads, h->hd, 80, st));
+    VIT_HIP(amx::launch_headpad_vec(b.qkb + c.heads * 80, nullptr, c.heads, h->hd, 80, st));     // EVA: the key projection has no bias
+    VIT_HIP(amx::launch_headpad_vec(b.vb, vb, c.heads, h->hd, 80, st));
     VIT_HIP(amx::launch_pack_gemm(next(), nullptr, nullptr, E, 0, 0, E, 0, 0, 0, b.proj.ntiles, b.proj.KS, b.proj.hi, nullptr, st));
     VIT_HIP(vec(b.projb, next(), E, up(E, 16)));
     if (c.qk_norm) {
-      VIT_HIP(vec(b.qnw, next(), h->hd));
-      VIT_HIP(vec(b.qnb, next(), h->hd));
-      VIT_HIP(vec(b.knw, next(), h->hd));
-      VIT_HIP(vec(b.knb, next(), h->hd));
+      VIT_HIP(vec(b.qnw, next(), h->hd, 80));
+      VIT_HIP(vec(b.qnb, next(), h->hd, 80));
+      VIT_HIP(vec(b.knw, next(), h->hd, 80));
+      VIT_HIP(vec(b.knb, next(), h->hd, 80));
     }
     if (c.scale_attn_inner) {
       VIT_HIP(vec(b.anw, next(), E));
@@ -354,7 +358,7 @@ struct Plan {
   char *a1_hi, *a1_lo;
   // blocks
   char *A1, *A2, *Hd, *att;
-  float *QKV, *AO;
+  float *AO;
   // decoder
   char *Ad_hi[3], *Ad_lo[3];
   float *rawd[3], *colsum, *mean;
@@ -399,7 +403,6 @@ Plan make_plan(const amx_vit* h, int n, char* base) {
   P.A1 = a.take((size_t)Mp * Ep * 2);
   P.A2 = a.take((size_t)Mp * up(hid, 32) * 2);
   P.Hd = a.take((size_t)Mp * hid * 2);
-  P.QKV = a.take<float>((size_t)M * 3 * E * 4);
   P.AO = a.take<float>((size_t)M * E * 4);
   P.att = a.take(amx::attention_scratch_bytes(n, c.heads, T));
   const size_t blk_end = a.off;
@@ -497,15 +500,26 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
 
   // ------------------------------------------------------------------ EVA blocks
   const int nb = n_blocks < 0 || n_blocks > c.depth ? c.depth : n_blocks;
+  void *Qp, *Kp, *Vt;
+  int att_npad, att_nblk;
+  amx::attention_operands(P.att, n, c.heads, T, &Qp, &Kp, &Vt, &att_npad, &att_nblk);
+  // padding of the operand buffers (token rows / keys beyond T, feature columns beyond head_dim) is zero and never written again
+  if (nb > 0) VIT_HIP(hipMemsetAsync(P.att, 0, amx::attention_scratch_bytes(n, c.heads, T), st));
   for (int bi = 0; bi < nb; ++bi) {
     const Block& b = h->blk[bi];
     amx::GemmParams g{};
     g.a_hi = P.A1; g.lda = Ep; g.M = M;
     VIT_HIP(amx::launch_ln_rows(P.tok, 0, E, E, b.n1w, b.n1b, 1e-6f, M, M, M, 0, 0, P.A1, nullptr, Ep, st));
-    g.KS = b.qkv.KS; g.w_hi = b.qkv.hi; g.ntiles = b.qkv.ntiles; g.Nreal = 3 * E; g.bias = b.qkvb; g.out = P.QKV; g.ldo = 3 * E;
-    VIT_HIP(amx::launch_gemm(g, amx::EPI_F32, st));
-    VIT_HIP(amx::launch_attention_ld(P.QKV, P.QKV + E, P.QKV + 2 * E, 3 * E, c.qk_norm ? b.qnw : nullptr, c.qk_norm ? b.qnb : nullptr,
-                                     c.qk_norm ? b.knw : nullptr, c.qk_norm ? b.knb : nullptr, 1e-5f, h->rope, nreg, n, T, c.heads, h->hd, P.AO, P.att, st));
+    // q | k and v projections write the attention kernel's f16 operands themselves (bias, per-head LayerNorm, rotary embedding,
+    // fragment layouts in the epilogue): no fp32 q / k / v tensors, no separate preparation pass
+    g.att_eps = 1e-5f; g.qscale = 1.4426950408889634f / sqrtf((float)h->hd); g.rope = h->rope; g.T = T; g.n_prefix = nreg; g.heads = c.heads;
+    g.hd = h->hd; g.npad = att_npad; g.nblk_pad = att_nblk; g.Qp = Qp; g.Kp = Kp; g.Vt = Vt; g.Cp = 80;
+    g.qnw = c.qk_norm ? b.qnw : nullptr; g.qnb = b.qnb; g.knw = c.qk_norm ? b.knw : nullptr; g.knb = b.knb;
+    g.KS = b.qk.KS; g.w_hi = b.qk.hi; g.ntiles = b.qk.ntiles; g.Nreal = b.qk.ntiles * 16; g.bias = b.qkb; g.out = Qp; g.ldo = 0;
+    VIT_HIP(amx::launch_gemm(g, amx::EPI_QK, st));
+    g.KS = b.v.KS; g.w_hi = b.v.hi; g.ntiles = b.v.ntiles; g.Nreal = b.v.ntiles * 16; g.bias = b.vb; g.out = Vt;
+    VIT_HIP(amx::launch_gemm(g, amx::EPI_VT, st));
+    VIT_HIP(amx::launch_attention_fwd(Qp, Kp, Vt, n, T, c.heads, h->hd, P.AO, st));
     VIT_HIP(amx::launch_ln_rows(P.AO, 0, E, E, c.scale_attn_inner ? b.anw : nullptr, b.anb, 1e-5f, M, M, M, 0, 0, P.A1, nullptr, Ep, st));
     g.KS = b.proj.KS; g.w_hi = b.proj.hi; g.ntiles = b.proj.ntiles; g.Nreal = E; g.bias = b.projb; g.gamma = b.g1; g.out = P.tok; g.ldo = E;
     VIT_HIP(amx::launch_gemm(g, amx::EPI_RESID, st));
