@@ -93,6 +93,7 @@ SYMBOLS = {
                               _I, _P, _I, _P, C.c_size_t, _I, _P]),
     "amx_attention_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "amx_attention_qknorm_rope": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
+    "amx_attention_prepared": (_I, [_P, C.c_size_t, _I, _I, _I, _I, _P, _P]),
     "amx_vit_create": (_I, [C.POINTER(_P), C.POINTER(VitCfg)]),
     "amx_vit_destroy": (None, [_P]),
     "amx_vit_num_params": (_I, [_P]),

@@ -48,6 +48,8 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
                            const float* kshift = nullptr);
 size_t attention_scratch_bytes(int b, int heads, int n);
+void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void** Kp, void** Vt, int* npad_out, int* nblk_pad_out);
+hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st);
 hipError_t launch_attention(const float* q, const float* k, const float* v, const float* qn_w, const float* qn_b, const float* kn_w,
                             const float* kn_b, float eps, const float* rope, int n_prefix, int b, int n, int heads, int hd,
                             float* out, void* scratch, hipStream_t st);
@@ -1242,6 +1244,18 @@ int amx_attention_qknorm_rope(const float* d_q, const float* d_k, const float* d
     return fail(AMX_ERR_WORKSPACE, "attention scratch needs %zu bytes, 16-byte aligned", amx::attention_scratch_bytes(b, heads, n));
   AMX_HIP(amx::launch_attention(d_q, d_k, d_v, d_qn_w, d_qn_b, d_kn_w, d_kn_b, norm_eps, d_rope, n_prefix, b, n, heads, head_dim, d_out,
                                 d_scratch, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_attention_prepared(const void* d_scratch, size_t scratch_bytes, int b, int n, int heads, int head_dim, float* d_out, void* stream) {
+  if (!d_scratch || !d_out) return fail(AMX_ERR_INVALID, "null argument");
+  if (b < 1 || n < 1 || heads < 1 || head_dim < 2 || head_dim > 80 || (head_dim & 1))
+    return fail(AMX_ERR_INVALID, "attention: head_dim must be even and <= 80 (got %d), b, n, heads >= 1", head_dim);
+  if (scratch_bytes < amx::attention_scratch_bytes(b, heads, n) || ((uintptr_t)d_scratch & 15))
+    return fail(AMX_ERR_WORKSPACE, "attention scratch needs %zu bytes, 16-byte aligned", amx::attention_scratch_bytes(b, heads, n));
+  void *Qp, *Kp, *Vt;
+  amx::attention_operands((void*)d_scratch, b, heads, n, &Qp, &Kp, &Vt, nullptr, nullptr);
+  AMX_HIP(amx::launch_attention_fwd(Qp, Kp, Vt, b, n, heads, head_dim, d_out, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -311,6 +311,11 @@ int amx_attention_qknorm_rope(const float* d_q, const float* d_k, const float* d
                               const float* d_kn_w, const float* d_kn_b, float norm_eps, const float* d_rope, int n_prefix, int b,
                               int n, int heads, int head_dim, float* d_out, void* d_scratch, size_t scratch_bytes, void* stream);
 
+/* softmax(q k^T / sqrt(head_dim)) v alone, on the f16 operands a previous amx_attention_qknorm_rope call with the SAME
+ * (b, n, heads, head_dim) left in d_scratch: the flash kernel without its preparation pass (what one EVA block of amx_vit_forward
+ * launches after its q | k and v projections; bench.py times it as the ViT's dominant kernel). */
+int amx_attention_prepared(const void* d_scratch, size_t scratch_bytes, int b, int n, int heads, int head_dim, float* d_out, void* stream);
+
 /* ---- The whole 3D ViT variant `anatomix-dev-vit` (PrimusV2-S) as one forward ------------------------------------------------
  * Replaces PrimusV2.forward (anatomix/model/vit3d/architectures.py:231-260 with the wrapper's extensions :89-165, tokenizer
  * deep_tokenizer.py:12-68, registry entry load_from_hf.py:25-35): conv tokenizer (stem + three stride-2 residual stages + 1x1x1

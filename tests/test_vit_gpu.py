@@ -57,6 +57,23 @@ def test_attention_is_deterministic_and_refuses_bad_shapes(device):
                       torch.randn(1, 64, 256, device=device), None, 0)
 
 
+def test_attention_on_prepared_operands_repeats_the_fused_call(device):
+    """amx_attention_prepared (the flash kernel alone on the operands the fused call left in the scratch) == the fused call."""
+    import ctypes
+    from anatomix_amd import _lib
+    att = EvaAttention(6 * 66, 6, True, False).to(device)
+    q, k, v = [torch.randn(2, 520, 396, device=device) for _ in range(3)]
+    table = build_rope_table((8, 8, 8), 66).to(device)
+    lib = _lib.load()
+    with torch.no_grad(), torch.cuda.device(device):
+        want = att.core_hip(q, k, v, table, 8)
+        got = torch.empty_like(want)
+        nb = lib.amx_attention_scratch_bytes(2, 6, 520, 66)
+        _lib.check(lib.amx_attention_prepared(_lib.ptr(att._scratch), nb, 2, 520, 6, 66, _lib.ptr(got),
+                                              ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    assert torch.equal(got, want)
+
+
 def test_vit_forward_on_the_hip_path_matches_the_oracle_at_128(device):
     """BASELINE configs[4]: 1 x 1 x 128^3 -> 1 x 32 x 128^3.  (One CPU oracle forward: ~0.5 TFLOP, about a minute.)"""
     kw = V.VIT_VARIANTS["anatomix-dev-vit"]
