@@ -120,7 +120,7 @@ def cpu_baseline_vit():
     torch.set_num_threads(cores)
     with torch.no_grad():
         t0 = time.perf_counter()
-        V.forward(x, sd, kw)
+        cpu_baseline.last_output = V.forward(x, sd, kw)      # checker: the line's parity figure (rank 0's first volume is this input)
         dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"1 forward of one 1x1x128^3 volume, fp32, torch CPU with {cores} of {avail} host threads: {dt:.1f} s"}
@@ -514,8 +514,18 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         if world == 1 and with_cpu:
             result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else \
                 (cpu_baseline_vit() if vit else cpu_baseline(S, cpu_forwards, variant))
+        if vit:
+            # checker on the GPU: the same module composed of stock torch fp32 ops (autograd mode routes around every own kernel)
+            with torch.enable_grad():
+                ref = model(x[:1]).detach()
+            d = float((y[:1].double() - ref.double()).norm() / ref.double().norm())
+            result["parity"] = {"rel_l2": float("%.3e" % d), "tolerance": 1e-3, "compliant": bool(d <= 1e-3),
+                                "against": "the same module composed of stock torch fp32 operators on the GPU (1e-4 from the fp64 "
+                                           "restatement, tests/test_vit_gpu.py); parity with the upstream package is UNPINNED"}
+            del ref
         if workload == "forward" and not sw_volume and not vit:
             result["parity"] = parity_vs_split(torch, ctx, variant, precision, x, y)
+        if workload == "forward" and not sw_volume:
             ref_cpu = getattr(cpu_baseline, "last_output", None) if (world == 1 and with_cpu) else None
             if ref_cpu is not None and rank == 0:     # rank 0's first volume is the oracle's input (seed 100)
                 d = (y[:1].cpu().double() - ref_cpu.double()).norm() / ref_cpu.double().norm()
