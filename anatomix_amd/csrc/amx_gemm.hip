@@ -672,12 +672,12 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
     case EPI_PLANAR:
       if (p.gw % 4) return hipErrorInvalidValue;
       return split ? launch_epi<EPI_PLANAR, true>(p, st) : launch_epi<EPI_PLANAR, false>(p, st);
-    case EPI_QK:
-      if (split || p.Cp != 80 || p.ntiles != 2 * p.heads * 5 || (size_t)5 * p.KS * 1024 > 160 * 1024) return hipErrorInvalidValue;
-      return launch_ws<2, 5, 4, EPI_QK, false>(p, st);
+    case EPI_QK:      // a head's 5 tiles with the whole K extent in LDS (embed_dim <= 1024); wider models stream the weights (direct kernel)
+      if (split || p.Cp != 80 || p.ntiles != 2 * p.heads * 5) return hipErrorInvalidValue;
+      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<2, 5, 4, EPI_QK, false>(p, st) : launch_one<2, 5, EPI_QK, false, 2>(p, st);
     case EPI_VT:
-      if (split || p.Cp != 80 || p.ntiles != p.heads * 5 || (size_t)5 * p.KS * 1024 > 160 * 1024) return hipErrorInvalidValue;
-      return launch_ws<2, 5, 4, EPI_VT, false>(p, st);
+      if (split || p.Cp != 80 || p.ntiles != p.heads * 5) return hipErrorInvalidValue;
+      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<2, 5, 4, EPI_VT, false>(p, st) : launch_one<2, 5, EPI_VT, false, 2>(p, st);
     case EPI_SCATTER_LN:
       if (p.Cp != 128 || p.ntiles != 64 || p.ldo > 128) return hipErrorInvalidValue;
       if ((size_t)8 * p.KS * 1024 * (split ? 2 : 1) <= 160 * 1024)
@@ -906,18 +906,19 @@ __global__ __launch_bounds__(256) void ln_rows_vec_kernel(const TIN* __restrict_
 
 hipError_t launch_ln_rows(const void* in, int in_f16, long long ldi, int C, const float* w, const float* b, float eps, int M, int rows_out,
                           int rows_in, int skip, int gelu, void* hi, void* lo, int ldo, hipStream_t st) {
-  if (C > 64 * 17 || ldo > 64 * 17 || ldo < C) return hipErrorInvalidValue;
+  if (ldo < C) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
-  if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && (ldo + 255) / 256 <= 5 && !(in_f16 && gelu)) {
+  if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && (ldo + 255) / 256 <= 12 && !(in_f16 && gelu)) {
 #define AMX_LNV(TIN, PERV, G) \
   hipLaunchKernelGGL((ln_rows_vec_kernel<TIN, PERV, G>), grid, block, 0, st, (const TIN*)in, ldi, C, w, b, eps, M, rows_out, rows_in, skip, (f16*)hi, (f16*)lo, ldo)
     const int perv = (ldo + 255) / 256;
-    if (in_f16) { if (perv <= 2) AMX_LNV(f16, 2, false); else AMX_LNV(f16, 5, false); }
-    else if (gelu) { if (perv <= 1) AMX_LNV(float, 1, true); else AMX_LNV(float, 2, true); }
-    else { if (perv <= 2) AMX_LNV(float, 2, false); else AMX_LNV(float, 5, false); }
+    if (in_f16) { if (perv <= 2) AMX_LNV(f16, 2, false); else if (perv <= 5) AMX_LNV(f16, 5, false); else AMX_LNV(f16, 12, false); }
+    else if (gelu) { if (perv <= 1) AMX_LNV(float, 1, true); else if (perv <= 2) AMX_LNV(float, 2, true); else AMX_LNV(float, 5, true); }
+    else { if (perv <= 2) AMX_LNV(float, 2, false); else if (perv <= 5) AMX_LNV(float, 5, false); else AMX_LNV(float, 12, false); }
 #undef AMX_LNV
     return hipGetLastError();
   }
+  if (C > 64 * 17 || ldo > 64 * 17) return hipErrorInvalidValue;      // scalar fallback: rows of up to 1088 columns
 #define AMX_LN(TIN, PER, G) \
   hipLaunchKernelGGL((ln_rows_kernel<TIN, PER, G>), grid, block, 0, st, (const TIN*)in, ldi, C, w, b, eps, M, rows_out, rows_in, skip, (f16*)hi, (f16*)lo, ldo)
   const int per = (ldo + 63) / 64;

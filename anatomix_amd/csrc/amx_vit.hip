@@ -219,10 +219,10 @@ int amx_vit_create(amx_vit_t** out, const amx_vit_cfg* cfg) {
   if (c.depth < 1 || c.num_register_tokens < 0) return vfail(AMX_ERR_INVALID, "vit: depth / register tokens");
   if (c.grid_d < 2 || c.grid_h < 2 || c.grid_w < 2 || (c.grid_w % 2) || ((long long)c.grid_d * c.grid_h * c.grid_w) % 64 || (c.grid_w * 8) % 16)
     return vfail(AMX_ERR_SHAPE, "vit: token grid %dx%dx%d (even width, a multiple of 64 tokens)", c.grid_d, c.grid_h, c.grid_w);
-  if (c.hidden < 16 || c.hidden % 16 || c.hidden > 64 * 17) return vfail(AMX_ERR_INVALID, "vit: SwiGLU hidden width %d must be a multiple of 16, <= 1088", c.hidden);
-  if (c.embed_dim > 64 * 7) return vfail(AMX_ERR_INVALID, "vit: embed_dim <= 448");
-  if (c.dec1 % 4 || c.dec2 % 4 || c.num_classes % 4 || c.dec1 < 4 || c.dec2 < 4 || c.num_classes < 4 || c.dec1 > 256 || c.dec2 > 256 || c.num_classes > 128)
-    return vfail(AMX_ERR_INVALID, "vit: decoder widths %d / %d / %d must be multiples of 4 (<= 256, classes <= 128)", c.dec1, c.dec2, c.num_classes);
+  if (c.hidden < 16 || c.hidden % 16 || c.hidden > 3072) return vfail(AMX_ERR_INVALID, "vit: SwiGLU hidden width %d must be a multiple of 16, <= 3072", c.hidden);
+  if (c.embed_dim > 1280) return vfail(AMX_ERR_INVALID, "vit: embed_dim <= 1280");
+  if (c.dec1 % 4 || c.dec2 % 4 || c.num_classes % 4 || c.dec1 < 4 || c.dec2 < 4 || c.num_classes < 4 || c.dec1 > 1024 || c.dec2 > 256 || c.num_classes > 128)
+    return vfail(AMX_ERR_INVALID, "vit: decoder widths %d / %d / %d must be multiples of 4 (<= 1024 / 256, classes <= 128)", c.dec1, c.dec2, c.num_classes);
   if (c.out_norm != 0 && c.out_norm != 1) return vfail(AMX_ERR_INVALID, "vit: out_norm 0 (none) or 1 (demean)");
   amx_vit* h = new amx_vit();
   h->cfg = c;

@@ -111,6 +111,23 @@ def test_engine_and_torch_composition_agree_and_other_configurations_run(device)
     assert rel_l2(y.cpu(), y_t.cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("name,embed,heads", [("B", 792, 12), ("M", 864, 12), ("L", 1056, 16)])
+def test_engine_runs_the_wider_primus_configurations(device, name, embed, heads):
+    """PRIMUS_CONFIGS B / M / L (architectures.py:20-25): head_dim 66 / 72 / 66, SwiGLU hidden 2112 / 2304 / 2816, decoder widths
+    derived from the embedding width; two blocks at 32^3 against the restatement.  (L: a head's weight slice no longer fits LDS --
+    the q | k and v projections take the streaming kernel.)"""
+    kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(32, 32, 32), eva_depth=2, embed_dim=embed, eva_numheads=heads)
+    m, sd = _model(kw, 7, device)
+    x = V.synthetic_input(15, 2, (32, 32, 32))
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+    ref = V.forward(x, sd, kw, dtype=torch.float64).float()
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    e = rel_l2(y, ref)
+    print(f"PrimusV2-{name}: rel-L2 {e:.2e}")
+    assert e < 6e-4, e
+
+
 def test_engine_refuses_what_it_cannot_run(device):
     kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(32, 32, 32), eva_depth=1)
     m, _ = _model(kw, 6, device)
