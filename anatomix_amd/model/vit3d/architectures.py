@@ -364,11 +364,47 @@ class PrimusV2(nn.Module):
                                               ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
         return out.view(dtype)
 
-    def _apply(self, fn, *args, **kwargs):
-        out = super()._apply(fn, *args, **kwargs)
+    def _drop_engine(self):
+        """The engine's packed parameters live on the device it was created on: a move / copy / replica starts over."""
+        hnd, self._handle = self.__dict__.get("_handle"), None
         self._engine_sig = None
         self._engine_ws = None
+        if hnd is not None:
+            try:
+                _lib.load().amx_vit_destroy(hnd)
+            except Exception:
+                pass
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_engine()
         return out
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_handle", "_engine_sig", "_engine_ws") else copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in ("_handle", "_engine_sig", "_engine_ws"):
+            state[k] = None
+        return state
+
+    def __copy__(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__getstate__())
+        return new
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        for k in ("_handle", "_engine_sig", "_engine_ws"):
+            replica.__dict__[k] = None
+        return replica
 
     def __del__(self):
         try:

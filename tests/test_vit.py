@@ -55,3 +55,18 @@ def test_constructor_refusals_and_output_norm_modes():
     assert torch.allclose(ln.mean(1), torch.zeros(1, 3, 3, 3), atol=1e-5)
     with pytest.raises(ValueError):
         build_out_norm("nope", 4, 1e-2)
+
+
+def test_copies_and_replicas_do_not_share_the_engine_handle():
+    """The native handle belongs to one module object on one device: copy / deepcopy / pickle / DataParallel replicas start
+    without it (a shared raw pointer would be a double free in __del__)."""
+    import copy
+    import pickle
+    kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(32, 32, 32), eva_depth=1)
+    m = PrimusV2(**kw)
+    m.__dict__["_handle"] = object()                 # stands for a live native handle
+    m.__dict__["_engine_sig"] = ("x",)
+    for other in (copy.copy(m), copy.deepcopy(m), m._replicate_for_data_parallel()):
+        assert other._handle is None and other._engine_sig is None
+    m.__dict__["_handle"] = None
+    assert pickle.loads(pickle.dumps(m))._handle is None
