@@ -480,12 +480,13 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_
   const int rb = xcd_order ? (blockIdx.x / (8 * ncb)) * 8 + xcd : blockIdx.x / ncb;
   if (rb * rows_per_wg >= p.M) return;
   const int nt0 = cb * NT, KS = p.KS;
+  const int nw = blockDim.x >> 6;                                       // 4 or 6 waves share the slice (6: three waves per SIMD where LDS allows two workgroups per CU)
   const int plane = NT * KS * 64;                                       // 16-byte units per plane
   // Fill: LDS-DMA, 1 KiB (one fragment) per instruction, every wave queues its whole share before the single wait.  (A load ->
   // ds_write loop is serialised on the memory latency by its data dependence: measured 35-50 us of a 60 us launch.)
   {
     const int nfrag = NT * KS * (SPLIT ? 2 : 1);
-    for (int j = wave; j < nfrag; j += 4) {
+    for (int j = wave; j < nfrag; j += nw) {
       const int pl = j / (NT * KS), r = j - pl * NT * KS, t = r / KS, ks = r - t * KS;
       const int nt = nt0 + t < p.ntiles ? nt0 + t : p.ntiles - 1;
       const char* src = (pl ? p.w_lo : p.w_hi) + (((long long)nt * KS + ks) * 64 + lane) * 16;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_
     if (c == nchunk - 1) gemm_epilogue<MT, NT, EPI>(p, acc, row0 + grp * MT * 16, nt0, li, g);
   };
   auto next = [&](int& gq, int& cq) {
-    if (++cq == nchunk) { cq = 0; gq += 4; }
+    if (++cq == nchunk) { cq = 0; gq += nw; }
   };
   int g0 = wave, c0 = 0, g1 = wave, c1 = 0;
   next(g1, c1);
@@ -591,8 +592,11 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   }
   // Row blocks: whole groups of 4 waves x MT tiles, sized so that ALL workgroups are resident at once (LDS decides how many fit
   // on a CU; a few workgroups more than slots cost a whole second round), in XCD order a multiple of 8 row blocks.
-  const int unit = MT * 64, G = (p.M + unit - 1) / unit;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  // (6 waves per workgroup -- three per SIMD at two workgroups per CU -- would need <= 170 registers; the epilogue-heavy variants
+  // use 180-256: measured no gain, 4 it is.  The kernel takes the wave count from blockDim.)
+  const int nw = 4;
+  const int unit = MT * 16 * nw, G = (p.M + unit - 1) / unit;
   const int xcd_order = ncb <= 16;
   int nrb = 256 * per_cu / ncb;
   if (xcd_order) nrb = nrb / 8 * 8;
@@ -600,7 +604,7 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   const int rows_per_wg = (G + nrb - 1) / nrb * unit;
   nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
   if (xcd_order) nrb = (nrb + 7) / 8 * 8;                          // whole groups of 8 row blocks (XCD-aware order in the kernel)
-  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(256), lds, st, p, rows_per_wg, xcd_order);
+  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(64 * nw), lds, st, p, rows_per_wg, xcd_order);
   return hipGetLastError();
 }
 
@@ -674,6 +678,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
       return split ? launch_epi<EPI_PLANAR, true>(p, st) : launch_epi<EPI_PLANAR, false>(p, st);
     case EPI_QK:      // a head's 5 tiles with the whole K extent in LDS (embed_dim <= 1024); wider models stream the weights (direct kernel)
       if (split || p.Cp != 80 || p.ntiles != 2 * p.heads * 5) return hipErrorInvalidValue;
+      // (4 row tiles per wave measured the same 64 us as 2: of those, ~10 us are the LDS fill, ~19 the K loop, ~34 the epilogue)
       return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<2, 5, 4, EPI_QK, false>(p, st) : launch_one<2, 5, EPI_QK, false, 2>(p, st);
     case EPI_VT:
       if (split || p.Cp != 80 || p.ntiles != p.heads * 5) return hipErrorInvalidValue;
