@@ -601,7 +601,11 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   int nrb = 256 * per_cu / ncb;
   if (xcd_order) nrb = nrb / 8 * 8;
   nrb = nrb < 1 ? 1 : (nrb > G ? G : nrb);
-  const int rows_per_wg = (G + nrb - 1) / nrb * unit;
+  int rows_per_wg = (G + nrb - 1) / nrb * unit;
+  // The planar-output stage moves exactly its algorithmic bytes (0.54 GB in, 1.07 GB out: profiles/r03_vit_pmc_traffic.json) yet
+  // runs at 2.7 TB/s.  Row blocks of 128 / 256 / 1024 / 5504 rows: 696 / 604 / 548 / 602 us -- 1024 it is (AMX_PLANAR_ROWS).
+  static const int planar_rows = gemm_env("AMX_PLANAR_ROWS", 1024);
+  if (EPI == EPI_PLANAR && planar_rows > 0 && rows_per_wg > planar_rows) rows_per_wg = (planar_rows + unit - 1) / unit * unit;
   nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
   if (xcd_order) nrb = (nrb + 7) / 8 * 8;                          // whole groups of 8 row blocks (XCD-aware order in the kernel)
   hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(64 * nw), lds, st, p, rows_per_wg, xcd_order);

@@ -5,7 +5,7 @@ TAG=${1:-rXX}; shift
 REPO=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  --output-format csv -d $OUT/${TAG}_pmc_sq -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $OUT/${TAG}_pmc_sq.log 2>&1
+  --output-format csv -d $OUT/${TAG}_pmc_sq -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-parity "$@" > $OUT/${TAG}_pmc_sq.log 2>&1
 cd $REPO
 f=$(ls $OUT/${TAG}_pmc_sq/*counter_collection.csv | head -1)
 python - "$f" "$OUT/${TAG}_pmc_sq.json" <<'PY'

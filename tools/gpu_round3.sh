@@ -12,7 +12,7 @@ tail -c 400 $OUT/${TAG}_bench.json; echo
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_$name -o p -- python $REPO/bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/${TAG}_prof_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_$name -o p -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-parity "$@" > $OUT/${TAG}_prof_$name.log 2>&1
   local f=$(ls $OUT/${TAG}_prof_$name/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && head -40 $f > $OUT/${TAG}_bench_${name}_kernel_stats.csv
   rm -rf $OUT/${TAG}_prof_$name
@@ -23,7 +23,7 @@ prof dev --variant anatomix-dev --batch 4 --steps 10 --warmup 3
 prof vit --variant anatomix-dev-vit --batch 4 --steps 8 --warmup 3
 prof step --workload step --no-graph --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/${TAG}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-parity > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 cd $REPO
 f=$(ls $OUT/${TAG}_pmc_FETCH_SIZE/*counter_collection.csv | head -1)
@@ -35,3 +35,6 @@ head -8 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-150
 # SQ-side counters of the headline (separate pass, counters only)
 tools/gpu_pmc_sq.sh ${TAG} > $OUT/${TAG}_pmc_sq.txt 2>&1
 tail -16 $OUT/${TAG}_pmc_sq.txt
+# the same for the ViT engine (attention / product / tokenizer kernels)
+tools/gpu_pmc_sq.sh ${TAG}_vit --variant anatomix-dev-vit > $OUT/${TAG}_vit_pmc_sq.txt 2>&1
+grep -E "attn_fwd|wsgemm_kernel<2, 4, 4, 3|tokconv_kernel<27, 2, 4, 2>" $OUT/${TAG}_vit_pmc_sq.txt

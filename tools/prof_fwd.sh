@@ -4,7 +4,7 @@ TAG=${1:-rXX}; shift
 OUT=$PWD/gpurun_out; REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python $REPO/bench.py --steps 20 --no-cpu-baseline --no-secondary "$@" > $OUT/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python $REPO/bench.py --steps 20 --no-cpu-baseline --no-secondary --no-parity "$@" > $OUT/${TAG}_prof.log 2>&1
 cd $REPO
 f=$(ls $OUT/${TAG}_prof/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && python - <<PY
