@@ -465,8 +465,8 @@ static int gemm_env(const char* name, int dflt) {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <int MT, int NT, int KC, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_wg, int xcd_order) {
+template <int MT, int NT, int KC, int EPI, bool SPLIT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void wsgemm_kernel(GemmParams p, int rows_per_wg, int xcd_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [hi | lo][NT][KS][64 lanes][16 B]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_
   const int rb = xcd_order ? (blockIdx.x / (8 * ncb)) * 8 + xcd : blockIdx.x / ncb;
   if (rb * rows_per_wg >= p.M) return;
   const int nt0 = cb * NT, KS = p.KS;
-  const int nw = blockDim.x >> 6;                                       // 4 or 6 waves share the slice (6: three waves per SIMD where LDS allows two workgroups per CU)
+  constexpr int nw = NW;                                                // waves sharing the slice (8 where LDS leaves room for one workgroup per CU only)
   const int plane = NT * KS * 64;                                       // 16-byte units per plane
   // Fill: LDS-DMA, 1 KiB (one fragment) per instruction, every wave queues its whole share before the single wait.  (A load ->
   // ds_write loop is serialised on the memory latency by its data dependence: measured 35-50 us of a 60 us launch.)
@@ -579,23 +579,21 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(GemmParams p, int rows_per_
   }
 }
 
-template <int MT, int NT, int KC, int EPI, bool SPLIT>
+template <int MT, int NT, int KC, int EPI, bool SPLIT, int NW = 4>
 static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   const int ncb = (p.ntiles + NT - 1) / NT;
   const size_t lds = (size_t)NT * p.KS * 1024 * (SPLIT ? 2 : 1);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t attr = 0;                                          // per instantiation
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)wsgemm_kernel<MT, NT, KC, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)wsgemm_kernel<MT, NT, KC, EPI, SPLIT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = lds;
   }
   // Row blocks: whole groups of 4 waves x MT tiles, sized so that ALL workgroups are resident at once (LDS decides how many fit
   // on a CU; a few workgroups more than slots cost a whole second round), in XCD order a multiple of 8 row blocks.
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
-  // (6 waves per workgroup -- three per SIMD at two workgroups per CU -- would need <= 170 registers; the epilogue-heavy variants
-  // use 180-256: measured no gain, 4 it is.  The kernel takes the wave count from blockDim.)
-  const int nw = 4;
+  constexpr int nw = NW;
   const int unit = MT * 16 * nw, G = (p.M + unit - 1) / unit;
   const int xcd_order = ncb <= 16;
   int nrb = 256 * per_cu / ncb;
@@ -608,7 +606,7 @@ static hipError_t launch_ws(const GemmParams& p, hipStream_t st) {
   if (EPI == EPI_PLANAR && planar_rows > 0 && rows_per_wg > planar_rows) rows_per_wg = (planar_rows + unit - 1) / unit * unit;
   nrb = (p.M + rows_per_wg - 1) / rows_per_wg;
   if (xcd_order) nrb = (nrb + 7) / 8 * 8;                          // whole groups of 8 row blocks (XCD-aware order in the kernel)
-  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT>), dim3((unsigned)ncb * nrb), dim3(64 * nw), lds, st, p, rows_per_wg, xcd_order);
+  hipLaunchKernelGGL((wsgemm_kernel<MT, NT, KC, EPI, SPLIT, NW>), dim3((unsigned)ncb * nrb), dim3(64 * nw), lds, st, p, rows_per_wg, xcd_order);
   return hipGetLastError();
 }
 
@@ -629,7 +627,14 @@ static hipError_t launch_ws_epi(const GemmParams& p, hipStream_t st) {
   const size_t per_tile = (size_t)p.KS * 1024 * (SPLIT ? 2 : 1);
   if (SPLIT) {
     if (five && 5 * per_tile <= 160 * 1024) return launch_ws<2, 5, 2, EPI, true>(p, st);
-    if (!five && 4 * per_tile <= 160 * 1024) return launch_ws<2, 4, 2, EPI, true>(p, st);
+    if (!five && 4 * per_tile <= 160 * 1024) {
+      // The store-bound planar stage: ONE row tile per wave (112 registers: 4 waves per SIMD).  Loads and stores share a wave's
+      // in-order memory counter, so a wave's next operands wait behind the acknowledgement of its previous stores; more waves =
+      // more independent queues (2 tiles per wave 547 us, 1 tile 476 us; deeper prefetch 550 -- no help).
+      if (EPI == EPI_PLANAR) return launch_ws<1, 4, 2, EPI, true>(p, st);
+      if (EPI == EPI_SCATTER && 4 * per_tile > 80 * 1024) return launch_ws<1, 4, 2, EPI, true, 8>(p, st);   // one workgroup per CU: 8 waves
+      return launch_ws<2, 4, 2, EPI, true>(p, st);
+    }
     return hipErrorNotSupported;
   }
   // measured in the ViT forward (tools/vit_gemm_sweep.sh): 4 row tiles per wave win for the wide fp32-output product (q | k | v),
@@ -690,7 +695,8 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
     case EPI_SCATTER_LN:
       if (p.Cp != 128 || p.ntiles != 64 || p.ldo > 128) return hipErrorInvalidValue;
       if ((size_t)8 * p.KS * 1024 * (split ? 2 : 1) <= 160 * 1024)
-        return split ? launch_ws<2, 8, 2, EPI_SCATTER_LN, true>(p, st) : launch_ws<2, 8, 4, EPI_SCATTER_LN, false>(p, st);
+        // the 112 KiB slice leaves one workgroup per CU: 8 waves of one row tile each (442 -> 369 us against 4 waves of two)
+        return split ? launch_ws<1, 8, 2, EPI_SCATTER_LN, true, 8>(p, st) : launch_ws<2, 8, 4, EPI_SCATTER_LN, false>(p, st);
       return split ? launch_one<2, 8, EPI_SCATTER_LN, true, 1>(p, st) : launch_one<2, 8, EPI_SCATTER_LN, false, 1>(p, st);
   }
   return hipErrorInvalidValue;
