@@ -244,20 +244,29 @@ __global__ __launch_bounds__(256) void tokstem_kernel(TokStemParams p) {
     }
   }
   float s[2][4] = {}, q[2][4] = {};
-  for (int x0 = 0; x0 < p.W; x0 += 16) {
-    f32x4 acc[2][4];
+  // The taps of the NEXT 16 voxels are gathered before this step's results are stored: loads and stores share the wave's in-order
+  // memory counter, so a gather issued after the stores would wait for their acknowledgement (and the gather latency itself
+  // overlaps the epilogue).
+  auto gather = [&](int x0, float (&v)[4][8]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int z = z0 + (u >> 1), y = y0 + (u & 1), x = x0 + li;
-      float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int iz = z + dz[e], iy = y + dy[e], ix = x + dx[e];
         const bool ok = tv[e] && iz >= 0 && iz < p.D && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        v[e] = ok ? xb[((long long)iz * p.H + iy) * p.W + ix] : 0.f;
+        v[u][e] = ok ? xb[((long long)iz * p.H + iy) * p.W + ix] : 0.f;
       }
+    }
+  };
+  float vc[4][8];
+  gather(0, vc);
+  for (int x0 = 0; x0 < p.W; x0 += 16) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
       uint4 h, l;
-      split8(v, h, l);
+      split8(vc[u], h, l);
       const f16x8 xh = __builtin_bit_cast(f16x8, h), xl = __builtin_bit_cast(f16x8, l);
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, a0, 0, 0, 0);
@@ -269,6 +278,8 @@ __global__ __launch_bounds__(256) void tokstem_kernel(TokStemParams p) {
       acc[0][u] = a0;
       acc[1][u] = a1;
     }
+    gather(x0 + 16 < p.W ? x0 + 16 : x0, vc);          // unconditional (the last step re-gathers its own taps)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float bb[4] = {bias[t].x, bias[t].y, bias[t].z, bias[t].w};
