@@ -688,10 +688,11 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st) {
     case EPI_QK:      // a head's 5 tiles with the whole K extent in LDS (embed_dim <= 1024); wider models stream the weights (direct kernel)
       if (split || p.Cp != 80 || p.ntiles != 2 * p.heads * 5) return hipErrorInvalidValue;
       // (4 row tiles per wave measured the same 64 us as 2: of those, ~10 us are the LDS fill, ~19 the K loop, ~34 the epilogue)
-      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<2, 5, 4, EPI_QK, false>(p, st) : launch_one<2, 5, EPI_QK, false, 2>(p, st);
+      // eight waves of ONE row tile (the epilogue is long: more waves hide it; 64 -> 56 us; the residual / SwiGLU products measured no gain)
+      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<1, 5, 4, EPI_QK, false, 8>(p, st) : launch_one<2, 5, EPI_QK, false, 2>(p, st);
     case EPI_VT:
       if (split || p.Cp != 80 || p.ntiles != p.heads * 5) return hipErrorInvalidValue;
-      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<2, 5, 4, EPI_VT, false>(p, st) : launch_one<2, 5, EPI_VT, false, 2>(p, st);
+      return (size_t)5 * p.KS * 1024 <= 160 * 1024 ? launch_ws<1, 5, 4, EPI_VT, false, 8>(p, st) : launch_one<2, 5, EPI_VT, false, 2>(p, st);
     case EPI_SCATTER_LN:
       if (p.Cp != 128 || p.ntiles != 64 || p.ldo > 128) return hipErrorInvalidValue;
       if ((size_t)8 * p.KS * 1024 * (split ? 2 : 1) <= 160 * 1024)
