@@ -19,7 +19,7 @@ prof() {  # name, bench args...
 }
 prof headline --steps 20
 prof strict --precision strict --steps 10 --warmup 3
-prof dev --variant anatomix-dev --batch 4 --steps 10 --warmup 3
+prof dev --variant anatomix-dev --precision strict --batch 4 --steps 5 --warmup 2
 prof vit --variant anatomix-dev-vit --batch 4 --steps 8 --warmup 3
 prof step --workload step --no-graph --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
