@@ -32,7 +32,7 @@ class VitCfg(C.Structure):
         ("heads", C.c_int32), ("num_register_tokens", C.c_int32), ("grid_d", C.c_int32), ("grid_h", C.c_int32),
         ("grid_w", C.c_int32), ("hidden", C.c_int32), ("dec1", C.c_int32), ("dec2", C.c_int32), ("qk_norm", C.c_int32),
         ("scale_attn_inner", C.c_int32), ("layer_scale", C.c_int32), ("in_eps", C.c_float), ("out_norm", C.c_int32),
-        ("decoder_split", C.c_int32),
+        ("decoder_split", C.c_int32), ("stem_split", C.c_int32),
     ]
 
 

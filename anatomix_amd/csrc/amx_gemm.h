@@ -65,7 +65,7 @@ hipError_t launch_export_planar(const float* in, int C, long long vox, int nb, c
 // ---- tokenizer (amx_tokenizer.hip) ----------------------------------------------------------------------------------
 struct TokConvParams {
   const char* x_hi;             // input activations, f16 channels-last [N][D][H][W][Cin] (hi plane)
-  const char* x_lo;             // remainder plane
+  const char* x_lo;             // remainder plane, or null (single-f16 input: two MFMAs per product)
   int N, D, H, W, Cin;          // INPUT extent
   int Do, Ho, Wo, Cout;         // OUTPUT extent (D / stride ...)
   const char* w_hi;             // packed [Cout / 16][taps * Cin / 32][64][8]
@@ -88,7 +88,7 @@ struct TokStemParams {
   const float* scale;           // pass 1: [N][32] gamma * rstd
   const float* shift;           //         [N][32] beta - mean * scale
   float slope;
-  char* h_hi; char* h_lo;       // pass 1: lrelu(IN(conv)) channels-last [N][D][H][W][32]
+  char* h_hi; char* h_lo;       // pass 1: lrelu(IN(conv)) channels-last [N][D][H][W][32] (h_lo null: no remainder plane)
   char* p_hi; char* p_lo;       //         its 2x2x2 average, [N][D/2][H/2][W/2][32]
 };
 hipError_t launch_tokstem(const TokStemParams& p, int pass, hipStream_t st);

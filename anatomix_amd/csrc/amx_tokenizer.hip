@@ -57,7 +57,7 @@ __device__ __forceinline__ float sum16(float x) {
 // =====================================================================================================================
 // 3x3x3 / 1x1x1 convolution, zero padding, stride 1 or 2.  grid (row blocks, Cout / (16 NT)), block 256 = 4 waves along M;
 // a wave owns MT tiles of 16 consecutive output voxels (raster order) x NT tiles of 16 output channels.
-template <int TAPS, int STRIDE, int MT, int NT>
+template <int TAPS, int STRIDE, int MT, int NT, bool XS>
 __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
     tz[u] = (int)(r2 % p.Do);
     tb[u] = (int)(r2 / p.Do);
   }
-  const long long lo_off = p.x_lo - p.x_hi, wlo_off = p.w_lo - p.w_hi;
+  const long long lo_off = XS ? p.x_lo - p.x_hi : 0, wlo_off = p.w_lo - p.w_hi;
   const char* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = p.w_hi + ((long long)(nt0 + t) * KS * 64 + lane) * 16;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
 #pragma unroll
     for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][MT];
+  f16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][XS ? MT : 1];   // XS: the input has a remainder plane (three MFMAs per product), else two
   int ks_n = 0;                                                         // the K step the next load() fetches (clamped: the tail re-fetches the last)
   auto load = [&](const int buf) {
     const int ksl = ks_n < KS ? ks_n : KS - 1, tap_n = ksl / nch, ch_n = ksl - tap_n * nch;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
       const char* src = p.x_hi + (vox * p.Cin + ch_n * 32 + g * 8) * 2;
       const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       xh[buf][u] = ok ? *(const f16x8*)src : z;
-      xl[buf][u] = ok ? *(const f16x8*)(src + lo_off) : z;
+      if (XS) xl[buf][u] = ok ? *(const f16x8*)(src + lo_off) : z;
     }
     ++ks_n;
   };
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], xh[buf][u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], xl[buf][u], acc[t][u], 0, 0, 0);
+        if (XS) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[buf][t], xl[buf][XS ? u : 0], acc[t][u], 0, 0, 0);
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[buf][t], xh[buf][u], acc[t][u], 0, 0, 0);
       }
   };
@@ -177,10 +177,16 @@ static hipError_t launch_tokconv_ts(const TokConvParams& p, hipStream_t st) {
   const int mt = tokconv_mt(p), nt = p.Cout >= 64 ? 4 : 2;
   const long long waves = (long long)p.N * p.Do * p.Ho * p.Wo / (16 * mt);
   const dim3 grid((unsigned)(((waves + 3) / 4 + 7) / 8 * 8), p.Cout / (16 * nt)), block(256);      // a multiple of 8 workgroups (XCD-aware order)
-  if (mt == 4 && nt == 4) hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, 4, 4>), grid, block, 0, st, p);
-  else if (mt == 4) hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, 4, 2>), grid, block, 0, st, p);
-  else if (nt == 4) hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, 2, 4>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, 2, 2>), grid, block, 0, st, p);
+#define AMX_TC(M_, N_)                                                                                        \
+  do {                                                                                                        \
+    if (p.x_lo) hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, M_, N_, true>), grid, block, 0, st, p);      \
+    else hipLaunchKernelGGL((tokconv_kernel<TAPS, STRIDE, M_, N_, false>), grid, block, 0, st, p);           \
+  } while (0)
+  if (mt == 4 && nt == 4) AMX_TC(4, 4);
+  else if (mt == 4) AMX_TC(4, 2);
+  else if (nt == 4) AMX_TC(2, 4);
+  else AMX_TC(2, 2);
+#undef AMX_TC
   return hipGetLastError();
 }
 
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256) void tokstem_kernel(TokStemParams p) {
           split4(yv, h, l);
           const long long vox = (((long long)b * p.D + z0 + (u >> 1)) * p.H + y0 + (u & 1)) * p.W + x0 + li;
           *(uint2*)(p.h_hi + (vox * 32 + t * 16 + 4 * g) * 2) = h;
-          *(uint2*)(p.h_lo + (vox * 32 + t * 16 + 4 * g) * 2) = l;
+          if (p.h_lo) *(uint2*)(p.h_lo + (vox * 32 + t * 16 + 4 * g) * 2) = l;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) pool[j] = (pool[j] + __shfl_xor(pool[j], 1, 64)) * 0.125f;

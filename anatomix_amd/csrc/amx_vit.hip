@@ -453,7 +453,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     sp.x = d_x; sp.N = n; sp.D = D0; sp.H = H0; sp.W = W0;
     sp.w_hi = h->stem_w.hi; sp.w_lo = h->stem_w.lo; sp.bias = h->stem_b; sp.stats = P.stats;
     sp.scale = P.sc[0]; sp.shift = P.sh[0]; sp.slope = 0.01f;
-    sp.h_hi = P.h_hi[0]; sp.h_lo = P.h_lo[0]; sp.p_hi = P.p_hi[0]; sp.p_lo = P.p_lo[0];
+    sp.h_hi = P.h_hi[0]; sp.h_lo = c.stem_split ? P.h_lo[0] : nullptr; sp.p_hi = P.p_hi[0]; sp.p_lo = P.p_lo[0];
     VIT_HIP(amx::launch_tokstem(sp, 0, st));
     VIT_HIP(amx::launch_tok_finalize(P.stats, n, amx::tokstem_slots(D0, H0, W0), 32, (long long)D0 * H0 * W0, h->stem_nw, h->stem_nb, c.in_eps, P.sc[0], P.sh[0], st));
     VIT_HIP(amx::launch_tokstem(sp, 1, st));
@@ -468,7 +468,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     amx::TokConvParams cp{};
     cp.N = n; cp.Do = Do; cp.Ho = Ho; cp.Wo = Wo; cp.Cout = s.cout; cp.stats = P.stats;
     // conv1: stride 2 from the stage input
-    cp.x_hi = P.h_hi[k]; cp.x_lo = P.h_lo[k]; cp.D = Dk; cp.H = Hk; cp.W = Wk; cp.Cin = s.cin;
+    cp.x_hi = P.h_hi[k]; cp.x_lo = (k == 0 && !c.stem_split) ? nullptr : P.h_lo[k]; cp.D = Dk; cp.H = Hk; cp.W = Wk; cp.Cin = s.cin;
     cp.w_hi = s.c1.hi; cp.w_lo = s.c1.lo; cp.bias = s.c1b; cp.raw = P.raw1;
     VIT_HIP(amx::launch_tokconv(cp, 27, 2, st));
     VIT_HIP(amx::launch_tok_finalize(P.stats, n, amx::tokconv_slots(cp), s.cout, vo, s.n1w, s.n1b, c.in_eps, P.sc[0], P.sh[0], st));

@@ -341,6 +341,8 @@ typedef struct amx_vit_cfg {
   float in_eps;                 /* tokenizer InstanceNorm epsilon (deep_tokenizer.py:66-68) */
   int32_t out_norm;             /* 0 none, 1 ChannelDemean (architectures.py:28-33); other modes are applied by the caller */
   int32_t decoder_split;        /* 1: hi + lo f16 operands in the decoder (fp32-grade), 0: plain f16 */
+  int32_t stem_split;           /* 1: the stem's output (the largest tensor) keeps its lo plane; 0: single f16 -- half the bytes of the
+                                 * two kernels that touch it, +3.7e-4 rel-L2 on the output (measured) */
 } amx_vit_cfg;
 typedef struct amx_vit amx_vit_t;
 

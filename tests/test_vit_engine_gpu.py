@@ -128,6 +128,21 @@ def test_engine_runs_the_wider_primus_configurations(device, name, embed, heads)
     assert e < 6e-4, e
 
 
+def test_single_f16_stem_output_is_an_opt_in_within_tolerance(device, monkeypatch):
+    """amx_vit_cfg.stem_split = 0 (env AMX_VIT_STEM_SPLIT=0): the stem's output without its lo plane -- faster, measured 3.7e-4 on
+    its own; the default keeps the plane (fp32-grade tokens, test_tokenizer_tokens_match_the_oracle)."""
+    monkeypatch.setenv("AMX_VIT_STEM_SPLIT", "0")
+    kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(64, 64, 64), eva_depth=2)
+    m, sd = _model(kw, 8, device)
+    assert m._vit_cfg["stem_split"] == 0
+    x = V.synthetic_input(16, 1, (64, 64, 64))
+    with torch.no_grad():
+        y = m(x.to(device)).cpu()
+    ref = V.forward(x, sd, kw, dtype=torch.float64).float()
+    e = rel_l2(y, ref)
+    assert 5e-5 < e < 1e-3, e
+
+
 def test_engine_refuses_what_it_cannot_run(device):
     kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(32, 32, 32), eva_depth=1)
     m, _ = _model(kw, 6, device)
