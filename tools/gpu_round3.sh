@@ -20,7 +20,7 @@ prof() {  # name, bench args...
 prof headline --steps 20
 prof strict --precision strict --steps 10 --warmup 3
 prof dev --variant anatomix-dev --precision strict --batch 4 --steps 5 --warmup 2
-prof vit --variant anatomix-dev-vit --batch 4 --steps 8 --warmup 3
+prof vit --variant anatomix-dev-vit --batch 8 --steps 6 --warmup 2
 prof step --workload step --no-graph --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-parity > $OUT/${TAG}_pmc_$c.log 2>&1
