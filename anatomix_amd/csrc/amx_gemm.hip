@@ -796,12 +796,12 @@ hipError_t launch_headpad_vec(float* dst, const float* src, int heads, int hd, i
 // SwiGLU bias in packed feature order: tile 2 s = gate bias of hidden 16 s .., tile 2 s + 1 = value bias of the same columns
 __global__ void swiglu_bias_kernel(float* dst, const float* bg, const float* bx, int hidden) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * hidden) return;
+  if (i >= 2 * ((hidden + 15) / 16 * 16)) return;                  // hidden rounded up to whole tiles (zeros behind it)
   const int tile = i >> 4, h = (tile >> 1) * 16 + (i & 15);
   dst[i] = h < hidden ? ((tile & 1) ? bx : bg)[h] : 0.f;
 }
 hipError_t launch_swiglu_bias(float* dst, const float* bg, const float* bx, int hidden, hipStream_t st) {
-  hipLaunchKernelGGL(swiglu_bias_kernel, dim3((2 * hidden + 255) / 256), dim3(256), 0, st, dst, bg, bx, hidden);
+  hipLaunchKernelGGL(swiglu_bias_kernel, dim3((2 * ((hidden + 15) / 16 * 16) + 255) / 256), dim3(256), 0, st, dst, bg, bx, hidden);
   return hipGetLastError();
 }
 

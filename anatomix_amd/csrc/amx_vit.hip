@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -186,10 +187,10 @@ void layout_params(amx_vit* h, Arena& a) {
     b.qk = take_packed(a, 2 * c.heads * 5, KSe, false);
     b.v = take_packed(a, c.heads * 5, KSe, false);
     b.proj = take_packed(a, up(E, 16) / 16, KSe, false);
-    b.fc1 = take_packed(a, 2 * hid / 16, KSe, false);
+    b.fc1 = take_packed(a, 2 * up(hid, 16) / 16, KSe, false);      // hidden rounded up to whole (gate, value) tile pairs, zero weights behind it
     b.fc2 = take_packed(a, up(E, 16) / 16, KSh, false);
     b.n1w = f(E); b.n1b = f(E); b.qkb = f(2 * c.heads * 80); b.vb = f(c.heads * 80); b.qnw = f(80); b.qnb = f(80); b.knw = f(80); b.knb = f(80);
-    b.anw = f(E); b.anb = f(E); b.projb = f(up(E, 16)); b.g1 = f(up(E, 16)); b.n2w = f(E); b.n2b = f(E); b.fc1b = f(2 * hid);
+    b.anw = f(E); b.anb = f(E); b.projb = f(up(E, 16)); b.g1 = f(up(E, 16)); b.n2w = f(E); b.n2b = f(E); b.fc1b = f(2 * up(hid, 16));
     b.mnw = f(hid); b.mnb = f(hid); b.fc2b = f(up(E, 16)); b.g2 = f(up(E, 16));
   }
   h->fnw = f(E); h->fnb = f(E);
@@ -219,7 +220,8 @@ int amx_vit_create(amx_vit_t** out, const amx_vit_cfg* cfg) {
   if (c.depth < 1 || c.num_register_tokens < 0) return vfail(AMX_ERR_INVALID, "vit: depth / register tokens");
   if (c.grid_d < 2 || c.grid_h < 2 || c.grid_w < 2 || (c.grid_w % 2) || ((long long)c.grid_d * c.grid_h * c.grid_w) % 64 || (c.grid_w * 8) % 16)
     return vfail(AMX_ERR_SHAPE, "vit: token grid %dx%dx%d (even width, a multiple of 64 tokens)", c.grid_d, c.grid_h, c.grid_w);
-  if (c.hidden < 16 || c.hidden % 16 || c.hidden > 3072) return vfail(AMX_ERR_INVALID, "vit: SwiGLU hidden width %d must be a multiple of 16, <= 3072", c.hidden);
+  if (c.hidden < 16 || c.hidden > 3072 || ((c.hidden % 4) && c.hidden > 1088))
+    return vfail(AMX_ERR_INVALID, "vit: SwiGLU hidden width %d must be 16 .. 3072 (a multiple of 4 above 1088)", c.hidden);
   if (c.embed_dim > 1280) return vfail(AMX_ERR_INVALID, "vit: embed_dim <= 1280");
   if (c.dec1 % 4 || c.dec2 % 4 || c.num_classes % 4 || c.dec1 < 4 || c.dec2 < 4 || c.num_classes < 4 || c.dec1 > 1024 || c.dec2 > 256 || c.num_classes > 128)
     return vfail(AMX_ERR_INVALID, "vit: decoder widths %d / %d / %d must be multiples of 4 (<= 1024 / 256, classes <= 128)", c.dec1, c.dec2, c.num_classes);
@@ -402,7 +404,7 @@ Plan make_plan(const amx_vit* h, int n, char* base) {
   const long long Mp = (M + 255) / 256 * 256;
   P.A1 = a.take((size_t)Mp * Ep * 2);
   P.A2 = a.take((size_t)Mp * up(hid, 32) * 2);
-  P.Hd = a.take((size_t)Mp * hid * 2);
+  P.Hd = a.take((size_t)Mp * up(hid, 16) * 2);
   P.AO = a.take<float>((size_t)M * E * 4);
   P.att = a.take(amx::attention_scratch_bytes(n, c.heads, T));
   const size_t blk_end = a.off;
@@ -444,6 +446,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
   const int E = h->E, Ep = h->Ep, T = h->T, V = h->V, hid = h->hidden, nreg = c.num_register_tokens;
   const int M = n * T;
   const int D0 = c.grid_d * 8, H0 = c.grid_h * 8, W0 = c.grid_w * 8;
+  static const int dbg_stop = getenv("AMX_VIT_STOP") ? atoi(getenv("AMX_VIT_STOP")) : 0;   // debugging aid (tools/vit_bisect.py): return after a stage
   h->dbg.clear();
   auto note = [&](const char* name, const void* p, size_t bytes) { h->dbg.push_back({name, (char*)p, bytes}); };
 
@@ -460,6 +463,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     note("h0_hi", P.h_hi[0], (size_t)n * D0 * H0 * W0 * 32 * 2);
     note("p0_hi", P.p_hi[0], (size_t)n * D0 * H0 * W0 * 4 * 2);
   }
+  if (dbg_stop == 10) return AMX_OK;
   int Dk = D0, Hk = H0, Wk = W0;
   for (int k = 0; k < 3; ++k) {
     const Stage& s = h->st[k];
@@ -487,6 +491,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
                                     k < 2 ? P.p_hi[k + 1] : nullptr, k < 2 ? P.p_lo[k + 1] : nullptr, st));
     if (k == 0) { note("raw1_s0", P.raw1, (size_t)n * vo * s.cout * 4); }
     Dk = Do; Hk = Ho; Wk = Wo;
+    if (dbg_stop == 11 + k) return AMX_OK;
   }
   {
     amx::GemmParams g{};
@@ -494,9 +499,11 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     g.w_hi = h->tokproj.hi; g.w_lo = h->tokproj.lo; g.ntiles = h->tokproj.ntiles; g.Nreal = E; g.bias = h->tokproj_b;
     g.out = P.tok; g.ldo = E; g.V = V; g.nreg = nreg; g.pos = h->pos;
     VIT_HIP(amx::launch_gemm(g, amx::EPI_TOKENS, st));
+    if (dbg_stop == 14) return AMX_OK;
     VIT_HIP(amx::launch_place_registers(h->regs, nreg, E, T, n, P.tok, st));
   }
   note("tokens", P.tok, (size_t)M * E * 4);
+  if (dbg_stop == 1) return AMX_OK;
 
   // ------------------------------------------------------------------ EVA blocks
   const int nb = n_blocks < 0 || n_blocks > c.depth ? c.depth : n_blocks;
@@ -524,9 +531,9 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
     g.KS = b.proj.KS; g.w_hi = b.proj.hi; g.ntiles = b.proj.ntiles; g.Nreal = E; g.bias = b.projb; g.gamma = b.g1; g.out = P.tok; g.ldo = E;
     VIT_HIP(amx::launch_gemm(g, amx::EPI_RESID, st));
     VIT_HIP(amx::launch_ln_rows(P.tok, 0, E, E, b.n2w, b.n2b, 1e-6f, M, M, M, 0, 0, P.A1, nullptr, Ep, st));
-    g.KS = b.fc1.KS; g.w_hi = b.fc1.hi; g.ntiles = b.fc1.ntiles; g.Nreal = 2 * hid; g.bias = b.fc1b; g.gamma = nullptr; g.out = P.Hd; g.ldo = hid;
+    g.KS = b.fc1.KS; g.w_hi = b.fc1.hi; g.ntiles = b.fc1.ntiles; g.Nreal = 2 * up(hid, 16); g.bias = b.fc1b; g.gamma = nullptr; g.out = P.Hd; g.ldo = up(hid, 16);
     VIT_HIP(amx::launch_gemm(g, amx::EPI_SWIGLU, st));
-    VIT_HIP(amx::launch_ln_rows(P.Hd, 1, hid, hid, b.mnw, b.mnb, 1e-6f, M, M, M, 0, 0, P.A2, nullptr, up(hid, 32), st));
+    VIT_HIP(amx::launch_ln_rows(P.Hd, 1, up(hid, 16), hid, b.mnw, b.mnb, 1e-6f, M, M, M, 0, 0, P.A2, nullptr, up(hid, 32), st));
     g.a_hi = P.A2; g.lda = up(hid, 32);
     g.KS = b.fc2.KS; g.w_hi = b.fc2.hi; g.ntiles = b.fc2.ntiles; g.Nreal = E; g.bias = b.fc2b; g.gamma = b.g2; g.out = P.tok; g.ldo = E;
     VIT_HIP(amx::launch_gemm(g, amx::EPI_RESID, st));
@@ -536,6 +543,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
   // ------------------------------------------------------------------ final norm (drops the register tokens) + decoder
   const int Mv = n * V;
   VIT_HIP(amx::launch_ln_rows(P.tok, 0, E, E, h->fnw, h->fnb, 1e-6f, Mv, V, T, nreg, 0, P.Ad_hi[0], P.Ad_lo[0], Ep, st));
+  if (dbg_stop == 2) return AMX_OK;
   int gd = c.grid_d, gh = c.grid_h, gw = c.grid_w;
   long long rows = Mv;
   for (int k = 0; k < 3; ++k) {
@@ -560,6 +568,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
                                   P.Ad_lo[k + 1], up(d.cout, 32), st));
     }
     rows *= 8; gd *= 2; gh *= 2; gw *= 2;
+    if (dbg_stop == 3 + k) return AMX_OK;
   }
   return AMX_OK;
 }

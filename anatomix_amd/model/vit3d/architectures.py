@@ -285,6 +285,11 @@ class PrimusV2(nn.Module):
             raise NotImplementedError("PrimusV2 (anatomix_amd): dropout / drop-path / patch-drop are not implemented")
         if input_shape is None or embed_dim % eva_numheads:
             raise ValueError("input_shape is required and embed_dim must be divisible by eva_numheads")
+        if (embed_dim // eva_numheads) % (2 * len(input_shape)):
+            # the rotary table holds head_dim // (2 * axes) frequency bands per axis, each for one (even, odd) channel pair: a head
+            # width that is not a multiple of 2 * axes leaves channels without a band (every PRIMUS_CONFIGS entry is: 66, 66, 72, 66)
+            raise ValueError(f"head_dim {embed_dim // eva_numheads} must be a multiple of {2 * len(input_shape)} "
+                             "(rotation pairs x spatial axes of the rotary embedding)")
         self.grid = tuple(int(s) // 8 for s in input_shape)
         self.num_register_tokens = int(num_register_tokens)
         self.down_projection = PatchEmbedDeeper(input_channels, embed_dim, 32, (1, 1, 1), in_eps)

@@ -333,7 +333,7 @@ typedef struct amx_vit_cfg {
   int32_t heads;                /* eva_numheads; head_dim = embed_dim / heads even, <= 80 */
   int32_t num_register_tokens;  /* architectures.py:117-120 */
   int32_t grid_d, grid_h, grid_w; /* token grid = input_shape / 8 */
-  int32_t hidden;               /* SwiGLU hidden width (int(embed_dim * 4 * 2 / 3)), a multiple of 16, <= 3072 */
+  int32_t hidden;               /* SwiGLU hidden width (int(embed_dim * 4 * 2 / 3)), 16 .. 3072 (a multiple of 4 above 1088) */
   int32_t dec1, dec2;           /* channel widths after the first / second transposed conv (oracle/vit_ref.py::vit_plan) */
   int32_t qk_norm;              /* architectures.py:108-115 */
   int32_t scale_attn_inner;     /* LayerNorm between attention and its output projection */

@@ -70,3 +70,8 @@ def test_copies_and_replicas_do_not_share_the_engine_handle():
         assert other._handle is None and other._engine_sig is None
     m.__dict__["_handle"] = None
     assert pickle.loads(pickle.dumps(m))._handle is None
+
+
+def test_head_width_must_carry_whole_rotary_bands():
+    with pytest.raises(ValueError, match="multiple of 6"):
+        PrimusV2(**dict(SMALL, embed_dim=256, eva_numheads=4))          # head_dim 64: 10 bands x 3 axes x 2 = 60 channels only

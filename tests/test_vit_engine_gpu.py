@@ -128,6 +128,34 @@ def test_engine_runs_the_wider_primus_configurations(device, name, embed, heads)
     assert e < 6e-4, e
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_engine_against_the_torch_composition_on_random_configurations(device, seed):
+    """Seeded sweep over the constructor envelope (token grids incl. non-cubic, batch, heads x head_dim, register tokens, classes,
+    flags): engine vs the same module composed of torch operators (fp32 everywhere except its HIP attention core)."""
+    rs = np.random.RandomState(1000 + seed)
+    grid = [(4, 4, 4), (4, 8, 4), (8, 4, 2), (2, 8, 4), (8, 8, 2), (4, 4, 8)][rs.randint(6)]
+    heads, hd = [(6, 66), (4, 60), (8, 36), (4, 78), (12, 66), (2, 18)][rs.randint(6)]      # head_dim: a multiple of 6 (rotary bands); embed_dim: a multiple of 4 (engine)
+    kw = dict(input_channels=1, num_classes=int(rs.choice([4, 16, 32, 36])), embed_dim=heads * hd, patch_embed_size=(8, 8, 8),
+              input_shape=tuple(8 * g for g in grid), eva_depth=int(rs.randint(1, 3)), eva_numheads=heads,
+              num_register_tokens=int(rs.choice([0, 3, 8])), init_values=[None, 0.1][rs.randint(2)], scale_attn_inner=bool(rs.randint(2)),
+              qk_norm=bool(rs.randint(2)), out_norm=["none", "demean", "instance"][rs.randint(3)], out_norm_eps=1e-2, in_eps=1e-2)
+    torch.manual_seed(seed)
+    m = PrimusV2(**kw).to(device).eval()
+    with torch.no_grad():
+        for prm in m.parameters():                                  # away from the all-ones / zeros defaults of norms and LayerScale
+            if prm.dim() == 1:
+                prm.add_(0.1 * torch.randn_like(prm))
+    batch = int(rs.randint(1, 4))
+    x = torch.rand(batch, 1, *kw["input_shape"], device=device)
+    with torch.no_grad():
+        y = m(x)
+        m.use_engine = False
+        y_t = m(x)
+    assert y.shape == y_t.shape and torch.isfinite(y).all()
+    e = rel_l2(y.cpu(), y_t.cpu())
+    assert e < 1e-3, (kw, batch, e)
+
+
 def test_single_f16_stem_output_is_an_opt_in_within_tolerance(device, monkeypatch):
     """amx_vit_cfg.stem_split = 0 (env AMX_VIT_STEM_SPLIT=0): the stem's output without its lo plane -- faster, measured 3.7e-4 on
     its own; the default keeps the plane (fp32-grade tokens, test_tokenizer_tokens_match_the_oracle)."""
