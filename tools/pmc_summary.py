@@ -39,6 +39,10 @@ def friendly(mangled):
     m = re.search(r"(attn_fwd_kernel|attn_prep_kernel|wsgemm_kernel|gemm_kernel|tokconv_kernel|tokstem_kernel|ln_rows_kernel)(<[^>]*>|I[A-Za-z0-9_]*?E(?=Ev|v))?", mangled)
     if m:
         return m.group(0)
+    # rocprofv3 mis-demangles the bf16 instantiations ("<bool _Accum, int, E, 2, 32, ...>"): keep the name and the numbers
+    m = re.search(r"amx::(\w+_kernel)<bool _Accum, (?:int|bool), E[L]?,? ?([^>]*)>", mangled)
+    if m:
+        return f"{m.group(1)}<bf16,{m.group(2).replace(' ', '')}>"
     return None
 
 
