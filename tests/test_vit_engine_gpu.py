@@ -153,6 +153,7 @@ def test_engine_against_the_torch_composition_on_random_configurations(device, s
         y_t = m(x)
     assert y.shape == y_t.shape and torch.isfinite(y).all()
     e = rel_l2(y.cpu(), y_t.cpu())
+    print(f"sweep seed {seed}: rel-L2 {e:.2e}")
     assert e < 1e-3, (kw, batch, e)
 
 
