@@ -64,7 +64,18 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each).  Each XCD gets a CONTIGUOUS eighth of the
   // output rows, in order, so the input rows that neighbouring output rows / z-slices share are fetched into one L2 close in time
   // (plain order: the 32 -> 32 stride-2 conv at 128^3 fetched 3.47 GB for a 1.07 GB input, profiles/r03_vit_pmc_traffic.json).
-  const int per_xcd = gridDim.x >> 3, blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int per_xcd = gridDim.x >> 3;
+  int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  // ... and WALKS Z FIRST: workgroup = 4 waves x MT tiles of 16 raster-order voxels = a few rows of ONE z-plane; consecutive
+  // workgroups take the same rows of consecutive z-planes, which share one (stride 2) or two (stride 1) of their three input
+  // planes -- re-used while still in L2 -- instead of consecutive rows, which share one input row in nine.
+  {
+    const int per_plane = p.Ho * p.Wo / (64 * MT), per_sample = per_plane * p.Do;      // workgroups per z-plane / per sample
+    if (per_plane >= 1 && per_plane * 64 * MT == p.Ho * p.Wo && blk < per_sample * p.N) {
+      const int bs = blk / per_sample, r = blk - bs * per_sample;
+      blk = bs * per_sample + (r % p.Do) * per_plane + r / p.Do;
+    }
+  }
   const int wid = blk * 4 + wave;                                      // wave index over all samples
   const long long tiles = (long long)p.N * p.Do * p.Ho * p.Wo / 16;
   if ((long long)wid * MT >= tiles) return;
@@ -94,9 +105,20 @@ __global__ __launch_bounds__(256) void tokconv_kernel(TokConvParams p) {
     for (int u = 0; u < MT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f16x8 wh[2][NT], wl[2][NT], xh[2][MT], xl[2][XS ? MT : 1];   // XS: the input has a remainder plane (three MFMAs per product), else two
+  // (valid when the wave's voxels share one z-plane: whole rows per wave)
+  const bool zflip = (p.Ho * p.Wo) % (16 * MT) == 0 && (__builtin_amdgcn_readfirstlane(tz[0]) & 1);
+  const bool yflip = p.Wo == 16 * MT && (__builtin_amdgcn_readfirstlane(ty[0]) & 1);
   int ks_n = 0;                                                         // the K step the next load() fetches (clamped: the tail re-fetches the last)
   auto load = [&](const int buf) {
-    const int ksl = ks_n < KS ? ks_n : KS - 1, tap_n = ksl / nch, ch_n = ksl - tap_n * nch;
+    const int ksq = ks_n < KS ? ks_n : KS - 1, tap_q = ksq / nch, ch_n = ksq - tap_q * nch;
+    // odd z-planes take their kz taps in REVERSE: the input plane two neighbouring output planes share is then read by both at the
+    // same phase of their K loops (the even one's last third, the odd one's last third) -- while it is still in L2
+    int tap_n = tap_q;
+    if (TAPS == 27) {
+      const int kzq = tap_q / 9, kyq = (tap_q / 3) % 3;
+      tap_n = (zflip ? 2 - kzq : kzq) * 9 + (yflip ? 2 - kyq : kyq) * 3 + tap_q % 3;    // the same for ky between neighbouring rows (one row per wave)
+    }
+    const int ksl = tap_n * nch + ch_n;
     const int kz = TAPS == 1 ? 1 : tap_n / 9, ky = TAPS == 1 ? 1 : (tap_n / 3) % 3, kx = TAPS == 1 ? 1 : tap_n % 3;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
