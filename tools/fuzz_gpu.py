@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-nconv = nnet = nbwd = nfail = nreg = nmlp = 0
+nconv = nnet = nbwd = nfail = nreg = nmlp = nvit = 0
 import torch.nn.functional as F
 from anatomix_amd.model import train_ops as T
 
@@ -99,6 +99,41 @@ def fuzz_mlp():
         return 1
     return 0
 
+def fuzz_vit():
+    """PrimusV2 engine (amx_vit_forward) against the same module composed of torch operators, random constructor arguments inside
+    the engine's envelope (token count a multiple of 64, even grid width, head_dim a multiple of 6, embed_dim a multiple of 4)."""
+    from anatomix_amd.model.vit3d import PrimusV2
+    while True:
+        grid = tuple(rng.choice([2, 4, 4, 8]) for _ in range(3))
+        if (grid[0] * grid[1] * grid[2]) % 64 == 0:
+            break
+    heads, hd = rng.choice([(6, 66), (4, 60), (8, 36), (4, 78), (12, 66), (2, 18), (3, 48), (16, 66), (5, 24)])
+    kw = dict(input_channels=1, num_classes=rng.choice([4, 16, 32, 36, 64]), embed_dim=heads * hd,
+              patch_embed_size=(8, 8, 8), input_shape=tuple(8 * g for g in grid), eva_depth=rng.randint(1, 3), eva_numheads=heads,
+              num_register_tokens=rng.choice([0, 1, 3, 8]), init_values=rng.choice([None, 0.1]),
+              scale_attn_inner=rng.random() < 0.5, qk_norm=rng.random() < 0.5, out_norm=rng.choice(["none", "demean", "instance"]),
+              out_norm_eps=1e-2, in_eps=1e-2)
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    try:
+        m = PrimusV2(**kw).to(dev).eval()
+    except (ValueError, NotImplementedError) as ex:                  # a constructor refusal is the documented behaviour
+        return 0
+    batch = rng.randint(1, 3)
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.1 * torch.randn_like(prm))
+        x = torch.rand(batch, kw["input_channels"], *kw["input_shape"], device=dev)
+        y = m(x)
+        m.use_engine = False
+        y_t = m(x)
+    e = rel_l2(y.cpu(), y_t.cpu())
+    if not (torch.isfinite(y).all() and e < 1e-3):
+        print("VIT FAIL", kw, batch, e)
+        return 1
+    return 0
+
+
 devnull = open(os.devnull, "w")
 POISON = os.environ.get("AMX_FUZZ_POISON", "0") == "1"   # refill the allocator's free memory with NaNs every few cases
 ncase = 0
@@ -116,6 +151,9 @@ while time.time() < t_end:
         elif pick < 0.14:
             nmlp += 1
             nfail += fuzz_mlp()
+        elif pick < 0.18:
+            nvit += 1
+            nfail += fuzz_vit()
         elif pick < 0.3:
             # ---- conv backward: weight gradient + data gradient against torch autograd (double, rounded operands)
             dt = rng.choice([torch.bfloat16, torch.float16])
@@ -246,5 +284,5 @@ while time.time() < t_end:
         nfail += 1
         print("EXCEPTION", type(ex).__name__, str(ex)[:300])
         traceback.print_exc(limit=2)
-print(f"fuzz: {nconv} convs, {nbwd} conv backwards, {nnet} networks, {nreg} registration-feature cases, {nmlp} projection heads, "
+print(f"fuzz: {nconv} convs, {nbwd} conv backwards, {nnet} networks, {nreg} registration-feature cases, {nmlp} projection heads, {nvit} ViT configurations, "
       f"{nfail} failures in {budget:.0f} s")
