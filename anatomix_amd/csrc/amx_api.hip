@@ -68,6 +68,8 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
 hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                                   const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
                                   int C, int act, float slope, void* scratch, int precision, hipStream_t st);
+hipError_t launch_adamw(const long long* table, int count, double lr, double b1, double b2, double eps, double wd, int maximize,
+                        hipStream_t st);
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
                            hipStream_t st);
 hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
@@ -86,7 +88,7 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
 hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
-                              int acc_skip, int precision, hipStream_t st);
+                              int acc_skip, int framed, int precision, hipStream_t st);
 hipError_t launch_import_input(const float* src, void* dst, int N, int Cin, long long vox, int precision, hipStream_t st);
 hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D, int H, int W, long long dn, long long dz,
                                long long dy, long long dx, int accumulate, int precision, hipStream_t st);
@@ -1192,6 +1194,21 @@ int amx_pad_fold(const void* d_g_framed, void* d_din, int n, int d, int hh, int 
   return AMX_OK;
 }
 
+int amx_adamw_step(const amx_adamw_tensor* tensors, int count, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int maximize, void* stream) {
+  static_assert(sizeof(amx_adamw_tensor) == 48, "six 64-bit fields");
+  if (count < 0 || (count && !tensors)) return fail(AMX_ERR_INVALID, "bad argument");
+  if (!(lr >= 0.0) || !(eps >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(weight_decay >= 0.0))
+    return fail(AMX_ERR_INVALID, "adamw: lr %g, betas (%g, %g), eps %g, weight_decay %g out of range", lr, beta1, beta2, eps, weight_decay);
+  for (int t = 0; t < count; ++t) {
+    const amx_adamw_tensor& r = tensors[t];
+    if (!r.param || !r.grad || !r.exp_avg || !r.exp_avg_sq || !r.step || r.numel < 0)
+      return fail(AMX_ERR_INVALID, "adamw: tensor %d has a null pointer or a negative size", t);
+  }
+  AMX_HIP(amx::launch_adamw((const long long*)tensors, count, lr, beta1, beta2, eps, weight_decay, maximize, (hipStream_t)stream));
+  return AMX_OK;
+}
+
 int amx_pool2_max_backward(const void* d_dp, const void* d_in, void* d_din, int n, int dout, int hout, int wout, int c,
                            int accumulate, int precision, void* stream) {
   if (!d_dp || !d_in || !d_din || c % 8) return fail(AMX_ERR_INVALID, "bad argument");
@@ -1421,7 +1438,16 @@ int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, in
                              int accumulate_skip, int precision, void* stream) {
   if (!d_dcat || !d_dskip || !d_dlow || n < 1 || dlow < 1 || hlow < 1 || wlow < 1 || c0 < 8 || c1 < 8 || c0 % 8 || c1 % 8)
     return fail(AMX_ERR_INVALID, "bad argument");
-  AMX_HIP(amx::launch_upcat_split(d_dcat, d_dskip, d_dlow, n, dlow, hlow, wlow, c0, c1, accumulate_skip, precision,
+  AMX_HIP(amx::launch_upcat_split(d_dcat, d_dskip, d_dlow, n, dlow, hlow, wlow, c0, c1, accumulate_skip, 0, precision,
+                                  (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_upcat_split_backward_framed(const void* d_g_framed, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0,
+                                    int c1, int accumulate_skip, int precision, void* stream) {
+  if (!d_g_framed || !d_dskip || !d_dlow || n < 1 || dlow < 1 || hlow < 1 || wlow < 1 || c0 < 8 || c1 < 8 || c0 % 8 || c1 % 8)
+    return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_upcat_split(d_g_framed, d_dskip, d_dlow, n, dlow, hlow, wlow, c0, c1, accumulate_skip, 1, precision,
                                   (hipStream_t)stream));
   return AMX_OK;
 }

@@ -367,7 +367,10 @@ __global__ __launch_bounds__(256) void pad_fold_kernel(const char* __restrict__ 
 // dcat [N][D][H][W][c0 + c1] (the data gradient of a concat conv) -> dskip [N][D][H][W][c0] (= or += the first c0 channels)
 // and dlow [N][D/2][H/2][W/2][c1] = sum of the 8 children of every low-resolution voxel (fp32 sum, one rounding).
 // One thread = one low-resolution voxel x one 8-channel group of EITHER part: the 8 children are read once.
-template <typename T>
+// FRAMED: dcat is the data-gradient conv's raw result on the padded domain, [N][D+4][H+4][W+4][c0 + c1]; the reflect-padding adjoint
+// (pad_fold above) is applied while reading -- a child collects its own position and, next to a face, the mirrored frame
+// positions -- so the folded full-resolution tensor is never written.
+template <typename T, bool FRAMED>
 __global__ void upcat_split_kernel(const char* __restrict__ dcat, char* __restrict__ dskip, char* __restrict__ dlow, int N,
                                    int Dl, int Hl, int Wl, int c0, int c1, int acc_skip) {
   const int C = c0 + c1, g0 = c0 >> 3, g1 = c1 >> 3, G = g0 + g1;
@@ -388,7 +391,26 @@ __global__ void upcat_split_kernel(const char* __restrict__ dcat, char* __restri
       const int z = 2 * zl + (k >> 2), y = 2 * yl + ((k >> 1) & 1), x = 2 * xl + (k & 1);
       const long long v = (((long long)n * D + z) * H + y) * W + x;
       float f[8];
-      t_unpack8<T>(*(const uint4*)(dcat + (v * C + g * 8) * 2), f);
+      if (!FRAMED) {
+        t_unpack8<T>(*(const uint4*)(dcat + (v * C + g * 8) * 2), f);
+      } else {
+        // framed coordinate e = padded coordinate j + 2; voxel i collects j = i, j = -1 (if i == 1), j = L (if i == L-2)
+        int ez[3], ey[3], ex[3], nz = 0, ny = 0, nx = 0;
+        ez[nz++] = z + 2; if (z == 1) ez[nz++] = 1; if (z == D - 2) ez[nz++] = D + 2;
+        ey[ny++] = y + 2; if (y == 1) ey[ny++] = 1; if (y == H - 2) ey[ny++] = H + 2;
+        ex[nx++] = x + 2; if (x == 1) ex[nx++] = 1; if (x == W - 2) ex[nx++] = W + 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        for (int a = 0; a < nz; ++a)
+          for (int b = 0; b < ny; ++b)
+            for (int c = 0; c < nx; ++c) {
+              const long long vf = (((long long)n * (D + 4) + ez[a]) * (H + 4) + ey[b]) * (W + 4) + ex[c];
+              float t[8];
+              t_unpack8<T>(*(const uint4*)(dcat + (vf * C + g * 8) * 2), t);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] += t[e];
+            }
+      }
       if (g < g0) {                                           // skip part: plain copy (or accumulate) per full-resolution voxel
         char* o = dskip + (v * c0 + g * 8) * 2;
         if (acc_skip) {
@@ -530,15 +552,18 @@ hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, 
 }
 
 hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
-                              int acc_skip, int precision, hipStream_t st) {
+                              int acc_skip, int framed, int precision, hipStream_t st) {
   if (c0 % 8 || c1 % 8 || c0 < 8 || c1 < 8) return hipErrorInvalidValue;
   const int blocks = grid_for((long long)N * Dl * Hl * Wl * ((c0 + c1) / 8));
-  if (precision == 0)
-    hipLaunchKernelGGL(upcat_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl,
-                       Hl, Wl, c0, c1, acc_skip);
-  else
-    hipLaunchKernelGGL(upcat_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl,
-                       Hl, Wl, c0, c1, acc_skip);
+#define AMX_UPS(T, F)                                                                                                            \
+  hipLaunchKernelGGL((upcat_split_kernel<T, F>), dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl, \
+                     Hl, Wl, c0, c1, acc_skip)
+  if (precision == 0) {
+    if (framed) { AMX_UPS(f16, true); } else { AMX_UPS(f16, false); }
+  } else {
+    if (framed) { AMX_UPS(bf16, true); } else { AMX_UPS(bf16, false); }
+  }
+#undef AMX_UPS
   return hipGetLastError();
 }
 

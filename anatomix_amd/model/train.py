@@ -16,6 +16,8 @@ into the concat convs) / 'trilinear' (materialised + its adjoint kernel), double
 norm / activation / pool / upsample ids and at the output conv.  Everything else raises (the caller can still opt into the stock-module
 path).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -25,6 +27,7 @@ _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "b
 
 
 OVERLAP_WGRAD = True           # weight gradients on a side stream, beside the data gradient of the same block
+FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
 _SIDE = {}
 
 
@@ -231,7 +234,10 @@ class _UnetTrainFn(torch.autograd.Function):
         ctx.model, ctx.tensors, ctx.ops, ctx.layers, ctx.dt = model, tensors, ops, sorted(taps), dt
         ctx.param_ids = [id(p) for p in model.parameters()]
         ctx.final_idx = blocks[-1]["idx"]
-        out = tensors[blocks[-1]["name"]]
+        # popped, not read: the backward never needs the network's output, and an OUTPUT kept in ctx is a reference cycle (output ->
+        # grad_fn -> ctx -> output) that only the garbage collector frees -- until then the parameters' AccumulateGrad nodes stay bound
+        # to the stream of this call, and a HIP-graph capture of the same modules would run them there (outside the capture)
+        out = tensors.pop(blocks[-1]["name"])
         return (out,) + tuple(taps[l] for l in sorted(taps))
 
     @staticmethod
@@ -369,7 +375,17 @@ class _UnetTrainFn(torch.autograd.Function):
                 if ctx.needs_input_grad[1]:                             # d loss / d image: the stem's data gradient (channel 0 of
                     dx_in = T.conv_dgrad(fr, conv.weight)[..., 0].float().unsqueeze(1)   # the 16-channel padded result)
                 continue
-            dcat = T.conv_dgrad(fr, conv.weight)
+            g_fr = T.conv_dgrad_framed(fr, conv.weight)
+            if (x1 is not None and blk.get("cat_parts") is None and g_fr.shape[-1] == c0 + x1.shape[-1] and c0 % 8 == 0
+                    and x1.shape[-1] % 8 == 0 and FUSED_FOLD_SPLIT):
+                # reflect-padding adjoint, channel split and the sum over the 8 children of every low-resolution voxel (adjoint of
+                # the nearest x2 upsample) in ONE pass over the framed result; the skip part accumulates in place when the skip
+                # already has a gradient
+                dskip, dlow = T.upcat_split_backward_framed(g_fr, c0, x1.shape[-1], skip_into=grads.get(blk["in0"]))
+                grads[blk["in0"]] = dskip
+                add_grad(blk["in1"], dlow)
+                continue
+            dcat = T.pad_fold(g_fr)
             if blk.get("cat_parts") is not None:                        # materialised trilinear concat: split, then the adjoint
                 skip_name, low_name = blk["cat_parts"]
                 cs = tensors[skip_name].shape[-1]

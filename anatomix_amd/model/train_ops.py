@@ -125,16 +125,24 @@ def conv_dgrad(dx_framed, weight, cin_keep=None, accumulate_into=None):
     """Data gradient of Conv3d(k3, reflect): the forward kernel on the framed output gradient with the flipped, transposed
     weights (packed straight from the forward tensor), then the reflect-padding adjoint.  weight fp32 [Cout, Cin, 3,3,3];
     returns 16-bit [N, D, H, W, Cin_pad16]."""
+    return pad_fold(conv_dgrad_framed(dx_framed, weight), accumulate_into)
+
+
+def conv_dgrad_framed(dx_framed, weight):
+    """First half of conv_dgrad: the raw result on the padded domain, 16-bit [N, D+4, H+4, W+4, Cin_pad16]."""
+    return conv_forward(dx_framed, None, weight, weight_mode=1)
+
+
+def pad_fold(g, accumulate_into=None):
+    """Second half: the reflect-padding adjoint, [N, D+4, H+4, W+4, C] -> [N, D, H, W, C]."""
     lib = _lib.load()
-    dev = dx_framed.device
-    n, df, hf, wf, cout = dx_framed.shape
-    g = conv_forward(dx_framed, None, weight, weight_mode=1)             # [N, D+4, H+4, W+4, Cin_pad]
-    cin_pad = g.shape[-1]
+    dev = g.device
+    n, df, hf, wf, cin_pad = g.shape
     d, h, w = df - 4, hf - 4, wf - 4
-    din = accumulate_into if accumulate_into is not None else torch.empty((n, d, h, w, cin_pad), dtype=dx_framed.dtype, device=dev)
+    din = accumulate_into if accumulate_into is not None else torch.empty((n, d, h, w, cin_pad), dtype=g.dtype, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.amx_pad_fold(_lib.ptr(g), _lib.ptr(din), n, d, h, w, cin_pad, int(accumulate_into is not None),
-                                    _PREC[dx_framed.dtype], _st(dev)))
+                                    _PREC[g.dtype], _st(dev)))
     return din
 
 
@@ -238,6 +246,20 @@ def import_ncdhw(g, dst, accumulate=False):
         _lib.check(lib.amx_import_ncdhw(_lib.ptr(g), ctypes.c_void_p(dst.data_ptr()), n, c, d, h, w, sn, sz, sy, sx,
                                         int(accumulate), _PREC[dst.dtype], _st(g.device)))
     return dst
+
+
+def upcat_split_backward_framed(g, c0, c1, skip_into=None):
+    """pad_fold + upcat_split_backward in one pass over the framed data-gradient result g [N, D+4, H+4, W+4, c0 + c1]."""
+    lib = _lib.load()
+    n, df, hf, wf, c = g.shape
+    d, h, w = df - 4, hf - 4, wf - 4
+    assert c == c0 + c1 and g.is_contiguous() and d % 2 == 0 and h % 2 == 0 and w % 2 == 0
+    dskip = skip_into if skip_into is not None else torch.empty((n, d, h, w, c0), dtype=g.dtype, device=g.device)
+    dlow = torch.empty((n, d // 2, h // 2, w // 2, c1), dtype=g.dtype, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.amx_upcat_split_backward_framed(_lib.ptr(g), _lib.ptr(dskip), _lib.ptr(dlow), n, d // 2, h // 2, w // 2, c0, c1,
+                                                       int(skip_into is not None), _PREC[g.dtype], _st(g.device)))
+    return dskip, dlow
 
 
 def upcat_split_backward(dcat, c0, c1, skip_into=None):

@@ -3,6 +3,7 @@
 from collections import OrderedDict
 
 import contextlib
+import gc
 import os
 
 import torch
@@ -57,8 +58,18 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     return total, layer_losses, ids, out
 
 
+def _total_norm(net):
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    if not grads:
+        return torch.zeros((), device=next(net.parameters()).device)
+    return nn.utils.get_total_norm(grads, norm_type=2)
+
+
 def _grad_norms(netG, netF):
-    # clip_grad_norm_(max_norm=inf) only measures (supcl_model.py:635-655)
+    # clip_grad_norm_(max_norm=inf) only measures (supcl_model.py:635-655): the norm is what is recorded; its second half -- every
+    # gradient multiplied by clamp(inf / norm, max=1) = 1 -- is an identity pass over all gradients and is left out
+    if hasattr(nn.utils, "get_total_norm"):
+        return _total_norm(netG), _total_norm(netF)
     gG = nn.utils.clip_grad_norm_(netG.parameters(), max_norm=float("inf"), norm_type=2)
     gF = nn.utils.clip_grad_norm_(netF.parameters(), max_norm=float("inf"), norm_type=2)
     return gG, gF
@@ -129,8 +140,11 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
     # goes, supcl_model.py:841; that only paces the host, the values are the same)
     scalars = torch.stack([total.detach(), gG.detach(), gF.detach()] + layer_losses).tolist()
     per_layer = OrderedDict((str(layer), v) for layer, v in zip(nce_layers, scalars[3:]))
+    # `out` detached: the backward has run, and a caller that keeps the record must not keep the autograd graph (and through it the
+    # parameters' AccumulateGrad nodes, bound to this stream) alive -- a later HIP-graph capture of the same modules would then run
+    # those nodes on the stream of THIS call, outside the capture
     return OrderedDict(loss=scalars[0], per_layer=per_layer, grad_norm_G=scalars[1], grad_norm_F=scalars[2], sample_ids=ids,
-                       out=out)
+                       out=out.detach() if torch.is_tensor(out) else out)
 
 
 class GraphedContrastiveStep:
@@ -143,7 +157,11 @@ class GraphedContrastiveStep:
     coordinates every replay), heads, losses, backward and the gradient norms; the optimizer steps too when every optimizer was
     built with ``capturable=True`` and no ``grad_sync`` is given.  With ``grad_sync`` (data parallel: the gradient
     all-reduce) the graph ends after the backward; the all-reduce, the norms and the optimizers run eagerly after it.
-    Returns the same OrderedDict as ``contrastive_step`` (ONE host synchronisation per call, for the scalars)."""
+    Returns the same OrderedDict as ``contrastive_step`` (ONE host synchronisation per call, for the scalars).
+
+    Torch's rule for graph capture applies: nothing alive at capture time may still reference an autograd graph of these modules
+    built on the default stream (e.g. a kept ``out`` / loss tensor of an eager step that has a ``grad_fn``) -- the parameters'
+    AccumulateGrad nodes would run there, outside the capture.  ``contrastive_step`` returns detached records for that reason."""
 
     def __init__(self, netG, netF, criterions, nce_layers, optimizers, nce_weights=None, num_patches=512, lambda_nce=1.0,
                  grad_sync=None, warmup=3, grad_buckets=None, tail_graph=True):
@@ -177,6 +195,9 @@ class GraphedContrastiveStep:
         return torch.stack([total.detach(), gG.detach(), gF.detach()] + layer_losses)
 
     def _capture(self, real_A, real_B, seg_A):
+        # autograd graphs of earlier eager steps that are only held by reference cycles still own the parameters' AccumulateGrad nodes,
+        # bound to the stream of those steps (usually the default stream, which cannot join a capture): collect them first
+        gc.collect()
         self.A, self.B, self.seg = real_A.clone(), real_B.clone(), seg_A.clone()
         side = torch.cuda.Stream(device=self.A.device)
         side.wait_stream(torch.cuda.current_stream(self.A.device))
@@ -191,7 +212,8 @@ class GraphedContrastiveStep:
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.total, self.layer_losses, self.ids, self.out = self._eager()
+            self.total, self.layer_losses, self.ids, out = self._eager()
+            self.out = out.detach() if torch.is_tensor(out) else out
             if self.grad_buckets is not None:
                 self.grad_buckets.collect()                 # part of every replay: fresh gradients -> the flat buckets
             if self.opt_in_graph or (self.grad_sync is None and self.optimizers is None):

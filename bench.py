@@ -406,9 +406,12 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         netF = netF.to(dev).train()
         nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
         crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
-        cap = not no_graph                            # capturable AdamW keeps its step count on the device
-        opts = (torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap),
-                torch.optim.AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, capturable=cap))
+        if os.environ.get("AMX_TORCH_ADAMW", "0") == "1":     # A/B: the stock optimizer (capturable keeps its step count on the device)
+            AdamW = lambda prm, **kw: torch.optim.AdamW(prm, capturable=not no_graph, **kw)
+        else:                                                 # same rule and state layout, one launch per optimizer (amx_adamw_step)
+            from anatomix_amd.pretraining import FusedAdamW as AdamW
+        opts = (AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5),
+                AdamW(netF.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5))
         vA, vB, seg = [t.to(dev) for t in PI.step_inputs(S)]
         vA = (vA + 0.01 * rank).clamp(0, 1)           # a different pair per rank
         # plain data parallel: the gradients of both networks live in flat buckets that RCCL averages in place

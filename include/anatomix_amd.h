@@ -229,6 +229,11 @@ int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int h
  * every low-resolution voxel).  One pass over d_dcat. */
 int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0, int c1,
                              int accumulate_skip, int precision, void* stream);
+/* The same with the reflect-padding adjoint (amx_pad_fold) applied while reading: d_g_framed is the data-gradient conv's raw result
+ * on the padded domain, [n][2 dlow + 4][2 hlow + 4][2 wlow + 4][c0 + c1]; the folded full-resolution gradient is never written and
+ * the children are summed in fp32 before the one rounding. */
+int amx_upcat_split_backward_framed(const void* d_g_framed, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0,
+                                    int c1, int accumulate_skip, int precision, void* stream);
 
 /* Layout conversions between the library's 16-bit channels-last activations and torch's fp32 NCDHW tensors, for the
  * feature taps of the differentiable forward (network.py:475-529 returns the taps as fp32 NCDHW tensors) and their
@@ -402,6 +407,26 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
  * d_coords int64 [num][3] receives the C-order coordinates of the first `num` distinct draws in draw order -- the same
  * distribution as a random permutation's head, without sorting every voxel.  num <= n_draws <= 4096.  One launch. */
 int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, int d1, int d2, long long* d_coords, void* stream);
+
+/* The optimizer step of the contrastive step: torch.optim.AdamW as the reference builds it for netG and netF
+ * (pretraining/models/supcl_model.py:510-516, 584-590; stepped at :628-661), every parameter tensor of one optimizer in ONE
+ * launch per 48 tensors.  `tensors` is a HOST array; every pointer in it is a device pointer to contiguous fp32 (step: one fp32
+ * scalar holding the step count t AFTER this step's increment -- torch's capturable state layout, so the call can be captured
+ * in a HIP graph and a state_dict moves between this and torch.optim.AdamW).  In place:
+ *   p *= 1 - lr wd;  m += (g - m)(1 - beta1);  v = v beta2 + (1 - beta2) g g;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)            (maximize: g -> -g).  amsgrad is not offered.
+ * The hyper-parameters are doubles because torch holds them as Python floats: 1 - beta2, 1 - lr wd and the bias corrections are
+ * formed in double and rounded once (1 - 0.999f differs from (float)(1 - 0.999) by 1.3e-5). */
+typedef struct {
+  void* param;
+  const void* grad;
+  void* exp_avg;
+  void* exp_avg_sq;
+  const void* step;
+  long long numel;
+} amx_adamw_tensor;
+int amx_adamw_step(const amx_adamw_tensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int maximize, void* stream);
 
 /* ---- registration feature post-processing (what the reference does to the extracted features before the convex
  * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */

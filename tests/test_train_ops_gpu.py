@@ -203,3 +203,41 @@ def test_upcat_split_backward(device, prec):
     prev = torch.randn(n, d, h, w, c0).to(dt).to(device)
     acc, _ = T.upcat_split_backward(dcat, c0, c1, skip_into=prev.clone())
     assert torch.equal(acc, (prev.float() + dcat[..., :c0].float()).to(dt))
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("size", [(6, 4, 10), (2, 2, 2), (4, 8, 2), (16, 12, 20)])
+def test_upcat_split_backward_framed_is_pad_fold_then_split(device, prec, size):
+    """amx_upcat_split_backward_framed = amx_pad_fold followed by amx_upcat_split_backward, without the folded tensor in between:
+    the skip part is bit-identical (same sums, same rounding), the low-resolution part skips one rounding (fp32 over fold + children)."""
+    dt = DT[prec]
+    torch.manual_seed(sum(size))
+    n, c0, c1 = 2, 16, 24
+    d, h, w = size
+    g = torch.randn(n, d + 4, h + 4, w + 4, c0 + c1).to(dt).to(device)
+    folded = T.pad_fold(g)
+    dskip_ref, dlow_ref = T.upcat_split_backward(folded, c0, c1)
+    dskip, dlow = T.upcat_split_backward_framed(g, c0, c1)
+    assert torch.equal(dskip, dskip_ref)
+    # the float64 value of fold + child sum
+    gd = g.double()
+    ref = _fold64(gd, d, h, w)[..., c0:].reshape(n, d // 2, 2, h // 2, 2, w // 2, 2, c1).sum((2, 4, 6))
+    err = (dlow.double() - ref).abs().max().item()
+    assert err <= ULP[prec] * 2 * ref.abs().max().item(), err
+    assert (dlow.float() - dlow_ref.float()).abs().max().item() <= ULP[prec] * 8 * ref.abs().max().item()
+    prev = torch.randn(n, d, h, w, c0).to(dt).to(device)
+    acc, _ = T.upcat_split_backward_framed(g, c0, c1, skip_into=prev.clone())
+    want = prev.double() + _fold64(gd, d, h, w)[..., :c0]            # one rounding of prev + fold (the two-pass form rounds the fold first)
+    assert (acc.double() - want).abs().max().item() <= ULP[prec] * want.abs().max().item()
+
+
+def _fold64(gd, d, h, w):
+    """Adjoint of reflect padding by one voxel, in float64, on a [N, D+4, H+4, W+4, C] tensor: padded coordinate j sits at framed
+    index j + 2; voxel 1 collects j = -1, voxel L-2 collects j = L."""
+    out = gd
+    for ax, L in ((1, d), (2, h), (3, w)):
+        core = out.narrow(ax, 2, L).clone()
+        core.narrow(ax, 1, 1).add_(out.narrow(ax, 1, 1))
+        core.narrow(ax, L - 2, 1).add_(out.narrow(ax, L + 2, 1))
+        out = core
+    return out
