@@ -87,6 +87,7 @@ SYMBOLS = {
     "amx_bn_train_forward": (_I, [_P, _P, _P, _P, C.c_float, _I, C.c_longlong, _I, _I, C.c_float, _P, _P, _P, _P, _P,
                                   C.c_float, _I, _P]),
     "amx_bn_act_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
+    "amx_bn_act_backward_recompute": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     "amx_pad_fold": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_adamw_step": (_I, [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     "amx_pool2_max_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

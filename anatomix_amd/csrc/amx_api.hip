@@ -66,8 +66,8 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
                                    int act, float slope, void* scratch, float* save_mean, float* save_rstd, float* running_mean,
                                    float* running_var, float momentum, int precision, hipStream_t st);
 hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                                  const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
-                                  int C, int act, float slope, void* scratch, int precision, hipStream_t st);
+                                  const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx_framed, int N, int D,
+                                  int H, int W, int C, int act, float slope, void* scratch, int precision, hipStream_t st);
 hipError_t launch_adamw(const long long* table, int count, double lr, double b1, double b2, double eps, double wd, int maximize,
                         hipStream_t st);
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
@@ -1182,8 +1182,18 @@ int amx_bn_act_backward(const void* d_dy, const void* d_y, const void* d_x, cons
                         int c, int act, float slope, void* d_scratch, int precision, void* stream) {
   if (!d_dy || !d_y || !d_dx_framed || !d_scratch || c % 8 || c > 2048) return fail(AMX_ERR_INVALID, "bad argument");
   if (d_mean && (!d_x || !d_rstd || !d_dgamma || !d_dbeta)) return fail(AMX_ERR_INVALID, "norm backward needs x, rstd, dgamma, dbeta");
-  AMX_HIP(amx::launch_bn_act_backward(d_dy, d_y, d_x ? d_x : d_y, d_mean, d_rstd, d_gamma, d_dgamma, d_dbeta, d_dx_framed, n, d, hh,
-                                      w, c, act, slope, d_scratch, precision, (hipStream_t)stream));
+  AMX_HIP(amx::launch_bn_act_backward(d_dy, d_y, d_x ? d_x : d_y, d_mean, d_rstd, d_gamma, nullptr, d_dgamma, d_dbeta, d_dx_framed, n,
+                                      d, hh, w, c, act, slope, d_scratch, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_bn_act_backward_recompute(const void* d_dy, const void* d_x, const float* d_mean, const float* d_rstd, const float* d_gamma,
+                                  const float* d_beta, float* d_dgamma, float* d_dbeta, void* d_dx_framed, int n, int d, int hh, int w,
+                                  int c, int act, float slope, void* d_scratch, int precision, void* stream) {
+  if (!d_dy || !d_x || !d_mean || !d_rstd || !d_dgamma || !d_dbeta || !d_dx_framed || !d_scratch || c % 8 || c > 2048)
+    return fail(AMX_ERR_INVALID, "bad argument");
+  AMX_HIP(amx::launch_bn_act_backward(d_dy, nullptr, d_x, d_mean, d_rstd, d_gamma, d_beta, d_dgamma, d_dbeta, d_dx_framed, n, d, hh, w,
+                                      c, act, slope, d_scratch, precision, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -211,18 +211,25 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const char* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restrict__ dy, const char* __restrict__ y,
                                                           const char* __restrict__ x, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, float* __restrict__ partial,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ partial,
                                                           long long rows, int C, int act, float slope) {
   extern __shared__ float red[];
   const int c8n = C >> 3;
   const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
   const long long per = (rows + gridDim.x - 1) / gridDim.x;
   const long long v0 = (long long)blockIdx.x * per, v1 = v0 + per < rows ? v0 + per : rows;
-  float mu[8], rs[8];
+  // y == nullptr: the activation's argument is RECOMPUTED from x, z = a x + b with the forward's coefficients (a = rstd gamma,
+  // b = beta - mean rstd gamma, the expressions of bn_finalize_kernel) -- act' only needs its sign, and sign(y) = sign(z) -- so the
+  // pass reads two tensors instead of three
+  float mu[8], rs[8], af[8], bf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     mu[e] = mean ? mean[c8 * 8 + e] : 0.f;
     rs[e] = rstd ? rstd[c8 * 8 + e] : 1.f;
+    const float gm = gamma ? gamma[c8 * 8 + e] : 1.f;
+    af[e] = rs[e] * gm;
+    bf[e] = (beta ? beta[c8 * 8 + e] : 0.f) - mu[e] * rs[e] * gm;
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (vrow < nrow)
@@ -230,8 +237,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restric
       float g[8], yy[8], xx[8];
       const long long o = (v * C + c8 * 8) * 2;
       t_unpack8<T>(*(const uint4*)(dy + o), g);
-      t_unpack8<T>(*(const uint4*)(y + o), yy);
       t_unpack8<T>(*(const uint4*)(x + o), xx);
+      if (y) {
+        t_unpack8<T>(*(const uint4*)(y + o), yy);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yy[e] = xx[e] * af[e] + bf[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float dz = g[e];
@@ -290,19 +302,22 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ y,
                                                           const char* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                          char* __restrict__ dxf, int N, int D, int H, int W, int C, int act,
-                                                          float slope) {
-  extern __shared__ float coef[];                            // [C][3]
+                                                          const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta, char* __restrict__ dxf, int N, int D, int H,
+                                                          int W, int C, int act, float slope) {
+  extern __shared__ float coef[];                            // [C][5]: a, b, k of dx and the forward's (a_f, b_f) for y == nullptr
   const float invM = 1.f / ((float)N * D * H * W);
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 1.f, b = 0.f, k = 0.f;
+    float a = 1.f, b = 0.f, k = 0.f, a_f = 1.f, b_f = 0.f;
     if (mean) {
-      a = (gamma ? gamma[c] : 1.f) * rstd[c];
+      const float gm = gamma ? gamma[c] : 1.f;
+      a = gm * rstd[c];
       b = -a * rstd[c] * dgamma[c] * invM;
       k = -a * dbeta[c] * invM - b * mean[c];
+      a_f = rstd[c] * gm;
+      b_f = (beta ? beta[c] : 0.f) - mean[c] * rstd[c] * gm;
     }
-    coef[3 * c] = a; coef[3 * c + 1] = b; coef[3 * c + 2] = k;
+    coef[5 * c] = a; coef[5 * c + 1] = b; coef[5 * c + 2] = k; coef[5 * c + 3] = a_f; coef[5 * c + 4] = b_f;
   }
   __syncthreads();
   const int row = blockIdx.x;                                // (n * D + z) * H + y
@@ -314,16 +329,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     const int c8 = i % c8n;
     float g[8], yv[8], xv[8];
     t_unpack8<T>(*(const uint4*)(dy + in_off + (size_t)i * 16), g);
-    t_unpack8<T>(*(const uint4*)(y + in_off + (size_t)i * 16), yv);
     if (mean) t_unpack8<T>(*(const uint4*)(x + in_off + (size_t)i * 16), xv);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) xv[e] = 0.f;              // bare activation adjoint: coefficients are (1, 0, 0)
     }
+    if (y) {
+      t_unpack8<T>(*(const uint4*)(y + in_off + (size_t)i * 16), yv);
+    } else {                                                 // recomputed argument of the activation (see bn_bwd_stats_kernel)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) yv[e] = xv[e] * coef[5 * (c8 * 8 + e) + 3] + coef[5 * (c8 * 8 + e) + 4];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float dz = act_bwd(g[e], yv[e], act_k(act, slope));
-      const float* q = coef + 3 * (c8 * 8 + e);
+      const float* q = coef + 5 * (c8 * 8 + e);
       g[e] = q[0] * dz + q[1] * xv[e] + q[2];               // no per-element test of `mean`
     }
     *(uint4*)(dxf + out_off + (size_t)i * 16) = t_pack8<T>(g);     // i = x * c8n + c8: the row is contiguous in the frame too
@@ -506,8 +526,9 @@ hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, c
 }
 
 hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                                  const float* gamma, float* dgamma, float* dbeta, void* dx_framed, int N, int D, int H, int W,
-                                  int C, int act, float slope, void* scratch, int precision, hipStream_t st) {
+                                  const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx_framed, int N, int D,
+                                  int H, int W, int C, int act, float slope, void* scratch, int precision, hipStream_t st) {
+  if (!y && !mean) return hipErrorInvalidValue;             // the activation's argument is either read (y) or recomputed from x
   if (C % 8 || C > 2048 || (long long)N * D * H * W * (C / 8) >= (1ll << 31)) return hipErrorInvalidValue;
   const long long rows = (long long)N * D * H * W;
   float* partial = (float*)scratch;
@@ -516,12 +537,12 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
 #define AMX_BNB(T)                                                                                                       \
   if (mean) {                                                                                                            \
     hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), lds, st, (const char*)dy, (const char*)y,          \
-                       (const char*)x, mean, rstd, partial, rows, C, act, slope);                                        \
+                       (const char*)x, mean, rstd, gamma, beta, partial, rows, C, act, slope);                           \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, C, nblk, dgamma, dbeta);    \
   }                                                                                                                      \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)(N * D * H)), dim3(256), (size_t)C * 3 * sizeof(float), st,  \
-                     (const char*)dy, (const char*)y, (const char*)x, mean, rstd, gamma, dgamma, dbeta, (char*)dx_framed, N, D, H, \
-                     W, C, act, slope)
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)(N * D * H)), dim3(256), (size_t)C * 5 * sizeof(float), st,  \
+                     (const char*)dy, (const char*)y, (const char*)x, mean, rstd, gamma, beta, dgamma, dbeta, (char*)dx_framed, N, D, \
+                     H, W, C, act, slope)
   if (precision == 0) { AMX_BNB(f16); } else { AMX_BNB(bf16); }
 #undef AMX_BNB
   return hipGetLastError();

@@ -27,6 +27,7 @@ _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "b
 
 
 OVERLAP_WGRAD = True           # weight gradients on a side stream, beside the data gradient of the same block
+RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
 FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
 _SIDE = {}
 
@@ -325,6 +326,7 @@ class _UnetTrainFn(torch.autograd.Function):
                     continue                                            # nothing downstream of this block was used
                 fr = frame((n, d, h, w), blk["cout"])
                 gam = None if bn.weight is None else bn.weight.detach()
+                bet = None if bn.bias is None else bn.bias.detach()
                 if dy is not None and blk.get("frozen"):
                     # du = dy * act'(y) (bare activation adjoint); d gamma / d beta from the recovered pre-activation u; then the
                     # gradient of the raw convolution output is a * du and everything downstream is the ordinary conv adjoint
@@ -339,13 +341,14 @@ class _UnetTrainFn(torch.autograd.Function):
                     du.mul_(blk["a"].to(dt))
                 elif dy is not None and isinstance(bn, nn.BatchNorm3d):
                     _, dgamma, dbeta = T.bn_act_backward(dy, blk["Y"], blk["X"], blk["mean"], blk["rstd"], gam,
-                                                         blk["act"], 0.3, framed=fr)
+                                                         blk["act"], 0.3, framed=fr, beta=bet, recompute=RECOMPUTE_ACT)
                     pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgamma, dbeta
                 elif dy is not None:                                    # InstanceNorm3d: per sample
                     dgs, dbs = [], []
                     for s_ in range(n):
                         _, dg_, db_ = T.bn_act_backward(dy[s_:s_ + 1], blk["Y"][s_:s_ + 1], blk["X"][s_:s_ + 1], blk["mean"][s_],
-                                                        blk["rstd"][s_], gam, blk["act"], 0.3, framed=fr[s_:s_ + 1])
+                                                        blk["rstd"][s_], gam, blk["act"], 0.3, framed=fr[s_:s_ + 1], beta=bet,
+                                                        recompute=RECOMPUTE_ACT)
                         dgs.append(dg_)
                         dbs.append(db_)
                     if bn.weight is not None:

@@ -102,8 +102,10 @@ def interior(framed):
     return framed[:, 2:-2, 2:-2, 2:-2, :]
 
 
-def bn_act_backward(dy, y, x, mean, rstd, gamma, act="relu", slope=0.3, framed=None):
-    """Adjoint of bn_train_forward (mean=None: of the bare activation).  Returns (dx_framed, dgamma, dbeta)."""
+def bn_act_backward(dy, y, x, mean, rstd, gamma, act="relu", slope=0.3, framed=None, beta=None, recompute=False):
+    """Adjoint of bn_train_forward (mean=None: of the bare activation).  Returns (dx_framed, dgamma, dbeta).
+    ``recompute`` (needs the norm's ``beta`` as the forward saw it): the activated output ``y`` is not read -- the sign act' needs is
+    recomputed from ``x`` (amx_bn_act_backward_recompute), two tensor reads per pass instead of three."""
     lib = _lib.load()
     dev = dy.device
     n, d, h, w, c = dy.shape
@@ -115,9 +117,14 @@ def bn_act_backward(dy, y, x, mean, rstd, gamma, act="relu", slope=0.3, framed=N
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         sc = _scratch(lib, dev, c)
-        _lib.check(lib.amx_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
-                                           _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(framed), n, d, h, w, c, ACT[act], slope,
-                                           _lib.ptr(sc), _PREC[dy.dtype], _st(dev)))
+        if recompute and mean is not None:
+            _lib.check(lib.amx_bn_act_backward_recompute(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                                                         _lib.ptr(beta), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(framed), n, d, h, w,
+                                                         c, ACT[act], slope, _lib.ptr(sc), _PREC[dy.dtype], _st(dev)))
+        else:
+            _lib.check(lib.amx_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                                               _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(framed), n, d, h, w, c, ACT[act], slope,
+                                               _lib.ptr(sc), _PREC[dy.dtype], _st(dev)))
     return framed, dgamma, dbeta
 
 

@@ -280,6 +280,14 @@ int amx_bn_train_forward(const void* d_x, void* d_y, const float* d_gamma, const
 int amx_bn_act_backward(const void* d_dy, const void* d_y, const void* d_x, const float* d_mean, const float* d_rstd,
                         const float* d_gamma, float* d_dgamma, float* d_dbeta, void* d_dx_framed, int n, int d, int hh, int w,
                         int c, int act, float slope, void* d_scratch, int precision, void* stream);
+/* The same adjoint of norm + activation WITHOUT reading the activated output: act' only needs the sign of its argument, and that
+ * argument is recomputed from the saved pre-norm tensor, z = a x + b with a = rstd gamma, b = beta - mean rstd gamma (the
+ * coefficients amx_bn_train_forward applied; d_gamma / d_beta NULL = 1 / 0).  Each of the two passes reads two tensors instead of
+ * three.  For relu / lrelu the result equals amx_bn_act_backward's wherever the stored y kept the sign of z (always in bf16; in f16
+ * except for |z| below its smallest subnormal). */
+int amx_bn_act_backward_recompute(const void* d_dy, const void* d_x, const float* d_mean, const float* d_rstd, const float* d_gamma,
+                                  const float* d_beta, float* d_dgamma, float* d_dbeta, void* d_dx_framed, int n, int d, int hh, int w,
+                                  int c, int act, float slope, void* d_scratch, int precision, void* stream);
 
 /* Adjoint of the reflect padding of nn.Conv3d(padding='same', padding_mode='reflect') (network.py:310-318).  The data
  * gradient of the conv is amx_conv3d_k3_reflect run on the framed (d+4)(h+4)(w+4) output gradient with the weights

@@ -57,6 +57,10 @@ def test_bn_train_forward_and_backward(device, prec, shape):
     assert not fz.any()                                            # the frame stays zero
     torch.testing.assert_close(dgamma.cpu().double(), gr.grad, rtol=2e-3, atol=2e-3 * gr.grad.abs().max().item())
     torch.testing.assert_close(dbeta.cpu().double(), br.grad, rtol=2e-3, atol=2e-3 * br.grad.abs().max().item())
+    # the variant that does not read y (amx_bn_act_backward_recompute): the sign act' needs comes from a x + b -- the same numbers
+    fr2, dg2, db2 = T.bn_act_backward(cl(dy, dt, device), None, cl(x, dt, device), mean, rstd, gamma.to(device), "relu",
+                                      beta=beta.to(device), recompute=True)
+    assert torch.equal(fr2, framed) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
