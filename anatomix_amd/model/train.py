@@ -28,6 +28,7 @@ _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "b
 
 OVERLAP_WGRAD = True           # weight gradients on a side stream, beside the data gradient of the same block
 RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
+SPLIT_CONCAT_DGRAD = int(os.environ.get("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
 _SIDE = {}
 
@@ -377,6 +378,19 @@ class _UnetTrainFn(torch.autograd.Function):
             if blk["in0"] == "x":
                 if ctx.needs_input_grad[1]:                             # d loss / d image: the stem's data gradient (channel 0 of
                     dx_in = T.conv_dgrad(fr, conv.weight)[..., 0].float().unsqueeze(1)   # the 16-channel padded result)
+                continue
+            if (x1 is not None and blk.get("cat_parts") is None and SPLIT_CONCAT_DGRAD and FUSED_FOLD_SPLIT
+                    and ((blk["cout"] == 16 and c0 == 16 and x1.shape[-1] == 32) or
+                         (SPLIT_CONCAT_DGRAD > 1 and c0 % 16 == 0 and x1.shape[-1] % 16 == 0))
+                    and tuple(conv.weight.shape[:2]) == (blk["cout"], c0 + x1.shape[-1])):
+                # the level-0 concat layer (48 -> 16): its data gradient is a 16 -> 48 convolution on the framed domain, which only the
+                # generic kernel takes as one launch (415 us at 128^3 x 2 views); as a 16 -> 16 (skip channels) and a 16 -> 32
+                # (upsampled channels) launch both halves run on the z-marching kernels, and the halves feed different consumers anyway
+                w = conv.weight.detach()
+                g_skip = T.conv_dgrad_framed(fr, w[:, :c0].contiguous())
+                g_up = T.conv_dgrad_framed(fr, w[:, c0:].contiguous())
+                grads[blk["in0"]] = T.pad_fold(g_skip, grads.get(blk["in0"]))
+                add_grad(blk["in1"], T.upcat_split_backward_framed(g_up, 0, x1.shape[-1])[1])
                 continue
             g_fr = T.conv_dgrad_framed(fr, conv.weight)
             if (x1 is not None and blk.get("cat_parts") is None and g_fr.shape[-1] == c0 + x1.shape[-1] and c0 % 8 == 0

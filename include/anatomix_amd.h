@@ -231,7 +231,7 @@ int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, in
                              int accumulate_skip, int precision, void* stream);
 /* The same with the reflect-padding adjoint (amx_pad_fold) applied while reading: d_g_framed is the data-gradient conv's raw result
  * on the padded domain, [n][2 dlow + 4][2 hlow + 4][2 wlow + 4][c0 + c1]; the folded full-resolution gradient is never written and
- * the children are summed in fp32 before the one rounding. */
+ * the children are summed in fp32 before the one rounding.  c0 == 0 (d_dskip may be NULL): the tensor has no skip part. */
 int amx_upcat_split_backward_framed(const void* d_g_framed, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0,
                                     int c1, int accumulate_skip, int precision, void* stream);
 

@@ -229,6 +229,8 @@ def test_upcat_split_backward_framed_is_pad_fold_then_split(device, prec, size):
     err = (dlow.double() - ref).abs().max().item()
     assert err <= ULP[prec] * 2 * ref.abs().max().item(), err
     assert (dlow.float() - dlow_ref.float()).abs().max().item() <= ULP[prec] * 8 * ref.abs().max().item()
+    _, low_only = T.upcat_split_backward_framed(g[..., c0:].contiguous(), 0, c1)       # no skip part at all
+    assert torch.equal(low_only, dlow)
     prev = torch.randn(n, d, h, w, c0).to(dt).to(device)
     acc, _ = T.upcat_split_backward_framed(g, c0, c1, skip_into=prev.clone())
     want = prev.double() + _fold64(gd, d, h, w)[..., :c0]            # one rounding of prev + fold (the two-pass form rounds the fold first)
