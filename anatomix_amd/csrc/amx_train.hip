@@ -55,8 +55,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* __restrict__ 
   float K[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (v0 < rows) t_unpack8<T>(*(const uint4*)(x + (v0 * C + c8 * 8) * 2), K);
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (vrow < nrow)
-    for (long long v = v0 + vrow; v < v1; v += nrow) {
+  if (vrow < nrow) {
+    long long v = v0 + vrow;
+    for (; v + 3ll * nrow < v1; v += 4ll * nrow) {          // four rows in flight; accumulated in row order (same sums as one by one)
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(x + ((v + (long long)u * nrow) * C + c8 * 8) * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        t_unpack8<T>(raw[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = f[e] - K[e];
+          s1[e] += d;
+          s2[e] += d * d;
+        }
+      }
+    }
+    for (; v < v1; v += nrow) {
       float f[8];
       t_unpack8<T>(*(const uint4*)(x + (v * C + c8 * 8) * 2), f);
 #pragma unroll
@@ -66,6 +83,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* __restrict__ 
         s2[e] += d * d;
       }
     }
+  }
   if (vrow < nrow)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -232,26 +250,43 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const char* __restric
     bf[e] = (beta ? beta[c8 * 8 + e] : 0.f) - mu[e] * rs[e] * gm;
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (vrow < nrow)
-    for (long long v = v0 + vrow; v < v1; v += nrow) {
-      float g[8], yy[8], xx[8];
-      const long long o = (v * C + c8 * 8) * 2;
-      t_unpack8<T>(*(const uint4*)(dy + o), g);
-      t_unpack8<T>(*(const uint4*)(x + o), xx);
-      if (y) {
-        t_unpack8<T>(*(const uint4*)(y + o), yy);
-      } else {
+  auto one_row = [&](const uint4& rg, const uint4& rx, const uint4& ry) {
+    float g[8], yy[8], xx[8];
+    t_unpack8<T>(rg, g);
+    t_unpack8<T>(rx, xx);
+    if (y) {
+      t_unpack8<T>(ry, yy);
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) yy[e] = xx[e] * af[e] + bf[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float dz = g[e];
-        dz = act_bwd(dz, yy[e], act_k(act, slope));
-        s1[e] += dz;
-        s2[e] += dz * (xx[e] - mu[e]) * rs[e];
-      }
+      for (int e = 0; e < 8; ++e) yy[e] = xx[e] * af[e] + bf[e];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float dz = g[e];
+      dz = act_bwd(dz, yy[e], act_k(act, slope));
+      s1[e] += dz;
+      s2[e] += dz * (xx[e] - mu[e]) * rs[e];
+    }
+  };
+  if (vrow < nrow) {
+    long long v = v0 + vrow;
+    for (; v + 3ll * nrow < v1; v += 4ll * nrow) {          // four rows in flight; accumulated in row order
+      uint4 rg[4], rx[4], ry[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long o = ((v + (long long)u * nrow) * C + c8 * 8) * 2;
+        rg[u] = *(const uint4*)(dy + o);
+        rx[u] = *(const uint4*)(x + o);
+        ry[u] = y ? *(const uint4*)(y + o) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one_row(rg[u], rx[u], ry[u]);
+    }
+    for (; v < v1; v += nrow) {
+      const long long o = (v * C + c8 * 8) * 2;
+      one_row(*(const uint4*)(dy + o), *(const uint4*)(x + o), y ? *(const uint4*)(y + o) : make_uint4(0, 0, 0, 0));
+    }
+  }
   if (vrow < nrow)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

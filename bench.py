@@ -483,7 +483,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
                    "point-to-point transfers of the touched planes; results stay sharded") if world > 1 else "1 GPU"
         elif workload == "step":
             workload_s = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
-                          "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; AdamW), bf16 "
+                          "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; " +
+                          ("torch.optim.AdamW" if os.environ.get("AMX_TORCH_ADAMW", "0") == "1" else "AdamW as one launch per optimizer") + "), bf16 "
                           "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels" +
                           ("" if no_graph else ", replayed from HIP graphs") + " (BASELINE configs[2])")
             par = f"data parallel x{world}: one pair per rank" + dp_note
