@@ -361,7 +361,8 @@ class _UnetTrainFn(torch.autograd.Function):
             # The weight gradient and the data gradient of a block both read `fr` and nothing else of each other: the weight
             # gradient goes to a side stream (result and scratch preallocated / cached on this one) and is joined before the next
             # block touches a framed buffer (they are shared per shape).  Letting it also run beside the next block's BatchNorm
-            # adjoint (second frame per shape + events) measured slower: 11.4 vs 10.7 ms per step.
+            # adjoint (second frame per shape + events) measured slower: 11.4 vs 10.7 ms per step in round 2, and again 9.04 vs 8.71 ms in
+            # round 3 with the one-round weight-gradient launches (the two MFMA kernels contend; the adjoint passes lose more than the join costs).
             if OVERLAP_WGRAD and x0.is_cuda:
                 dw = torch.empty((blk["cout"], blk["cin"], 3, 3, 3), dtype=torch.float32, device=x0.device)
                 T.wgrad_scratch(x0, x1, blk["cout"])                   # make sure the cached scratch exists (allocated here)
