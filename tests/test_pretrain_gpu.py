@@ -292,7 +292,8 @@ def test_graphed_step_with_gradient_sync_hook_runs_the_optimizers_eagerly():
     assert not torch.equal(w0, next(netG.parameters()).detach())
 
 
-def test_graphed_step_with_gradient_buckets():
+@pytest.mark.parametrize("optimizer", ["torch", "fused"])
+def test_graphed_step_with_gradient_buckets(optimizer):
     """The data-parallel shape bench.py runs for N > 1, exercised on one GPU: gradients are views into GradientBuckets' flat
     buffers, [graph 1: forward + backward + gather of the gradients into the buckets] -> bucket sync (the RCCL all-reduce; a
     no-op on one rank, forced through the same code path here) -> [graph 2: gradient norms + capturable AdamW]."""
@@ -313,7 +314,11 @@ def test_graphed_step_with_gradient_buckets():
     nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
     crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
     A, B, seg = [t.to(dev) for t in PI.step_inputs(64)]
-    opts = (torch.optim.AdamW(netG.parameters(), lr=1e-3, capturable=True), torch.optim.AdamW(netF.parameters(), lr=1e-3, capturable=True))
+    if optimizer == "fused":                                   # what bench.py builds: one amx_adamw_step launch per optimizer, reading the views
+        from anatomix_amd.pretraining import FusedAdamW
+        opts = (FusedAdamW(netG.parameters(), lr=1e-3), FusedAdamW(netF.parameters(), lr=1e-3))
+    else:
+        opts = (torch.optim.AdamW(netG.parameters(), lr=1e-3, capturable=True), torch.optim.AdamW(netF.parameters(), lr=1e-3, capturable=True))
     buckets = GradientBuckets((netG, netF), bucket_mb=8.0)
     assert 2 <= len(buckets.buckets) <= 8 and buckets.nbytes == 4 * sum(p.numel() for n in (netG, netF) for p in n.parameters())
     calls = []
