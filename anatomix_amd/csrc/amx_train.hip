@@ -112,14 +112,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const char* __restrict
                                                          float* running_mean, float* running_var, float momentum) {
   constexpr int FC = 2, FL = 128;                  // channels per block x lanes per channel
   __shared__ double sh[2][FC][FL];
-  __shared__ double smean[FC];
   const int cl = threadIdx.x % FC, l = threadIdx.x / FC;
   const int c = blockIdx.x * FC + cl;
   const long long per = (rows + nblk - 1) / nblk;
   const double inv_per = 1.0 / (double)per;
   // Slab b holds sums shifted by its own first element K_b: mean_b = K_b + s1 / n_b, M2_b = s2 - s1^2 / n_b.
   // Pass 1: total mean = sum n_b mean_b / N.  Pass 2: M2 = sum M2_b + n_b (mean_b - mean)^2.  Plain fp64 sums in a fixed
-  // order (lane l takes slabs l, l + 128, ...; the 128 lane sums are added in lane order) -- no division per slab, and
+  // order (lane l takes slabs l, l + 128, ...; the 128 lane sums are folded by a fixed pairwise tree) -- no division per slab, and
   // few enough slabs per lane that the scattered K_b loads do not serialise.
   double sn = 0.0, sm = 0.0;
   if (c < C)
@@ -135,16 +134,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const char* __restrict
   sh[0][cl][l] = sn;
   sh[1][cl][l] = sm;
   __syncthreads();
-  if (threadIdx.x < FC) {
-    double tn = 0.0, tm = 0.0;
-    for (int k = 0; k < FL; ++k) {
-      tn += sh[0][cl][k];
-      tm += sh[1][cl][k];
+  // fixed-order pairwise tree over the 128 lane sums (a serial walk by one thread was 256 dependent LDS reads = most of this kernel's time)
+  for (int s = FL / 2; s >= 1; s >>= 1) {
+    if (l < s) {
+      sh[0][cl][l] += sh[0][cl][l + s];
+      sh[1][cl][l] += sh[1][cl][l + s];
     }
-    smean[cl] = tn > 0.0 ? tm / tn : 0.0;
+    __syncthreads();
   }
+  const double cnt = sh[0][cl][0];
+  const double mean_all = cnt > 0.0 ? sh[1][cl][0] / cnt : 0.0;
   __syncthreads();
-  const double mean_all = smean[cl];
   double m2 = 0.0;
   if (c < C)
     for (int b = l; b < nblk; b += FL) {
@@ -156,16 +156,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const char* __restrict
       const double dm = (double)K + s1 * inb - mean_all;
       m2 += (s2 - s1 * s1 * inb) + nb * dm * dm;
     }
-  __syncthreads();
   sh[1][cl][l] = m2;
   __syncthreads();
-  if (threadIdx.x >= FC || c >= C) return;
-  double cnt = 0.0;
-  m2 = 0.0;
-  for (int k = 0; k < FL; ++k) {
-    cnt += sh[0][cl][k];
-    m2 += sh[1][cl][k];
+  for (int s = FL / 2; s >= 1; s >>= 1) {
+    if (l < s) sh[1][cl][l] += sh[1][cl][l + s];
+    __syncthreads();
   }
+  if (threadIdx.x >= FC || c >= C) return;
+  m2 = sh[1][cl][0];
   const double mean = mean_all;
   double var = m2 / cnt;
   var = var < 0.0 ? 0.0 : var;
@@ -320,14 +318,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   sh[0][cl][l] = a;
   sh[1][cl][l] = b;
   __syncthreads();
-  if (threadIdx.x >= 8 || c >= C) return;
-  a = 0.0; b = 0.0;
-  for (int k = 0; k < 32; ++k) {
-    a += sh[0][cl][k];
-    b += sh[1][cl][k];
+  for (int s = 16; s >= 1; s >>= 1) {                       // fixed pairwise tree over the 32 lane sums
+    if (l < s) {
+      sh[0][cl][l] += sh[0][cl][l + s];
+      sh[1][cl][l] += sh[1][cl][l + s];
+    }
+    __syncthreads();
   }
-  dbeta[c] = (float)a;
-  dgamma[c] = (float)b;
+  if (threadIdx.x >= 8 || c >= C) return;
+  dbeta[c] = (float)sh[0][cl][0];
+  dgamma[c] = (float)sh[1][cl][0];
 }
 
 // dx into the interior of the framed buffer [N][D+4][H+4][W+4][C].  One block per (n, z, y) row: the row decomposition
