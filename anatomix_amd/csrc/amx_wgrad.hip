@@ -288,6 +288,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// nchunk <= 16 (the wide layers: 16 or more channel-tile pairs share the 256 workgroups): one thread per element walks the chunks in
+// order.  The same sums as the kernel above -- there every chunk lane holds at most one chunk and the lane sums are added in lane
+// order -- without 27 648 blocks of 16 elements each (75 -> ~10 us on 128 -> 128).
+__global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
+                                                              int Cin, int CinPad, int nchunk, int accumulate) {
+  const int ncit = CinPad / 16, npairs = (Cout / 16) * ncit;
+  const long long E = (long long)npairs * 27 * 256;
+  const long long ee = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (ee >= E) return;
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = c < nchunk ? partial[(size_t)c * E + ee] : 0.f;
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t += v[c];
+  const int ci16 = ee % 16, co16 = (ee / 16) % 16, tap = (ee / 256) % 27, pair = ee / (256 * 27);
+  const int co = (pair / ncit) * 16 + co16, ci = (pair % ncit) * 16 + ci16;
+  if (ci < Cin) {
+    float* o = dw + ((long long)co * Cin + ci) * 27 + tap;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
 static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* nitems, int* nchunk, int* ipc, int* nyt) {
   const int ty = wg_ty((W + 31) / 32 * 32);
   *nyt = (H + ty - 1) / ty;
@@ -350,8 +373,12 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
 #undef AMX_WG2
 #undef AMX_WG
   const long long E = (long long)npairs * 27 * 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 15) / 16)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
-                     CinReal, CinPad, nchunk, accumulate);
+  if (nchunk <= 16)
+    hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
+                       CinReal, CinPad, nchunk, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 15) / 16)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
+                       CinReal, CinPad, nchunk, accumulate);
   return hipGetLastError();
 }
 

@@ -14,7 +14,9 @@ def short(n):
 
 
 # steps: the AdamW kernel of the network closes a step; use the LAST kernel name of the trace as the marker
-mk = [i for i, k in enumerate(ks) if re.search(r"multi_tensor_apply|adam", k[2])]
+mk = [i for i, k in enumerate(ks) if "adamw_kernel" in k[2]]          # FusedAdamW: the last launch of a step
+if not mk:
+    mk = [i for i, k in enumerate(ks) if re.search(r"multi_tensor_apply|adam", k[2])]
 if mk:                                                   # a step ends with the last optimizer kernel of a cluster
     ends = [i for i, j in zip(mk, mk[1:] + [10 ** 9]) if j > i + 50]
     marker = ks[mk[-1]][2]
