@@ -14,7 +14,10 @@ ACT = {"none": 0, "relu": 1, "lrelu": 2}
 POOL = {"Max": 0, "Avg": 1}
 INTERP = {"nearest": 0, "trilinear": 1}
 # "strict" = bf16x2: split hi + lo operands, fp32-grade results with fp32's exponent range (include/anatomix_amd.h)
-PRECISION = {"f16": 0, "fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1, "f16x2": 2, "bf16x2": 3, "strict": 3, "fp32": 3}
+# "f16x2mx" (alias "strict_mx") = f16 hi + lo pairs whose correction products run on the block-scaled fp8 MFMA (2 instead of 3 MFMA-
+# equivalents per product); implemented for the InstanceNorm configurations, where it is the default (Unet.precision)
+PRECISION = {"f16": 0, "fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1, "f16x2": 2, "bf16x2": 3, "strict": 3, "fp32": 3,
+             "f16x2mx": 4, "strict_mx": 4}
 
 
 class UnetCfg(C.Structure):

@@ -15,6 +15,8 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
                                int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0,
                                int C0Real = 0, int C0Phys = 0);
+hipError_t launch_pack_weights_mx(const float* w, const float* scale, void* wpk, int* mxs, int CinReal, int CinPad, int Cout, int Q,
+                                  hipStream_t st, int CoutReal = 0, int CinStride = 0, int C0Real = 0, int C0Phys = 0);
 size_t conv_upmerge_packed_bytes(int C1, int Cout, int split);
 bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split);
 hipError_t launch_conv_upmerge(const UpmergeParams& p, int precision, hipStream_t st);
@@ -25,7 +27,7 @@ hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* 
                             const float* conv_bias, float eps, int C, float* scale, float* shift,
                             hipStream_t st);
 hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo, int C, int avg,
-                        int precision, hipStream_t st);
+                        int precision, hipStream_t st, int skip_lo = 0);
 hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long long voxels, hipStream_t st);
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
@@ -46,7 +48,7 @@ bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
 int last_conv_stats_slots();
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
-                           const float* kshift = nullptr);
+                           const float* kshift = nullptr, int W = 0, int skip_lo = 0);
 size_t attention_scratch_bytes(int b, int heads, int n);
 void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void** Kp, void** Vt, int* npad_out, int* nblk_pad_out);
 hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st);
@@ -55,7 +57,7 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, cons
                             float* out, void* scratch, hipStream_t st);
 hipError_t launch_poison_if_flag(const int* flag, int* host_flag, float* y, long long count, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
-                                      hipStream_t st);
+                                      hipStream_t st, int skip_lo = 0);
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
                              float slope, int precision, hipStream_t st, int* oflow = nullptr);
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
@@ -156,6 +158,7 @@ struct ConvLayer {
   float* shift = nullptr; // epilogue bias
   // eval-BatchNorm layers only: UNFOLDED weights + the norm's own shift, for forwards that tap the pre-norm output
   void* wpk_raw = nullptr;
+  int* mxs = nullptr;     // AMX_PREC_F16X2_MX: {E8M0 block-scale word of the fp8 weights, scratch for their maximum}
   bool raw_has_bias = false;  // conv bias under BatchNorm (the reference never builds that: use_bias == (norm=='instance'))
   bool loaded = false;
 };
@@ -297,11 +300,17 @@ struct Arena {
 };
 
 // strict precision (AMX_PREC_F16X2 / AMX_PREC_BF16X2): every stored voxel holds [hi(C) | lo(C)] 16-bit channels
+// AMX_PREC_F16X2_MX: the pair plus 2 bytes of e4m3 copies per channel (amx_common.h, voxel layout FMT 2)
 inline bool is_split(int precision) { return precision >= AMX_PREC_F16X2; }
+inline bool is_mx(int precision) { return precision == AMX_PREC_F16X2_MX; }
+inline long long elem_bytes(int precision) { return amx::fmt_elem_bytes(amx::fmt_of_precision(precision)); }
+inline bool f16_stored(int precision) { return precision == AMX_PREC_F16 || precision == AMX_PREC_F16X2 || precision == AMX_PREC_F16X2_MX; }
+// kernels without an fp8 stage of their own (the single-channel stem: its operand is the fp32 input) run their f16x2 variant
+inline int stem_precision(int precision) { return is_mx(precision) ? AMX_PREC_F16X2 : precision; }
 
 size_t level_bytes(const amx_unet* h, int level, int n, int d, int hh, int w) {
   const size_t vox = (size_t)(d >> level) * (hh >> level) * (w >> level);
-  return align_up((size_t)n * vox * level_channels(h, level) * 2 * (is_split(h->cfg.precision) ? 2 : 1), 256);
+  return align_up((size_t)n * vox * level_channels(h, level) * (size_t)elem_bytes(h->cfg.precision), 256);
 }
 
 // InstanceNorm scratch of a forward: the separate statistics pass needs 65536 entries per sample; a conv epilogue that writes the
@@ -348,8 +357,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
   // two run once per window (windows overlap: their accumulations must stay ordered on the stream); every layer
   // in between runs on the whole batch of windows.
   const amx_unet_cfg& c = h->cfg;
-  const bool split = is_split(c.precision);
-  const long long eb = split ? 4 : 2;          // bytes per stored channel value (hi + lo halves in strict precision)
+  const bool split = is_split(c.precision), mx = is_mx(c.precision);
+  const long long eb = elem_bytes(c.precision);   // bytes per stored channel value (hi + lo halves in strict precision, + 2 of e4m3 copies)
   if (int e = check_shape(h, n, d, hh, w)) return e;
   for (const ConvLayer& L : h->convs)
     if (!L.loaded) return fail(AMX_ERR_NOT_LOADED, "conv model.%d has no parameters", L.module_idx);
@@ -399,6 +408,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     return nullptr;
   };
   const int stop = taps ? taps->stop : -1;
+  // f16x2mx: a tensor whose only reader is the convolution at module `nxt` needs no lo plane (convolutions read hi and the e4m3 copies);
+  // feature taps read the pair, so any tap request keeps every plane
+  auto conv_only = [&](size_t nxt) -> int { return mx && !taps && nxt < h->kinds.size() && h->kinds[nxt] == K_CONV; };
   // tap = fp32 NCDHW copy of a stored 16-bit tensor
   auto export_slot = [&](const Tensor& t, float* dst) -> hipError_t {
     return amx::launch_export_ncdhw(A.slot[t.level][t.slot], t.Cr, nullptr, 0, 0, n, d >> t.level, hh >> t.level, w >> t.level,
@@ -428,29 +440,32 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         const Tensor& lo = cur;
         // nearest: `lo` is the half-resolution tensor, read through >> 1; trilinear: already materialised at this level
         const int lw = cur_is_full_up ? dw : dw / 2, lh = cur_is_full_up ? dh : dh / 2, ld = cur_is_full_up ? dd : dd / 2;
+        // row-planar layout of f16x2mx (amx_common.h FMT 2): a voxel's 32-byte pieces are 32 bytes apart along x and one row
+        // plane (W * 32 bytes) apart per 16-channel chunk; rows, planes and samples keep their channels-last sizes
         const long long lx = (long long)lo.C * eb, ly = lx * lw, lz = ly * lh;
         p.up_shift = cur_is_full_up ? 0 : 1;
         if (have_skip) {
           const long long sx = (long long)pend_skip.C * eb, sy = sx * dw, sz = sy * dh;
           p.src0 = A.slot[pend_skip.level][pend_skip.slot];
-          p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = pend_skip.C;
+          p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = mx ? 32 : sx; p.C0 = pend_skip.C; p.cs0 = mx ? dw * 32 : 32;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = mx ? 32 : lx; p.C1 = lo.C; p.cs1 = mx ? lw * 32 : 32;
         } else {  // no skip connection: the whole input is the upsampled tensor
           p.src0 = A.slot[lo.level][lo.slot];  // unused segment of zero channels
           p.C0 = 0;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = lx; p.C1 = lo.C;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = mx ? 32 : lx; p.C1 = lo.C; p.cs1 = mx ? lw * 32 : 32;
         }
       } else {
         const long long sx = (long long)cur.C * eb, sy = sx * dw, sz = sy * dh;
         p.src0 = A.slot[cur.level][cur.slot];
-        p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = sx; p.C0 = cur.C; p.C1 = 0;
+        p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = mx ? 32 : sx; p.C0 = cur.C; p.C1 = 0; p.cs0 = mx ? dw * 32 : 32;
       }
       if (p.C0 + p.C1 != L.cin_pad)
         return fail(AMX_ERR_INVALID, "internal: conv model.%d expects %d channels, schedule has %d",
                     L.module_idx, L.cin_pad, p.C0 + p.C1);
       p.wpk = (const char*)L.wpk;
+      p.mxs = L.mxs;
       p.bias = L.shift;
       p.oflow = h->d_flag;
       const bool inorm = L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE);
@@ -496,6 +511,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
         p.out = A.slot[lv][out.slot];
         p.ox = (long long)L.cout_p * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
+        if (mx) { p.ox = 32; p.ocs = dw * 32; }
       }
       if (prof) {
         amx_launch_record r;
@@ -552,7 +568,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
                               amx::conv_fuses_stats(p, c.precision, L.q);
       if (fuse_stats) p.stats = (float*)in_scratch;
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
-        if (q.src0_f32c1) return amx::launch_conv_stem(q, c.precision, st);
+        if (q.src0_f32c1) return amx::launch_conv_stem(q, stem_precision(c.precision), st);
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
         return amx::launch_conv(q, c.precision, L.q, st);
       };
@@ -610,7 +626,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         }
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
                                      L.cout_p, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
-                                     fuse_stats ? amx::last_conv_stats_slots() : 0, fuse_stats ? L.shift : nullptr));
+                                     fuse_stats ? amx::last_conv_stats_slots() : 0, fuse_stats ? L.shift : nullptr, dw,
+                                     conv_only(i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0))));
       }
       if (final_via_export)
         AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st, L.cout_p, 0));
@@ -663,7 +680,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
       AMX_HIP(amx::launch_pool2(A.slot[cur.level][cur.slot], A.slot[lv][out.slot], n, d >> lv, hh >> lv,
-                                w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st));
+                                w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st, conv_only(i + 1)));
       // the pooled-from tensor stays alive only if it was pushed as a skip
       bool is_skip = false;
       for (const Tensor& s : skips)
@@ -689,7 +706,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_upsample2_trilinear(A.slot[cur.level][cur.slot], A.slot[lv][up.slot], n, d >> cur.level,
-                                                hh >> cur.level, w >> cur.level, cur.C, c.precision, st));
+                                                hh >> cur.level, w >> cur.level, cur.C, c.precision, st, conv_only(i + 1)));
         A.used[cur.level][cur.slot] = false;
         cur = up;
         cur_is_full_up = true;
@@ -724,7 +741,7 @@ int pending_numerics_error(amx_unet* h) {
     *(volatile int*)h->h_flag = 0;      // the device slots are per forward and cleared by their own forwards
     return fail(AMX_ERR_OVERFLOW, "a previous forward of this network produced values outside the f16 range (or NaN) in %s storage; "
                 "its output was overwritten with NaN.  Use precision bf16 or strict (bf16x2), which keep fp32's exponent range",
-                h->cfg.precision == AMX_PREC_F16X2 ? "f16x2" : "f16");
+                h->cfg.precision == AMX_PREC_F16X2 ? "f16x2" : (is_mx(h->cfg.precision) ? "f16x2mx" : "f16"));
   }
   return AMX_OK;
 }
@@ -735,14 +752,14 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
                 hipStream_t st, Profiler* prof = nullptr, const long long* x_offs = nullptr,
                 const long long* y_offs = nullptr, const TapReq* taps = nullptr) {
   if (int e = pending_numerics_error(h)) return e;
-  const bool f16_store = h->cfg.precision == AMX_PREC_F16 || h->cfg.precision == AMX_PREC_F16X2;
+  const bool f16_store = f16_stored(h->cfg.precision);
   if (h->d_flags) {
     h->d_flag = h->d_flags + (h->flag_next++ % amx_unet::kFlagSlots);
     if (f16_store) AMX_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   }
   int rc = run_forward_impl(h, x, xs_n, xs_z, xs_y, y, ys_n, ys_c, ys_z, ys_y, wmap, n, d, hh, w, ws, ws_bytes, st, prof, x_offs,
                             y_offs, taps);
-  const bool f16_storage = h->cfg.precision == AMX_PREC_F16 || h->cfg.precision == AMX_PREC_F16X2;
+  const bool f16_storage = f16_stored(h->cfg.precision);
   if (rc == AMX_OK && f16_storage && h->d_flag) {
     // the output tensor (plain forward: dense [n][Cout][d][hh][w]; windows: the accumulation volume is the caller's, its
     // extent is not known here -- the flag and the status call cover that path) is poisoned when the flag is up
@@ -787,8 +804,15 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
   if (cfg->activation < AMX_ACT_NONE || cfg->activation > AMX_ACT_LRELU || cfg->final_act < AMX_ACT_NONE ||
       cfg->final_act > AMX_ACT_LRELU)
     return fail(AMX_ERR_INVALID, "unsupported activation");
-  if (cfg->precision < AMX_PREC_F16 || cfg->precision > AMX_PREC_BF16X2)
+  if (cfg->precision < AMX_PREC_F16 || cfg->precision > AMX_PREC_F16X2_MX)
     return fail(AMX_ERR_INVALID, "unsupported precision %d", cfg->precision);
+  // the fp8 correction stages exist in the generic kernel only; the consumers of a conv's output must be passes that write the e4m3
+  // copies (norm apply, pool, upsample) -- i.e. networks that normalise with live statistics, the ones that need a strict mode at all
+  if (is_mx(cfg->precision) && cfg->norm != AMX_NORM_INSTANCE && cfg->norm != AMX_NORM_INSTANCE_AFFINE)
+    return fail(AMX_ERR_INVALID, "precision f16x2mx is implemented for the InstanceNorm configurations (norm='instance' / 'instance_affine'); "
+                "use 'strict' (bf16x2) for this network");
+  if (is_mx(cfg->precision) && cfg->input_nc != 1)
+    return fail(AMX_ERR_INVALID, "precision f16x2mx needs input_nc == 1 (got %d)", cfg->input_nc);
   amx_unet* h = new amx_unet();
   h->cfg = *cfg;
   build_plan(h);
@@ -810,7 +834,8 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
       e = hipMalloc(&L.wpk_up, amx::conv_upcat16_packed_bytes());
     // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
     // that are at least 32 voxels wide at the reference operating point
-    if (e == hipSuccess && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr && L.cout_p == L.cout &&
+    if (e == hipSuccess && is_mx(cfg->precision)) e = hipMalloc((void**)&L.mxs, 2 * sizeof(int));
+    if (e == hipSuccess && !is_mx(cfg->precision) && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr && L.cout_p == L.cout &&
         amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1, is_split(cfg->precision))) {
       e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2 * (is_split(cfg->precision) ? 2 : 1));
       if (e == hipSuccess) e = hipMalloc(&L.wpk_merge, amx::conv_upmerge_packed_bytes(L.cin - L.cout, L.cout, is_split(cfg->precision)));
@@ -855,6 +880,7 @@ void amx_unet_destroy(amx_unet_t* h) {
     if (L.wpk) (void)hipFree(L.wpk);
     if (L.wpk_up) (void)hipFree(L.wpk_up);
     if (L.wpk_raw) (void)hipFree(L.wpk_raw);
+    if (L.mxs) (void)hipFree(L.mxs);
     if (L.wpk_skip) (void)hipFree(L.wpk_skip);
     if (L.wpk_merge) (void)hipFree(L.wpk_merge);
     if (L.scale) (void)hipFree(L.scale);
@@ -896,8 +922,10 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
       AMX_HIP(hipMemcpyAsync(L.in_beta, d_beta, L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     if (L.cin == 1 && &L == &h->convs[0]) {   // stem: 27 taps packed into one K = 32 MFMA step
-      AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout_p, h->cfg.precision, st, L.cout));
-      if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout_p, h->cfg.precision, st, L.cout));
+      AMX_HIP(amx::launch_pack_stem(d_weight, L.scale, L.wpk, L.cout_p, stem_precision(h->cfg.precision), st, L.cout));
+      if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout_p, stem_precision(h->cfg.precision), st, L.cout));
+    } else if (is_mx(h->cfg.precision)) {
+      AMX_HIP(amx::launch_pack_weights_mx(d_weight, L.scale, L.wpk, L.mxs, L.cin, L.cin_pad, L.cout_p, L.q, st, L.cout, 0, L.c0_real, L.c0_p));
     } else {
       if (L.wpk_raw)
         AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, L.wpk_raw, L.cin, L.cin_pad, L.cout_p, L.q, h->cfg.precision, st, 0, L.cout,
@@ -1052,7 +1080,7 @@ size_t amx_conv3d_packed_bytes(int cin, int cout) {
   const int cin_pad = (cin + 15) / 16 * 16;
   size_t bytes = (size_t)cout * cin_pad * 28 * 2;
   if (cin == 48 && cout == 16) bytes = (bytes + 255) / 256 * 256 + amx::conv_upcat16_packed_bytes();
-  return 2 * bytes;     // room for the [Wh | Wl] packing of the strict precisions
+  return 2 * bytes + 256;     // room for the [Wh | Wl] packing of the strict precisions (+ the block-scale words of f16x2mx)
 }
 
 static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
@@ -1065,15 +1093,24 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
   if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
   if (d < 2 || hh < 2 || w < 2) return fail(AMX_ERR_SHAPE, "reflect padding needs >= 2 voxels per axis");
   hipStream_t st = (hipStream_t)stream;
-  if (precision < AMX_PREC_F16 || precision > AMX_PREC_BF16X2) return fail(AMX_ERR_INVALID, "unsupported precision %d", precision);
-  const long long eb = is_split(precision) ? 4 : 2;    // strict precision: x0 / x1 / out16 voxels hold [hi(C) | lo(C)]
+  if (precision < AMX_PREC_F16 || precision > AMX_PREC_F16X2_MX) return fail(AMX_ERR_INVALID, "unsupported precision %d", precision);
+  if (is_mx(precision) && weight_mode != 0) return fail(AMX_ERR_INVALID, "f16x2mx packs forward weights only");
+  // strict precision: x0 / x1 / out16 voxels hold [hi(C) | lo(C)]; f16x2mx: [hi(C) | lo(C) | e4m3 copies (2C bytes)] -- the INPUT
+  // voxels must carry valid copies (tests/_util.py to_ndhwc_mx), the output's copy section is left untouched
+  const long long eb = elem_bytes(precision);
   const int q = amx::conv_pick_q(cout, w);
   if (d_out32 && (q > 2 || w < 32)) return fail(AMX_ERR_INVALID, "fp32 planar output needs cout <= 32 and w >= 32");
   if (cin_real < 1 || cin_real > c0 + c1 || cout_real < 1 || cout_real > cout || (weight_mode != 0 && weight_mode != 1))
     return fail(AMX_ERR_INVALID, "bad weight description (mode %d, cin_real %d, cout_real %d)", weight_mode, cin_real, cout_real);
-  AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, cin_real, c0 + c1, cout, q, precision, st, weight_mode, cout_real));
   amx::ConvParams p;
   memset(&p, 0, sizeof p);
+  if (is_mx(precision)) {
+    int* mxs = (int*)((char*)d_wpk + align_up((size_t)cout * (c0 + c1) * 28 * 2 * 2, 256));
+    AMX_HIP(amx::launch_pack_weights_mx(d_weight, d_scale, d_wpk, mxs, cin_real, c0 + c1, cout, q, st, cout_real));
+    p.mxs = mxs;
+  } else {
+    AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, cin_real, c0 + c1, cout, q, precision, st, weight_mode, cout_real));
+  }
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
   p.src0 = (const char*)d_x0; p.C0 = c0;
   p.s0x = (long long)c0 * eb; p.s0y = p.s0x * w; p.s0z = p.s0y * hh; p.s0n = p.s0z * d;
@@ -1081,12 +1118,17 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     p.src1 = (const char*)d_x1; p.C1 = c1; p.up_shift = 1;
     p.s1x = (long long)c1 * eb; p.s1y = p.s1x * (w / 2); p.s1z = p.s1y * (hh / 2); p.s1n = p.s1z * (d / 2);
   }
+  if (is_mx(precision)) {      // row-planar tensors (amx_common.h FMT 2)
+    p.s0x = 32; p.cs0 = w * 32;
+    p.s1x = 32; p.cs1 = (w / 2) * 32;
+  }
   p.wpk = (const char*)d_wpk;
   p.bias = d_shift;
   p.act = act; p.slope = slope;
   if (d_out16) {
     p.out = (char*)d_out16;
     p.ox = (long long)cout * eb; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+    if (is_mx(precision)) { p.ox = 32; p.ocs = w * 32; }
   } else {
     p.out32 = d_out32;
     p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
@@ -1306,8 +1348,10 @@ int amx_instance_norm(void* d_x, const float* d_gamma, const float* d_beta, floa
                       int act, float slope, void* d_scratch, int precision, void* stream) {
   if (!d_x || !d_scratch || c % 8 || c > 2048 || n < 1 || voxels < 1) return fail(AMX_ERR_INVALID, "bad argument");
   if (!d_gamma != !d_beta) return fail(AMX_ERR_INVALID, "gamma and beta come together");
+  // f16x2mx (row-planar layout): this entry has no row length -- a sample is taken as ONE row of `voxels` voxels
+  if (precision == AMX_PREC_F16X2_MX && voxels > (1 << 24)) return fail(AMX_ERR_INVALID, "f16x2mx: at most 2^24 voxels per sample here");
   AMX_HIP(amx::launch_instnorm(d_x, d_gamma, d_beta, eps, n, voxels, c, act, slope, d_scratch, precision,
-                               (hipStream_t)stream));
+                               (hipStream_t)stream, nullptr, 0, nullptr, (int)voxels));
   return AMX_OK;
 }
 

@@ -59,7 +59,22 @@ struct ConvParams {
   int* oflow;                  // optional device flag: set to 1 when a value that is about to be stored in f16 is out of the
                                //   f16 range (|v| > 65504) or NaN -- see amx_unet_numerics_status (include/anatomix_amd.h)
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
+  const int* mxs;              // AMX_PREC_F16X2_MX: device word holding the E8M0 block-scale byte (x4) of this layer's fp8 weights
+  int cs0, cs1, ocs;           // byte stride between the 32-byte pieces (16-channel chunks) of one voxel in src0 / src1 / out; 0 = 32
+                               //   (channels-last voxels).  Voxel layout FMT 2 keeps a ROW's pieces of one chunk together: W * 32.
 };
+
+// Activation layouts (C stored channels; amx_norm.hip load8 / store8):
+//   FMT 0  channels-last voxels [v(C)]                one 16-bit value per channel                    2C bytes per voxel
+//   FMT 1  channels-last voxels [hi(C) | lo(C)]       strict: value = hi + lo                         4C bytes
+//   FMT 2  AMX_PREC_F16X2_MX: the f16 pair + e4m3 copies of hi and of 2^11 lo, 6C bytes per voxel, stored ROW-PLANAR: a row (n, z, y)
+//          of W voxels is 3 C/16 planes of W x 32 bytes -- plane k: hi of channels 16k .. 16k+15; C/16 + k: their lo; 2 C/16 + k: the
+//          copies [xl8(16) | xh8(16)] -- so that the 32 bytes per voxel a conv stage gathers are CONTIGUOUS along x.  (In channels-last
+//          voxels of 128 .. 6144 bytes a stage used 32 bytes of every cache line it touched: LDS-DMA ran at 11-15 B/clk/CU instead
+//          of 44-48, profiles/r03_dma_stride_ubench.txt, and bounded the generic kernel.)
+//          byte(n, z, y, x, plane P, b) = ((n D + z) H + y) * 6 C W + P * 32 W + 32 x + b
+__host__ __device__ constexpr int fmt_of_precision(int precision) { return precision < 2 ? 0 : (precision == 4 ? 2 : 1); }
+__host__ __device__ constexpr int fmt_elem_bytes(int fmt) { return fmt == 0 ? 2 : (fmt == 1 ? 4 : 6); }
 
 // Merged-tap convolution over the upsampled segment of a concat layer (amx_conv3d_upmerge.hip).
 struct UpmergeParams {

@@ -72,6 +72,79 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
   }
 }
 
+// ---- AMX_PREC_F16X2_MX: the correction operands of a layer as fp8 A fragments of v_mfma_scale_f32_16x16x128_f8f6f4 -------------
+// mxs[1] <- max |w * scale| of the layer (bit pattern of a non-negative float: atomicMax on the unsigned image is monotonic).
+__global__ void mx_absmax_kernel(const float* __restrict__ w, const float* __restrict__ scale, long long per_cout, long long total,
+                                 int* __restrict__ mxs) {
+  float m = 0.f;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    float v = w[idx];
+    if (scale) v *= scale[idx / per_cout];
+    v = __builtin_fabsf(v);
+    m = v > m ? v : m;            // (a NaN weight never wins: the packed values carry it anyway)
+  }
+  for (int o = 32; o; o >>= 1) {
+    const float t = __shfl_xor(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)(mxs + 1), __builtin_bit_cast(unsigned, m));
+}
+// Sw = floor(log2(448 / max)): the largest weight lands in e4m3's top binade
+__device__ __forceinline__ int mx_weight_shift(const int* mxs) {
+  const float mx = __builtin_bit_cast(float, (unsigned)mxs[1]);
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 0;
+  int e;
+  const float m = __builtin_frexpf(mx, &e);                  // mx = m 2^e, m in [0.5, 1)
+  int sw = (m > 0.875f ? 8 : 9) - e;
+  return sw < -100 ? -100 : (sw > 100 ? 100 : sw);
+}
+// Second half of a cout group's packing: [chunk][step j 0..6][q][r 0..1][lane 64][16 bytes].  MFMA row m / tile q -> output channel
+// as in pack_weights_kernel; lane group g = lane >> 4: taps 4j + 2 (g >> 1) + r (r = the two 16-byte halves of the lane's 32 K bytes;
+// tap 27 = zero); g & 1 = 0: Wh8 (meets xl8), 1: Wl8 (meets xh8); byte e = input channel chunk * 16 + e.
+__global__ void pack_weights_mx_kernel(const float* __restrict__ w, const float* __restrict__ scale, unsigned char* __restrict__ wpk,
+                                       int CinReal, int CinPad, int Cout, int Q, int CoutReal, int CinStride, int C0Real, int C0Phys,
+                                       int* __restrict__ mxs) {
+  const int nchunk = CinPad / 16;
+  const int sw = mx_weight_shift(mxs);
+  if (blockIdx.x == 0 && threadIdx.x == 0) mxs[0] = ((127 - (sw + 11)) & 255) * 0x01010101;     // E8M0 byte of 2^-(Sw + 11)
+  const float sh = __builtin_ldexpf(1.f, sw), sl = __builtin_ldexpf(1.f, sw + 11);
+  const long long total = (long long)(Cout / 16) * nchunk * 7 * 2 * 64 * 4;                      // one thread = 4 bytes
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int e4 = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    long long r = idx >> 8;
+    const int half = r & 1;
+    r >>= 1;
+    const int q = r % Q;
+    r /= Q;
+    const int j = r % 7;
+    r /= 7;
+    const int chunk = r % nchunk;
+    const int cg = r / nchunk;
+    const int m = lane & 15, g = lane >> 4;
+    const int cout = cg * 16 * Q + (m >> 2) * 4 * Q + q * 4 + (m & 3);
+    const int tap = 4 * j + 2 * (g >> 1) + half;
+    float v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cphys = chunk * 16 + e4 * 4 + k;
+      int cin = cphys;
+      if (C0Phys > C0Real) cin = cphys < C0Phys ? (cphys < C0Real ? cphys : CinReal) : C0Real + (cphys - C0Phys);
+      float v = 0.f;
+      if (tap < 27 && cin < CinReal && (CoutReal <= 0 || cout < CoutReal)) {
+        v = w[((long long)cout * CinStride + cin) * 27 + tap];
+        if (scale) v *= scale[cout];
+      }
+      const float hi = (float)(f16)v;
+      v4[k] = (g & 1) ? (v - hi) * sl : hi * sh;
+    }
+    // position inside the cout group: Wh chunks first (nchunk * 14 Q KiB), then these
+    const long long off = ((long long)cg * 2 * nchunk + nchunk + chunk) * (kSteps * Q * 1024) + ((long long)(j * Q + q) * 2 + half) * 1024 +
+                          lane * 16 + e4 * 4;
+    *(unsigned*)(wpk + off) = e4m3_pk4(v4[0], v4[1], v4[2], v4[3]);
+  }
+}
+
 // Folds eval-mode BatchNorm (network.py:154-155 -> nn.BatchNorm3d) into a per-channel gain and
 // shift: s = gamma / sqrt(var + eps), t = beta - mean * s (+ conv_bias * s).  Without a norm the
 // gain is 1 and the shift is the conv bias.
@@ -92,12 +165,16 @@ __global__ void fold_norm_kernel(const float* gamma, const float* beta, const fl
 
 // 2x2x2 stride-2 pooling on channels-last 16-bit tensors (nn.MaxPool3d(2) / nn.AvgPool3d(2),
 // network.py:297,368).  One thread = one output voxel x 8 channels (16 B).
-template <typename T, int AVG, bool SPLIT>
+// FMT: voxel layout 0 / 1 / 2 (amx_common.h); FMT 2 also writes the e4m3 copies of the pooled values (AMX_PREC_F16X2_MX).
+template <typename T, int AVG, int FMT>
 __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out, int N, int Do,
-                             int Ho, int Wo, int C) {
+                             int Ho, int Wo, int C, int skip_lo) {
+  constexpr bool SPLIT = FMT >= 1;
   const int c8n = C >> 3;
   const long long total = (long long)N * Do * Ho * Wo * c8n;
-  const long long sx = (long long)C * 2 * (SPLIT ? 2 : 1), sy = sx * (Wo * 2), sz = sy * (Ho * 2);
+  // FMT 2 (row-planar, amx_common.h): 32 bytes per voxel inside plane c8 >> 1 of its row; rows are C * 6 * W bytes in every layout
+  const long long sx = FMT == 2 ? 32 : (long long)C * fmt_elem_bytes(FMT), sy = (long long)C * fmt_elem_bytes(FMT) * (Wo * 2), sz = sy * (Ho * 2);
+  const long long lo_in = FMT == 2 ? 2ll * C * (Wo * 2) : 2 * C, lo_out = FMT == 2 ? 2ll * C * Wo : 2 * C;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = idx % c8n;
@@ -108,7 +185,8 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
     r /= Ho;
     const int z = r % Do;
     const int n = r / Do;
-    const char* base = in + (long long)n * sz * (Do * 2) + (2 * z) * sz + (2 * y) * sy + (2 * x) * sx + c8 * 16;
+    const char* base = in + (long long)n * sz * (Do * 2) + (2 * z) * sz + (2 * y) * sy + (2 * x) * sx +
+                       (FMT == 2 ? (long long)(c8 >> 1) * (Wo * 2 * 32) + (c8 & 1) * 16 : c8 * 16);
     float m[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -116,7 +194,7 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
       const uint4 raw = *(const uint4*)vp;
       const unsigned wv[4] = {raw.x, raw.y, raw.z, raw.w};
       uint4 rawl = make_uint4(0, 0, 0, 0);
-      if (SPLIT) rawl = *(const uint4*)(vp + C * 2);
+      if (SPLIT) rawl = *(const uint4*)(vp + lo_in);
       const unsigned wl[4] = {rawl.x, rawl.y, rawl.z, rawl.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -128,17 +206,24 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
       }
     }
     unsigned o[4], ol[4];
+    if (AVG) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] *= 0.125f;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float a = AVG ? m[2 * e] * 0.125f : m[2 * e];
-      const float bq = AVG ? m[2 * e + 1] * 0.125f : m[2 * e + 1];
+      const float a = m[2 * e];
+      const float bq = m[2 * e + 1];
       o[e] = (unsigned)to_bits<T>(a) | ((unsigned)to_bits<T>(bq) << 16);
       if (SPLIT) ol[e] = (unsigned)to_bits<T>(a - (float)(T)a) | ((unsigned)to_bits<T>(bq - (float)(T)bq) << 16);
     }
     if (SPLIT) {
-      char* op = out + (idx / c8n) * (sx) + c8 * 16;
+      const long long vlin = idx / c8n;                     // output voxel; FMT 2: row vlin / Wo, plane c8 >> 1
+      char* op = FMT == 2 ? out + (vlin / Wo) * (6ll * C * Wo) + (long long)(c8 >> 1) * (Wo * 32) + x * 32 + (c8 & 1) * 16
+                          : out + vlin * (long long)(C * fmt_elem_bytes(FMT)) + c8 * 16;
       *(uint4*)op = make_uint4(o[0], o[1], o[2], o[3]);
-      *(uint4*)(op + C * 2) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+      if (!(FMT == 2 && skip_lo)) *(uint4*)(op + lo_out) = make_uint4(ol[0], ol[1], ol[2], ol[3]);   // (conv-only readers: hi + copies)
+      if (FMT == 2) mx_store_copies(op - (c8 & 1) * 16 + 2 * lo_out, c8 & 1, m);
     } else {
       *(uint4*)(out + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -174,13 +259,13 @@ bool conv_fuses_stats(const ConvParams& p, int precision, int Q) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_FUSED_STATS") ? 1 : 0;
   if (off || p.src0_f32c1 || p.out32) return false;
-  return !((((precision < 2 && conv_zmarch_eligible(p)) || (precision >= 2 && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16));
+  return !((((precision < 2 && conv_zmarch_eligible(p)) || ((precision == 2 || precision == 3) && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16));
 }
 int last_conv_stats_slots() { return last_conv_v2_stats_slots(); }
 
 hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st) {
   const bool planar = p.out32 != nullptr;
-  if (((precision < 2 && conv_zmarch_eligible(p)) || (precision >= 2 && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16) {
+  if (((precision < 2 && conv_zmarch_eligible(p)) || ((precision == 2 || precision == 3) && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16) {
     // narrow full/half-resolution layers: z-marching ring kernel
     hipError_t e = launch_conv_zmarch(p, precision, st);
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_zm_kernel_name());
@@ -197,6 +282,7 @@ hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, in
                                int Cout, int Q, int precision, hipStream_t st, int mode, int CoutReal, int CinStride, int C0Real,
                                int C0Phys) {
   if (CinStride <= 0) CinStride = CinReal;
+  if (precision == 4) return hipErrorInvalidValue;     // launch_pack_weights_mx
   const int split = precision >= 2;
   const long long total = (long long)(Cout / 16) * (CinPad / 16) * kSteps * 64 * 8 * (split ? 2 : 1);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -209,6 +295,25 @@ hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, in
   return hipGetLastError();
 }
 
+// AMX_PREC_F16X2_MX: [Wh f16 chunks | fp8 correction chunks] per cout group (same bytes as the [Wh | Wl] packing of the strict
+// precisions) + the layer's block-scale word mxs[0] (mxs[1]: scratch for the weight maximum).  Forward weights only.
+hipError_t launch_pack_weights_mx(const float* w, const float* scale, void* wpk, int* mxs, int CinReal, int CinPad, int Cout, int Q,
+                                  hipStream_t st, int CoutReal, int CinStride, int C0Real, int C0Phys) {
+  if (CinStride <= 0) CinStride = CinReal;
+  hipError_t e = launch_pack_weights(w, scale, wpk, CinReal, CinPad, Cout, Q, 2, st, 0, CoutReal, CinStride, C0Real, C0Phys);   // Wh (| Wl, overwritten below)
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(mxs, 0, 2 * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  const int couts = CoutReal > 0 ? CoutReal : Cout;
+  const long long per_cout = (long long)CinStride * 27, total_w = per_cout * couts;
+  hipLaunchKernelGGL(mx_absmax_kernel, dim3((unsigned)((total_w + 255) / 256 > 1024 ? 1024 : (total_w + 255) / 256)), dim3(256), 0, st, w,
+                     scale, per_cout, total_w, mxs);
+  const long long total = (long long)(Cout / 16) * (CinPad / 16) * 7 * 2 * 64 * 4;
+  hipLaunchKernelGGL(pack_weights_mx_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, st, w,
+                     scale, (unsigned char*)wpk, CinReal, CinPad, Cout, Q, CoutReal, CinStride, C0Real, C0Phys, mxs);
+  return hipGetLastError();
+}
+
 hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
                             const float* conv_bias, float eps, int C, float* scale, float* shift,
                             hipStream_t st) {
@@ -218,17 +323,18 @@ hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* 
 }
 
 hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo, int C, int avg,
-                        int precision, hipStream_t st) {
+                        int precision, hipStream_t st, int skip_lo) {
   const long long total = (long long)N * Do * Ho * Wo * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define AMX_POOL(T, A, S)                                                                            \
   hipLaunchKernelGGL((pool2_kernel<T, A, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, \
-                     N, Do, Ho, Wo, C)
+                     N, Do, Ho, Wo, C, skip_lo)
   switch (precision) {
     case 0: if (avg) AMX_POOL(f16, 1, false); else AMX_POOL(f16, 0, false); break;
     case 1: if (avg) AMX_POOL(bf16, 1, false); else AMX_POOL(bf16, 0, false); break;
     case 2: if (avg) AMX_POOL(f16, 1, true); else AMX_POOL(f16, 0, true); break;
     case 3: if (avg) AMX_POOL(bf16, 1, true); else AMX_POOL(bf16, 0, true); break;
+    case 4: if (avg) AMX_POOL(f16, 1, 2); else AMX_POOL(f16, 0, 2); break;
     default: return hipErrorInvalidValue;
   }
 #undef AMX_POOL

@@ -130,7 +130,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   const int lanepos = ((wrow * HX) + li) * 4;
   const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
   const int yl = y0 + wrow, xl = x0 + li;
-  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + g * 8 * Q;
+  const int ocs = p.ocs ? p.ocs : 32;                          // bytes between a voxel's 16-channel chunks (amx_common.h)
+  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (long long)((g * 4 * Q) >> 4) * ocs + ((g * 4 * Q) & 15) * 2;
 
   bool bad = false;
   for (int s = 0; s < nsteps; ++s) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
 #pragma unroll
           for (int j = 0; j < 2 * Q; ++j)
             w[j] = (unsigned)to_bits<T>(v[2 * j] - (float)(T)v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1] - (float)(T)v[2 * j + 1]) << 16);
-          char* dlo = dst + p.Cout * 2;
+          char* dlo = dst + (long long)(p.Cout >> 4) * ocs;
           if (Q == 1) *(uint2*)dlo = make_uint2(w[0], w[1]);
           else *(uint4*)dlo = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -427,7 +428,7 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   nseg = (p.D + zseg - 1) / zseg;
   static int valu = -1;
   if (valu < 0) valu = getenv("AMX_STEM_VALU") ? 1 : 0;     // opt-in: measured slower (below)
-  if (valu) {
+  if (valu && (p.ocs == 0 || p.ocs == 32)) {      // (the experiment writes channels-last voxels only)
     snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem_valu<%s,q%d,%dx%dx%d,c%d+l1,r%d>",
              __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q, TZ, TY, TX, NC, R);
     hipLaunchKernelGGL((conv3d_stem_valu_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),

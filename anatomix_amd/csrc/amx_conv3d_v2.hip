@@ -91,8 +91,16 @@ __device__ __forceinline__ void advance_item(ItemCoord& c, const ConvParams& p) 
 // stages -- Wh*xh, Wh*xl, Wl*xh, the dropped Wl*xl term is 2^-16 (bf16) / 2^-22 (f16) relative -- into the same fp32
 // accumulators, and the epilogue splits the fp32 result into hi / lo again.  Everything else (halo staging, LDS-DMA, tap
 // steps) is unchanged: a stage is still 16 channels of one tensor behind one base pointer.
-template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW, int NBUF, bool SPLIT>
+//
+// MX (AMX_PREC_F16X2_MX; implies SPLIT storage of the output, T = f16): TWO stages per 16-channel chunk instead of three.  Part 0 is
+// Wh * xh as above; part 1 stages the chunk's 32 bytes of e4m3 copies per voxel -- [xl8(16) | xh8(16)], the same halo bytes and the
+// same two LDS planes as a 16-bit stage -- and sweeps them in 7 steps of v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 = 4 taps x 16
+// channels x {Wh8 * xl8, Wl8 * xh8}; 32 cycles, twice the f16 rate) against the fp8 fragments of pack_weights_mx_kernel with one
+// uniform block scale.  Lane group g: plane g & 1 (xl8 / xh8), taps 4 j + 2 (g >> 1) + {0, 1} = the two 16-byte reads of a fragment.
+template <typename T, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW, int NBUF, bool SPLIT, bool MX = false>
 __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(const ConvParams p) {
+  static_assert(!MX || (SPLIT && __is_same(T, f16)), "the fp8 correction stages extend the f16 hi / lo storage");
+  constexpr bool LOWUP = Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF>::LOWUP && !MX;
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
   typedef typename Ops<T>::vec8 vec8;
   constexpr int HY = C::HY, HX = C::HX, PLANE = C::PLANE, HALO = C::HALO, NW = C::NW;
@@ -114,7 +122,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   if ((G & 7) == 0) jw = (jw & 7) * (G >> 3) + (jw >> 3);
   const int it0 = (int)(items * jw / G), it1 = (int)(items * (jw + 1) / G);
   const int nchunk = (p.C0 + p.C1) >> 4;                  // 16-channel chunks of the LOGICAL input
-  const int nstage = (SPLIT ? 3 : 1) * nchunk / NCH;
+  const int nstage = (MX ? 2 : (SPLIT ? 3 : 1)) * nchunk / NCH;
+  const int mx_sa = MX ? __builtin_amdgcn_readfirstlane(*p.mxs) : 0;    // E8M0 block scale of the fp8 weights (x4 bytes)
   const int T_total = (it1 - it0) * nstage;
   if (T_total <= 0) return;
   const bool resident = NLW == 0 && nstage == 1 && ncg == 1;     // weights + bias loaded once per workgroup
@@ -138,7 +147,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   // ---- lane-constant LDS read bases for LOW-RES staged (upsampled) stages.  Output voxel (z,y,x) of the
   //      brick reads low-res halo voxel ((z+kz-1)>>1, (y+ky-1)>>1, (x+kx-1)>>1) + 1 per axis.
   int U1[3], U2e[3], U2o[3], Uz = 0;
-  if (C::LOWUP) {
+  if (LOWUP) {
     constexpr int LXH = C::LXH, LYH = C::LYH;
     const int Lx0 = ((li - 1) >> 1) + 1, Lx1 = (li >> 1) + 1, Lx2 = ((li + 1) >> 1) + 1;
     const int ub = (g & 1) * PLANE + ((wy * WY / 2) * LXH) * 16;
@@ -203,16 +212,19 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int vch = stage * NCH + k;                      // wave-uniform; SPLIT: virtual chunk in [0, 3 * nchunk)
-      const int part = SPLIT ? vch / nchunk : 0;            // 0: Wh * xh   1: Wh * xl   2: Wl * xh
+      const int part = SPLIT ? vch / nchunk : 0;            // 0: Wh * xh   1: Wh * xl   2: Wl * xh   (MX: 1 = both, in fp8)
       const int ch = (vch - part * nchunk) << 4;
       const bool second = ch >= p.C0;
       const int sh = second ? p.up_shift : 0;
-      const int lo_off = part == 1 ? (second ? p.C1 : p.C0) * 2 : 0;    // the lo half follows the hi half of the voxel
-      const char* base = second ? p.src1 + (long long)it.n * p.s1n + (ch - p.C0) * 2 + lo_off
-                                : p.src0 + (long long)it.n * p.s0n + ch * 2 + lo_off;
+      const int cseg = second ? p.C1 : p.C0, chs = second ? ch - p.C0 : ch;
+      // a voxel's 32-byte pieces: hi chunks, then the lo chunks, then (MX) the chunks of e4m3 copies; `cs` bytes apart
+      const int sec = part == 1 ? (MX ? 2 : 1) : 0;
+      const int cs = second ? (p.cs1 ? p.cs1 : 32) : (p.cs0 ? p.cs0 : 32);
+      const long long coff = (long long)(sec * (cseg >> 4) + (chs >> 4)) * cs;
+      const char* base = (second ? p.src1 + (long long)it.n * p.s1n : p.src0 + (long long)it.n * p.s0n) + coff;
       const long long sz = second ? p.s1z : p.s0z, sy = second ? p.s1y : p.s0y;
       const int xoff = (gx >> sh) * (int)(second ? p.s1x : p.s0x);
-      if (C::LOWUP && second && p.up_shift) {
+      if (LOWUP && second && p.up_shift) {
         // low-res halo of the upsampled segment: reflect padding at high resolution == replicate (clamp)
         // at low resolution; brick origins are even.
         const int LD = p.D >> 1, LH = p.H >> 1, LW = p.W >> 1;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
       // packed weights of these sub-chunks: linear copy, 1 KiB per instruction
       // SPLIT: packed as [cg][Wh chunks | Wl chunks]; parts 0 and 1 read Wh, part 2 reads Wl
       const int vch0 = stage * NCH, part0 = SPLIT ? vch0 / nchunk : 0;
-      const long long wchunk = SPLIT ? (long long)it.cg * 2 * nchunk + (vch0 - part0 * nchunk) + (part0 == 2 ? nchunk : 0)
+      const long long wchunk = SPLIT ? (long long)it.cg * 2 * nchunk + (vch0 - part0 * nchunk) + (part0 == (MX ? 1 : 2) ? nchunk : 0)
                                      : (long long)it.cg * nchunk + vch0;
       const char* ws = p.wpk + wchunk * C::WSUB;
       constexpr int NWI = NCH * C::WSUB / 1024;
@@ -342,8 +354,9 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     const bool full = (z0 + C::TZ <= p.D) & (y0 + C::TY <= p.H) & (x0 + C::TX <= p.W);
     const int zl = z0 + wz * WZ, yl = y0 + wy * WY + dy, xl = x0 + dx;
     if (OUTMODE == 0) {
+      const int ocs = p.ocs ? p.ocs : 32;              // the lane's 4Q <= 16 channels sit inside one 16-channel chunk
       char* lbase = p.out + (long long)pd.n * p.on + (long long)zl * p.oz + (long long)yl * p.oy +
-                    (long long)xl * p.ox + cb * 2;
+                    (long long)xl * p.ox + (long long)(cb >> 4) * ocs + (cb & 15) * 2;
 #pragma unroll
       for (int c = 0; c < CTW; ++c) {
         const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
@@ -351,7 +364,7 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
         char* dst = lbase + cz * p.oz + (cy * LY) * p.oy + (cx * LX) * p.ox;
 #pragma unroll
         for (int half = 0; half < (SPLIT ? 2 : 1); ++half) {          // SPLIT: hi channels, then the lo channels Cout further on
-          char* d = dst + half * (p.Cout * 2);
+          char* d = dst + (long long)half * (p.Cout >> 4) * ocs;
           const int o = half * 2 * Q;
           if (Q == 1) {
             *(uint2*)d = make_uint2(pend[c][o], pend[c][o + 1]);
@@ -457,11 +470,73 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
     }
 
     // ---- MFMA sweep: 14 paired-tap steps per 16-channel sub-chunk
-    const bool up_stage = C::LOWUP && p.up_shift && (((cu_stage * NCH) % nchunk) << 4) >= p.C0;
+    const bool up_stage = LOWUP && p.up_shift && (((cu_stage * NCH) % nchunk) << 4) >= p.C0;
+    const bool mx_stage = MX && cu_stage * NCH >= nchunk;
     // Both sweeps are software-pipelined one step deep by hand: the fragments of step i+1 are requested before the MFMAs of
     // step i, and scheduling fences keep that order (left alone, hipcc issues a step's reads right before a full
     // `s_waitcnt lgkmcnt(0)` and exposes the LDS latency every four MFMAs -- measured 38 % MFMA-busy with the DMA switched off).
-    if (!(p.dbg & 2) && up_stage) {
+    if (MX && mx_stage) {
+      if (!(p.dbg & 2)) {
+        // fp8 correction stage: 7 steps x NCH chunks; fragments are 2 x 16 bytes per lane (A: two 1-KiB halves, B: two taps).
+        // The (step, column tile) sequence is pipelined one item deep: a 32-cycle MFMA per (tile, q) leaves the LDS far more time per
+        // fragment than the f16 sweep has, and whole-step double buffering of the 32-byte B fragments does not fit 256 VGPRs.
+        constexpr int TSX = NCH * 7;
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        constexpr int NA = CTW == 1 ? 3 : 2;                    // a step's A fragments are requested two ITEMS ahead: with one item per
+        i32x4 fa[NA][Q][2], fb[3][2];                           // step that is two steps, i.e. three sets in flight
+        auto tapoff = [&](const int tp) {                       // byte offset of tap tp in the halo image (27 -> 26: zero weights)
+          const int t = tp > 26 ? 26 : tp;
+          return (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * 16;
+        };
+        auto load_a = [&](const int i, const int set) {
+          const int k = i / 7, j = i - k * 7;
+#pragma unroll
+          for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              fa[set][q][r] = *(const i32x4*)(wbuf + WOFF + (((k * 7 + j) * Q + q) * 2 + r) * 1024 + lane * 16);
+        };
+        auto load_b = [&](const int i, const int c, const int set) {
+          const int k = i / 7, j = i - k * 7;
+          const int cx = c % XT, cy = (c / XT) % YT, cz = c / (XT * YT);
+          const int coff = ((cz * HY + cy * LY) * HX + cx * LX) * 16;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int lo = tapoff(4 * j + r), up = tapoff(4 * j + 2 + r);
+            fb[set][r] = *(const i32x4*)(buf + base_d0 + hi * (up - lo) + (lo + k * HALO + coff));   // per lane: tap 4 j + 2 hi + r
+          }
+        };
+        // item u = (step i, column tile c); its fragments are requested two items ahead (a wave issues only Q 32-cycle MFMAs per
+        // item: one item of lookahead left the LDS latency exposed), the step's A fragments with its first item
+        auto request = [&](const int u2) {
+          if (u2 < TSX * CTW) {
+            const int i2 = u2 / CTW, c2 = u2 - i2 * CTW;
+            load_b(i2, c2, u2 % 3);
+            if (c2 == 0) load_a(i2, i2 % NA);
+          }
+        };
+        const int sb = 0x7f7f7f7f;                              // activations: scale 1
+        request(0);
+        request(1);
+#pragma unroll
+        for (int i = 0; i < TSX; ++i) {
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            const int u = i * CTW + c;
+            request(u + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x8 b8 = __builtin_shufflevector(fb[u % 3][0], fb[u % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+              const i32x8 a8 = __builtin_shufflevector(fa[i % NA][q][0], fa[i % NA][q][1], 0, 1, 2, 3, 4, 5, 6, 7);
+              acc[c][q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[c][q], 0, 0, 0, mx_sa, 0, sb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!NLW && u == kLateStep && issue_due) late_issue(t);
+          }
+        }
+      }
+    } else if (!(p.dbg & 2) && up_stage) {
       // the stage buffer holds the LOW-RES halo of 16 upsampled channels
       constexpr int LXH = C::LXH;
       vec8 fa[2][Q], fb[2][CTW];
@@ -637,17 +712,19 @@ int conv_v2_stats_slots(int D, int H, int W, int Q);
 
 static int g_num_cus = 0;
 
-template <typename T, bool SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
+template <typename T, int SPLITM, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE, int NLW = 0, int NBUF = 2>
 static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
+  constexpr bool SPLIT = SPLITM >= 1, MX = SPLITM == 2;          // SPLITM: 0 single value, 1 hi / lo split, 2 split + fp8 correction stages
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF> C;
-  const char* tn = __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16");
+  if (MX && !p.mxs) return hipErrorInvalidValue;
+  const char* tn = __is_same(T, f16) ? (MX ? "f16x2mx" : (SPLIT ? "f16x2" : "f16")) : (SPLIT ? "bf16x2" : "bf16");
   if (NLW)
     snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d+l%d,b%d,q%d,nch%d,o%d>",
              tn, C::TZ, C::TY, C::TX, C::NW, NLW, NBUF, Q, NCH, OUTMODE);
   else
     snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
              tn, C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
-  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF, SPLIT>;
+  auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF, SPLIT, MX>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -704,7 +781,7 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
 // Loader-wave mode (4 loader waves, ring of 3 buffers) where three stage buffers fit the LDS -- the deep, small levels,
 // whose stages are short: 128 -> 128 @16^3 32 -> 27 us, 384 -> 128 @16^3 66 -> 52 us, 256 -> 256 @8^3 36 -> 30 us at batch 4.
 // With only two buffers the loaders cannot run ahead and the classic barrier pipeline is faster (96 -> 32 @64^3: 202 vs 223 us).
-template <typename T, bool SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
+template <typename T, int SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
 static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
   static int classic = -1;
   if (classic < 0) classic = getenv("AMX_V2_CLASSIC") ? 1 : 0;
@@ -716,7 +793,7 @@ static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
   return launch_cfg2<T, SPLIT, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>(p, st);
 }
 
-template <typename T, int OUTMODE, bool SPLIT>
+template <typename T, int OUTMODE, int SPLIT>
 static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   const int nch = (p.C0 + p.C1) / 16;
   if (p.W >= 32) {
@@ -773,6 +850,7 @@ hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t
     case 1: return planar ? launch_conv2_t<bf16, 1, false>(p, Q, st) : launch_conv2_t<bf16, 0, false>(p, Q, st);
     case 2: return planar ? launch_conv2_t<f16, 1, true>(p, Q, st) : launch_conv2_t<f16, 0, true>(p, Q, st);
     case 3: return planar ? launch_conv2_t<bf16, 1, true>(p, Q, st) : launch_conv2_t<bf16, 0, true>(p, Q, st);
+    case 4: return planar ? launch_conv2_t<f16, 1, 2>(p, Q, st) : launch_conv2_t<f16, 0, 2>(p, Q, st);
   }
   return hipErrorInvalidValue;
 }

@@ -40,6 +40,51 @@ __device__ __forceinline__ int reflect_clamp(int g, int n) {
   return g >= n ? n - 1 : g;
 }
 
+// ---- fp8 side of precision AMX_PREC_F16X2_MX (include/anatomix_amd.h) ---------------------------------------------------------
+// A stored value v = hi + lo (f16 pair).  The conv multiplies Wh * hi on the f16 MFMA and forms the two correction products
+// Wh * lo + Wl * hi on the block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, twice the f16 rate) from OCP e4m3 copies
+//   xh8 = e4m3(hi)          xl8 = e4m3(2^11 lo)          Wh8 = e4m3(2^Sw Wh)          Wl8 = e4m3(2^(Sw+11) Wl)
+// (|lo| <= 2^-11 |hi|, so both activation copies share the range of the value itself and both products carry the same power of
+// two, which the instruction's block scale removes: ONE uniform scale 2^-(Sw+11)).  Conversions saturate at +-448: a correction term
+// of a value beyond that is clipped, i.e. that value is handled with plain f16 accuracy -- never an Inf / NaN.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+constexpr float kMxLoScale = 2048.f;        // 2^11
+__device__ __forceinline__ unsigned e4m3_pk4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned)v;
+}
+// the eight values of one 8-channel group -> {xl8 bytes (uint2), xh8 bytes (uint2)}
+__device__ __forceinline__ void mx_split8(const float (&f)[8], uint2& xl8, uint2& xh8) {
+  float h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (float)(_Float16)f[e];
+    l[e] = (float)(_Float16)(f[e] - h[e]) * kMxLoScale;       // from the STORED pair: the copies are a function of the voxel's hi / lo
+  }
+  xl8 = make_uint2(e4m3_pk4(l[0], l[1], l[2], l[3]), e4m3_pk4(l[4], l[5], l[6], l[7]));
+  xh8 = make_uint2(e4m3_pk4(h[0], h[1], h[2], h[3]), e4m3_pk4(h[4], h[5], h[6], h[7]));
+}
+
+// Store the copies of one 8-channel group.  The lanes (2k, 2k + 1) of a wave hold the two groups of ONE 16-channel chunk of one voxel
+// (every pass maps consecutive threads to consecutive groups and C / 8 is even): they exchange halves (DPP quad_perm [1,0,3,2]) so
+// that the even lane writes the chunk's 16 xl8 bytes and the odd lane its 16 xh8 bytes -- two 16-byte stores per 32-byte chunk
+// instead of four 8-byte ones (norm apply at level 0 of anatomix-dev: 670 -> see DESIGN.md).  `chunk` = voxel + 4 C + 32 (c8 >> 1).
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void mx_store_copies(char* chunk, int odd, const float (&f)[8]) {
+  uint2 xl8, xh8;
+  mx_split8(f, xl8, xh8);
+  const uint2 send = odd ? xl8 : xh8;             // what the partner stores
+  const unsigned r0 = dpp_xor1(send.x), r1 = dpp_xor1(send.y);
+  *(uint4*)(chunk + odd * 16) = odd ? make_uint4(r0, r1, xh8.x, xh8.y) : make_uint4(xl8.x, xl8.y, r0, r1);
+}
+
 template <typename T>
 __device__ __forceinline__ unsigned short to_bits(float v) {
   T t = (T)v;

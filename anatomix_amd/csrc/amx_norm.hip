@@ -30,27 +30,48 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// Strict precision (SPLIT): a voxel holds [hi(C) | lo(C)] 16-bit channels, value = hi + lo.  load8 / store8 move one
-// 8-channel group of one voxel: `p` points at the group's hi half, the lo half sits `lo_off` = 2*C bytes further on.
-template <typename T, bool SPLIT>
+// Voxel layouts FMT 0 / 1 / 2 (amx_common.h).  Strict precision (FMT >= 1): a voxel holds [hi(C) | lo(C)] 16-bit channels, value =
+// hi + lo.  load8 / store8 move one 8-channel group of one voxel: `p` points at the group's hi half, the lo half sits `lo_off` =
+// 2*C bytes further on.  FMT 2 (AMX_PREC_F16X2_MX): store8 also writes the e4m3 copies the convolutions multiply with -- group c8
+// of the voxel: xl8 at voxel + 4C + 32 (c8 >> 1) + 8 (c8 & 1), xh8 16 bytes behind it; nothing reads them but the conv kernels.
+template <int FMT> struct Fmt {
+  static constexpr bool SPLIT = FMT >= 1;
+  static constexpr int M = FMT == 0 ? 1 : (FMT == 1 ? 2 : 3);      // voxel bytes = 2 C M
+  // byte offset of 8-channel group c8 (its hi half) of voxel v -- a linear index whose rows are W voxels long -- and the distance to
+  // the lo half.  FMT 2 is row-planar (amx_common.h): plane c8 >> 1 of row v / W, 32 bytes per voxel.
+  static __device__ __forceinline__ long long group(long long v, int C, int W, int c8) {
+    if (FMT < 2) return v * (2 * C * M) + c8 * 16;
+    const long long row = v / W;
+    const int x = (int)(v - row * W);
+    return row * (6ll * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
+  }
+  static __device__ __forceinline__ long long group_rx(long long row, int x, int C, int W, int c8) {     // the same from (row, x)
+    if (FMT < 2) return (row * W + x) * (2ll * C * M) + c8 * 16;
+    return row * (6ll * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
+  }
+  static __device__ __forceinline__ int lo_off(int C, int W) { return FMT < 2 ? 2 * C : 2 * C * W; }
+};
+template <typename T, int FMT>
 __device__ __forceinline__ void load8(const char* p, int lo_off, float (&f)[8]) {
   unpack8<T>(*(const uint4*)p, f);
-  if (SPLIT) {
+  if (FMT) {
     float g[8];
     unpack8<T>(*(const uint4*)(p + lo_off), g);
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] += g[e];
   }
 }
-template <typename T, bool SPLIT>
-__device__ __forceinline__ void store8(char* p, int lo_off, const float (&f)[8]) {
+template <typename T, int FMT>
+// skip_lo (FMT 2, wave-uniform): the tensor's only readers are convolutions, which read hi and the copies -- the lo plane is not written
+__device__ __forceinline__ void store8(char* p, int lo_off, const float (&f)[8], int c8 = 0, bool skip_lo = false) {
   *(uint4*)p = pack8<T>(f);
-  if (SPLIT) {
+  if (FMT && !(FMT == 2 && skip_lo)) {
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = f[e] - (float)(T)f[e];
     *(uint4*)(p + lo_off) = pack8<T>(r);
   }
+  if (FMT == 2) mx_store_copies(p - (c8 & 1) * 16 + 2 * lo_off, c8 & 1, f);   // the chunk's plane of copies; with the lane of group c8 ^ 1
 }
 
 // slabs per sample in the statistics pass: enough blocks to fill the chip on the big planes, >= 8 loads per
@@ -63,24 +84,24 @@ __host__ __device__ inline int in_num_blocks(long long vox, int C) {
 }
 
 // grid (kInBlocks, N), block 256.  partial[n][blk][c][2]
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ x, float* __restrict__ partial, long long vox,
-                                                      int C) {
-  constexpr int M = SPLIT ? 2 : 1;
+                                                      int C, int W) {
+  constexpr int M = Fmt<FMT>::M;
   extern __shared__ float red[];                       // [256/c8n rows][C][2]
   const int c8n = C >> 3;
   const int n = blockIdx.y, blk = blockIdx.x;
   const int c8 = threadIdx.x % c8n, vrow = threadIdx.x / c8n, nrow = 256 / c8n;
   const char* xs = x + (long long)n * vox * C * 2 * M;
   float K[8];
-  unpack8<T>(*(const uint4*)(xs + c8 * 16), K);       // the channel's first voxel (its hi half): shift of the sums
+  unpack8<T>(*(const uint4*)(xs + Fmt<FMT>::group(0, C, W, c8)), K);       // the channel's first voxel (its hi half): shift of the sums
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long per = (vox + gridDim.x - 1) / gridDim.x;
   const long long v0 = (long long)blk * per, v1 = v0 + per < vox ? v0 + per : vox;
   if (vrow < nrow)
     for (long long v = v0 + vrow; v < v1; v += nrow) {
       float f[8];
-      load8<T, SPLIT>(xs + (v * C * M + c8 * 8) * 2, C * 2, f);
+      load8<T, FMT>(xs + Fmt<FMT>::group(v, C, W, c8), Fmt<FMT>::lo_off(C, W), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = f[e] - K[e];
@@ -110,10 +131,10 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const char* __restrict__ 
 
 // grid (C/8, N), block 256 = 8 channels x 32 partial lanes.  ab[n][c][2] = (a, b) with y = a*x + b.
 // Lane l adds partials l, l+32, ... in order, then the 32 lane sums are added in lane order: fixed order, no atomics.
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict__ x, const float* __restrict__ partial,
                                                          const float* gamma, const float* beta, float eps, long long vox,
-                                                         int C, int nblk, float* __restrict__ ab, const float* kshift, int use_kshift) {
+                                                         int C, int nblk, float* __restrict__ ab, const float* kshift, int use_kshift, int W) {
   __shared__ double red[2][8][32];
   const int n = blockIdx.y, c = blockIdx.x * 8 + (threadIdx.x & 7), l = threadIdx.x >> 3;
   double s1 = 0.0, s2 = 0.0;
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const char* __restrict
     float K;
     if (use_kshift) K = kshift ? kshift[cc] : 0.f;
     else {
-      const unsigned short kb = *(const unsigned short*)(x + ((long long)n * vox * C * (SPLIT ? 2 : 1) + cc) * 2);
+      const unsigned short kb = *(const unsigned short*)(x + (long long)n * vox * C * Fmt<FMT>::M * 2 + Fmt<FMT>::group(0, C, W, cc >> 3) + (cc & 7) * 2);
       K = (float)__builtin_bit_cast(T, kb);
     }
     const double m1 = s1 / (double)vox;
@@ -180,9 +201,9 @@ __global__ __launch_bounds__(256) void in_prereduce_kernel(const float* __restri
   }
 }
 
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox, int C, int N, int act,
-                                float slope, int* oflow) {
+                                float slope, int* oflow, int W, int skip_lo) {
   bool bad = false;
   const int c8n = C >> 3;
   const long long total = (long long)N * vox * c8n;
@@ -191,8 +212,8 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
     const long long nv = idx / c8n;
     const int n = nv / vox;
     float f[8];
-    char* xp = SPLIT ? x + nv * (C * 4) + c8 * 16 : x + idx * 16;
-    load8<T, SPLIT>(xp, C * 2, f);
+    char* xp = x + Fmt<FMT>::group(nv, C, W, c8);          // (a sample is a whole number of rows: nv / W is the global row)
+    load8<T, FMT>(xp, Fmt<FMT>::lo_off(C, W), f);
     const float* q = ab + ((long long)n * C + c8 * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -201,7 +222,7 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
-    store8<T, SPLIT>(xp, C * 2, f);
+    store8<T, FMT>(xp, Fmt<FMT>::lo_off(C, W), f, c8, skip_lo != 0);
   }
   if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
@@ -210,9 +231,9 @@ __global__ void in_apply_kernel(char* __restrict__ x, const float* __restrict__ 
 // group for its whole grid-stride walk (the stride is a multiple of C / 8), so its 16 coefficients sit in registers and the
 // loop has no 64-bit division -- the generic kernel above spends more time on index arithmetic and coefficient loads than on
 // memory (3.2 vs 4.6 TB/s on the 268 MB level-0 tensors of anatomix-dev).
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x, const float* __restrict__ ab, long long vox,
-                                                            int C, int act, float slope, int* oflow) {
+                                                            int C, int act, float slope, int* oflow, int W, int skip_lo) {
   bool bad = false;
   const int c8n = C >> 3, c8 = threadIdx.x % c8n, n = blockIdx.y;
   const float* q = ab + ((long long)n * C + c8 * 8) * 2;
@@ -223,14 +244,25 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
     b[e] = q[2 * e + 1];
   }
   const long long total = vox * c8n;
-  char* xs = x + (long long)n * total * 16 * (SPLIT ? 2 : 1);
+  constexpr bool SPLIT = Fmt<FMT>::SPLIT;
+  char* xs = x + (long long)n * total * 16 * Fmt<FMT>::M;
   // SPLIT: a thread's group index c8 is fixed, its voxel advances by (gridDim.x * 256) / c8n per iteration
   const long long vstep = (long long)gridDim.x * 256 / c8n;
   long long vv = (blockIdx.x * 256ll + threadIdx.x) / c8n;
+  // FMT 2 (row-planar): the thread's voxel as (row, x), advanced by increment-and-carry -- no division in the loop
+  long long row = FMT == 2 ? vv / W : 0;
+  int xr = FMT == 2 ? (int)(vv - row * W) : 0;
+  const long long rstep = FMT == 2 ? vstep / W : 0;
+  const int xstep = FMT == 2 ? (int)(vstep - rstep * W) : 0;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256, vv += vstep) {
     float f[8];
-    char* xp = SPLIT ? xs + vv * (C * 4) + c8 * 16 : xs + idx * 16;
-    load8<T, SPLIT>(xp, C * 2, f);
+    char* xp = FMT == 2 ? xs + Fmt<FMT>::group_rx(row, xr, C, W, c8) : (SPLIT ? xs + vv * (C * 2 * Fmt<FMT>::M) + c8 * 16 : xs + idx * 16);
+    if (FMT == 2) {
+      row += rstep;
+      xr += xstep;
+      if (xr >= W) { xr -= W; ++row; }
+    }
+    load8<T, FMT>(xp, Fmt<FMT>::lo_off(C, W), f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * a[e] + b[e];
@@ -238,7 +270,7 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
-    store8<T, SPLIT>(xp, C * 2, f);
+    store8<T, FMT>(xp, Fmt<FMT>::lo_off(C, W), f, c8, skip_lo != 0);
   }
   if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
@@ -248,10 +280,10 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
 // vectors once and writes eight outputs -- cache reads equal the output bytes instead of 8x (the per-output version was
 // L1-bound at 2.0 TB/s on the 537 MB level-0 tensor of anatomix-dev).  Cells run from -1 to L-1 per axis with clamped
 // inputs, which reproduces the border rows (output 0 and 2L-1) of align_corners=False.  One block per (n, cz, cy).
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __restrict__ in, char* __restrict__ out, int N,
-                                                                  int D, int H, int W, int C) {
-  constexpr int M = SPLIT ? 2 : 1;
+                                                                  int D, int H, int W, int C, int skip_lo) {
+  constexpr int M = Fmt<FMT>::M;
   const int c8n = C >> 3;
   int r = blockIdx.x;
   const int cy = r % (H + 1) - 1;
@@ -265,12 +297,16 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
                          in + (((long long)n * D + z1) * H + y0) * rowb, in + (((long long)n * D + z1) * H + y1) * rowb};
   const long long orowb = 2 * rowb;                        // bytes of one output row
   for (int t = threadIdx.x; t < (W + 1) * c8n; t += 256) {
-    const int c8 = t % c8n, cx = t / c8n - 1;
+    // channels-last: consecutive threads walk the groups of one cell; row-planar (FMT 2): the two groups of a chunk, then the cells
+    // along x, then the chunks -- a wavefront then covers 32 consecutive voxels of ONE plane (1 KiB runs instead of 32-byte pieces;
+    // the groups-first order ran this pass at 3.2 TB/s against 4.9 in the channels-last strict mode)
+    const int c8 = FMT == 2 ? ((t >> 1) / (W + 1)) * 2 + (t & 1) : t % c8n;
+    const int cx = (FMT == 2 ? (t >> 1) % (W + 1) : t / c8n) - 1;
     const int x0 = cx < 0 ? 0 : cx, x1 = cx + 1 < W ? cx + 1 : W - 1;
     float v[8][8];                                         // [(zi, yi, xi)][channel]
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      load8<T, SPLIT>(rows[k >> 1] + ((k & 1 ? x1 : x0) * C * M + c8 * 8) * 2, C * 2, v[k]);
+      load8<T, FMT>(rows[k >> 1] + Fmt<FMT>::group_rx(0, (k & 1 ? x1 : x0), C, W, c8), Fmt<FMT>::lo_off(C, W), v[k]);
 #pragma unroll
     for (int o = 0; o < 8; ++o) {                          // output (pz, py, px): 0 = odd position 2c+1, 1 = even position 2c+2
       const int pz = o >> 2, py = (o >> 1) & 1, px = o & 1;
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += wt * v[k][e];
       }
-      store8<T, SPLIT>(out + (((long long)n * 2 * D + oz) * 2 * H + oy) * orowb + ((long long)ox * C * M + c8 * 8) * 2, C * 2, acc);
+      store8<T, FMT>(out + (((long long)n * 2 * D + oz) * 2 * H + oy) * orowb + Fmt<FMT>::group_rx(0, ox, C, 2 * W, c8), Fmt<FMT>::lo_off(C, 2 * W), acc, c8, skip_lo != 0);
     }
   }
 }
@@ -332,7 +368,7 @@ __global__ void upsample2_trilinear_bwd_kernel(const char* __restrict__ gout, ch
 
 // y = scale[c] * x + shift[c], then the activation, in place (eval-mode BatchNorm applied as its own pass: only
 // used when a feature tap asks for the pre-norm convolution output, network.py:475-529).
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                   long long nvox, int C, int act, float slope, int* oflow) {
   bool bad = false;
@@ -341,8 +377,9 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = idx % c8n;
     float f[8];
-    char* xp = SPLIT ? x + (idx / c8n) * (C * 4) + c8 * 16 : x + idx * 16;
-    load8<T, SPLIT>(xp, C * 2, f);
+    static_assert(FMT < 2, "eval-BatchNorm networks do not run in the row-planar layout");
+    char* xp = x + (idx / c8n) * (C * 2 * Fmt<FMT>::M) + c8 * 16;
+    load8<T, FMT>(xp, C * 2, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = f[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
@@ -350,7 +387,7 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
       if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);   // the value about to be stored
       f[e] = v;
     }
-    store8<T, SPLIT>(xp, C * 2, f);
+    store8<T, FMT>(xp, C * 2, f, c8);
   }
   if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
@@ -359,10 +396,9 @@ __global__ void affine_act_kernel(char* __restrict__ x, const float* __restrict_
 // callers.  Channels [0,C0) come from src0 (full resolution), [C0,C0+C1) from src1, read through >> up_shift
 // (the tap at an nn.Upsample id is taken after torch.cat((skip, up), 1), network.py:500-502).
 // One thread = one voxel x 8 channels; a wavefront writes 64 consecutive floats of each of its 8 planes.
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const char* __restrict__ src1, int C1, int up_shift,
                                     int N, int D, int H, int W, float* __restrict__ out, int S0, int S1) {     // S: stored channels per voxel (>= C)
-  constexpr int M = SPLIT ? 2 : 1;
   const int C = C0 + C1, c8n = (C + 7) >> 3;         // C1 == 0 may leave a ragged last group (stored channels cover it)
   const long long vox = (long long)D * H * W;
   const long long total = (long long)N * c8n * vox;
@@ -373,17 +409,17 @@ __global__ void export_ncdhw_kernel(const char* __restrict__ src0, int C0, const
     const int c8 = r % c8n, n = r / c8n;
     const int c = c8 * 8;
     const char* sp;
-    int lo_off = S0 * 2;
+    int lo_off = Fmt<FMT>::lo_off(S0, W);
     if (c < C0) {
-      sp = src0 + (((long long)n * vox + v) * S0 * M + c) * 2;
+      sp = src0 + Fmt<FMT>::group((long long)n * vox + v, S0, W, c8);
     } else {
-      lo_off = S1 * 2;
+      lo_off = Fmt<FMT>::lo_off(S1, lw);
       const int x = v % W, y = (v / W) % H, z = v / ((long long)W * H);
       const long long lv = (((long long)n * ld + (z >> up_shift)) * lh + (y >> up_shift)) * lw + (x >> up_shift);
-      sp = src1 + (lv * S1 * M + (c - C0)) * 2;
+      sp = src1 + Fmt<FMT>::group(lv, S1, lw, (c - C0) >> 3);
     }
     float f[8];
-    load8<T, SPLIT>(sp, lo_off, f);
+    load8<T, FMT>(sp, lo_off, f);
     float* o = out + ((long long)n * C + c) * vox + v;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -425,7 +461,7 @@ __global__ void import_ncdhw_kernel(const float* __restrict__ src, char* __restr
 // pretraining/options/base_options.py:69-73): fp32 [N][Cin][D][H][W] -> 16-bit channels-last with 16 stored channels (Cin real, the
 // rest zero), after which the first conv is an ordinary 16 -> ngf layer (the single-channel stem kernel is not involved).
 // One thread per voxel; SPLIT: [hi(16) | lo(16)].
-template <typename T, bool SPLIT>
+template <typename T, int FMT>
 __global__ void import_input_kernel(const float* __restrict__ src, char* __restrict__ dst, int N, int Cin, long long vox) {
   const long long total = (long long)N * vox;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -436,9 +472,10 @@ __global__ void import_input_kernel(const float* __restrict__ src, char* __restr
       f0[c] = c < Cin ? src[(n * Cin + c) * vox + v] : 0.f;
       f1[c] = c + 8 < Cin ? src[(n * Cin + c + 8) * vox + v] : 0.f;
     }
-    char* o = dst + idx * (SPLIT ? 64 : 32);
-    store8<T, SPLIT>(o, 32, f0);
-    store8<T, SPLIT>(o + 16, 32, f1);
+    static_assert(FMT < 2, "the multi-channel input import writes channels-last voxels");
+    char* o = dst + idx * (32 * Fmt<FMT>::M);
+    store8<T, FMT>(o, 32, f0, 0);
+    store8<T, FMT>(o + 16, 32, f1, 1);
   }
 }
 
@@ -492,10 +529,12 @@ static size_t in_coeff_offset(int N, long long vox, int C, int fused_slots) {   
 
 // fused_slots > 0: the partial sums [N][fused_slots][C][2] were written by the producing conv's epilogue (shift = kshift, the conv
 // bias, or 0): only finalize + apply run here.
+// W: row length of the row-planar layout (precision 4 only; amx_common.h FMT 2)
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow, int fused_slots = 0,
-                           const float* kshift = nullptr) {
+                           const float* kshift = nullptr, int W = 0, int skip_lo = 0) {
   if (C % 8) return hipErrorInvalidValue;
+  if (precision == 4 && (W <= 0 || vox % W || C % 16)) return hipErrorInvalidValue;
   float* partial = (float*)scratch;
   float* ab = partial + in_coeff_offset(N, vox, C, fused_slots);
   int nblk = fused_slots > 0 ? fused_slots : in_num_blocks(vox, C);
@@ -515,20 +554,21 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define AMX_IN(T, S)                                                                                                   \
   if (fused_slots <= 0)                                                                                                \
-    hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C);   \
+    hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C, W);   \
   hipLaunchKernelGGL((in_finalize_kernel<T, S>), dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
-                     nblk, ab, kshift, fused_slots > 0 ? 1 : 0);                                                  \
+                     nblk, ab, kshift, fused_slots > 0 ? 1 : 0, W);                                               \
   if (256 % c8n == 0) {                                                                                          \
     const long long per = vox * c8n;                                                                             \
     const int bx = (int)((per + 255) / 256 > 4096 ? 4096 : (per + 255) / 256);                                   \
-    hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope, oflow); \
+    hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope, oflow, W, skip_lo); \
   } else                                                                                                         \
-    hipLaunchKernelGGL((in_apply_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope, oflow)
+    hipLaunchKernelGGL((in_apply_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (char*)x, ab, vox, C, N, act, slope, oflow, W, skip_lo)
   switch (precision) {
     case 0: { AMX_IN(f16, false); } break;
     case 1: { AMX_IN(bf16, false); } break;
     case 2: { AMX_IN(f16, true); } break;
     case 3: { AMX_IN(bf16, true); } break;
+    case 4: { AMX_IN(f16, 2); } break;
     default: return hipErrorInvalidValue;
   }
 #undef AMX_IN
@@ -536,14 +576,15 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
 }
 
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
-                                      hipStream_t st) {
+                                      hipStream_t st, int skip_lo = 0) {
   const unsigned blocks = (unsigned)((long long)N * (D + 1) * (H + 1));
-#define AMX_UP(T, S) hipLaunchKernelGGL((upsample2_trilinear_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C)
+#define AMX_UP(T, S) hipLaunchKernelGGL((upsample2_trilinear_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C, skip_lo)
   switch (precision) {
     case 0: AMX_UP(f16, false); break;
     case 1: AMX_UP(bf16, false); break;
     case 2: AMX_UP(f16, true); break;
     case 3: AMX_UP(bf16, true); break;
+    case 4: AMX_UP(f16, 2); break;
     default: return hipErrorInvalidValue;
   }
 #undef AMX_UP
@@ -594,6 +635,7 @@ hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C
     case 1: AMX_EX(bf16, false); break;
     case 2: AMX_EX(f16, true); break;
     case 3: AMX_EX(bf16, true); break;
+    case 4: AMX_EX(f16, 2); break;
     default: return hipErrorInvalidValue;
   }
 #undef AMX_EX

@@ -151,15 +151,20 @@ class Unet(nn.Module):
 
     @property
     def precision(self):
-        """Storage precision of the HIP path: ``"f16"``, ``"bf16"``, ``"f16x2"`` or ``"strict"`` (= ``"bf16x2"``).
+        """Storage precision of the HIP path: ``"f16"``, ``"bf16"``, ``"f16x2"``, ``"strict"`` (= ``"bf16x2"``) or ``"f16x2mx"``.
 
         Unless set explicitly (attribute or env ``AMX_PRECISION``) it is the fastest mode that keeps the features within 1e-3
         (relative) of the reference's fp32 inference (convex_adam_utils.py:194-219 runs the network in fp32): ``"f16"`` where the
-        norm folds into the convolution weights (the 6 M ``anatomix`` variant), ``"strict"`` for InstanceNorm networks
-        (``anatomix-dev``, load_from_hf.py:18-24), on which single 16-bit storage is 10x outside the tolerance."""
+        norm folds into the convolution weights (the 6 M ``anatomix`` variant); for InstanceNorm networks (``anatomix-dev``,
+        load_from_hf.py:18-24), on which single 16-bit storage is 10x outside the tolerance, ``"f16x2mx"`` -- f16 hi + lo pairs whose
+        correction products run on the block-scaled fp8 matrix instruction (2.5e-4 rel-L2 / 4.4e-4 max-norm on ``anatomix-dev`` at
+        128^3, 1.34x the throughput of ``"strict"``; its f16 range is guarded like ``"f16"``: AmxOverflowError, never silent Inf) --
+        or ``"strict"`` (1.65e-4, fp32's exponent range) where that mode is not implemented (input_nc > 1)."""
         if self._precision is not None:
             return self._precision
-        return "strict" if self._cfg["norm"] in ("instance", "instance_affine") else "f16"
+        if self._cfg["norm"] in ("instance", "instance_affine"):
+            return "f16x2mx" if self._cfg["input_nc"] == 1 else "strict"
+        return "f16"
 
     @property
     def train_precision(self):

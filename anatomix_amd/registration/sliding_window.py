@@ -307,7 +307,7 @@ def _run_fused(inputs, roi, starts, wmap, model, cnt):
         if pipelined:
             for s_, _ in lanes:
                 cur.wait_stream(s_)
-        if model.precision in ("f16", "fp16", "float16", "f16x2") and not torch.cuda.is_current_stream_capturing():
+        if model.precision in ("f16", "fp16", "float16", "f16x2", "f16x2mx", "strict_mx") and not torch.cuda.is_current_stream_capturing():
             # the accumulation volume leaves the library here: one synchronising range check per volume (f16 storage only)
             model.check_numerics(synchronize=True)
     return acc

@@ -41,7 +41,7 @@ def parse():
                          "(higher throughput, reported as a secondary; the headline stays at one chunk so that its per-launch "
                          "times are those of kernels running alone)")
     ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "strict", "f16x2", "bf16x2"],
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "strict", "f16x2", "bf16x2", "f16x2mx"],
                     help="storage precision of the HIP path; strict (= bf16x2) / f16x2: split hi+lo 16-bit operands, three MFMAs per "
                          "product, fp32-grade results (the reference's inference callers run fp32)")
     ap.add_argument("--no-secondary", action="store_true",

@@ -46,8 +46,20 @@ enum { AMX_INTERP_NEAREST = 0, AMX_INTERP_TRILINEAR = 1 };
  *                  [hi(C) | lo(C)], each product runs as three MFMAs (Wh*xh + Wh*xl + Wl*xh).  fp32-grade results --
  *                  the reference's inference callers run the network in fp32
  *                  (anatomix/registration/convex_adam_utils.py:194-219: .float().cuda(), no autocast).  BF16X2 keeps
- *                  fp32's exponent range; F16X2 is ~8x more accurate but overflows beyond 65504 like F16. */
-enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1, AMX_PREC_F16X2 = 2, AMX_PREC_BF16X2 = 3 };
+ *                  fp32's exponent range; F16X2 is ~8x more accurate but overflows beyond 65504 like F16.
+ *   F16X2_MX       strict storage (f16 hi + lo pairs) whose two CORRECTION products run on the block-scaled fp8 matrix
+ *                  instruction of CDNA4 at twice the f16 rate: Wh*xh on the f16 MFMA, Wh*xl + Wl*xh from e4m3 copies the
+ *                  producing kernels store beside the pair (6C bytes per voxel, row-planar: see below).  2.0 instead of 3.0
+ *                  MFMA-equivalents per product; operands carry 15-16 significant bits instead of 22: the InstanceNorm
+ *                  variant `anatomix-dev` stays inside the 1e-3 tolerance of the fp32 reference. */
+enum { AMX_PREC_F16 = 0, AMX_PREC_BF16 = 1, AMX_PREC_F16X2 = 2, AMX_PREC_BF16X2 = 3, AMX_PREC_F16X2_MX = 4 };
+/* Tensor layouts of the single-operator entries below.  F16 .. BF16X2: channels-last voxels, [n][d][h][w][c] (x2 in the strict
+ * precisions: [hi(c) | lo(c)]).  F16X2_MX: ROW-PLANAR, 6 c bytes per voxel -- a row (n, z, y) of w voxels is 3 c/16 planes of w x 32
+ * bytes: plane k = the f16 hi halves of channels 16k .. 16k+15 of the row's voxels, plane c/16 + k their lo halves, plane 2 c/16 + k
+ * the e4m3 copies [e4m3(2^11 lo) x 16 | e4m3(hi) x 16]; so the 32 bytes per voxel that a convolution stage gathers are contiguous
+ * along x.  Convolutions read hi and the copies; norm apply / pool / upsample write all three; a convolution writes hi and lo only
+ * (its output is normalised before the next convolution reads it).  amx_instance_norm, which has no row length, takes a sample as
+ * one row of `voxels` voxels. */
 
 /* Constructor arguments of anatomix/model/network.py:262-279 (Unet.__init__) that shape the
  * arithmetic.  dimension is fixed at 3, pad_type at 'reflect', residual_connection at False. */

@@ -7,8 +7,54 @@ import torch.nn.functional as F
 
 from anatomix_amd import _lib
 
-TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16, "f16x2": torch.float16, "bf16x2": torch.bfloat16, "strict": torch.bfloat16}
-SPLIT = {"f16x2", "bf16x2", "strict"}
+TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16, "f16x2": torch.float16, "bf16x2": torch.bfloat16, "strict": torch.bfloat16,
+           "f16x2mx": torch.float16}
+SPLIT = {"f16x2", "bf16x2", "strict", "f16x2mx"}
+MX = {"f16x2mx"}           # AMX_PREC_F16X2_MX: voxel = [hi(C) | lo(C) | per 16-channel chunk: xl8(16) xh8(16)] (include/anatomix_amd.h)
+
+
+def e4m3(t):
+    """OCP e4m3fn rounding (nearest even) with saturation at +-448, as fp32 values."""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def e4m3_bytes(t):
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def mx_weight_shift(w):
+    """Sw = floor(log2(448 / max|w|)) the way pack_weights_mx_kernel forms it (frexp of the maximum)."""
+    mx = float(w.abs().max())
+    if not (mx > 0.0):
+        return 0
+    m, e = np.frexp(np.float32(mx))
+    return int((8 if m > 0.875 else 9) - e)
+
+
+def to_ndhwc_mx(x_ncdhw):
+    """NCDHW fp32 -> the row-planar tensor of f16x2mx (include/anatomix_amd.h) as uint8 [N, D, H, 3 C/16, W, 32]: per row the planes
+    hi (C/16) | lo (C/16) | e4m3 copies (C/16: [e4m3(2^11 lo) x 16 | e4m3(hi) x 16] per voxel)."""
+    xc = x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().float()          # [N, D, H, W, C]
+    hi, lo = split_pair(xc, torch.float16)
+    n, d, h, w, c = xc.shape
+    assert c % 16 == 0
+    k = c // 16
+    plane = lambda t: t.reshape(n, d, h, w, k, 16).permute(0, 1, 2, 4, 3, 5)     # [N, D, H, k, W, 16]
+    ph = plane(hi).contiguous().view(torch.uint8).reshape(n, d, h, k, w, 32)
+    pl = plane(lo).contiguous().view(torch.uint8).reshape(n, d, h, k, w, 32)
+    px = torch.cat((plane(e4m3_bytes(lo.float() * 2048.0)), plane(e4m3_bytes(hi.float()))), dim=-1)
+    return torch.cat((ph, pl, px), dim=3).contiguous()
+
+
+def from_ndhwc_mx(raw, c, parts=False):
+    """uint8 [N, D, H, 3 C/16, W, 32] -> (NCDHW fp32 value hi + lo, the copy planes [N, D, H, C/16, W, 32][, stored hi, lo as [N, D, H, W, C]])."""
+    k = c // 16
+    n, d, h, _, w, _ = raw.shape
+    unplane = lambda t: t.contiguous().view(torch.float16).reshape(n, d, h, k, w, 16).permute(0, 1, 2, 4, 3, 5).reshape(n, d, h, w, c)
+    hi, lo = unplane(raw[:, :, :, :k]), unplane(raw[:, :, :, k:2 * k])
+    val = (hi.float() + lo.float()).permute(0, 4, 1, 2, 3).contiguous()
+    x8 = raw[:, :, :, 2 * k:]
+    return (val, x8, hi, lo) if parts else (val, x8)
 
 
 def split_pair(x, dtype):
@@ -65,7 +111,8 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
     n, c0, d, h, ww = x0.shape
     cout = w.shape[0]
     c1 = 0 if x1 is None else x1.shape[1]
-    pack = (lambda t: to_ndhwc_split(t, tdt)) if split else (lambda t: to_ndhwc(t, tdt))
+    mx = precision in MX
+    pack = to_ndhwc_mx if mx else ((lambda t: to_ndhwc_split(t, tdt)) if split else (lambda t: to_ndhwc(t, tdt)))
     dx0 = pack(x0).to(device)
     dx1 = None if x1 is None else pack(x1).to(device)
     dw = w.reshape(cout, c0 + c1, 27).contiguous().float().to(device)
@@ -76,7 +123,9 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
         out = torch.full((n, cout, d, h, ww), float("nan"), dtype=torch.float32, device=device)
         o16, o32 = None, out
     else:
-        out = torch.full((n, d, h, ww, cout * (2 if split else 1)), float("nan"), dtype=tdt, device=device)
+        out = torch.full((n, d, h, ww, cout * (3 if mx else (2 if split else 1))), float("nan"), dtype=tdt, device=device)
+        if mx:
+            out = torch.full((n, d, h, 3 * cout // 16, ww, 32), 0x7f, dtype=torch.uint8, device=device)
         o16, o32 = out, None
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc),
@@ -86,7 +135,35 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
     out = out.cpu()
     if planar:
         return out
+    if mx:                    # the conv writes the pair only (its consumers -- norm apply, pool, upsample -- write the copies)
+        return from_ndhwc_mx(out, cout)[0]
     return from_ndhwc_split(out) if split else from_ndhwc(out.float())
+
+
+def ref_conv_mx(x0, x1, w, scale, shift, act, slope=0.3):
+    """The arithmetic of AMX_PREC_F16X2_MX restated on the CPU (fp64 sums): Wh * xh exactly as the f16 MFMA multiplies it, plus the
+    two correction products from e4m3 copies under one power-of-two scale."""
+    def parts(t):
+        hi, lo = split_pair(t.float(), torch.float16)
+        return hi.float(), lo.float()
+    xh, xl = parts(x0)
+    if x1 is not None:
+        uh, ul = parts(x1)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+        xh, xl = torch.cat((xh, up(uh)), 1), torch.cat((xl, up(ul)), 1)
+    wf = w.float() if scale is None else w.float() * scale.float()[:, None, None, None, None]
+    wh = wf.to(torch.float16).float()
+    wl = wf - wh
+    sw = mx_weight_shift(wf)
+    conv = lambda a, b: F.conv3d(F.pad(a.double(), (1,) * 6, mode="reflect"), b.double())
+    y = conv(xh, wh) + (conv(e4m3(xl * 2048.0), e4m3(wh * 2.0 ** sw)) + conv(e4m3(xh), e4m3(wl * 2.0 ** (sw + 11)))) * 2.0 ** (-(sw + 11))
+    if shift is not None:
+        y = y + shift.double()[None, :, None, None, None]
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, slope)
+    return y.float()
 
 
 def ref_conv(x0, x1, w, scale, shift, act, precision, slope=0.3):
