@@ -93,6 +93,7 @@ SYMBOLS = {
     "amx_bn_act_backward_recompute": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P]),
     "amx_pad_fold": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_adamw_step": (_I, [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
+    "amx_adamw_step_dev": (_I, [_P, _I, _P, _I, _P]),
     "amx_pool2_max_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "amx_conv3d_wgrad_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I, _I]),
     "amx_conv3d_wgrad": (_I, [_P, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _I,

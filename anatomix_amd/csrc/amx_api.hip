@@ -71,7 +71,7 @@ hipError_t launch_bn_act_backward(const void* dy, const void* y, const void* x, 
                                   const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx_framed, int N, int D,
                                   int H, int W, int C, int act, float slope, void* scratch, int precision, hipStream_t st);
 hipError_t launch_adamw(const long long* table, int count, double lr, double b1, double b2, double eps, double wd, int maximize,
-                        hipStream_t st);
+                        hipStream_t st, const double* d_hyper = nullptr);
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
                            hipStream_t st);
 hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
@@ -1258,6 +1258,17 @@ int amx_adamw_step(const amx_adamw_tensor* tensors, int count, double lr, double
       return fail(AMX_ERR_INVALID, "adamw: tensor %d has a null pointer or a negative size", t);
   }
   AMX_HIP(amx::launch_adamw((const long long*)tensors, count, lr, beta1, beta2, eps, weight_decay, maximize, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_adamw_step_dev(const amx_adamw_tensor* tensors, int count, const double* d_hyper, int maximize, void* stream) {
+  if (count < 0 || (count && !tensors) || !d_hyper) return fail(AMX_ERR_INVALID, "bad argument");
+  for (int t = 0; t < count; ++t) {
+    const amx_adamw_tensor& r = tensors[t];
+    if (!r.param || !r.grad || !r.exp_avg || !r.exp_avg_sq || !r.step || r.numel < 0)
+      return fail(AMX_ERR_INVALID, "adamw: tensor %d has a null pointer or a negative size", t);
+  }
+  AMX_HIP(amx::launch_adamw((const long long*)tensors, count, 0.0, 0.0, 0.0, 0.0, 0.0, maximize, (hipStream_t)stream, d_hyper));
   return AMX_OK;
 }
 

@@ -26,6 +26,10 @@ struct AdamArgs {
   int maximize;
   double lr, b1, b2;                         // for the bias corrections (torch forms them in double on the host)
   float decay, w1, b2f, w2, eps;             // 1 - lr wd, 1 - b1, b2, 1 - b2: formed in double, then rounded once, as torch's scalars are
+  // non-null: {lr, beta1, beta2, eps, weight_decay} are READ FROM THE DEVICE at launch time instead of the values above -- a step
+  // captured in a HIP graph then follows an lr schedule (the reference changes lr every epoch: base_model.py update_learning_rate)
+  // through a captured host-to-device copy of five doubles, instead of replaying the lr that was current at capture
+  const double* hyper;
 };
 
 struct AdamCoef {
@@ -50,16 +54,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
   const double step = (double)*a.step[t];
-  const double bc1 = 1.0 - pow(a.b1, step), bc2 = 1.0 - pow(a.b2, step);
+  double lr = a.lr, b1 = a.b1, b2 = a.b2;
   AdamCoef c;
   c.decay = a.decay;
   c.w1 = a.w1;
-  c.b1 = 1.f - a.w1;
   c.b2 = a.b2f;
   c.w2 = a.w2;
-  c.inv_bc2s = (float)(1.0 / sqrt(bc2));
   c.eps = a.eps;
-  c.step_size = (float)(a.lr / bc1);
+  if (a.hyper) {                               // same expressions as launch_adamw forms on the host, in double, rounded once
+    lr = a.hyper[0]; b1 = a.hyper[1]; b2 = a.hyper[2];
+    c.eps = (float)a.hyper[3];
+    c.decay = (float)(1.0 - lr * a.hyper[4]);
+    c.w1 = (float)(1.0 - b1);
+    c.b2 = (float)b2;
+    c.w2 = (float)(1.0 - b2);
+  }
+  const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+  c.b1 = 1.f - c.w1;
+  c.inv_bc2s = (float)(1.0 / sqrt(bc2));
+  c.step_size = (float)(lr / bc1);
   c.gsign = a.maximize ? -1.f : 1.f;
   const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   if (vec && base + kAdamChunk <= n) {
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 // table: count rows of 6 x 64-bit {p, g, m, v, step, numel} on the HOST
 hipError_t launch_adamw(const long long* table, int count, double lr, double b1, double b2, double eps, double wd, int maximize,
-                        hipStream_t st) {
+                        hipStream_t st, const double* d_hyper) {
   for (int t0 = 0; t0 < count; t0 += kAdamTensors) {
     AdamArgs a;
     const int c = count - t0 < kAdamTensors ? count - t0 : kAdamTensors;
@@ -107,7 +120,7 @@ hipError_t launch_adamw(const long long* table, int count, double lr, double b1,
       a.p[t] = nullptr; a.g[t] = nullptr; a.m[t] = nullptr; a.v[t] = nullptr; a.step[t] = nullptr; a.n[t] = 0;
     }
     for (int t = c; t <= kAdamTensors; ++t) a.blk0[t] = (int)blocks;
-    a.count = c; a.maximize = maximize; a.lr = lr; a.b1 = b1; a.b2 = b2;
+    a.count = c; a.maximize = maximize; a.lr = lr; a.b1 = b1; a.b2 = b2; a.hyper = d_hyper;
     a.decay = (float)(1.0 - lr * wd); a.w1 = (float)(1.0 - b1); a.b2f = (float)b2; a.w2 = (float)(1.0 - b2); a.eps = (float)eps;
     if (blocks == 0) continue;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -2,7 +2,7 @@
 ``anatomix.model.load_from_hf`` (reference: anatomix/model/load_from_hf.py:11-79).
 
 The Hub download itself needs network access; everything after it (variant -> constructor kwargs,
-``_orig_mod.`` prefix stripping, ``load_state_dict(strict=True)``) is reproduced so that a local
+``_orig_mod.`` / ``module.`` prefix stripping, ``load_state_dict(strict=True)``) is reproduced so that a local
 ``.pth`` can be loaded with ``load_from_hf(variant, weights_path=...)``.
 """
 from __future__ import annotations
@@ -37,10 +37,26 @@ ANATOMIX_VARIANTS = {
 }
 
 
+def convert_dict(state_dict):
+    """pretraining/models/base_model.py:458-466: strips the ``module.`` (nn.DataParallel) and ``_orig_mod.`` (torch.compile) parts
+    of every key -- wherever they sit, e.g. ``_orig_mod.module.model.0.weight`` -- so that the trainer's ``*_net_G.pth`` files load
+    into a bare network whatever wrapper they were saved through.  Plain state dicts pass through untouched."""
+    out = type(state_dict)() if isinstance(state_dict, dict) else {}
+    for k, v in state_dict.items():
+        out[k.replace("module.", "").replace("_orig_mod.", "")] = v
+    return out
+
+
 def _load_handling_compile(model, state_dict):
-    """load_from_hf.py:39-49: accept checkpoints saved from a torch.compile()-wrapped module."""
-    if state_dict and next(iter(state_dict)).startswith("_orig_mod."):
-        state_dict = {k.removeprefix("_orig_mod."): v for k, v in state_dict.items()}
+    """load_from_hf.py:39-49 accepts checkpoints saved from a torch.compile()-wrapped module (``_orig_mod.`` prefix); the trainer's
+    own loader (base_model.py:340-349) also accepts nn.DataParallel's ``module.`` prefix, decided -- as there -- on the FIRST key.
+    Both are handled here, so the published ``<variant>.pth`` files and the pretraining checkpoints load through one function."""
+    if state_dict:
+        first = next(iter(state_dict))
+        if "module." in first or "_orig_mod." in first:
+            state_dict = convert_dict(state_dict)
+    if hasattr(state_dict, "_metadata"):              # base_model.py:347-348
+        del state_dict._metadata
     model.load_state_dict(state_dict, strict=True)
     return model
 

@@ -15,11 +15,16 @@ What is kept from the reference surface:
     residual_connection`` attributes and the two constructor prints (network.py:447-448);
   * ``forward(input, layers=[], encode_only=False, verbose=False)`` (network.py:467).
 
-What is different: for CUDA(ROCm) inputs under ``torch.no_grad()``/eval the forward is ONE call
-into libanatomix_amd.so (20 fused conv launches + 4 pools for the 6M model) instead of 66 module
-calls.  Anything the HIP path does not cover yet (autograd, train-mode BatchNorm, ``layers`` taps,
-CPU tensors) raises, unless the stock-module path is explicitly enabled with
-``model.allow_torch_path = True`` (or env AMX_ALLOW_TORCH_PATH=1).
+What is different: for CUDA(ROCm) inputs under ``torch.no_grad()`` the forward -- plain, or with ``layers`` /
+``encode_only`` feature taps (``amx_unet_forward_taps``) -- is ONE call into libanatomix_amd.so (20 fused conv
+launches for the 6M model) instead of 66 module calls; with autograd enabled the whole network is one
+``torch.autograd.Function`` whose forward AND backward run on the HIP kernels (``anatomix_amd/model/train.py``:
+train-mode BatchNorm / InstanceNorm, pooling and upsampling adjoints, data and weight gradients -- what the contrastive
+step and the segmentation finetuning call).  What the HIP path does not cover raises with the reason
+(``hip_unsupported_reason``): CPU tensors, ``dimension`` 1 / 2, ``pad_type`` other than reflect,
+``residual_connection=True``, activations other than relu / lrelu / none, input_nc > 16, ngf outside {8, 16, 24, 32} --
+unless the stock-module path is explicitly enabled with ``model.allow_torch_path = True`` (or env
+AMX_ALLOW_TORCH_PATH=1).  There is no silent fallback.
 """
 from __future__ import annotations
 
@@ -180,7 +185,7 @@ class Unet(nn.Module):
             self._warned_precision = True
             warnings.warn(f"anatomix_amd.Unet: precision={value!r} on an InstanceNorm network is outside the 1e-3 tolerance of the fp32 "
                           f"reference (measured rel-L2 {self._F16_ERROR_WITH_LIVE_NORM:.1e} on anatomix-dev at 128^3); the default for this "
-                          "configuration is 'strict'")
+                          "configuration is 'f16x2mx' (or 'strict')")
         self._precision = value
 
     # ------------------------------------------------------------------------------------------

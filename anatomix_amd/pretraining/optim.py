@@ -5,7 +5,13 @@ capturable AdamW is ~170 launches of a few microseconds each.
 
 Same constructor arguments, same update rule, same ``state_dict`` layout as ``torch.optim.AdamW(capturable=True)`` (per parameter:
 ``step`` a 0-dim fp32 device tensor, ``exp_avg``, ``exp_avg_sq``), so a checkpoint moves between the two.  GPU only: fp32
-parameters on a CUDA device -- anything else raises, there is no host path."""
+parameters on a CUDA device -- anything else raises, there is no host path.
+
+Hyper-parameters and HIP graphs.  The reference changes ``lr`` every epoch (base_model.py: get_scheduler / update_learning_rate
+set ``param_group['lr']``).  Kernel arguments passed by value are frozen into a captured graph, so the kernel reads {lr, betas, eps,
+weight_decay} from a small per-group DEVICE buffer, which ``step()`` refreshes from a pinned host mirror with a copy that is part
+of the stream (and of a capture): ``GraphedContrastiveStep`` calls ``refresh_hyperparameters()`` -- a host write into that mirror --
+before every replay, and the replayed copy carries the current ``param_groups`` values to the kernel."""
 import ctypes
 
 import numpy as np
@@ -37,6 +43,37 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize, foreach=None,
                         capturable=True, differentiable=False, fused=None, decoupled_weight_decay=True)
         super().__init__(params, defaults)
+        self._hyper = {}            # (group index, device) -> (pinned host mirror [5] float64, device buffer [5] float64)
+
+    @staticmethod
+    def _hyper_values(group):
+        lr = group["lr"]
+        if isinstance(lr, torch.Tensor):
+            raise ValueError("FusedAdamW: lr must be a Python number (schedulers set group['lr'] to one)")
+        beta1, beta2 = group["betas"]
+        vals = (float(lr), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]))
+        if not (vals[0] >= 0.0 and vals[3] >= 0.0 and 0.0 <= vals[1] < 1.0 and 0.0 <= vals[2] < 1.0 and vals[4] >= 0.0):
+            raise ValueError(f"FusedAdamW: hyper-parameters out of range: lr {vals[0]}, betas ({vals[1]}, {vals[2]}), eps {vals[3]}, "
+                             f"weight_decay {vals[4]}")
+        return vals
+
+    def refresh_hyperparameters(self):
+        """Write the current ``param_groups`` values into the pinned host mirrors (host-side only; nothing is enqueued).  Called by
+        ``step()``, and -- because ``step()`` does not run when a captured graph is replayed -- by ``GraphedContrastiveStep`` before
+        every replay.  A CHANGED value first waits for the device: an earlier replay may not have read the mirror yet."""
+        for gi, group in enumerate(self.param_groups):
+            vals = self._hyper_values(group)
+            for (g2, dev), (host, _) in self._hyper.items():
+                if g2 == gi and tuple(host.tolist()) != vals:
+                    torch.cuda.synchronize(dev)
+                    host.copy_(torch.tensor(vals, dtype=torch.float64))
+
+    def _hyper_buffers(self, gi, group, dev):
+        key = (gi, dev)
+        if key not in self._hyper:
+            host = torch.tensor(self._hyper_values(group), dtype=torch.float64).pin_memory()
+            self._hyper[key] = (host, torch.empty(5, dtype=torch.float64, device=dev))
+        return self._hyper[key]
 
     def _state_of(self, p):
         st = self.state[p]
@@ -56,7 +93,8 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
+        self.refresh_hyperparameters()
+        for gi, group in enumerate(self.param_groups):
             per_device = {}
             for p in group["params"]:
                 g = p.grad
@@ -75,13 +113,13 @@ class FusedAdamW(torch.optim.Optimizer):
                              p.numel()))
                 steps.append(st["step"])
                 keep.append(g)
-            beta1, beta2 = group["betas"]
             for dev, (rows, steps, keep) in per_device.items():
                 with torch.cuda.device(dev):
+                    host, dbuf = self._hyper_buffers(gi, group, dev)
+                    dbuf.copy_(host, non_blocking=True)                               # captured with the step: replays re-read the mirror
                     torch._foreach_add_(steps, 1.0)                                   # t: one launch for the whole list
                     table = np.asarray(rows, dtype=np.int64)
-                    _lib.check(lib.amx_adamw_step(table.ctypes.data_as(ctypes.c_void_p), len(rows), float(group["lr"]), float(beta1),
-                                                  float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                                                  int(bool(group["maximize"])),
-                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                    _lib.check(lib.amx_adamw_step_dev(table.ctypes.data_as(ctypes.c_void_p), len(rows), _lib.ptr(dbuf),
+                                                      int(bool(group["maximize"])),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return loss

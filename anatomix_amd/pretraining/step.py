@@ -70,9 +70,12 @@ def _grad_norms(netG, netF):
     # gradient multiplied by clamp(inf / norm, max=1) = 1 -- is an identity pass over all gradients and is left out
     if hasattr(nn.utils, "get_total_norm"):
         return _total_norm(netG), _total_norm(netF)
-    gG = nn.utils.clip_grad_norm_(netG.parameters(), max_norm=float("inf"), norm_type=2)
-    gF = nn.utils.clip_grad_norm_(netF.parameters(), max_norm=float("inf"), norm_type=2)
-    return gG, gF
+    # older torch: the norm of the per-tensor norms (clip_grad_norm_(max_norm=inf) would also multiply every gradient by
+    # clamp(inf / norm) -- NaN when the norm itself is inf)
+    def total(net):
+        norms = [torch.linalg.vector_norm(p.grad, 2) for p in net.parameters() if p.grad is not None]
+        return torch.linalg.vector_norm(torch.stack(norms), 2) if norms else torch.zeros((), device=next(net.parameters()).device)
+    return total(netG), total(netF)
 
 
 def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, nce_weights=None, num_patches=512,
@@ -120,7 +123,12 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
         if scaler is not None:
             for opt in optimizers:                   # unscale first: the norms below are those of the true gradients
                 scaler.unscale_(opt)
-    gG, gF = _grad_norms(netG, netF)
+    # the reference records the norms on stepping iterations only (supcl_model.py:631-655, after unscale_): on a non-stepping call the
+    # gradients are partial sums still multiplied by the loss scale -- reported as NaN rather than as a number that means something else
+    if do_step:
+        gG, gF = _grad_norms(netG, netF)
+    else:
+        gG = gF = torch.full((), float("nan"), device=total.device)
     if optimizers is not None and do_step:
         for opt in optimizers:
             if scaler is not None:
@@ -223,6 +231,15 @@ class GraphedContrastiveStep:
             with torch.cuda.graph(self.tail_graph):
                 self.tail_scalars = self._tail(self.total, self.layer_losses)
 
+    def _check_frozen_hyperparameters(self, opt):
+        """A stock capturable optimizer inside a graph replays the hyper-parameters of the capture: refuse to diverge silently."""
+        snap = tuple((g["lr"] if not torch.is_tensor(g["lr"]) else None, tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in opt.param_groups)
+        seen = self.__dict__.setdefault("_hyper_snap", {})
+        if seen.setdefault(id(opt), snap) != snap:
+            raise RuntimeError("GraphedContrastiveStep: the hyper-parameters of a captured torch optimizer changed (lr / betas / eps / "
+                               "weight_decay are frozen into the graph); use anatomix_amd.pretraining.FusedAdamW, a tensor lr, or build a "
+                               "new GraphedContrastiveStep")
+
     def _zero(self):
         if self.grad_buckets is not None:
             self.grad_buckets.release()
@@ -239,6 +256,13 @@ class GraphedContrastiveStep:
             self.A.copy_(real_A)
             self.B.copy_(real_B)
             self.seg.copy_(seg_A)
+        # optimizer.step() does not run on a replay: hand the CURRENT param_groups values (lr schedulers change them every epoch,
+        # base_model.py update_learning_rate) to the captured step through the optimizers' host mirrors
+        for opt in self.optimizers or ():
+            if hasattr(opt, "refresh_hyperparameters"):
+                opt.refresh_hyperparameters()
+            elif self.opt_in_graph or self.tail_graph is not None:
+                self._check_frozen_hyperparameters(opt)
         self.graph.replay()
         if hasattr(self, "scalars") and (self.opt_in_graph or self.optimizers is None):
             scalars = self.scalars

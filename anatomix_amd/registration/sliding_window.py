@@ -37,6 +37,7 @@ import math
 from typing import Callable, List, Sequence, Tuple
 
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
@@ -90,10 +91,41 @@ def importance_map(roi_size: Sequence[int], mode: str = "constant", sigma_scale:
     return m.clamp_(min=floor).to(torch.float32)
 
 
-def _fused_ok(predictor, inputs) -> bool:
+def _fused_ok(predictor, inputs, roi) -> bool:
+    """The fused window step (amx_unet_forward_windows) takes a bare Unet on the HIP path whose output conv can accumulate straight
+    into the fp32 volume: output_nc a multiple of 16 and <= 32, roi width >= 32 (include/anatomix_amd.h; other shapes leave through
+    the export pass, which the generic window loop below handles)."""
     from ..model.network import Unet
     return (isinstance(predictor, Unet) and inputs.is_cuda and inputs.shape[1] == 1 and
+            predictor._cfg["output_nc"] % 16 == 0 and predictor._cfg["output_nc"] <= 32 and roi[2] >= 32 and
             predictor.hip_unsupported_reason(inputs[:, :, :1, :1, :1].expand(-1, -1, 2, 2, 2)) is None)
+
+
+def _pointwise_affine(module) -> bool:
+    """True if `module` is a composition of 1x1x1 convolutions (stride 1, no padding, any bias) and identities -- a per-voxel AFFINE
+    map A f + b.  MONAI's UnetOutBlock (the head of segmentation_utils.py:113-115) is one: Convolution(conv_only=True, k=1)."""
+    leaves = [m for m in module.modules() if not list(m.children())]
+    if not leaves:
+        return False
+    for m in leaves:
+        if isinstance(m, (nn.Identity, nn.Dropout, nn.Dropout3d)) and not (isinstance(m, (nn.Dropout, nn.Dropout3d)) and m.training):
+            continue
+        if isinstance(m, nn.Conv3d) and m.kernel_size == (1, 1, 1) and m.stride == (1, 1, 1) and m.padding in ((0, 0, 0), "valid", "same") \
+                and m.dilation == (1, 1, 1) and m.groups == 1:
+            continue
+        return False
+    return True
+
+
+def _split_unet_and_head(predictor, inputs, roi):
+    """train_segmentation.py:194-199 validates with predictor = nn.Sequential(Unet, UnetOutBlock).  A per-voxel affine head commutes
+    with the window averaging -- sum_w w (A f + b) / sum_w w = A (sum_w w f / sum_w w) + b -- so the windows run through the fused
+    path up to the Unet's output and the head is applied once to the normalised volume.  Any other head: generic window loop."""
+    if isinstance(predictor, nn.Sequential) and len(predictor) >= 2 and _fused_ok(predictor[0], inputs, roi):
+        head = predictor[1] if len(predictor) == 2 else nn.Sequential(*list(predictor.children())[1:])
+        if not torch.is_grad_enabled() and _pointwise_affine(head):
+            return predictor[0], head
+    return None
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable,
@@ -147,7 +179,13 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
 
     cnt = torch.zeros(lsize, dtype=torch.float32, device=inputs.device)
     acc = None
-    if _fused_ok(predictor, inputs):
+    head = None
+    fused = _fused_ok(predictor, inputs, roi)
+    if not fused:
+        split = _split_unet_and_head(predictor, inputs, roi)
+        if split is not None:
+            (predictor, head), fused = split, True
+    if fused:
         acc = _run_fused(inputs, roi, mine, wmap, predictor, cnt)
     else:
         for b0 in range(0, len(mine) * B, sw_batch_size):
@@ -167,6 +205,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     if world > 1:
         slab, slab_cnt, z0, z1 = _exchange_slabs(acc, cnt, t0, size[0], touched, rank, world, group)
         _normalize(slab, slab_cnt)
+        if head is not None:
+            slab = _apply_head(head, slab)
         if return_slab:
             if need_pad:
                 raise ValueError("return_slab needs a volume at least as large as the roi (no padding)")
@@ -174,10 +214,23 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         acc = _gather_slabs(slab, size[0], world, group)
     else:
         _normalize(acc, cnt)
+        if head is not None:
+            acc = _apply_head(head, acc)
     if need_pad:
         zs, ys, xs = pads[4], pads[2], pads[0]
         acc = acc[:, :, zs:zs + orig[0], ys:ys + orig[1], xs:xs + orig[2]]
     return acc
+
+
+def _apply_head(head, feat, planes=32):
+    """The per-voxel head on the normalised feature volume, a few z-planes at a time (bounded temporaries)."""
+    out = None
+    for z in range(0, feat.shape[2], planes):
+        y = head(feat[:, :, z:z + planes])
+        if out is None:
+            out = torch.empty((feat.shape[0], y.shape[1]) + tuple(feat.shape[2:]), dtype=y.dtype, device=y.device)
+        out[:, :, z:z + planes] = y
+    return out
 
 
 def _normalize(acc, cnt):

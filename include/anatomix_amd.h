@@ -447,6 +447,11 @@ typedef struct {
 } amx_adamw_tensor;
 int amx_adamw_step(const amx_adamw_tensor* tensors, int count, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int maximize, void* stream);
+/* The same step with the hyper-parameters READ FROM THE DEVICE when the kernel runs: d_hyper = five doubles {lr, beta1, beta2, eps,
+ * weight_decay}.  By-value arguments are frozen into a captured HIP graph; the reference changes lr every epoch through its
+ * schedulers (pretraining/models/base_model.py: update_learning_rate / get_scheduler), so a graph-replayed step takes them from a
+ * buffer that a captured host-to-device copy refreshes (anatomix_amd/pretraining/optim.py).  Values are not range-checked here. */
+int amx_adamw_step_dev(const amx_adamw_tensor* tensors, int count, const double* d_hyper, int maximize, void* stream);
 
 /* ---- registration feature post-processing (what the reference does to the extracted features before the convex
  * optimisation; all fp32, planar [C][H][W][D] device tensors, batch 1 as everywhere in that pipeline) ---- */

@@ -60,6 +60,32 @@ def test_compiled_checkpoint_prefix_is_stripped():
         build_variant("nope")
 
 
+@pytest.mark.parametrize("wrap", ["module.", "_orig_mod.", "_orig_mod.module.", "module._orig_mod.", ""])
+def test_wrapped_checkpoints_of_the_trainer_load(wrap, tmp_path):
+    """pretraining/models/base_model.py:340-349,458-466: the trainer saves its networks through nn.DataParallel (``module.``) and / or
+    torch.compile (``_orig_mod.``); its loader strips both, decided on the first key.  A real DataParallel / compile wrapper produces
+    the keys here, the file goes through torch.save / load_from_hf(weights_path=) like a published checkpoint."""
+    from collections import OrderedDict
+    from anatomix_amd.model.load_from_hf import build_variant, convert_dict, load_from_hf
+    kw = R.VARIANTS["anatomix"]
+    ref = R.synthetic_state_dict(kw, 3)
+    src = build_variant("anatomix")
+    src.load_state_dict(ref)
+    if wrap == "module.":
+        saved = torch.nn.DataParallel(src).state_dict()                       # the real wrapper's key layout
+    else:
+        saved = OrderedDict((wrap + k, v) for k, v in src.state_dict().items())
+    assert all(k.startswith(wrap) for k in saved)
+    path = tmp_path / "latest_net_G.pth"
+    torch.save(saved, path)
+    m = load_from_hf("anatomix", weights_path=str(path))
+    got = m.state_dict()
+    assert list(got) == list(ref)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    assert list(convert_dict(ref)) == list(ref)                               # plain dicts pass through untouched
+
+
 def test_stock_module_path_equals_oracle_when_opted_in():
     kw = R.VARIANTS["anatomix"]
     sd = R.synthetic_state_dict(kw, 0)

@@ -108,6 +108,56 @@ def test_fused_adamw_replays_from_a_graph(device):
         assert torch.equal(p, q)                                     # same kernel, same inputs: bit-identical
 
 
+def test_a_replayed_step_follows_the_learning_rate_schedule(device):
+    """Advisor finding (round 3): by-value kernel arguments are frozen into a captured graph, and the reference changes lr every
+    epoch (pretraining/models/base_model.py: update_learning_rate).  The step reads {lr, betas, eps, weight_decay} from a device
+    buffer refreshed by a captured copy of a pinned host mirror: replays after `group['lr'] = ...` + refresh_hyperparameters()
+    (what GraphedContrastiveStep does before every replay) must equal eager steps with the same schedule, bit for bit."""
+    kw = dict(lr=1e-2, weight_decay=1e-2)
+    sched = [1e-2, 1e-2, 5e-3, 2.5e-3, 0.0, 1e-3]
+    a = _params(device, 4)[:12]
+    opt_a = FusedAdamW(a, **kw)
+    grads = _grads(a, 11)
+    for p, g in zip(a, grads):
+        p.grad = g.clone()
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        opt_a.step()                                                 # schedule entry 0, eagerly (creates the state)
+    torch.cuda.current_stream(device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt_a.step()
+    for lr in sched[1:]:
+        opt_a.param_groups[0]["lr"] = lr
+        if lr == 2.5e-3:
+            opt_a.param_groups[0]["weight_decay"] = 0.1              # the other hyper-parameters travel the same way
+        opt_a.refresh_hyperparameters()
+        graph.replay()
+    torch.cuda.synchronize(device)
+    b2 = [torch.nn.Parameter(p.detach().clone()) for p in _params(device, 4)[:12]]
+    opt_c = FusedAdamW(b2, **kw)
+    for p, g in zip(b2, grads):
+        p.grad = g.clone()
+    for lr in sched:
+        opt_c.param_groups[0]["lr"] = lr
+        if lr == 2.5e-3:
+            opt_c.param_groups[0]["weight_decay"] = 0.1
+        opt_c.step()
+    frozen = [torch.nn.Parameter(p.detach().clone()) for p in _params(device, 4)[:12]]
+    opt_f = FusedAdamW(frozen, **kw)
+    for p, g in zip(frozen, grads):
+        p.grad = g.clone()
+    for _ in sched:
+        opt_f.step()                                                 # what a frozen lr would have produced
+    for p, q, r in zip(a, b2, frozen):
+        assert torch.equal(p, q)
+        assert not torch.equal(p, r)
+    with pytest.raises(ValueError):
+        opt_a.param_groups[0]["lr"] = -1.0
+        opt_a.refresh_hyperparameters()
+
+
 def test_refusals(device):
     with pytest.raises(NotImplementedError):
         FusedAdamW([torch.nn.Parameter(torch.zeros(3, device=device))], amsgrad=True)

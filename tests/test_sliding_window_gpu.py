@@ -30,7 +30,7 @@ def test_fused_equals_generic_path(device):
     m, _ = _model(device)
     x = torch.from_numpy(np.random.RandomState(5).rand(1, 1, 96, 64, 80).astype(np.float32)).to(device)
     with torch.no_grad():
-        assert _fused_ok(m, x)
+        assert _fused_ok(m, x, (64, 64, 64))
         fused = sliding_window_inference(x, (64, 64, 64), 2, m, overlap=0.8, mode="gaussian", sigma_scale=0.25)
         generic = sliding_window_inference(x, (64, 64, 64), 2, lambda t: m(t), overlap=0.8, mode="gaussian", sigma_scale=0.25)
     assert fused.shape == (1, 16, 96, 64, 80) and torch.isfinite(fused).all()
@@ -90,9 +90,55 @@ def test_real_operating_point_roi128_overlap08_matches_cpu_oracle(device):
     assert [tuple(s) for s in starts] == [(0, 0, 0), (0, 0, 25), (0, 0, 32)]
     with torch.no_grad():
         x = torch.from_numpy(vol)[None].to(device)
-        assert _fused_ok(m, x)
+        assert _fused_ok(m, x, (128, 128, 128))
         got = sliding_window_inference(x, (128, 128, 128), 2, m, overlap=0.8, mode="gaussian", sigma_scale=0.25).cpu()[0]
         torch.set_num_threads(16)
         ref = O.sliding_window(vol, (128, 128, 128), lambda a: R.forward(torch.from_numpy(a), sd, KW).numpy(), 0.8, "gaussian", 0.25)
     assert got.shape == (16, 128, 128, 160) and torch.isfinite(got).all()
     assert rel_l2(got, torch.from_numpy(ref)) <= 1e-3
+
+
+def test_segmentation_validation_predictor_takes_the_fused_path(device):
+    """train_segmentation.py:194-199: sliding_window_inference(val_images, roi, 4, nn.Sequential(Unet, UnetOutBlock), overlap=0.7),
+    constant importance map.  The 1x1x1 head commutes with the window averaging, so the windows run fused up to the Unet's output
+    and the head is applied once; the generic loop (head inside every window) is the reference order of operations."""
+    from anatomix_amd.registration import sliding_window as SW
+    m, _ = _model(device)
+    torch.manual_seed(0)
+    head = torch.nn.Conv3d(16, 5, kernel_size=1, bias=True).to(device)      # what MONAI's UnetOutBlock(3, 16, n_classes + 1) holds
+    wrapped = torch.nn.Sequential(m, torch.nn.Sequential(torch.nn.Sequential(head))).eval()
+    x = torch.from_numpy(np.random.RandomState(6).rand(1, 1, 64, 96, 80).astype(np.float32)).to(device)
+    with torch.no_grad():
+        assert SW._split_unet_and_head(wrapped, x, (64, 64, 64)) is not None
+        calls = []
+        orig = SW._run_fused
+        SW._run_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            fused = sliding_window_inference(x, (64, 64, 64), 4, wrapped, overlap=0.7)
+        finally:
+            SW._run_fused = orig
+        generic = sliding_window_inference(x, (64, 64, 64), 4, lambda t: wrapped(t), overlap=0.7)
+    assert calls and fused.shape == generic.shape == (1, 5, 64, 96, 80)
+    assert rel_l2(fused, generic) < 1e-5
+    # a head that is not per-voxel affine keeps the generic loop
+    nonlin = torch.nn.Sequential(m, torch.nn.Sequential(head, torch.nn.Softmax(dim=1))).eval()
+    with torch.no_grad():
+        assert SW._split_unet_and_head(nonlin, x, (64, 64, 64)) is None
+    with torch.enable_grad():
+        assert SW._split_unet_and_head(wrapped, x, (64, 64, 64)) is None
+
+
+def test_output_widths_the_fused_step_cannot_accumulate_use_the_generic_loop(device):
+    """output_nc = 8 leaves the network through the export pass (amx_api.hip: final_via_export): the fused window entry would
+    return AMX_ERR_SHAPE, so the dispatcher must not pick it (advisor finding, round 3)."""
+    kw = dict(dimension=3, input_nc=1, output_nc=8, num_downs=2, ngf=16)
+    m = anatomix_amd.Unet(**kw)
+    sd = R.synthetic_state_dict(kw, 1)
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    x = torch.from_numpy(np.random.RandomState(7).rand(1, 1, 32, 48, 64).astype(np.float32)).to(device)
+    with torch.no_grad():
+        assert not _fused_ok(m, x, (32, 32, 32))
+        got = sliding_window_inference(x, (32, 32, 32), 2, m, overlap=0.5).cpu()
+    ref = O.sliding_window(x.cpu().numpy()[0], (32, 32, 32), lambda a: R.forward(torch.from_numpy(a), sd, kw).numpy(), 0.5, "constant", 0.125)
+    assert got.shape == (1, 8, 32, 48, 64) and rel_l2(got[0], torch.from_numpy(ref)) <= 1e-3

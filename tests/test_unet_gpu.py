@@ -287,4 +287,4 @@ def test_input_and_output_channel_counts_of_the_constructor_envelope(device, kw,
         assert a.shape == b.shape and rel_l2(a.cpu(), b) <= (2e-4 if strict else 2e-3), (a.shape, rel_l2(a.cpu(), b))
     # the fused sliding-window entry is single-channel only: the generic path serves these networks
     from anatomix_amd.registration.sliding_window import _fused_ok
-    assert not _fused_ok(m, x.to(device)) or kw["input_nc"] == 1
+    assert not _fused_ok(m, x.to(device), size) or kw["input_nc"] == 1
