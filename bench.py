@@ -54,6 +54,13 @@ def parse():
                          "stock torch ViT modules -- would show up in the kernel statistics of the product path)")
     ap.add_argument("--no-graph", action="store_true", help="step workload: launch every kernel eagerly instead of replaying one HIP graph")
     ap.add_argument("--cpu-forwards", type=int, default=6, help="timed CPU forwards of one 128^3 volume")
+    ap.add_argument("--plumbing-cpu", action="store_true",
+                    help="NOT a measurement: run `--workload step --no-graph` on the host (stock torch modules, gloo) at a small --size so "
+                         "that the N-rank plumbing -- self-launch, rendezvous, flat gradient buckets, all-reduce, barrier-bracketed timing, the "
+                         "one JSON line -- is exercised end to end where no GPU node is available (tests/test_bench_launch.py)")
+    ap.add_argument("--sustain", type=float, default=2.5,
+                    help="N=1: after the K timed steps, run the same loop for this many seconds with rocm-smi power / clock sampling and "
+                         "report it as `sustained` (0: off)")
     ap.add_argument("--variant", default="anatomix", choices=["anatomix", "anatomix-dev", "anatomix-dev-vit"],
                     help="anatomix = the 6M UNet the metric is quoted on; anatomix-dev = BASELINE configs[3] (94M); "
                          "anatomix-dev-vit = BASELINE configs[4] (26M PrimusV2 3D ViT, MFMA attention path)")
@@ -103,9 +110,32 @@ def cpu_baseline(size, forwards, variant="anatomix"):
                 break
     best = min(ts)
     cpu_baseline.last_output = R.forward(x, sd, kw) if forwards else None      # checker: the headline's parity figure
+    if forwards:
+        _ORACLE_CACHE[(variant, size)] = cpu_baseline.last_output
     return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{len(ts)} forwards of one 1x1x{size}^3 volume, fp32 eval, torch CPU (oneDNN) with {cores} of "
                       f"{avail} host threads (best of a {cands} probe), best time; median {sorted(ts)[len(ts)//2]*1e3:.0f} ms"}
+
+
+_ORACLE_CACHE = {}
+
+
+def fp32_cpu_oracle(variant, size):
+    """The fp32 CPU oracle's features of volume seed 100 (rank 0's first volume), one forward per variant and process: the checker
+    behind `parity.rel_l2_vs_fp32_cpu_oracle` of every forward line (headline and secondaries), never inside a timed region."""
+    key = (variant, size)
+    if key not in _ORACLE_CACHE:
+        import torch
+        from oracle import unet_ref as R
+        kw = R.VARIANTS[variant]
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(min(avail, 32))
+        with torch.no_grad():
+            _ORACLE_CACHE[key] = R.forward(R.synthetic_input(100, 1, (size,) * 3), R.synthetic_state_dict(kw, 0), kw)
+    return _ORACLE_CACHE[key]
 
 
 def cpu_baseline_vit():
@@ -271,6 +301,60 @@ def parity_vs_split(torch, ctx, variant, precision, x, y):
             "tolerance": 1e-3, "compliant": bool(rel <= 1e-3)}
 
 
+def _smi_sample():
+    """(socket power W, shader clock MHz) from rocm-smi, or (None, None)."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+    except Exception:
+        return None, None
+    pw = re.search(r"Socket Graphics Package Power \(W\):\s*([0-9.]+)", out)
+    ck = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", out)
+    return (float(pw.group(1)) if pw else None), (float(ck.group(1)) if ck else None)
+
+
+def sustained_run(torch, dev, step, grad_ctx, units_per_step, short_ms_step, seconds):
+    """The same step loop for >= `seconds` of wall time (the driver-timed region of the default line is ~30 ms: a burst on a part
+    that is power-managed over hundreds of ms), with the socket power and shader clock sampled beside it by a thread (rocm-smi)."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(_smi_sample())
+            stop.wait(0.25)
+
+    n_est = max(10, int(seconds * 1e3 / max(short_ms_step, 1e-3)))
+    th = threading.Thread(target=sampler, daemon=True)
+    with grad_ctx:
+        torch.cuda.synchronize(dev)
+        th.start()
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for _ in range(n_est):
+                step()
+            done += n_est
+            torch.cuda.synchronize(dev)
+            if time.perf_counter() - t0 >= seconds:
+                break
+            n_est = max(1, n_est // 4)
+        el = time.perf_counter() - t0
+        stop.set()
+        th.join(timeout=6)
+    pw = [p for p, _ in samples[1:] if p is not None]
+    ck = [c for _, c in samples[1:] if c is not None]
+    val = units_per_step * done / el
+    out = {"value": round(val, 2), "unit": "volumes/s", "seconds": round(el, 2), "steps": done, "ms_per_step": round(el / done * 1e3, 4),
+           "mean_socket_power_w": round(sum(pw) / len(pw), 0) if pw else None, "mean_sclk_mhz": round(sum(ck) / len(ck), 0) if ck else None,
+           "smi_samples": len(pw), "ratio_to_short_run": round(val / (units_per_step / short_ms_step * 1e3), 4)}
+    if abs(out["ratio_to_short_run"] - 1.0) > 0.05:
+        out["note"] = ("differs from the short timed region by more than 5 %: the short region is a burst (tens of ms) on a socket whose "
+                       "1.4 kW power management acts over hundreds of ms -- the sustained figure is the steady state")
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: re-exec this script under torch.distributed.run, one rank per
     GPU of this node (rendezvous on 127.0.0.1), and pass its exit code on.  Rank 0 of the child job prints the JSON line."""
@@ -368,12 +452,13 @@ def build_model(ctx, variant, precision):
     finally:
         sys.stdout = so
     model.load_state_dict(R.synthetic_state_dict(kw, 0), strict=True)
-    model.precision = precision
+    if precision is not None:                      # None: the module's own default for the configuration (Unet.precision)
+        model.precision = precision
     return model.to(ctx.dev).eval()
 
 
 def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, precision="f16", steps=100, warmup=10, batch=4, size=128,
-                 no_graph=False, with_cpu=True, cpu_forwards=6, with_parity=True):
+                 no_graph=False, with_cpu=True, cpu_forwards=6, with_parity=True, sustain_s=0.0):
     """One measured workload -> the result dict of the JSON line (rank 0; None on the other ranks)."""
     torch, dist, dev, world, rank = ctx.torch, ctx.dist, ctx.dev, ctx.world, ctx.rank
     from oracle import unet_ref as R
@@ -381,11 +466,15 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
     S, B = size, batch
     x = R.synthetic_input(100 + rank, B, (S, S, S)).to(dev)      # resident before the timed region
 
+    on_gpu = dev.type == "cuda"
+
     def barrier():
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
 
     step = lambda: model(x)
     units_per_step = world * B          # 128^3 volumes all ranks process per step
@@ -397,6 +486,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         from oracle import pretrain_inputs as PI      # synthetic two-view inputs only
         model.precision = "bf16"                      # the reference trains under bf16 autocast
         model.train()
+        if not on_gpu:                                # --plumbing-cpu: the stock-module composition of the same network
+            model.allow_torch_path = True
         so, sys.stdout = sys.stdout, open(os.devnull, "w")
         try:
             netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
@@ -406,7 +497,11 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         netF = netF.to(dev).train()
         nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
         crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
-        if os.environ.get("AMX_TORCH_ADAMW", "0") == "1":     # A/B: the stock optimizer (capturable keeps its step count on the device)
+        if not on_gpu:
+            model._warned = True
+            for c_ in crits:
+                c_.allow_torch_path = True
+        if os.environ.get("AMX_TORCH_ADAMW", "0") == "1" or not on_gpu:     # A/B: the stock optimizer (capturable keeps its step count on the device)
             AdamW = lambda prm, **kw: torch.optim.AdamW(prm, capturable=not no_graph, **kw)
         else:                                                 # same rule and state layout, one launch per optimizer (amx_adamw_step)
             from anatomix_amd.pretraining import FusedAdamW as AdamW
@@ -453,10 +548,23 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if not on_gpu:        # plumbing run: no kernel roofline, no host baseline -- the line only proves the N-rank path end to end
+        if rank != 0:
+            return None
+        return {"metric": "plumbing run on the host (NOT a measurement)", "value": round(units_per_step * steps / float(t.item()), 4),
+                "unit": "volumes/s", "n_gpus": world, "ranks_seen": getattr(ctx, "ranks_seen", 1), "devices": getattr(ctx, "devices", None),
+                "steps": steps, "warmup": warmup, "ms_per_step": round(float(t.item()) / steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "fp32 (stock torch modules on the CPU)", "data": "synthetic",
+                "config": {"workload": f"contrastive step at {size}^3 on the host, gloo, one pair per rank" + dp_note,
+                           "parallelism": f"data parallel x{world}"},
+                "finite": bool(torch.isfinite(y).all())}
     elapsed = float(t.item())
     ms_step = elapsed / steps * 1e3
     value = units_per_step * steps / elapsed
     assert torch.isfinite(y).all()
+    sustained = None
+    if sustain_s > 0 and world == 1:
+        sustained = sustained_run(torch, dev, step, grad_ctx, units_per_step, ms_step, sustain_s)
 
     result = None
     if rank == 0:
@@ -472,8 +580,11 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         name = "anatomix 6M UNet (ngf=16,num_downs=4)" if variant == "anatomix" else \
             ("anatomix-dev-vit 26M PrimusV2-S 3D ViT (conv tokenizer, 4096+8 tokens, 12 EVA blocks, 6 heads x 66)" if vit else
              "anatomix-dev 94M UNet (ngf=32,num_downs=5,InstanceNorm,trilinear,AvgPool)")
+        precision = model.precision if hasattr(model, "precision") else precision      # None -> the module's per-configuration default
         storage = {"f16": "16-bit (f16) channels-last activations, fp32 accumulate",
-                   "bf16": "16-bit (bf16) channels-last activations, fp32 accumulate"}.get(
+                   "bf16": "16-bit (bf16) channels-last activations, fp32 accumulate",
+                   "f16x2mx": "f16 hi+lo pairs, row-planar, + e4m3 copies: Wh*xh on the f16 MFMA, the two correction products on the "
+                              "block-scaled fp8 MFMA (2 MFMA-equivalents per product), fp32 accumulate"}.get(
             precision, f"split hi+lo 16-bit operands ({'bf16x2' if precision == 'strict' else precision}: three MFMAs per product), "
                        "fp32 accumulate -- fp32-grade results")
         if sw_volume:
@@ -490,8 +601,9 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             par = f"data parallel x{world}: one pair per rank" + dp_note
             gflop_vol *= 3.0      # forward + data gradient + weight gradient
         else:
-            workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 (the predictor call of "
-                          f"sliding_window_inference, BASELINE configs[1]); fp32 NCDHW in/out, {storage}" +
+            cfg_s = ("the predictor call of sliding_window_inference, BASELINE configs[1] / the metric" if variant == "anatomix"
+                     else "BASELINE configs[3]")
+            workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 ({cfg_s}); fp32 NCDHW in/out, {storage}" +
                           ("; the module runs the batch as chunks of 4 on two HIP streams" if B >= 8 and not vit else ""))
             if vit:
                 workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]), one amx_vit_forward call: "
@@ -518,6 +630,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             "end_to_end_mfma_frac": round(value / world * gflop_vol / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "roofline": roofline,
         }
+        if sustained is not None:
+            result["sustained"] = sustained
         if world == 1 and with_cpu:
             result["cpu_baseline"] = cpu_baseline_step(S) if workload == "step" else \
                 (cpu_baseline_vit() if vit else cpu_baseline(S, cpu_forwards, variant))
@@ -532,13 +646,16 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             del ref
         if workload == "forward" and not sw_volume and not vit and with_parity:
             result["parity"] = parity_vs_split(torch, ctx, variant, precision, x, y)
-        if workload == "forward" and not sw_volume:
-            ref_cpu = getattr(cpu_baseline, "last_output", None) if (world == 1 and with_cpu) else None
-            if ref_cpu is not None and rank == 0 and "parity" in result:     # rank 0's first volume is the oracle's input (seed 100)
-                d = (y[:1].cpu().double() - ref_cpu.double()).norm() / ref_cpu.double().norm()
-                result["parity"]["rel_l2_vs_fp32_cpu_oracle"] = float("%.3e" % float(d))
-                result["parity"]["compliant"] = bool(float(d) <= 1e-3)
-                cpu_baseline.last_output = None
+        if workload == "forward" and not sw_volume and not vit and with_parity and world == 1 and "parity" in result:
+            # against the fp32 CPU oracle itself (rank 0's first volume is the oracle's input, seed 100): the figure the tolerance is
+            # stated on, for the headline AND for every forward secondary (one cached oracle forward per variant)
+            ref_cpu = fp32_cpu_oracle(variant, S).double()
+            d = y[:1].cpu().double() - ref_cpu
+            result["parity"]["rel_l2_vs_fp32_cpu_oracle"] = float("%.3e" % float(d.norm() / ref_cpu.norm()))
+            result["parity"]["max_rel_vs_fp32_cpu_oracle"] = float("%.3e" % float(d.abs().max() / ref_cpu.abs().max()))
+            result["parity"]["compliant"] = bool(result["parity"]["rel_l2_vs_fp32_cpu_oracle"] <= 1e-3)
+            result["parity"]["compliant_max_norm"] = bool(result["parity"]["max_rel_vs_fp32_cpu_oracle"] <= 1e-3)
+            cpu_baseline.last_output = None
     del model, x, y
     torch.cuda.empty_cache()
     return result
@@ -550,9 +667,12 @@ def secondary_workloads(ctx, args):
     plan = [
         ("anatomix_batch8_two_chunks_in_flight", dict(variant="anatomix", precision="f16", steps=60, warmup=15, batch=8)),
         ("anatomix_strict", dict(variant="anatomix", precision="strict", steps=10, warmup=3, batch=args.batch)),
-        # anatomix-dev (BASELINE configs[3]): `strict` is the module's default for InstanceNorm networks and the compliant number;
-        # single f16 storage is an explicit opt-in that misses the 1e-3 tolerance (reported with its measured error, not credited)
-        ("anatomix_dev", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),
+        # anatomix-dev (BASELINE configs[3]) in the module's DEFAULT precision for InstanceNorm networks (f16x2mx since round 4:
+        # f16 pairs + fp8 correction products) -- the compliant number; `strict` (bf16x2, three f16-rate MFMAs per product) is the
+        # round-3 default, kept for continuity; single f16 storage is an explicit opt-in that misses the 1e-3 tolerance (reported
+        # with its measured error, not credited)
+        ("anatomix_dev", dict(variant="anatomix-dev", precision=None, steps=8, warmup=3, batch=4, sustain_s=2.0)),
+        ("anatomix_dev_bf16x2", dict(variant="anatomix-dev", precision="strict", steps=5, warmup=2, batch=4)),
         ("anatomix_dev_f16_noncompliant", dict(variant="anatomix-dev", precision="f16", steps=10, warmup=3, batch=4)),
         # the ViT has no prescribed batch: 8 fills the chip better (attention: 1584 workgroups on 512 slots = 3.1 rounds instead of 1.55);
         # the batch-4 line is kept for continuity with round 2 (109 volumes/s there)
@@ -567,7 +687,7 @@ def secondary_workloads(ctx, args):
         try:
             r = run_workload(ctx, size=S, with_cpu=False, **kw)
             keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "end_to_end_TFLOPs",
-                                      "end_to_end_mfma_frac", "roofline", "parity") if k in r}
+                                      "end_to_end_mfma_frac", "roofline", "parity", "sustained") if k in r}
             keep["workload"] = r["config"]["workload"]
             keep["batch_per_gpu"] = r["config"]["batch_per_gpu"]
             keep["roofline"].pop("per_kernel", None)
@@ -605,35 +725,56 @@ def main():
             print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "volumes/s", "n_gpus": world, "ranks_seen": seen,
                               "steps": args.steps, "warmup": args.warmup}))
         return
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    if world > 1 and torch.cuda.device_count() < world:
-        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+    plumbing = bool(args.plumbing_cpu)
+    if plumbing and not (args.workload == "step" and args.no_graph):
+        print("bench.py: --plumbing-cpu runs `--workload step --no-graph` only", file=sys.stderr)
         sys.exit(2)
+    if not plumbing:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        if world > 1 and torch.cuda.device_count() < world:
+            print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+            sys.exit(2)
     ctx = Ctx()
     ctx.torch, ctx.dist, ctx.world, ctx.rank = torch, dist, world, rank
-    ctx.dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(ctx.dev)
+    ctx.dev = torch.device("cpu") if plumbing else torch.device("cuda", local_rank if world > 1 else 0)
+    if not plumbing:
+        torch.cuda.set_device(ctx.dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=ctx.dev)
+        if plumbing:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=ctx.dev)
     # auditability of the N-rank line: every rank adds a one over RCCL (ranks_seen must equal n_gpus) and reports its device
-    ctx.ranks_seen, ctx.devices = 1, [f"cuda:{ctx.dev.index} {torch.cuda.get_device_name(ctx.dev)}"]
+    dev_name = "host CPU (gloo)" if plumbing else f"cuda:{ctx.dev.index} {torch.cuda.get_device_name(ctx.dev)}"
+    ctx.ranks_seen, ctx.devices = 1, [dev_name]
     if world > 1:
         ones = torch.ones(1, dtype=torch.int32, device=ctx.dev)
         dist.all_reduce(ones)
         ctx.ranks_seen = int(ones.item())
         names = [None] * world
-        dist.all_gather_object(names, f"rank {rank}: cuda:{ctx.dev.index} {torch.cuda.get_device_name(ctx.dev)} "
-                                      f"(uuid {getattr(torch.cuda.get_device_properties(ctx.dev), 'uuid', 'n/a')})")
+        uuid = "n/a" if plumbing else getattr(torch.cuda.get_device_properties(ctx.dev), "uuid", "n/a")
+        dist.all_gather_object(names, f"rank {rank}: {dev_name} (uuid {uuid})")
         ctx.devices = names
 
     result = run_workload(ctx, variant=args.variant, workload=args.workload, sw_volume=args.sw_volume, precision=args.precision,
                           steps=args.steps, warmup=args.warmup, batch=args.batch, size=args.size, no_graph=args.no_graph,
-                          with_cpu=not args.no_cpu_baseline, cpu_forwards=args.cpu_forwards, with_parity=not args.no_parity)
+                          with_cpu=not args.no_cpu_baseline, cpu_forwards=args.cpu_forwards, with_parity=not args.no_parity,
+                          sustain_s=args.sustain)
     headline = args.variant == "anatomix" and args.workload == "forward" and not args.sw_volume and args.precision == "f16"
     if rank == 0 and world == 1 and headline and not args.no_secondary:
         result["secondary"] = secondary_workloads(ctx, args)
+        # The precision contract of the headline, in the line itself.  f16 storage meets the north-star tolerance (<= 1e-3 relative
+        # to the fp32 reference) in rel-L2 (parity.rel_l2_vs_fp32_cpu_oracle) but NOT always in the max-norm (0.86e-3 .. 1.4e-3 over
+        # four weight seeds, tests/test_unet_gpu.py); the mode that holds it in BOTH norms is `strict`, and its rate is a
+        # first-class figure here rather than a buried secondary.
+        st_ = result["secondary"].get("anatomix_strict", {})
+        if "value" in st_:
+            result["value_strict"] = {"value": st_["value"], "unit": st_["unit"], "dtype": st_.get("dtype"), "ms_per_step": st_.get("ms_per_step"),
+                                      "parity": st_.get("parity"),
+                                      "note": "the same workload in the precision that holds 1e-3 in rel-L2 AND in the max-norm; `value` "
+                                              "(f16 storage) holds it in rel-L2, see parity.max_rel_vs_fp32_cpu_oracle"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

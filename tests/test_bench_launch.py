@@ -29,3 +29,20 @@ def test_bench_under_an_external_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2
+
+
+def test_data_parallel_step_end_to_end_on_the_host():
+    """not only the rendezvous -- the data-parallel contrastive step of `bench.py --workload step --no-graph`
+    itself, self-launched at world size 2: two pairs of views, flat gradient buckets averaged by all-reduce (gloo here, RCCL on a GPU
+    node: the same GradientBuckets code), both ranks' optimizers stepping, max-over-ranks timing, ONE JSON line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "step", "--no-graph", "--plumbing-cpu",
+                        "--size", "32", "--steps", "2", "--warmup", "1", "--sustain", "0"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2 and line["steps"] == 2
+    assert line["finite"] and line["value"] > 0 and "flat buckets" in line["config"]["workload"]
