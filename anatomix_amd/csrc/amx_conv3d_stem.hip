@@ -21,7 +21,6 @@ namespace amx {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int kStemF32Offset = 8192;    // byte offset of the fp32 [27][Cout] weight table inside the stem's packed-weight buffer
 
 template <int TY, int TX, int TZ, int NC, int R>
 struct StemCfg {
@@ -227,29 +226,51 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
 
 
 // -------------------------------------------------------------------------------------------------------------------------------
-// VALU variant (round 3) -- MEASURED, NOT THE DEFAULT (AMX_STEM_VALU=1 selects it).  6 M stem, batch 4 x 128^3, same box: 144 us
-// against 131 us for the MFMA kernel (strict, 32 channels: 385 vs 259).  Ablations of both (profiles/r03_stem_ablation.txt): input
-// ring + output stores alone take 76-92 us (the 268 MB of output leave at ~3.5 TB/s at best), the arithmetic phase (37 us of
-// gather + MFMA there, 54 us of packed fp32 FMAs here -- v_pk_fma_f32 is 4 cycles per wave, the stencil is 46 us of pure VALU at
-// 2.4 GHz) adds to that almost serially in BOTH formulations, and more workgroups per CU (512 .. 2048) change nothing.  The stem is
-// bound by its store stream plus whatever arithmetic sits in front of it, not by the operand path the verdict suspected.
-// The MFMA kernel above spends ~125 instructions per MFMA gathering, converting and packing the 27 taps
-// of a voxel into a K = 32 fragment: it is instruction-bound at 2.1x its write floor.  With one input channel the layer is
-// 27 x Cout multiply-adds per voxel on an operand that needs no rounding at all -- the fp32 input and the fp32 (norm-folded)
-// weights: here a lane owns ONE voxel, reads its 27 fp32 taps from the same LDS ring, and runs 27 x Cout v_fma_f32 whose second
-// operand is a scalar register (the weight table [tap][cout] comes through the scalar cache: the constant address space makes
-// hipcc use s_load for it).  No conversions, no packing, no MFMA -- and the arithmetic is exact fp32 instead of 16-bit operands.
-// Same tile (8 x 32 x 2 planes per step), same loader wave, same flag protocol as above.
-typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+// Row-fragment formulation (round 4) -- the default.  The kernel above is VALU-ISSUE bound, not LDS- or HBM-bound: per 16-voxel
+// tile a lane issues 8 ds_read_b32 + 12 conversions / packs to build ONE K = 32 fragment (~125 instructions per MFMA with the
+// epilogue; profiles/r03_stem_ablation.txt: 47 of its 130 us are gather + MFMA, the matrix pipe is 3 % busy).  (A VALU-only variant
+// -- one voxel per lane, 27 x Cout v_pk_fma_f32 with the weights through the scalar cache, round 3 -- was slower still: 144 us; its
+// ablation numbers are in that file.)  Here the matrix pipe pays instead of the VALU:
+//   * a converter wave loads the fp32 halo rows into registers, rounds them ONCE per input voxel (instead of once per tap = 27 x)
+//     and writes each row to the LDS ring as 16-bit values, twice: copy A as is, copy B shifted by one element, so that the four
+//     consecutive values x-1 .. x+2 of ANY x start at a 4-byte aligned address in one of the two copies;
+//   * K is laid out as 16 row slots of 4 (dx = -1, 0, +1, zero) over TWO MFMAs: lane group g of MFMA m holds the rows 2p, 2p + 1
+//     (p = g + 4m) of the nine (kz, ky) rows -- i.e. a lane's 16-byte B fragment IS two 8-byte LDS reads, no conversion, no packing;
+//     MFMA 1 only carries row 8 (one read).  3 reads + 2 MFMAs per tile instead of 8 reads + 12 VALU + 1 MFMA.
+// SPLIT: the converter writes the hi and the lo image of every row, the products are Wh*xh + Wh*xl + Wl*xh (6 MFMAs, 6 reads).
+template <int TY, int TX, int TZ, int NC, int R, bool SPLIT>
+struct Stem2Cfg {
+  static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
+  static constexpr int RS = ((HX + 2) * 2 + 7) / 8 * 8;               // row stride: HX values + 2 zero pads, 8-byte multiple
+  static constexpr int CPSZ = HY * RS;                                // one copy of one image of one plane
+  static constexpr int IMSZ = 2 * CPSZ;                               // copies A | B
+  static constexpr int PLSZ = ((IMSZ * (SPLIT ? 2 : 1) + 8 + 63) / 64) * 64;     // + 8 bytes nobody reads: where the converter's idle lanes write
+  static constexpr int DUMMY = PLSZ - 8;
+  static constexpr int FLAGOFF = R * PLSZ;                            // ready at +0, done[8] at +32
+  static constexpr int NLD = (HVP + 63) / 64;                         // 4-byte DMA instructions (= staged values per lane) per plane
+  static constexpr int STGOFF = R * PLSZ + 64;                        // staging ring of fp32 planes as the DMA delivers them
+  static constexpr int STGSZ = NLD * 256;
+  static constexpr int LDS_BYTES = STGOFF + R * STGSZ;
+  static constexpr int XT = TX / 16;
+  static constexpr int TILES = TZ * TY * XT;
+  static constexpr int CTW = TILES / NC;
+  static constexpr int WPZ = NC / TZ;
+  static constexpr int ROWS_W = TY / WPZ;
+  static_assert(TILES % NC == 0 && NC % TZ == 0 && TY % WPZ == 0 && CTW == ROWS_W * XT, "tile/wave decomposition");
+  static_assert(R * NLD <= 60, "vmcnt range");
+};
 
 template <typename T, int Q, int TY, int TX, int TZ, int NC, int R, bool SPLIT>
-__global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_valu_kernel(const ConvParams p, int zseg, int nseg) {
-  typedef StemCfg<TY, TX, TZ, NC, R> C;
-  constexpr int HX = C::HX, PLSZ = C::PLSZ, NDMA = C::NDMA, CO = 16 * Q;
-  static_assert(TX == 32 && NC * 64 == TZ * TY * TX, "one lane per voxel of a step");
+__global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem2_kernel(const ConvParams p, int zseg, int nseg) {
+  typedef Stem2Cfg<TY, TX, TZ, NC, R, SPLIT> C;
+  typedef typename Ops<T>::vec8 vec8;
+  constexpr int HX = C::HX, PLSZ = C::PLSZ, XT = C::XT, CTW = C::CTW, NLD = C::NLD, RS = C::RS, CPSZ = C::CPSZ, IMSZ = C::IMSZ;
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
   int b = blockIdx.x;
   const int nb = gridDim.x;
   if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
@@ -267,57 +288,106 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_valu_kernel(const C
 
   int* ready = (int*)(smem + C::FLAGOFF);
   int* done = (int*)(smem + C::FLAGOFF + 32);
-  if (tid < 16) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  // the pad slots of every row (and the flags) start as zeros and are never written again: a fragment's fourth value meets a zero
+  // weight, so it must be finite
+  for (int i = tid; i < C::LDS_BYTES / 4; i += (NC + 1) * 64) ((int*)smem)[i] = 0;
   __syncthreads();
 
   if (wave >= NC) {
-    // ================================ loader wave (as in the MFMA kernel) ================================
-    int off[NDMA];
-    bool valid[NDMA];
+    // ================================ converter wave ================================
+    // The fp32 halo plane arrives by 4-byte LDS-DMA in a staging ring (no register destinations: loads whose results land
+    // asynchronously in VGPRs cannot be expressed safely around hipcc's register allocation, and its own wait counting collapsed
+    // to one plane of lookahead); this wave then reads ITS six values back, rounds them and writes the two row copies.  Every LDS
+    // access of this wave is inline asm: with an LDS-DMA pending hipcc would put vmcnt(0) in front of each one.  Lanes without a
+    // voxel write a dummy slot -- no predication, no branches.
+    int goff[NLD], la[NLD], lb[NLD];
+    bool valid[NLD];
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) {
+    for (int j = 0; j < NLD; ++j) {
       const int hv = j * 64 + lane;
-      const int hy = hv / HX, hx = hv - hy * HX;
       valid[j] = hv < C::HVP;
-      off[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x;
+      const int hvc = valid[j] ? hv : C::HVP - 1;
+      const int hy = hvc / HX, hx = hvc - hy * HX;
+      goff[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x;
+      la[j] = valid[j] ? hy * RS + hx * 2 : C::DUMMY;                            // copy A: value hx at element hx
+      lb[j] = (valid[j] && hx > 0) ? CPSZ + hy * RS + (hx - 1) * 2 : C::DUMMY;   // copy B: value hx at element hx - 1
     }
+    static_assert(NLD == 6, "the staging read below names six registers");
     const char* src_n = p.src0 + (long long)n * p.s0n;
+    char* stg = smem + C::STGOFF;
     auto issue_plane = [&](int q) {
       const char* plane = src_n + (long long)reflect_clamp(zs - 1 + q, p.D) * p.s0z;
-      char* dstp = smem + (q % R) * PLSZ;
+      char* dstp = stg + (q % R) * C::STGSZ;
 #pragma unroll
-      for (int j = 0; j < NDMA; ++j)
-        if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + off[j]), (lptr_t)(dstp + j * 256), 4, 0, 0);
+      for (int j = 0; j < NLD; ++j)
+        if (valid[j]) __builtin_amdgcn_global_load_lds((gptr_t)(plane + goff[j]), (lptr_t)(dstp + j * 256), 4, 0, 0);
     };
     int next_issue = 0, next_pub = 0;
     const unsigned a_ready = lds_addr(ready), a_done = lds_addr(done);
+    const unsigned a_stg = lds_addr(stg) + lane * 4, a_ring = lds_addr(smem);
     while (next_pub < nplanes) {
-      if (next_issue < nplanes) {
-        const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done));
-        int lim = R + TZ * md;
+      {
+        int lim = next_pub + R;                               // staging slot q % R is free once plane q - R has been converted
         lim = lim < nplanes ? lim : nplanes;
         while (next_issue < lim) issue_plane(next_issue++);
       }
-      if (next_issue == next_pub) {
-        __builtin_amdgcn_s_sleep(2);
-        continue;
+      // the ring slot of plane next_pub is free once the consumers are done with plane next_pub - R: planes < TZ * min(done) are dead
+      while (next_pub >= R + TZ * __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done))) __builtin_amdgcn_s_sleep(1);
+      WaitVm<NLD, R - 1>::run(next_issue - next_pub - 1);     // the oldest unconverted plane has landed in the staging ring
+      float f[NLD];
+      asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:256\n\tds_read_b32 %2, %6 offset:512\n\t"
+                   "ds_read_b32 %3, %6 offset:768\n\tds_read_b32 %4, %6 offset:1024\n\tds_read_b32 %5, %6 offset:1280\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
+                   : "v"(a_stg + (unsigned)((next_pub % R) * C::STGSZ))
+                   : "memory");
+      const unsigned dst = a_ring + (unsigned)((next_pub % R) * PLSZ);
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) {
+        const T h = (T)f[j];
+        const unsigned hb = __builtin_bit_cast(unsigned short, h);
+        asm volatile("ds_write_b16 %0, %2\n\tds_write_b16 %1, %2" ::"v"(dst + (unsigned)la[j]), "v"(dst + (unsigned)lb[j]), "v"(hb) : "memory");
+        if (SPLIT) {
+          const T l = (T)(f[j] - (float)h);
+          const unsigned lbits = __builtin_bit_cast(unsigned short, l);
+          asm volatile("ds_write_b16 %0, %2\n\tds_write_b16 %1, %2" ::"v"(dst + (unsigned)(la[j] == C::DUMMY ? C::DUMMY : IMSZ + la[j])),
+                       "v"(dst + (unsigned)(lb[j] == C::DUMMY ? C::DUMMY : IMSZ + lb[j])), "v"(lbits) : "memory");
+        }
       }
-      WaitVm<NDMA, R - 1>::run(next_issue - next_pub - 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       flag_store_asm(a_ready, ++next_pub);
     }
     return;
   }
 
-  // ================================ consumer wave: one voxel per lane ================================
-  constexpr int WPZ = NC / TZ;                              // waves per output plane
-  const int tz = wave / WPZ;
-  const int row = (wave % WPZ) * (TY / WPZ) + (lane >> 5), col = lane & 31;
-  const int lanepos = (row * HX + col) * 4;
-  const int yl = y0 + row, xl = x0 + col;
-  const bool in_xy = (yl < p.H) & (xl < p.W);
-  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox;
-  const cfloat_ptr wt = (cfloat_ptr)(p.wpk + kStemF32Offset);          // [27][CO] fp32, norm gain folded in
-  const cfloat_ptr bs = (cfloat_ptr)p.bias;
+  // ================================ consumer wave ================================
+  const int li = lane & 15, g = lane >> 4;
+  // A fragments: [part (Wh | Wl)][mfma m][q]
+  vec8 wreg[2][Q], wlo[SPLIT ? 2 : 1][SPLIT ? Q : 1];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      wreg[m][q] = *(const vec8*)(p.wpk + 4096 + (m * Q + q) * 1024 + lane * 16);
+      if (SPLIT) wlo[SPLIT ? m : 0][SPLIT ? q : 0] = *(const vec8*)(p.wpk + 4096 + ((2 + m) * Q + q) * 1024 + lane * 16);
+    }
+  f32x4 bias[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) bias[q] = p.bias ? *(const f32x4*)(p.bias + g * 4 * Q + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int tz = wave / C::WPZ;
+  const int wrow = (wave % C::WPZ) * C::ROWS_W;
+  const bool full_xy = (y0 + TY <= p.H) & (x0 + TX <= p.W);
+  const int yl = y0 + wrow, xl = x0 + li;
+  const int ocs = p.ocs ? p.ocs : 32;
+  char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (long long)((g * 4 * Q) >> 4) * ocs + ((g * 4 * Q) & 15) * 2;
+  // lane constants of the three reads: rows (2g, 2g + 1) of MFMA 0, row 8 of MFMA 1; row r = 3 kz + ky
+  const int r0 = 2 * g, r1 = 2 * g + 1;
+  const int kz0 = r0 / 3, kz1 = r1 / 3;
+  // odd lanes read copy B (value hx sits at element hx - 1: their four values start 4-byte aligned there)
+  const int xpart = (li & 1) * CPSZ + (li - (li & 1)) * 2 + wrow * RS;
+  const int ro0 = (r0 % 3) * RS + xpart, ro1 = (r1 % 3) * RS + xpart, ro8 = 2 * RS + xpart;
 
   bool bad = false;
   for (int s = 0; s < nsteps; ++s) {
@@ -328,63 +398,108 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_valu_kernel(const C
       asm volatile("" ::: "memory");
     }
     const int zo = zs + s * TZ + tz;
-    float x[27];
+    int sl[3];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      const char* pl = smem + ((s * TZ + tz + kz) % R) * PLSZ + lanepos;
+    for (int kz = 0; kz < 3; ++kz) sl[kz] = ((s * TZ + tz + kz) % R) * PLSZ;
+    const int b0 = (kz0 == 0 ? sl[0] : (kz0 == 1 ? sl[1] : sl[2])) + ro0;
+    const int b1 = (kz1 == 0 ? sl[0] : (kz1 == 1 ? sl[1] : sl[2])) + ro1;
+    const int b8 = sl[2] + ro8;
+
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    auto rd = [&](int addr) -> u32x2 {             // two dwords at a 4-byte aligned address (ds_read2_b32)
+      const unsigned* q = (const unsigned*)(smem + addr);
+      return u32x2{q[0], q[1]};
+    };
+    vec8 f0[CTW], f1[CTW], l0[SPLIT ? CTW : 1], l1[SPLIT ? CTW : 1];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) x[kz * 9 + e] = *(const float*)(pl + ((e / 3) * HX + e % 3) * 4);
+    for (int c = 0; c < CTW; ++c) {
+      const int cx = c % XT, cy = c / XT;
+      const int toff = cy * RS + cx * 32;
+      const u32x2 a = rd(b0 + toff), bq = rd(b1 + toff), e = rd(b8 + toff);
+      f0[c] = __builtin_bit_cast(vec8, u32x4{a[0], a[1], bq[0], bq[1]});
+      f1[c] = __builtin_bit_cast(vec8, u32x4{g == 0 ? e[0] : 0u, g == 0 ? e[1] : 0u, 0u, 0u});
+      if (SPLIT) {
+        const u32x2 al = rd(b0 + toff + IMSZ), bl = rd(b1 + toff + IMSZ), el = rd(b8 + toff + IMSZ);
+        l0[SPLIT ? c : 0] = __builtin_bit_cast(vec8, u32x4{al[0], al[1], bl[0], bl[1]});
+        l1[SPLIT ? c : 0] = __builtin_bit_cast(vec8, u32x4{g == 0 ? el[0] : 0u, g == 0 ? el[1] : 0u, 0u, 0u});
+      }
     }
-    float acc[CO];
+    f32x4 acc[CTW][Q];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = p.bias ? bs[c] : 0.f;
-    if (!(p.dbg & 2)) {
+    for (int c = 0; c < CTW; ++c)
 #pragma unroll
-      for (int t = 0; t < 27; ++t)
-#pragma unroll
-        for (int c = 0; c < CO; ++c) acc[c] = __builtin_fmaf(x[t], wt[t * CO + c], acc[c]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
+      for (int q = 0; q < Q; ++q) {
+        acc[c][q] = Ops<T>::mfma(wreg[0][q], f0[c], bias[q]);
+        acc[c][q] = Ops<T>::mfma(wreg[1][q], f1[c], acc[c][q]);
+        if (SPLIT) {
+          acc[c][q] = Ops<T>::mfma(wreg[0][q], l0[SPLIT ? c : 0], acc[c][q]);
+          acc[c][q] = Ops<T>::mfma(wreg[1][q], l1[SPLIT ? c : 0], acc[c][q]);
+          acc[c][q] = Ops<T>::mfma(wlo[SPLIT ? 0 : 0][SPLIT ? q : 0], f0[c], acc[c][q]);
+          acc[c][q] = Ops<T>::mfma(wlo[SPLIT ? 1 : 0][SPLIT ? q : 0], f1[c], acc[c][q]);
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned (the MFMAs consumed them)
     flag_store(done + wave, s + 1);
-    if (p.act == ACT_RELU) {
-#pragma unroll
-      for (int c = 0; c < CO; ++c) acc[c] = acc[c] > 0.f ? acc[c] : 0.f;
-    } else if (p.act == ACT_LRELU) {
-#pragma unroll
-      for (int c = 0; c < CO; ++c) acc[c] = acc[c] > 0.f ? acc[c] : acc[c] * p.slope;
-    }
+    act_inplace<CTW * Q>(&acc[0][0], p.act, p.slope);
     if (RangeCheck<T>::on) {
 #pragma unroll
-      for (int c = 0; c < CO; ++c) bad |= RangeCheck<T>::bad(acc[c]);
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bad |= RangeCheck<T>::bad(acc[c][q][j]);   // the values about to be stored
     }
-    if (zo < ze && in_xy && !(p.dbg & 4)) {
-      char* dst = out_l + (long long)zo * p.oz;
-      unsigned w[CO / 2];
+    if (zo < ze && !(p.dbg & 4)) {
 #pragma unroll
-      for (int j = 0; j < CO / 2; ++j) w[j] = (unsigned)to_bits<T>(acc[2 * j]) | ((unsigned)to_bits<T>(acc[2 * j + 1]) << 16);
+      for (int c = 0; c < CTW; ++c) {
+        const int cx = c % XT, cy = c / XT;
+        if (!full_xy && !((yl + cy < p.H) & (xl + cx * 16 < p.W))) continue;
+        char* dst = out_l + (long long)zo * p.oz + cy * p.oy + (cx * 16) * p.ox;
+        float v[4 * Q];
 #pragma unroll
-      for (int j = 0; j < CO / 8; ++j) *(uint4*)(dst + j * 16) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-      if (SPLIT) {
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int j = 0; j < CO / 2; ++j)
-          w[j] = (unsigned)to_bits<T>(acc[2 * j] - (float)(T)acc[2 * j]) | ((unsigned)to_bits<T>(acc[2 * j + 1] - (float)(T)acc[2 * j + 1]) << 16);
+          for (int j = 0; j < 4; ++j) v[q * 4 + j] = acc[c][q][j];
+        unsigned w[2 * Q];
 #pragma unroll
-        for (int j = 0; j < CO / 8; ++j) *(uint4*)(dst + p.Cout * 2 + j * 16) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+        for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+        if (Q == 1) *(uint2*)dst = make_uint2(w[0], w[1]);
+        else *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+        if (SPLIT) {
+#pragma unroll
+          for (int j = 0; j < 2 * Q; ++j)
+            w[j] = (unsigned)to_bits<T>(v[2 * j] - (float)(T)v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1] - (float)(T)v[2 * j + 1]) << 16);
+          char* dlo = dst + (long long)(p.Cout >> 4) * ocs;
+          if (Q == 1) *(uint2*)dlo = make_uint2(w[0], w[1]);
+          else *(uint4*)dlo = make_uint4(w[0], w[1], w[2], w[3]);
+        }
       }
     }
   }
   if (RangeCheck<T>::on) raise_flag(p.oflow, bad);
 }
 
-// Stem weights: fp32 [Cout][1][3][3][3] (* folded norm gain) -> [q][lane 64][8] A fragments with
+// Packed stem weights.  Bytes [0, 4096): the tap-gather kernel's tiles [part][q][lane][8], k = 8*g + e <-> tap as described at the top.
+// Bytes [4096, 12288): the row-fragment kernel's tiles [part (Wh | Wl)][mfma m][q][lane][8]: k = 8 g + e of MFMA m <-> row
+// r = 2 (g + 4 m) + (e >> 2) = 3 kz + ky, dx = e & 3 (3: zero), i.e. tap 3 r + dx; rows >= 9: zero.
 // k = 8*g + e <-> tap as described above; row m of tile q is channel (m>>2)*4Q + q*4 + (m&3).
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ wpk,
                                  int Q, int split, int CoutReal) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < 27 * 16 * Q) {                          // fp32 table of the VALU kernel: [tap][cout], gain folded in
-    const int t = idx / (16 * Q), c = idx % (16 * Q);
-    ((float*)((char*)wpk + kStemF32Offset))[idx] = c < CoutReal ? w[c * 27 + t] * (scale ? scale[c] : 1.f) : 0.f;
+  if (idx < 2 * Q * 512 * (split ? 2 : 1)) {       // the row-fragment kernel's tiles
+    const int e = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int q = r % Q;
+    r /= Q;
+    const int m = r & 1, part = r >> 1;
+    const int mm = lane & 15, g = lane >> 4;
+    const int cout = (mm >> 2) * 4 * Q + q * 4 + (mm & 3);
+    const int row = 2 * (g + 4 * m) + (e >> 2), dx = e & 3;
+    float v = 0.f;
+    if (row < 9 && dx < 3 && cout < CoutReal) v = w[cout * 27 + row * 3 + dx] * (scale ? scale[cout] : 1.f);
+    ((T*)((char*)wpk + 4096))[idx] = part ? (T)(v - (float)(T)v) : (T)v;
   }
   if (idx >= Q * 512 * (split ? 2 : 1)) return;
   const int part = idx / (Q * 512);                 // split: [Wh tiles | Wl tiles]
@@ -426,13 +541,18 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   zseg = (zseg + TZ - 1) / TZ * TZ;
   if (zseg < 8) zseg = 8;
   nseg = (p.D + zseg - 1) / zseg;
-  static int valu = -1;
-  if (valu < 0) valu = getenv("AMX_STEM_VALU") ? 1 : 0;     // opt-in: measured slower (below)
-  if (valu && (p.ocs == 0 || p.ocs == 32)) {      // (the experiment writes channels-last voxels only)
-    snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem_valu<%s,q%d,%dx%dx%d,c%d+l1,r%d>",
+  // The row-fragment kernel is the default where it measured faster: single 16-bit storage (6 M stem, batch 4 x 128^3, same box:
+  // 135.3 -> 91.5 us).  In the split precisions the layer writes twice the bytes and is store-bound either way (tap-gather
+  // 220 / 145 us vs rows 235 / 152 us for 32 / 16 channels): those keep the tap-gather kernel.  AMX_STEM_GATHER=1 / =0 force one.
+  static int gather = -1;
+  if (gather < 0) gather = getenv("AMX_STEM_GATHER") ? atoi(getenv("AMX_STEM_GATHER")) : 2;
+  if (gather == 0 || (gather == 2 && !SPLIT)) {
+    if (p.dbg & 2) p.dbg |= 4;
+    typedef Stem2Cfg<TY, TX, TZ, NC, R, SPLIT> C2;
+    snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem<%s,q%d,%dx%dx%d,c%d+cv1,r%d,rows>",
              __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q, TZ, TY, TX, NC, R);
-    hipLaunchKernelGGL((conv3d_stem_valu_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
-                       C::LDS_BYTES, st, p, zseg, nseg);
+    hipLaunchKernelGGL((conv3d_stem2_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
+                       C2::LDS_BYTES, st, p, zseg, nseg);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((conv3d_stem_kernel<T, Q, TY, TX, TZ, NC, R, SPLIT>), dim3((unsigned)(tiles * nseg)), dim3((NC + 1) * 64),
@@ -455,7 +575,7 @@ hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st) 
 hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st, int CoutReal) {
   if (CoutReal <= 0) CoutReal = Cout;
   const int Q = Cout / 16, split = precision >= 2;
-  const int n = Q * 512 * (split ? 2 : 1);
+  const int n = 2 * Q * 512 * (split ? 2 : 1);     // threads: the larger (row-fragment) packing
   if ((precision & 1) == 0)
     hipLaunchKernelGGL(pack_stem_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, st, w, scale, (f16*)wpk, Q, split, CoutReal);
   else

@@ -1,4 +1,7 @@
 #!/bin/bash
-for v in "" "AMX_STEM_MFMA=1"; do for wgs in 512 768 1024 2048; do
-  env $v AMX_STEM_WGS=$wgs python tools/layer_profile.py anatomix 4 2>&1 | grep -E "m 0 " | sed "s/^/$v wgs=$wgs /"
+# stem A/B + ablations (AMX_DBG 4: no stores; AMX_STEM_WGS: workgroups the launch aims for)
+for dbg in 0 4; do for wgs in 256 512 1024; do
+  AMX_DBG=$dbg AMX_STEM_WGS=$wgs python tools/stem_time.py 2>&1 | tail -1 | sed "s/^/wgs=$wgs /"
 done; done
+AMX_STEM_GATHER=1 python tools/stem_time.py 2>&1 | tail -1 | sed "s/^/gather /"
+AMX_STEM_GATHER=1 AMX_DBG=4 python tools/stem_time.py 2>&1 | tail -1 | sed "s/^/gather /"
