@@ -242,6 +242,8 @@ int conv_pick_q(int Cout, int W) {
   if (Cout == 16) return 1;
   if (Cout == 32) return 2;
   int q = W >= 32 ? 4 : 2;    // Cout >= 64 at 32^3 and larger: 4; 16^3 and below: more cout groups to fill the chip
+  // (round 4, same box, batch 4: Q = 1 or 4 instead of 2 at the 8^3 level: 128 -> 256 22.2 -> 22.8 / 27.9 us, 256 -> 256 32.8 -> 34.7 / 44.9;
+  //  at the 16^3 level Q = 1 / 4: 128 -> 128 28.1 -> 52.1 / 39.2 us -- more or fewer cout groups do not help: profiles/r04_deep_level_q.txt)
   while (Cout % (16 * q)) q >>= 1;   // 48 / 96 / 192 output channels (data gradients of the concat convs): 1 / 2 / 4
   return q;
 }
