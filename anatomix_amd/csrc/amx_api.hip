@@ -27,7 +27,7 @@ hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* 
                             const float* conv_bias, float eps, int C, float* scale, float* shift,
                             hipStream_t st);
 hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo, int C, int avg,
-                        int precision, hipStream_t st, int skip_lo = 0);
+                        int precision, hipStream_t st, int skip_lo = 0, int planar = 0);
 hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long long voxels, hipStream_t st);
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
@@ -61,7 +61,7 @@ hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, i
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
                              float slope, int precision, hipStream_t st, int* oflow = nullptr);
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
-                               float* out, int precision, hipStream_t st, int S0 = 0, int S1 = 0);
+                               float* out, int precision, hipStream_t st, int S0 = 0, int S1 = 0, int planar = 0);
 const char* last_conv_kernel_name();
 size_t train_scratch_bytes(int C);
 hipError_t launch_bn_train_forward(const void* x, void* y, const float* gamma, const float* beta, float eps, long long rows, int C,
@@ -391,7 +391,20 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     return -1;
   };
 
-  struct Tensor { int level = 0, slot = -1, C = 0, Cr = 0; };     // C: stored channels per voxel, Cr: the reference's channel count
+  struct Tensor { int level = 0, slot = -1, C = 0, Cr = 0; bool planar = false; };     // C: stored channels per voxel, Cr: the reference's channel count
+  // Row-planar storage (amx_common.h, layouts FMT 2 / 3) of the tensors the generic kernel gathers 32 bytes per voxel from: every
+  // tensor of f16x2mx; in the single 16-bit precisions the WIDE ones (>= 64 channels: the 32^3 .. 8^3 levels of the 6 M network),
+  // whose channels-last voxels of 128 .. 512 bytes left the LDS-DMA at 11-15 B/clk/CU (profiles/r03_dma_stride_ubench.txt).  Their
+  // producers and consumers are the generic conv, the merged-tap kernel and the pool kernel; the passes that only know
+  // channels-last voxels (norm apply, trilinear upsample, feature-tap export) keep the whole forward channels-last.
+  // MEASURED for the single 16-bit precisions and left OFF (AMX_PLANAR16=1 enables it): the wide tensors of the 6 M forward sit at
+  // 32^3 .. 8^3, where a stage's time is weight streaming and latency, not the halo gather -- 64 -> 64 @32^3 45.9 -> 44.0 us,
+  // 128 -> 128 @16^3 27.6 -> 26.7, 8^3 unchanged; 2743 -> 2772 volumes/s (+1 %, inside the box-to-box noise).  f16x2mx, whose
+  // 192-byte voxels sit at 128^3, gained 28 % per layer from the same layout and always uses it.
+  static int planar_env = -1;
+  if (planar_env < 0) planar_env = getenv("AMX_PLANAR16") ? 1 : 0;
+  const bool planar16 = planar_env && !split && !taps && c.interp == AMX_INTERP_NEAREST &&
+                        (c.norm == AMX_NORM_NONE || c.norm == AMX_NORM_BATCH_EVAL);
   Tensor cur;              // current activation (slot -1: the fp32 network input)
   bool have_cur_up = false;  // cur is to be read through a x2 upsample by the next conv
   std::vector<Tensor> skips;
@@ -447,19 +460,22 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (have_skip) {
           const long long sx = (long long)pend_skip.C * eb, sy = sx * dw, sz = sy * dh;
           p.src0 = A.slot[pend_skip.level][pend_skip.slot];
-          p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = mx ? 32 : sx; p.C0 = pend_skip.C; p.cs0 = mx ? dw * 32 : 32;
+          const bool pl0 = mx || pend_skip.planar, pl1 = mx || lo.planar;
+          p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = pl0 ? 32 : sx; p.C0 = pend_skip.C; p.cs0 = pl0 ? dw * 32 : 32;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = mx ? 32 : lx; p.C1 = lo.C; p.cs1 = mx ? lw * 32 : 32;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = pl1 ? 32 : lx; p.C1 = lo.C; p.cs1 = pl1 ? lw * 32 : 32;
         } else {  // no skip connection: the whole input is the upsampled tensor
           p.src0 = A.slot[lo.level][lo.slot];  // unused segment of zero channels
           p.C0 = 0;
           p.src1 = A.slot[lo.level][lo.slot];
-          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = mx ? 32 : lx; p.C1 = lo.C; p.cs1 = mx ? lw * 32 : 32;
+          const bool pl1 = mx || lo.planar;
+          p.s1n = lz * ld; p.s1z = lz; p.s1y = ly; p.s1x = pl1 ? 32 : lx; p.C1 = lo.C; p.cs1 = pl1 ? lw * 32 : 32;
         }
       } else {
         const long long sx = (long long)cur.C * eb, sy = sx * dw, sz = sy * dh;
         p.src0 = A.slot[cur.level][cur.slot];
-        p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = mx ? 32 : sx; p.C0 = cur.C; p.C1 = 0; p.cs0 = mx ? dw * 32 : 32;
+        const bool pl0 = mx || cur.planar;
+        p.s0n = sz * dd; p.s0z = sz; p.s0y = sy; p.s0x = pl0 ? 32 : sx; p.C0 = cur.C; p.C1 = 0; p.cs0 = pl0 ? dw * 32 : 32;
       }
       if (p.C0 + p.C1 != L.cin_pad)
         return fail(AMX_ERR_INVALID, "internal: conv model.%d expects %d channels, schedule has %d",
@@ -511,7 +527,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
         p.out = A.slot[lv][out.slot];
         p.ox = (long long)L.cout_p * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
-        if (mx) { p.ox = 32; p.ocs = dw * 32; }
+        // >= 64 output channels never take the z-marching / merged 48 -> 16 kernels: the generic conv or the merged-tap pair writes them
+        out.planar = planar16 && L.cout_p >= 64 && !L.is_final;
+        if (mx || out.planar) { p.ox = 32; p.ocs = dw * 32; }
       }
       if (prof) {
         amx_launch_record r;
@@ -558,6 +576,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         u.part = A.slot[lv][p_slot]; u.out = p.out;
         u.bias = p.bias; u.act = p.act; u.slope = p.slope;
         u.oflow = h->d_flag;
+        u.cs = p.cs1; u.ocs = p.ocs;                 // the low-resolution source / the partial sums and the output (same layout)
         p.out = A.slot[lv][p_slot];                  // same strides as the layer's output
         p.bias = nullptr; p.act = AMX_ACT_NONE;
         p.src1 = nullptr; p.C1 = 0; p.up_shift = 0;
@@ -669,7 +688,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     } else if (kind == K_POOL) {
       const int lv = cur.level + 1;
       Tensor out;
-      out.level = lv; out.C = cur.C; out.Cr = cur.Cr; out.slot = grab(lv);
+      out.level = lv; out.C = cur.C; out.Cr = cur.Cr; out.slot = grab(lv); out.planar = cur.planar;
       if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv);
       if (prof) {
         amx_launch_record r;
@@ -680,7 +699,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
       AMX_HIP(amx::launch_pool2(A.slot[cur.level][cur.slot], A.slot[lv][out.slot], n, d >> lv, hh >> lv,
-                                w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st, conv_only(i + 1)));
+                                w >> lv, cur.C, c.pooling == AMX_POOL_AVG, c.precision, st, conv_only(i + 1), cur.planar));
       // the pooled-from tensor stays alive only if it was pushed as a skip
       bool is_skip = false;
       for (const Tensor& s : skips)

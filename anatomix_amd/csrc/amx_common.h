@@ -73,6 +73,8 @@ struct ConvParams {
 //          voxels of 128 .. 6144 bytes a stage used 32 bytes of every cache line it touched: LDS-DMA ran at 11-15 B/clk/CU instead
 //          of 44-48, profiles/r03_dma_stride_ubench.txt, and bounded the generic kernel.)
 //          byte(n, z, y, x, plane P, b) = ((n D + z) H + y) * 6 C W + P * 32 W + 32 x + b
+//   FMT 3  single 16-bit values stored ROW-PLANAR like FMT 2 (2C bytes per voxel, C/16 planes of W x 32 bytes per row): the wide
+//          (>= 64-channel) tensors of the f16 / bf16 forward, for the same reason -- byte(n, z, y, x, P, b) = ((n D + z) H + y) * 2 C W + P * 32 W + 32 x + b
 __host__ __device__ constexpr int fmt_of_precision(int precision) { return precision < 2 ? 0 : (precision == 4 ? 2 : 1); }
 __host__ __device__ constexpr int fmt_elem_bytes(int fmt) { return fmt == 0 ? 2 : (fmt == 1 ? 4 : 6); }
 
@@ -91,6 +93,8 @@ struct UpmergeParams {
   int nbz, nby, nbx;
   int* oflow;
   int dbg;
+  int cs, ocs;                  // bytes between a voxel's 16-channel chunks in src / in part and out (0 = 32: channels-last voxels;
+                                //   row-planar tensors: row length x 32, see ConvParams::cs0)
 };
 
 // Weight-gradient launch (amx_wgrad.hip).

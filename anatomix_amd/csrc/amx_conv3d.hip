@@ -169,11 +169,12 @@ __global__ void fold_norm_kernel(const float* gamma, const float* beta, const fl
 template <typename T, int AVG, int FMT>
 __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out, int N, int Do,
                              int Ho, int Wo, int C, int skip_lo) {
-  constexpr bool SPLIT = FMT >= 1;
+  constexpr bool SPLIT = FMT == 1 || FMT == 2, PLANAR = FMT >= 2;      // FMT 3: single values, row-planar (amx_common.h)
   const int c8n = C >> 3;
   const long long total = (long long)N * Do * Ho * Wo * c8n;
   // FMT 2 (row-planar, amx_common.h): 32 bytes per voxel inside plane c8 >> 1 of its row; rows are C * 6 * W bytes in every layout
-  const long long sx = FMT == 2 ? 32 : (long long)C * fmt_elem_bytes(FMT), sy = (long long)C * fmt_elem_bytes(FMT) * (Wo * 2), sz = sy * (Ho * 2);
+  constexpr int EB = FMT == 3 ? 2 : fmt_elem_bytes(FMT);
+  const long long sx = PLANAR ? 32 : (long long)C * EB, sy = (long long)C * EB * (Wo * 2), sz = sy * (Ho * 2);
   const long long lo_in = FMT == 2 ? 2ll * C * (Wo * 2) : 2 * C, lo_out = FMT == 2 ? 2ll * C * Wo : 2 * C;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -186,7 +187,7 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
     const int z = r % Do;
     const int n = r / Do;
     const char* base = in + (long long)n * sz * (Do * 2) + (2 * z) * sz + (2 * y) * sy + (2 * x) * sx +
-                       (FMT == 2 ? (long long)(c8 >> 1) * (Wo * 2 * 32) + (c8 & 1) * 16 : c8 * 16);
+                       (PLANAR ? (long long)(c8 >> 1) * (Wo * 2 * 32) + (c8 & 1) * 16 : c8 * 16);
     float m[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -224,6 +225,9 @@ __global__ void pool2_kernel(const char* __restrict__ in, char* __restrict__ out
       *(uint4*)op = make_uint4(o[0], o[1], o[2], o[3]);
       if (!(FMT == 2 && skip_lo)) *(uint4*)(op + lo_out) = make_uint4(ol[0], ol[1], ol[2], ol[3]);   // (conv-only readers: hi + copies)
       if (FMT == 2) mx_store_copies(op - (c8 & 1) * 16 + 2 * lo_out, c8 & 1, m);
+    } else if (FMT == 3) {
+      const long long vlin = idx / c8n;
+      *(uint4*)(out + (vlin / Wo) * (2ll * C * Wo) + (long long)(c8 >> 1) * (Wo * 32) + x * 32 + (c8 & 1) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     } else {
       *(uint4*)(out + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -324,14 +328,18 @@ hipError_t launch_fold_norm(const float* gamma, const float* beta, const float* 
   return hipGetLastError();
 }
 
+// planar (precisions 0 / 1 only): input AND output are row-planar (layout FMT 3)
 hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo, int C, int avg,
-                        int precision, hipStream_t st, int skip_lo) {
+                        int precision, hipStream_t st, int skip_lo, int planar) {
+  if (planar && (precision > 1 || C % 16)) return hipErrorInvalidValue;
   const long long total = (long long)N * Do * Ho * Wo * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
 #define AMX_POOL(T, A, S)                                                                            \
   hipLaunchKernelGGL((pool2_kernel<T, A, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, \
                      N, Do, Ho, Wo, C, skip_lo)
-  switch (precision) {
+  switch (precision + (planar ? 10 : 0)) {
+    case 10: if (avg) AMX_POOL(f16, 1, 3); else AMX_POOL(f16, 0, 3); break;
+    case 11: if (avg) AMX_POOL(bf16, 1, 3); else AMX_POOL(bf16, 0, 3); break;
     case 0: if (avg) AMX_POOL(f16, 1, false); else AMX_POOL(f16, 0, false); break;
     case 1: if (avg) AMX_POOL(bf16, 1, false); else AMX_POOL(bf16, 0, false); break;
     case 2: if (avg) AMX_POOL(f16, 1, true); else AMX_POOL(f16, 0, true); break;

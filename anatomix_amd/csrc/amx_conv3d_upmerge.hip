@@ -112,15 +112,17 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
         off[m] = hv < C::HV ? gz * (int)p.sz + gy * (int)p.sy + gx * (int)p.sx : -1;
       }
     }
-    const char* base = p.src + (long long)I.n * p.sn + stage * (64 * KS);
+    const char* base = p.src + (long long)I.n * p.sn;
+    const int cs = p.cs ? p.cs : 32;                       // a voxel's 32-byte pieces: channels-last (32) or one row plane apart
     char* buf = smem + bsel * C::BUF;
 #pragma unroll
     for (int m = 0; m < C::PER_WAVE; ++m) {
       const int id = wave + 8 * m;
       if (id < C::NDMA) {
         const int plane = id / C::NJ, j = id - plane * C::NJ;
+        const int cbyte = stage * (64 * KS) + (SPLIT && plane >= 4 ? p.C1 * 2 + (plane - 4) * 16 : plane * 16);
         if (off[m] >= 0)
-          dma16_asm(base + off[m] + (SPLIT && plane >= 4 ? p.C1 * 2 + (plane - 4) * 16 : plane * 16),
+          dma16_asm(base + off[m] + (long long)(cbyte >> 5) * cs + (cbyte & 31),
                     (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(buf + plane * PL + j * 1024)));
       }
     }
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
   auto load_part = [&](const int it) {
     const Item I = decode(it);
     const int lx = I.bx * LXT + lix;
-    const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
-    const char* pb = p.part + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
+    const int ocs = p.ocs ? p.ocs : 32, cb2 = (I.cg * 16 * Q + g * 4 * Q) * 2;
+    const long long sy = (long long)p.Cout * 2 * NP * (2 * p.LW), sz = sy * (2 * p.LH), sx = ocs == 32 ? (long long)p.Cout * 2 * NP : 32;
+    const char* pb = p.part + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (long long)(cb2 >> 5) * ocs + (cb2 & 31);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int lz = I.bz * TZ + i / TY, ly = I.by * BY + (i % TY) * RPT + liy;
@@ -198,8 +201,9 @@ __global__ __launch_bounds__(512) void conv3d_upmerge_kernel(const UpmergeParams
     const Item I = decode(pend_it);
     pend_it = -1;
     const int lx = I.bx * LXT + lix;
-    const long long sx = (long long)p.Cout * 2 * NP, sy = sx * (2 * p.LW), sz = sy * (2 * p.LH);
-    char* pb = p.out + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (I.cg * 16 * Q + g * 4 * Q) * 2;
+    const int ocs = p.ocs ? p.ocs : 32, cb2 = (I.cg * 16 * Q + g * 4 * Q) * 2;
+    const long long sy = (long long)p.Cout * 2 * NP * (2 * p.LW), sz = sy * (2 * p.LH), sx = ocs == 32 ? (long long)p.Cout * 2 * NP : 32;
+    char* pb = p.out + (long long)I.n * sz * (2 * p.LD) + pz * sz + py * sy + (2 * lx + px) * sx + (long long)(cb2 >> 5) * ocs + (cb2 & 31);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int lz = I.bz * TZ + i / TY, ly = I.by * BY + (i % TY) * RPT + liy;

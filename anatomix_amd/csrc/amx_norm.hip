@@ -35,26 +35,27 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 // 2*C bytes further on.  FMT 2 (AMX_PREC_F16X2_MX): store8 also writes the e4m3 copies the convolutions multiply with -- group c8
 // of the voxel: xl8 at voxel + 4C + 32 (c8 >> 1) + 8 (c8 & 1), xh8 16 bytes behind it; nothing reads them but the conv kernels.
 template <int FMT> struct Fmt {
-  static constexpr bool SPLIT = FMT >= 1;
-  static constexpr int M = FMT == 0 ? 1 : (FMT == 1 ? 2 : 3);      // voxel bytes = 2 C M
+  static constexpr bool SPLIT = FMT == 1 || FMT == 2;
+  static constexpr int M = (FMT == 0 || FMT == 3) ? 1 : (FMT == 1 ? 2 : 3);      // voxel bytes = 2 C M
+  static constexpr bool PLANAR = FMT >= 2;                          // FMT 3: single values, row-planar (amx_common.h)
   // byte offset of 8-channel group c8 (its hi half) of voxel v -- a linear index whose rows are W voxels long -- and the distance to
   // the lo half.  FMT 2 is row-planar (amx_common.h): plane c8 >> 1 of row v / W, 32 bytes per voxel.
   static __device__ __forceinline__ long long group(long long v, int C, int W, int c8) {
     if (FMT < 2) return v * (2 * C * M) + c8 * 16;
     const long long row = v / W;
     const int x = (int)(v - row * W);
-    return row * (6ll * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
+    return row * (2ll * M * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
   }
   static __device__ __forceinline__ long long group_rx(long long row, int x, int C, int W, int c8) {     // the same from (row, x)
     if (FMT < 2) return (row * W + x) * (2ll * C * M) + c8 * 16;
-    return row * (6ll * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
+    return row * (2ll * M * C * W) + (long long)(c8 >> 1) * (W * 32) + x * 32 + (c8 & 1) * 16;
   }
   static __device__ __forceinline__ int lo_off(int C, int W) { return FMT < 2 ? 2 * C : 2 * C * W; }
 };
 template <typename T, int FMT>
 __device__ __forceinline__ void load8(const char* p, int lo_off, float (&f)[8]) {
   unpack8<T>(*(const uint4*)p, f);
-  if (FMT) {
+  if (FMT == 1 || FMT == 2) {
     float g[8];
     unpack8<T>(*(const uint4*)(p + lo_off), g);
 #pragma unroll
@@ -65,7 +66,7 @@ template <typename T, int FMT>
 // skip_lo (FMT 2, wave-uniform): the tensor's only readers are convolutions, which read hi and the copies -- the lo plane is not written
 __device__ __forceinline__ void store8(char* p, int lo_off, const float (&f)[8], int c8 = 0, bool skip_lo = false) {
   *(uint4*)p = pack8<T>(f);
-  if (FMT && !(FMT == 2 && skip_lo)) {
+  if ((FMT == 1 || FMT == 2) && !(FMT == 2 && skip_lo)) {
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = f[e] - (float)(T)f[e];
@@ -620,8 +621,10 @@ hipError_t launch_affine_act(void* x, const float* scale, const float* shift, in
   return hipGetLastError();
 }
 
+// planar0 / planar1 (precisions 0 / 1): that segment is stored row-planar (layout FMT 3); both or neither when both are given
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
-                               float* out, int precision, hipStream_t st, int S0, int S1) {
+                               float* out, int precision, hipStream_t st, int S0, int S1, int planar) {
+  if (planar && precision > 1) return hipErrorInvalidValue;
   if (S0 <= 0) S0 = C0;
   if (S1 <= 0) S1 = C1;
   // a ragged channel count is only possible for a single segment whose storage is padded (the output conv of a network whose
@@ -630,7 +633,9 @@ hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C
   const long long total = (long long)N * ((C0 + C1 + 7) / 8) * D * H * W;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
 #define AMX_EX(T, S) hipLaunchKernelGGL((export_ncdhw_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)src0, C0, (const char*)src1, C1, up_shift, N, D, H, W, out, S0, S1)
-  switch (precision) {
+  switch (precision + (planar ? 10 : 0)) {
+    case 10: AMX_EX(f16, 3); break;
+    case 11: AMX_EX(bf16, 3); break;
     case 0: AMX_EX(f16, false); break;
     case 1: AMX_EX(bf16, false); break;
     case 2: AMX_EX(f16, true); break;
