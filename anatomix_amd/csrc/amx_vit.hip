@@ -446,7 +446,11 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
   const int E = h->E, Ep = h->Ep, T = h->T, V = h->V, hid = h->hidden, nreg = c.num_register_tokens;
   const int M = n * T;
   const int D0 = c.grid_d * 8, H0 = c.grid_h * 8, W0 = c.grid_w * 8;
-  static const int dbg_stop = getenv("AMX_VIT_STOP") ? atoi(getenv("AMX_VIT_STOP")) : 0;   // debugging aid (tools/vit_bisect.py): return after a stage
+#ifdef AMX_VIT_DEBUG_STOP    // debugging aid of tools/vit_bisect.py (build with -DAMX_VIT_DEBUG_STOP): return after a stage.  Compiled OUT of the product.
+  static const int dbg_stop = getenv("AMX_VIT_STOP") ? atoi(getenv("AMX_VIT_STOP")) : 0;
+#else
+  constexpr int dbg_stop = 0;
+#endif
   h->dbg.clear();
   auto note = [&](const char* name, const void* p, size_t bytes) { h->dbg.push_back({name, (char*)p, bytes}); };
 

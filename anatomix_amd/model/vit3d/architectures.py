@@ -339,6 +339,12 @@ class PrimusV2(nn.Module):
                 _lib.check(lib.amx_vit_create(ctypes.byref(hnd), ctypes.byref(cfg)))
                 self._handle = hnd
             tensors = self._engine_tensors(lib)
+            # the engine is handed raw device pointers: a parameter still on the host (module never moved, or moved after the input)
+            # would fault the GPU instead of raising torch's device-mismatch error
+            stray = [tuple(t.shape) for t in list(tensors) + [self.rope_table] if t.device != dev]
+            if stray:
+                raise RuntimeError(f"PrimusV2.forward_hip: input on {dev} but {len(stray)} parameter / buffer tensors are elsewhere "
+                                   f"(first shape {stray[0]}): move the module with .to({str(dev)!r}) first")
             sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(dev),)
             if sig != self._engine_sig:
                 held = [t.detach().float().contiguous() for t in tensors]
@@ -439,7 +445,14 @@ class PrimusV2(nn.Module):
         if isinstance(layers, bool):
             ret_mask, layers = layers, None
         if x.is_cuda and not torch.is_grad_enabled() and self.use_engine:
-            output = self.forward_hip(x)
+            try:
+                output = self.forward_hip(x)
+            except _lib.AmxError as e:
+                # configurations outside the engine's envelope (amx_vit_create refuses them: input_channels != 1, token grids that
+                # are not multiples of 64 or have an odd width, widths beyond its tiles, other decoders) ran on the torch modules
+                # before the engine existed: name the switch instead of leaving an engine status code as the only message
+                raise RuntimeError(f"PrimusV2: the HIP engine does not cover this configuration ({e}); set `model.use_engine = False` "
+                                   "to run the stock torch composition of the same modules") from e
         else:
             output = self.out_norm(self._body(x))
         if ret_mask:

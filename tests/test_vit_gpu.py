@@ -104,3 +104,22 @@ def test_vit_hip_and_torch_attention_paths_agree_small(device):
         y_t = m(x).detach()
     ref = V.forward(x.cpu(), sd, kw, dtype=torch.float64).float()
     assert rel_l2(y.cpu(), ref) <= 1e-3 and rel_l2(y_t.cpu(), ref) <= 1e-4
+
+
+def test_vit_engine_refuses_host_parameters_and_names_the_switch_outside_its_envelope(device):
+    """Advisor findings (round 3): the engine takes raw device pointers, so a module still on the host with a GPU input must raise
+    (it used to fault the GPU); a configuration the engine does not cover must say how to run the torch composition instead."""
+    kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(64, 64, 64), eva_depth=1)
+    m = PrimusV2(**kw).eval()                                        # parameters on the CPU
+    x = V.synthetic_input(7, 1, (64, 64, 64)).to(device)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="move the module"):
+        m.forward_hip(x)
+    kw2 = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(80, 80, 80), eva_depth=1)   # 10^3 token grid: not a multiple of 64
+    m2 = PrimusV2(**kw2).to(device).eval()
+    x2 = V.synthetic_input(7, 1, (80, 80, 80)).to(device)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="use_engine = False"):
+            m2(x2)
+        m2.use_engine = False
+        y = m2(x2)
+    assert y.shape == (1, 32, 80, 80, 80) and torch.isfinite(y).all()
