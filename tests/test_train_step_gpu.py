@@ -440,3 +440,54 @@ def test_loss_trajectory_over_adamw_steps_follows_the_stock_modules(device):
     np.testing.assert_allclose(gh[:1], gr[:1], rtol=2e-2)
     np.testing.assert_allclose(gh[1:2], gr[1:2], rtol=0.10)
     np.testing.assert_allclose(gh[2:], gr[2:], rtol=0.35)
+
+
+@pytest.mark.parametrize("switch,off,exact", [("RECOMPUTE_ACT", False, True), ("FUSED_FOLD_SPLIT", False, False),
+                                             ("SPLIT_CONCAT_DGRAD", 0, False)])
+def test_backward_code_paths_agree_parameter_by_parameter(device, switch, off, exact, monkeypatch):
+    """Advisor finding (round 3): the round-3 rewrites of the backward (norm adjoint that recomputes the activation's sign from x,
+    reflect-padding adjoint fused into the concat split, the 48 -> 16 data gradient as two launches) are switchable, and the only
+    end-to-end gradient check past the first step is a 35 % band.  Here each rewrite is held DETERMINISTICALLY: identical weights,
+    inputs and cotangents with the switch on and off, every parameter gradient compared on its own -- bit-identical where the
+    arithmetic is the same, within bf16 storage rounding of the intermediate gradients where the summation order differs."""
+    from anatomix_amd.model import train as TR
+    layers = [27, 31, 38, 45, 52, 65]
+    x = torch.from_numpy(np.random.RandomState(3).rand(2, 1, 64, 64, 64).astype(np.float32)).to(device)
+    grads = {}
+    for state in ("on", "off"):
+        if state == "off":
+            monkeypatch.setattr(TR, switch, off)
+        hip, _ = _pair(device, "bf16")
+        out, feats = hip(x, layers)
+        g = torch.Generator().manual_seed(5)
+        loss = 0.1 * out.square().mean()
+        for f in feats:
+            loss = loss + (f * (torch.randn(f.shape, generator=g).to(device) / f[0].numel() ** 0.5)).sum()
+        loss.backward()
+        grads[state] = {k: p.grad.detach().clone() for k, p in hip.named_parameters()}
+    assert grads["on"].keys() == grads["off"].keys() and len(grads["on"]) > 50
+    worst_w, worst_v, worst_cos = 0.0, 0.0, 1.0
+    for k in grads["on"]:
+        a, b = grads["on"][k].double(), grads["off"][k].double()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), k
+        if exact:
+            assert torch.equal(a, b), k
+            continue
+        err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        cos = float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
+        worst_cos = min(worst_cos, cos)
+        if a.dim() > 1:                       # conv weights: thousands of entries, each a sum over every voxel
+            worst_w = max(worst_w, err)
+            assert err <= 2e-2 and cos >= 0.9995, (k, err, cos)
+        else:                                 # BatchNorm gain / shift: 16 .. 256 entries, each a CANCELLING sum of the bf16-stored dz over every
+            worst_v = max(worst_v, err)       # voxel -- one more rounding of dz on the way (fused fold) or another summation order shows here first
+            assert err <= 0.12 and cos >= 0.995, (k, err, cos)
+    if not exact:
+        ga = torch.cat([grads["on"][k].flatten().double() for k in grads["on"]])
+        gb = torch.cat([grads["off"][k].flatten().double() for k in grads["on"]])
+        tot = float((ga - gb).norm() / gb.norm())
+        print(switch, f"whole gradient rel-L2 {tot:.2e}; worst conv weight {worst_w:.2e}, worst norm vector {worst_v:.2e}, worst cosine {worst_cos:.5f}")
+        # measured: 1.2e-2 / 1.1e-2 whole gradient (three bf16 ulps: the gradient passes ~20 bf16-stored tensors), conv weights <= 1.3e-2,
+        # norm vectors <= 7.2e-2, cosines >= 0.998
+        assert tot <= 2e-2, tot
+        assert abs(float(ga.norm() / gb.norm()) - 1.0) <= 5e-3            # the recorded gradient norm: 0.5 %, not a 35 % band
