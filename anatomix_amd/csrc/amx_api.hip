@@ -48,7 +48,13 @@ bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
 int last_conv_stats_slots();
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
-                           const float* kshift = nullptr, int W = 0, int skip_lo = 0);
+                           const float* kshift = nullptr, int W = 0, int skip_lo = 0, int apply = 1, float* ab_out = nullptr);
+bool conv_zx_eligible(const ConvParams& p);
+int conv_zx_stats_slots(int H, int W);
+size_t conv_zx_packed_bytes();
+hipError_t launch_pack_weights_zx(const float* w, const float* scale, void* wx, const int* mxs, int CoutReal, hipStream_t st);
+hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st);
+const char* last_conv_zx_kernel_name();
 size_t attention_scratch_bytes(int b, int heads, int n);
 void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void** Kp, void** Vt, int* npad_out, int* nblk_pad_out);
 hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st);
@@ -159,6 +165,7 @@ struct ConvLayer {
   // eval-BatchNorm layers only: UNFOLDED weights + the norm's own shift, for forwards that tap the pre-norm output
   void* wpk_raw = nullptr;
   int* mxs = nullptr;     // AMX_PREC_F16X2_MX: {E8M0 block-scale word of the fp8 weights, scratch for their maximum}
+  void* wx = nullptr;     // AMX_PREC_F16X2_MX, 32 -> 32 layers: fp8 fragments of the normalise-on-load z-march kernel (amx_conv3d_zx.hip)
   bool raw_has_bias = false;  // conv bias under BatchNorm (the reference never builds that: use_bias == (norm=='instance'))
   bool loaded = false;
 };
@@ -315,6 +322,9 @@ size_t level_bytes(const amx_unet* h, int level, int n, int d, int hh, int w) {
 
 // InstanceNorm scratch of a forward: the separate statistics pass needs 65536 entries per sample; a conv epilogue that writes the
 // partial sums itself needs one slot per (brick, wave) of that layer
+// (a, b) pairs of a norm whose apply pass is left to the consuming conv (f16x2mx, amx_conv3d_zx.hip): two buffers, used alternately,
+// behind the statistics scratch -- the consumer writes ITS statistics into that scratch while it still reads its input's pairs
+inline size_t kPendingAbBytes(int n) { return (size_t)n * 2048 * 2 * sizeof(float); }
 size_t in_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
   long long worst = 0;
   if (h->cfg.norm == AMX_NORM_INSTANCE || h->cfg.norm == AMX_NORM_INSTANCE_AFFINE)
@@ -323,7 +333,7 @@ size_t in_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
       const long long s = (long long)amx::conv_v2_stats_slots(d >> L.level, hh >> L.level, w >> L.level, L.q) * L.cout_p;
       worst = s > worst ? s : worst;
     }
-  return align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs, worst), 256);
+  return align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs, worst), 256) + 2 * kPendingAbBytes(n);
 }
 
 int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
@@ -391,7 +401,16 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     return -1;
   };
 
-  struct Tensor { int level = 0, slot = -1, C = 0, Cr = 0; bool planar = false; };     // C: stored channels per voxel, Cr: the reference's channel count
+  struct Tensor {                                   // C: stored channels per voxel, Cr: the reference's channel count
+    int level = 0, slot = -1, C = 0, Cr = 0;
+    bool planar = false;
+    const float* ab = nullptr;                      // non-null: the tensor is RAW, its norm + activation pending: y = act(a x + b)
+  };
+  float* ab_buf[2] = {(float*)((char*)in_scratch + in_scratch_bytes(h, n, d, hh, w) - 2 * kPendingAbBytes(n)),
+                      (float*)((char*)in_scratch + in_scratch_bytes(h, n, d, hh, w) - kPendingAbBytes(n))};
+  int ab_next = 0;
+  static int zx_env = -1;
+  if (zx_env < 0) zx_env = getenv("AMX_NO_ZX") ? 0 : 1;
   // Row-planar storage (amx_common.h, layouts FMT 2 / 3) of the tensors the generic kernel gathers 32 bytes per voxel from: every
   // tensor of f16x2mx; in the single 16-bit precisions the WIDE ones (>= 64 channels: the 32^3 .. 8^3 levels of the 6 M network),
   // whose channels-last voxels of 128 .. 512 bytes left the LDS-DMA at 11-15 B/clk/CU (profiles/r03_dma_stride_ubench.txt).  Their
@@ -583,12 +602,18 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         p.wpk = (const char*)L.wpk_skip;
       }
       // InstanceNorm layers on the generic kernel: the conv epilogue writes the partial sums of the statistics pass itself
+      const bool zx_shape = mx && zx_env && L.wx && !have_cur_up && !x_offs && cur.slot >= 0 && !L.is_final && inorm && amx::conv_zx_eligible(p);
       const bool fuse_stats = inorm && !use_merge && !use_upcat && !p.src0_f32c1 && !L.is_final && !x_offs &&
-                              amx::conv_fuses_stats(p, c.precision, L.q);
+                              (zx_shape || amx::conv_fuses_stats(p, c.precision, L.q));
       if (fuse_stats) p.stats = (float*)in_scratch;
+      // f16x2mx 32 -> 32 at whole tiles: the normalise-on-load z-march kernel (amx_conv3d_zx.hip).  It is the ONLY consumer of a
+      // tensor whose norm was left pending (below), and takes already-normalised inputs too.
+      const bool use_zx = mx && zx_env && L.wx && !have_cur_up && !x_offs && cur.slot >= 0 && !L.is_final && inorm && amx::conv_zx_eligible(p);
+      if (cur.ab && !use_zx) return fail(AMX_ERR_INVALID, "internal: model.%d got an input whose norm is pending but cannot run the fused kernel", L.module_idx);
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, stem_precision(c.precision), st);
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
+        if (use_zx) return amx::launch_conv_zx(q, cur.ab, c.activation, c.act_slope, L.wx, st);
         return amx::launch_conv(q, c.precision, L.q, st);
       };
       // pipelined windows (two batches in flight on two streams): the accumulating launches of this batch wait for the other
@@ -624,7 +649,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         else
           snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s",
                    p.src0_f32c1 ? amx::last_conv_stem_kernel_name()
-                                : use_upcat ? amx::last_conv_upcat_kernel_name() : amx::last_conv_kernel_name());
+                                : use_upcat ? amx::last_conv_upcat_kernel_name()
+                                            : (use_zx ? amx::last_conv_zx_kernel_name() : amx::last_conv_kernel_name()));
       }
       if (raw_bn) {
         AMX_HIP(export_slot(out, tap_conv));
@@ -643,10 +669,30 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
           r.bytes = (double)eb * L.cout * (double)n * dd * dh * dw * 3.0;
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
+        // Leave the apply pass to the consumer when that is the fused 32 -> 32 kernel: the module after this conv -> norm -> act group is
+        // a conv of that shape at this resolution (so this tensor is no skip connection, no pool / upsample input, no tap)
+        bool defer = false;
+        {
+          const size_t nxt = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
+          if (mx && zx_env && !taps && !x_offs && act_on == L.has_act && nxt < h->kinds.size() && h->kinds[nxt] == K_CONV && conv_i < h->convs.size()) {
+            const ConvLayer& Nx = h->convs[conv_i];
+            amx::ConvParams t;
+            memset(&t, 0, sizeof t);
+            t.N = n; t.D = dd; t.H = dh; t.W = dw; t.C0 = L.cout_p; t.C1 = 0; t.Cout = Nx.cout_p; t.out = (char*)1; t.mxs = Nx.mxs; t.s0x = 32; t.ox = 32;
+            defer = Nx.wx && Nx.level == lv && !Nx.is_final && Nx.norm_idx >= 0 && Nx.cin_pad == L.cout_p && amx::conv_zx_eligible(t);
+          }
+        }
+        const int slots = fuse_stats ? (use_zx ? amx::conv_zx_stats_slots(dh, dw) : amx::last_conv_stats_slots()) : 0;
+        float* abo = defer ? ab_buf[ab_next] : nullptr;
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
                                      L.cout_p, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
-                                     fuse_stats ? amx::last_conv_stats_slots() : 0, fuse_stats ? L.shift : nullptr, dw,
-                                     conv_only(i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0))));
+                                     slots, fuse_stats ? L.shift : nullptr, dw,
+                                     conv_only(i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0)), defer ? 0 : 1, abo));
+        if (defer) {
+          out.ab = abo;
+          ab_next ^= 1;
+          if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "instnorm statistics only (apply fused into the next conv)");
+        }
       }
       if (final_via_export)
         AMX_HIP(amx::launch_export_ncdhw(A.slot[lv][out.slot], L.cout, nullptr, 0, 0, n, dd, dh, dw, y, c.precision, st, L.cout_p, 0));
@@ -854,6 +900,8 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
     // that are at least 32 voxels wide at the reference operating point
     if (e == hipSuccess && is_mx(cfg->precision)) e = hipMalloc((void**)&L.mxs, 2 * sizeof(int));
+    if (e == hipSuccess && is_mx(cfg->precision) && L.cin_pad == 32 && L.cout_p == 32 && L.cin == 32 && !L.is_final && L.cin != 1)
+      e = hipMalloc(&L.wx, amx::conv_zx_packed_bytes());
     if (e == hipSuccess && !is_mx(cfg->precision) && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr && L.cout_p == L.cout &&
         amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1, is_split(cfg->precision))) {
       e = hipMalloc(&L.wpk_skip, (size_t)L.cout * L.cout * 28 * 2 * (is_split(cfg->precision) ? 2 : 1));
@@ -900,6 +948,7 @@ void amx_unet_destroy(amx_unet_t* h) {
     if (L.wpk_up) (void)hipFree(L.wpk_up);
     if (L.wpk_raw) (void)hipFree(L.wpk_raw);
     if (L.mxs) (void)hipFree(L.mxs);
+    if (L.wx) (void)hipFree(L.wx);
     if (L.wpk_skip) (void)hipFree(L.wpk_skip);
     if (L.wpk_merge) (void)hipFree(L.wpk_merge);
     if (L.scale) (void)hipFree(L.scale);
@@ -945,6 +994,7 @@ int amx_unet_load_conv(amx_unet_t* h, int module_idx, const float* d_weight, con
       if (L.wpk_raw) AMX_HIP(amx::launch_pack_stem(d_weight, nullptr, L.wpk_raw, L.cout_p, stem_precision(h->cfg.precision), st, L.cout));
     } else if (is_mx(h->cfg.precision)) {
       AMX_HIP(amx::launch_pack_weights_mx(d_weight, L.scale, L.wpk, L.mxs, L.cin, L.cin_pad, L.cout_p, L.q, st, L.cout, 0, L.c0_real, L.c0_p));
+      if (L.wx) AMX_HIP(amx::launch_pack_weights_zx(d_weight, L.scale, L.wx, L.mxs, L.cout, st));      // (after: it reads the layer's max |w|)
     } else {
       if (L.wpk_raw)
         AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, L.wpk_raw, L.cin, L.cin_pad, L.cout_p, L.q, h->cfg.precision, st, 0, L.cout,

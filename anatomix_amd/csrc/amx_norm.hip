@@ -533,16 +533,19 @@ static size_t in_coeff_offset(int N, long long vox, int C, int fused_slots) {   
 // W: row length of the row-planar layout (precision 4 only; amx_common.h FMT 2)
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow, int fused_slots = 0,
-                           const float* kshift = nullptr, int W = 0, int skip_lo = 0) {
+                           const float* kshift = nullptr, int W = 0, int skip_lo = 0, int apply = 1, float* ab_out = nullptr) {
+  // apply = 0: statistics and finalize only -- the (a, b) pairs go to ab_out [N][C][2] and the CONSUMER normalises on the way in
+  // (amx_conv3d_zx.hip); the tensor stays raw
   if (C % 8) return hipErrorInvalidValue;
   if (precision == 4 && (W <= 0 || vox % W || C % 16)) return hipErrorInvalidValue;
   float* partial = (float*)scratch;
-  float* ab = partial + in_coeff_offset(N, vox, C, fused_slots);
+  float* ab_in = partial + in_coeff_offset(N, vox, C, fused_slots);
+  float* ab = ab_out ? ab_out : ab_in;
   int nblk = fused_slots > 0 ? fused_slots : in_num_blocks(vox, C);
   if (fused_slots > 4096) {
     // fold the slots into kPreChunks chunks first (the chunk sums live behind the coefficients: N * kPreChunks * C * 2 floats, which
     // fit the 65536-entry floor of the scratch of the separate statistics pass only when C * 64 <= 65536 -- true for C <= 1024)
-    float* partial2 = ab + (size_t)N * C * 2;
+    float* partial2 = ab_in + (size_t)N * C * 2;
     hipLaunchKernelGGL(in_prereduce_kernel, dim3(C / 8, N, kPreChunks), dim3(256), 0, st, partial, partial2, C, nblk);
     partial = partial2;
     nblk = kPreChunks;
@@ -558,7 +561,8 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
     hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C, W);   \
   hipLaunchKernelGGL((in_finalize_kernel<T, S>), dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
                      nblk, ab, kshift, fused_slots > 0 ? 1 : 0, W);                                               \
-  if (256 % c8n == 0) {                                                                                          \
+  if (!apply) {                                                                                                  \
+  } else if (256 % c8n == 0) {                                                                                   \
     const long long per = vox * c8n;                                                                             \
     const int bx = (int)((per + 255) / 256 > 4096 ? 4096 : (per + 255) / 256);                                   \
     hipLaunchKernelGGL((in_apply_fast_kernel<T, S>), dim3(bx, N), dim3(256), 0, st, (char*)x, ab, vox, C, act, slope, oflow, W, skip_lo); \

@@ -72,6 +72,20 @@ def conv_mx(x, w, _):
     return y + c * 2.0 ** (-(sw + 11))
 
 
+def conv_mx_part(x, w, _, keep_xl=True, keep_wl=True):
+    """conv_mx with one of the two correction products dropped (what a K = 128 MFMA over four taps of ONE kind would compute)."""
+    xh, wh = f16r(x), f16r(w)
+    xl, wl = x - xh, w - wh
+    sw = torch.floor(torch.log2(448.0 / w.abs().max()))
+    y = R.conv3_reflect(xh, wh)
+    c = 0
+    if keep_xl:
+        c = c + R.conv3_reflect(e4m3(xl * 2.0 ** 11), e4m3(wh * 2.0 ** sw))
+    if keep_wl:
+        c = c + R.conv3_reflect(e4m3(xh), e4m3(wl * 2.0 ** (sw + 11)))
+    return y + c * 2.0 ** (-(sw + 11))
+
+
 # Winograd F(2,3):  Y = A^T [ (G g G^T) . (B^T d B) ] A
 BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
@@ -204,6 +218,9 @@ def main():
         ("fp8corr store15", conv_fp8corr, None, 15),
         ("fp8corr store22", conv_fp8corr, None, 22),
         ("mx e4m3 f16x2store", conv_mx, None, "f16x2"),
+        ("mxpart no Wl", lambda a, b, c: conv_mx_part(a, b, c, True, False), None, "f16x2"),
+        ("mxpart no xl", lambda a, b, c: conv_mx_part(a, b, c, False, True), None, "f16x2"),
+        ("mxpart neither, f16x2 store", lambda a, b, c: conv_mx_part(a, b, c, False, False), None, "f16x2"),
         ("wino1 16b", lambda a, b, c: conv_wino(a, b, c, 1), 16, 16),
         ("wino2 16b", lambda a, b, c: conv_wino(a, b, c, 2), 16, 16),
         ("wino3 16b", lambda a, b, c: conv_wino(a, b, c, 3), 16, 16),
