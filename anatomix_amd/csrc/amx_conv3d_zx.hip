@@ -147,7 +147,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         if (qq < nplanes) {
           // ring slot qq % R is free once every consumer is done with plane qq - R: planes < TZ * min(done) are dead
           while (qq >= R + TZ * __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done))) __builtin_amdgcn_s_sleep(1);
-          if (!(p.dbg & 16) || qq < R) convert_plane(qq, h);      // (AMX_DBG 16: timing ablation, the ring is only filled once)
+          if (!(p.dbg & 16) || qq < R) convert_plane(qq, h);      // (AMX_ZX_DBG 16: timing ablation, the ring is only filled once)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS is in-order per CU: the flag lands after the plane's data
           flag_store(ready + cw, qq + 1);
         }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         // the two x halves as a RUN-TIME loop: unrolled, hipcc kept the whole step's fragments and addresses alive (447 spilled
         // registers inside the 168 of three waves per SIMD; 97 registers, none spilled, this way)
 #pragma unroll 1
-        for (int xh = 0; xh < ((p.dbg & 2) ? 0 : 2); ++xh) {     // (AMX_DBG 2: timing ablation without the MFMA sweeps)
+        for (int xh = 0; xh < ((p.dbg & (2 | 32)) ? 0 : 2); ++xh) {   // (AMX_ZX_DBG 2 / 32: timing ablation without the sweeps)
           const int lanebase = vbase + xh * 256;
           f32x4 acc[2][2];
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
       for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = bias;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      if (p.dbg & 2) break;
+      if (p.dbg & (2 | 64)) break;
       const int koff = k * 2 * PPL;                          // channel planes 2k, 2k + 1
 #pragma unroll
       for (int pl = 0; pl < 4; ++pl) {
@@ -504,7 +504,7 @@ hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in
     attr_done = true;
   }
   static int dbg = -1;
-  if (dbg < 0) dbg = getenv("AMX_DBG") ? atoi(getenv("AMX_DBG")) : 0;
+  if (dbg < 0) dbg = getenv("AMX_ZX_DBG") ? atoi(getenv("AMX_ZX_DBG")) : 0;
   p.dbg = dbg;
   p.nby = p.H / C::TY;
   p.nbx = p.W / C::TX;

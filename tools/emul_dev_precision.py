@@ -86,6 +86,36 @@ def conv_mx_part(x, w, _, keep_xl=True, keep_wl=True):
     return y + c * 2.0 ** (-(sw + 11))
 
 
+def e2m3(u):
+    """OCP MX fp6 e2m3 grid: steps of 1/8 below 2, 1/4 below 4, 1/2 up to the maximum 7.5 (round to nearest even, saturating)."""
+    a = u.abs().clamp(max=7.5)
+    step = torch.where(a < 2, 0.125, torch.where(a < 4, 0.25, 0.5)).to(u.dtype)
+    return torch.sign(u) * torch.round(a / step) * step
+
+
+def mx6(t, dim, block=32):
+    """Block-scaled e2m3 (MXFP6): blocks of `block` consecutive entries along `dim` share one power-of-two scale 2^(floor(log2 max) - 2)."""
+    t = t.movedim(dim, -1)
+    shp = t.shape
+    b = t.reshape(*shp[:-1], shp[-1] // block, block)
+    amax = b.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax))))
+    scale = torch.pow(torch.tensor(2.0, dtype=t.dtype), e - 2)
+    q = e2m3(b / scale) * scale
+    return q.reshape(shp).movedim(-1, dim)
+
+
+def conv_mx6(x, w, _, blk=32):
+    """Corrections on the MXFP6 (e2m3) MFMA -- twice the fp8 rate on gfx950: Wh*xh on f16 + (Wh6*xl6 + Wl6*xh6), every 32-channel
+    block of a voxel / of a (cout, tap) weight row with its own E8M0 scale."""
+    xh, wh = f16r(x), f16r(w)
+    xl, wl = x - xh, w - wh
+    if x.shape[1] % blk:
+        return R.conv3_reflect(xh, wh) + R.conv3_reflect(xl, wh) + R.conv3_reflect(xh, wl)      # the stem is not an mx layer
+    y = R.conv3_reflect(xh, wh)
+    return y + R.conv3_reflect(mx6(xl, 1, blk), mx6(wh, 1, blk)) + R.conv3_reflect(mx6(xh, 1, blk), mx6(wl, 1, blk))
+
+
 # Winograd F(2,3):  Y = A^T [ (G g G^T) . (B^T d B) ] A
 BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
@@ -218,6 +248,8 @@ def main():
         ("fp8corr store15", conv_fp8corr, None, 15),
         ("fp8corr store22", conv_fp8corr, None, 22),
         ("mx e4m3 f16x2store", conv_mx, None, "f16x2"),
+        ("mx6 e2m3 block32", conv_mx6, None, "f16x2"),
+        ("mx6 e2m3 block16", lambda a, b, c: conv_mx6(a, b, c, 16), None, "f16x2"),
         ("mxpart no Wl", lambda a, b, c: conv_mx_part(a, b, c, True, False), None, "f16x2"),
         ("mxpart no xl", lambda a, b, c: conv_mx_part(a, b, c, False, True), None, "f16x2"),
         ("mxpart neither, f16x2 store", lambda a, b, c: conv_mx_part(a, b, c, False, False), None, "f16x2"),
