@@ -46,6 +46,7 @@ size_t instnorm_scratch_bytes(int N, int C, long long max_slots_x_C);
 int conv_v2_stats_slots(int D, int H, int W, int Q);
 bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
 int last_conv_stats_slots();
+int conv_stem_stats_slots(const ConvParams& p, int precision);
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
                            const float* kshift = nullptr, int W = 0, int skip_lo = 0, int apply = 1, float* ab_out = nullptr);
@@ -602,13 +603,16 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         p.wpk = (const char*)L.wpk_skip;
       }
       // InstanceNorm layers on the generic kernel: the conv epilogue writes the partial sums of the statistics pass itself
-      const bool zx_shape = mx && zx_env && L.wx && !have_cur_up && !x_offs && cur.slot >= 0 && !L.is_final && inorm && amx::conv_zx_eligible(p);
-      const bool fuse_stats = inorm && !use_merge && !use_upcat && !p.src0_f32c1 && !L.is_final && !x_offs &&
-                              (zx_shape || amx::conv_fuses_stats(p, c.precision, L.q));
+      const bool zx_shape = mx && zx_env && L.wx && !have_cur_up && !x_offs && cur.slot >= 0 && (inorm || (L.is_final && !final_via_export)) &&
+                            amx::conv_zx_eligible(p);
+      // (the stem of the split precisions likewise: amx_conv3d_stem.hip)
+      const int stem_slots = (p.src0_f32c1 && inorm && !x_offs) ? amx::conv_stem_stats_slots(p, stem_precision(c.precision)) : 0;
+      const bool fuse_stats = inorm && !use_merge && !use_upcat && !L.is_final && !x_offs &&
+                              (p.src0_f32c1 ? stem_slots > 0 : (zx_shape || amx::conv_fuses_stats(p, c.precision, L.q)));
       if (fuse_stats) p.stats = (float*)in_scratch;
       // f16x2mx 32 -> 32 at whole tiles: the normalise-on-load z-march kernel (amx_conv3d_zx.hip).  It is the ONLY consumer of a
       // tensor whose norm was left pending (below), and takes already-normalised inputs too.
-      const bool use_zx = mx && zx_env && L.wx && !have_cur_up && !x_offs && cur.slot >= 0 && !L.is_final && inorm && amx::conv_zx_eligible(p);
+      const bool use_zx = zx_shape;
       if (cur.ab && !use_zx) return fail(AMX_ERR_INVALID, "internal: model.%d got an input whose norm is pending but cannot run the fused kernel", L.module_idx);
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, stem_precision(c.precision), st);
@@ -679,10 +683,12 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
             amx::ConvParams t;
             memset(&t, 0, sizeof t);
             t.N = n; t.D = dd; t.H = dh; t.W = dw; t.C0 = L.cout_p; t.C1 = 0; t.Cout = Nx.cout_p; t.out = (char*)1; t.mxs = Nx.mxs; t.s0x = 32; t.ox = 32;
-            defer = Nx.wx && Nx.level == lv && !Nx.is_final && Nx.norm_idx >= 0 && Nx.cin_pad == L.cout_p && amx::conv_zx_eligible(t);
+            // (the output conv takes a pending norm too: fp32 planar epilogue, no importance map, no activation of its own)
+            const bool nx_kind = Nx.is_final ? (!wmap && c.final_act == AMX_ACT_NONE && dw >= 32 && Nx.cout_p == Nx.cout) : Nx.norm_idx >= 0;
+            defer = Nx.wx && Nx.level == lv && nx_kind && Nx.cin_pad == L.cout_p && amx::conv_zx_eligible(t);
           }
         }
-        const int slots = fuse_stats ? (use_zx ? amx::conv_zx_stats_slots(dh, dw) : amx::last_conv_stats_slots()) : 0;
+        const int slots = !fuse_stats ? 0 : p.src0_f32c1 ? stem_slots : use_zx ? amx::conv_zx_stats_slots(dh, dw) : amx::last_conv_stats_slots();
         float* abo = defer ? ab_buf[ab_next] : nullptr;
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
                                      L.cout_p, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
@@ -900,7 +906,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     // wider concat layers (nearest upsample): split into skip conv + merged-tap conv over the upsampled channels, at the levels
     // that are at least 32 voxels wide at the reference operating point
     if (e == hipSuccess && is_mx(cfg->precision)) e = hipMalloc((void**)&L.mxs, 2 * sizeof(int));
-    if (e == hipSuccess && is_mx(cfg->precision) && L.cin_pad == 32 && L.cout_p == 32 && L.cin == 32 && !L.is_final && L.cin != 1)
+    if (e == hipSuccess && is_mx(cfg->precision) && L.cin_pad == 32 && L.cout_p == 32 && L.cin == 32 && L.cout == 32)
       e = hipMalloc(&L.wx, amx::conv_zx_packed_bytes());
     if (e == hipSuccess && !is_mx(cfg->precision) && L.after_up && cfg->interp == AMX_INTERP_NEAREST && L.wpk_up == nullptr && L.cout_p == L.cout &&
         amx::conv_upmerge_eligible(L.cout, L.cin - L.cout, L.cout, w_at, w_at, w_at, 1, is_split(cfg->precision))) {

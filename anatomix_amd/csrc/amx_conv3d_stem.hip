@@ -133,6 +133,9 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
   char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (long long)((g * 4 * Q) >> 4) * ocs + ((g * 4 * Q) & 15) * 2;
 
   bool bad = false;
+  float s1[4 * Q], s2[4 * Q];                                  // InstanceNorm statistics of the stored values, shifted by the bias
+#pragma unroll
+  for (int k = 0; k < 4 * Q; ++k) s1[k] = s2[k] = 0.f;
   for (int s = 0; s < nsteps; ++s) {
     {
       int need = TZ * s + TZ + 2;
@@ -203,6 +206,14 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
         for (int q = 0; q < Q; ++q)
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[q * 4 + j] = acc[c][q][j];
+        if (p.stats) {
+#pragma unroll
+          for (int k = 0; k < 4 * Q; ++k) {
+            const float d = v[k] - bias[k >> 2][k & 3];
+            s1[k] += d;
+            s2[k] += d * d;
+          }
+        }
         unsigned w[2 * Q];
 #pragma unroll
         for (int j = 0; j < 2 * Q; ++j) w[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
@@ -222,6 +233,27 @@ __global__ __launch_bounds__((NC + 1) * 64) void conv3d_stem_kernel(const ConvPa
     flag_store(done + wave, s + 1);
   }
   if (RangeCheck<T>::on) raise_flag(p.oflow, bad);
+  if (p.stats) {
+    // sum over the 16 voxel lanes of the lane group (row_shr 1, 2, 4, 8: lane 15 of the row holds it); slot = (tile, z segment, wave)
+#pragma unroll
+    for (int k = 0; k < 4 * Q; ++k) {
+      s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x111, 0xF, 0xF, true));
+      s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x111, 0xF, 0xF, true));
+      s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x112, 0xF, 0xF, true));
+      s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x112, 0xF, 0xF, true));
+      s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x114, 0xF, 0xF, true));
+      s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x114, 0xF, 0xF, true));
+      s1[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[k]), 0x118, 0xF, 0xF, true));
+      s2[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[k]), 0x118, 0xF, 0xF, true));
+    }
+    if (li == 15) {
+      const long long nslots = (long long)p.nby * p.nbx * nseg * NC;
+      const long long slot = (((long long)by * p.nbx + bx) * nseg + sg) * NC + wave;
+      float* o = p.stats + (((long long)n * nslots + slot) * p.Cout + g * 4 * Q) * 2;
+#pragma unroll
+      for (int k = 0; k < 4 * Q; k += 2) *(float4*)(o + 2 * k) = make_float4(s1[k], s2[k], s1[k + 1], s2[k + 1]);
+    }
+  }
 }
 
 
@@ -517,6 +549,32 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __res
 static thread_local char g_kernel_name4[64] = "";
 const char* last_conv_stem_kernel_name() { return g_kernel_name4; }
 
+// z segments per (n, y, x) tile -- tiny LDS footprint: several workgroups per CU
+static void stem_segments(const ConvParams& p, int TY, int TX, int TZ, int* zseg_out, int* nseg_out) {
+  const int tiles = ((p.H + TY - 1) / TY) * ((p.W + TX - 1) / TX) * p.N;
+  static int wgs = -1;
+  if (wgs < 0) wgs = getenv("AMX_STEM_WGS") ? atoi(getenv("AMX_STEM_WGS")) : 512;
+  int nseg = (wgs + tiles - 1) / tiles;
+  if (nseg < 1) nseg = 1;
+  int zseg = (p.D + nseg - 1) / nseg;
+  zseg = (zseg + TZ - 1) / TZ * TZ;
+  if (zseg < 8) zseg = 8;
+  *zseg_out = zseg;
+  *nseg_out = (p.D + zseg - 1) / zseg;
+}
+
+// InstanceNorm statistics in the epilogue (ConvParams::stats): the tap-gather kernel of the split precisions, whole tiles only.
+// Returns the slots per sample ([n][slot][Cout][2] partial sums), 0 when the layer must keep its separate statistics pass.
+int conv_stem_stats_slots(const ConvParams& p, int precision) {
+  if (precision < 2 || getenv("AMX_NO_FUSED_STATS")) return 0;
+  constexpr int TY = 8, TX = 32, TZ = 2, NC = 8;
+  if (p.H % TY || p.W % TX || p.D % TZ) return 0;
+  int zseg, nseg;
+  stem_segments(p, TY, TX, TZ, &zseg, &nseg);
+  if (p.D % zseg) return 0;
+  return (p.H / TY) * (p.W / TX) * nseg * NC;
+}
+
 template <typename T, int Q, bool SPLIT>
 static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   constexpr int TY = 8, TX = 32, TZ = 2, NC = 8, R = 10;
@@ -533,20 +591,14 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   p.nby = (p.H + TY - 1) / TY;
   p.nbx = (p.W + TX - 1) / TX;
   const int tiles = p.nby * p.nbx * p.N;
-  static int wgs = -1;
-  if (wgs < 0) wgs = getenv("AMX_STEM_WGS") ? atoi(getenv("AMX_STEM_WGS")) : 512;
-  int nseg = (wgs + tiles - 1) / tiles;       // tiny LDS footprint: several workgroups per CU
-  if (nseg < 1) nseg = 1;
-  int zseg = (p.D + nseg - 1) / nseg;
-  zseg = (zseg + TZ - 1) / TZ * TZ;
-  if (zseg < 8) zseg = 8;
-  nseg = (p.D + zseg - 1) / zseg;
+  int zseg, nseg;
+  stem_segments(p, TY, TX, TZ, &zseg, &nseg);
   // The row-fragment kernel is the default where it measured faster: single 16-bit storage (6 M stem, batch 4 x 128^3, same box:
   // 135.3 -> 91.5 us).  In the split precisions the layer writes twice the bytes and is store-bound either way (tap-gather
   // 220 / 145 us vs rows 235 / 152 us for 32 / 16 channels): those keep the tap-gather kernel.  AMX_STEM_GATHER=1 / =0 force one.
   static int gather = -1;
   if (gather < 0) gather = getenv("AMX_STEM_GATHER") ? atoi(getenv("AMX_STEM_GATHER")) : 2;
-  if (gather == 0 || (gather == 2 && !SPLIT)) {
+  if (!p.stats && (gather == 0 || (gather == 2 && !SPLIT))) {
     if (p.dbg & 2) p.dbg |= 4;
     typedef Stem2Cfg<TY, TX, TZ, NC, R, SPLIT> C2;
     snprintf(g_kernel_name4, sizeof g_kernel_name4, "conv3d_stem<%s,q%d,%dx%dx%d,c%d+cv1,r%d,rows>",

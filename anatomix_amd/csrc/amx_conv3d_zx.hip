@@ -102,8 +102,9 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
     const float ak = act_k(e.in_ab ? e.in_act : ACT_NONE, e.in_slope);
     const char* src_n = p.src0 + (long long)n * p.s0n;
     const unsigned a_done = lds_addr(done);
-    uint4 rh[2][NJ], rl[2][NJ];
-    auto load_plane = [&](int q, int set) {                  // unconditional (clamped) loads: one plane ahead in registers
+    constexpr int PF = 1;                                    // planes in flight ahead of the one being converted
+    uint4 rh[PF + 1][NJ], rl[PF + 1][NJ];
+    auto load_plane = [&](int q, int set) {                  // unconditional (clamped) loads: PF planes ahead in registers
       const int qq = q < nplanes ? q : nplanes - 1;
       const char* plane = src_n + (long long)reflect_clamp(qq - 1, p.D) * p.s0z;
 #pragma unroll
@@ -138,12 +139,13 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         }
       }
     };
-    load_plane(0, 0);
-    for (int q = 0; q < nplanes; q += 2) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < PF; ++i) load_plane(i, i);
+    for (int q = 0; q < nplanes; q += PF + 1) {
+#pragma unroll
+      for (int h = 0; h < PF + 1; ++h) {
         const int qq = q + h;
-        load_plane(qq + 1, (h + 1) & 1);
+        load_plane(qq + PF, (h + PF) % (PF + 1));
         if (qq < nplanes) {
           // ring slot qq % R is free once every consumer is done with plane qq - R: planes < TZ * min(done) are dead
           while (qq >= R + TZ * __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done))) __builtin_amdgcn_s_sleep(1);
@@ -310,6 +312,8 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
   const int yl = y0, xl = x0 + wcx * 16 + li;
   char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (long long)(cbc >> 4) * ocs + (cbc & 15) * 2;
   const long long out_lo = (long long)(p.Cout >> 4) * ocs;
+  // the network's output conv: fp32 [n][c][z][y][x] -- per channel j of the lane a 64-byte run of the 16 voxel lanes
+  float* out32_l = p.out32 ? p.out32 + (long long)n * p.pn + (long long)cbc * p.pc + (long long)yl * p.py + xl : nullptr;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   bool bad = false;
 
@@ -396,6 +400,12 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
           s2[j] += d * d;
         }
         if (p.dbg & 4) continue;
+        if (out32_l) {
+          float* d32 = out32_l + (long long)(s * TZ + tz) * p.pz + cy * p.py;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d32[(long long)j * p.pc] = v[j];
+          continue;
+        }
         char* dst = out_l + (long long)(s * TZ + tz) * p.oz + cy * p.oy;
         *(uint2*)dst = make_uint2((unsigned)to_bits<f16>(v[0]) | ((unsigned)to_bits<f16>(v[1]) << 16),
                                   (unsigned)to_bits<f16>(v[2]) | ((unsigned)to_bits<f16>(v[3]) << 16));
@@ -406,7 +416,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
                                              (unsigned)to_bits<f16>(r[2]) | ((unsigned)to_bits<f16>(r[3]) << 16));
       }
   }
-  raise_flag(p.oflow, bad);
+  if (!p.out32) raise_flag(p.oflow, bad);
   if (p.stats) {
     // sum over the 16 voxel lanes of the lane group (row_shr 1, 2, 4, 8: lane 15 of the row holds it); slot = (tile, x half), this
     // wave's 16 channels of it -- the pair (wq = 0, 1) of an x half fills all 32 channels of the slot
@@ -480,12 +490,14 @@ hipError_t launch_pack_weights_zx(const float* w, const float* scale, void* wx, 
   return hipGetLastError();
 }
 
-// One full-resolution row-planar f16x2mx segment of 32 channels -> 32 channels, whole tiles, 16-bit output
+// One full-resolution row-planar f16x2mx segment of 32 channels -> 32 channels, whole tiles; 16-bit row-planar output, or the network's
+// fp32 planar output (no importance map, no activation of its own)
 bool conv_zx_eligible(const ConvParams& p) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_ZX") ? 1 : 0;
-  return !off && !p.src0_f32c1 && p.C0 == 32 && p.C1 == 0 && p.Cout == 32 && !p.out32 && p.out && p.mxs && p.W % 32 == 0 && p.H % 2 == 0 &&
-         p.D % 2 == 0 && p.D >= 4 && p.s0x == 32 && p.ox == 32;
+  const bool out_ok = p.out32 ? (!p.wmap && p.act == ACT_NONE && !p.stats) : (p.out && p.ox == 32);
+  return !off && !p.src0_f32c1 && p.C0 == 32 && p.C1 == 0 && p.Cout == 32 && out_ok && p.mxs && p.W % 32 == 0 && p.H % 2 == 0 &&
+         p.D % 2 == 0 && p.D >= 4 && p.s0x == 32;
 }
 int conv_zx_stats_slots(int H, int W) { return (H / 2) * (W / 32) * 2; }
 
@@ -494,8 +506,8 @@ const char* last_conv_zx_kernel_name() { return g_kernel_name_zx; }
 
 hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
   typedef ZxCfg C;
-  snprintf(g_kernel_name_zx, sizeof g_kernel_name_zx, "conv3d_k3_zx<f16x2mx,32->32,%dx%dx%d,m4+x4+cv4,r%d%s>", C::TZ, C::TY, C::TX, C::R,
-           in_ab ? ",norm-in" : "");
+  snprintf(g_kernel_name_zx, sizeof g_kernel_name_zx, "conv3d_k3_zx<f16x2mx,32->32,%dx%dx%d,m4+x4+cv4,r%d%s%s>", C::TZ, C::TY, C::TX, C::R,
+           in_ab ? ",norm-in" : "", p.out32 ? ",o1" : "");
   static bool attr_done = false;
   auto kern = conv3d_k3_zx_kernel<0>;
   if (!attr_done) {
