@@ -47,6 +47,9 @@ int conv_v2_stats_slots(int D, int H, int W, int Q);
 bool conv_fuses_stats(const ConvParams& p, int precision, int Q);
 int last_conv_stats_slots();
 int conv_stem_stats_slots(const ConvParams& p, int precision);
+bool in_apply_pool_eligible(int precision, int D, int H, int W, int C);
+hipError_t launch_in_apply_pool(void* x, const float* ab, void* pooled, int N, int D, int H, int W, int C, int act, float slope, int avg,
+                                int skip_lo, int pool_skip_lo, int* oflow, hipStream_t st);
 hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float eps, int N, long long vox, int C, int act,
                            float slope, void* scratch, int precision, hipStream_t st, int* oflow = nullptr, int fused_slots = 0,
                            const float* kshift = nullptr, int W = 0, int skip_lo = 0, int apply = 1, float* ab_out = nullptr);
@@ -688,12 +691,26 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
             defer = Nx.wx && Nx.level == lv && nx_kind && Nx.cin_pad == L.cout_p && amx::conv_zx_eligible(t);
           }
         }
+        // f16x2mx, pool right after this group: the apply pass also writes the pooled tensor (amx_norm.hip in_apply_pool_kernel); the
+        // in-place tensor then has no reader left but the decoder's convolution, which takes hi and the copies
+        const size_t nxt_mod = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
+        const bool apply_pool = !defer && mx && !taps && !x_offs && act_on == L.has_act && nxt_mod < h->kinds.size() && h->kinds[nxt_mod] == K_POOL &&
+                                !have_fused_pool && amx::in_apply_pool_eligible(c.precision, dd, dh, dw, L.cout_p);
         const int slots = !fuse_stats ? 0 : p.src0_f32c1 ? stem_slots : use_zx ? amx::conv_zx_stats_slots(dh, dw) : amx::last_conv_stats_slots();
-        float* abo = defer ? ab_buf[ab_next] : nullptr;
+        float* abo = (defer || apply_pool) ? ab_buf[ab_next] : nullptr;
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
                                      L.cout_p, act_on ? c.activation : AMX_ACT_NONE, c.act_slope, in_scratch, c.precision, st, h->d_flag,
                                      slots, fuse_stats ? L.shift : nullptr, dw,
-                                     conv_only(i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0)), defer ? 0 : 1, abo));
+                                     conv_only(i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0)), (defer || apply_pool) ? 0 : 1, abo));
+        if (apply_pool) {
+          fused_pool.level = lv + 1; fused_pool.C = L.cout_p; fused_pool.Cr = L.cout; fused_pool.slot = grab(lv + 1);
+          if (fused_pool.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level %d", lv + 1);
+          AMX_HIP(amx::launch_in_apply_pool(A.slot[lv][out.slot], abo, A.slot[lv + 1][fused_pool.slot], n, dd, dh, dw, L.cout_p,
+                                            act_on ? c.activation : AMX_ACT_NONE, c.act_slope, c.pooling == AMX_POOL_AVG, 1,
+                                            conv_only(nxt_mod + 1), h->d_flag, st));
+          have_fused_pool = true;
+          if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "instnorm+act+pool2<%s>", c.pooling == AMX_POOL_AVG ? "avg" : "max");
+        }
         if (defer) {
           out.ab = abo;
           ab_next ^= 1;

@@ -276,6 +276,62 @@ __global__ __launch_bounds__(256) void in_apply_fast_kernel(char* __restrict__ x
   if (RangeCheck<T>::on) raise_flag(oflow, bad);
 }
 
+// f16x2mx (row-planar, FMT 2): the apply pass of a layer whose output is pooled next -- y = act(a x + b) in place AND the 2x2x2
+// pooled tensor in one read of the raw values (network.py:368: conv -> norm -> act -> pool; the in-place tensor stays alive as the
+// skip connection).  One block per pooled row (n, zp, yp); a thread owns the 8-channel group c8 of full-resolution column xr of the
+// four source rows: lane bit 0 = c8 & 1 (the lane pair mx_store_copies exchanges with), lane bit 1 = xr & 1 (the pooling partner
+// along x, one quad_perm away), so every load and store of a wavefront is one contiguous 1 KiB run of a plane.
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_pool_kernel(char* __restrict__ x, const float* __restrict__ ab, char* __restrict__ pooled,
+                                                            int D2, int H2, int W, int C, int act, float slope, int avg, int skip_lo,
+                                                            int pool_skip_lo, int* oflow) {
+  bool bad = false;
+  int r = blockIdx.x;
+  const int yp = r % H2;
+  r /= H2;
+  const int zp = r % D2, n = r / D2;
+  const int c8n = C >> 3, W2 = W >> 1;
+  const long long rowb = 6ll * C * W, prowb = 6ll * C * W2;
+  const int lo = 2 * C * W, plo = 2 * C * W2;
+  const float ak = act_k(act, slope);
+  for (int t = threadIdx.x; t < W * c8n; t += 256) {
+    const int c8 = ((t >> 1) / W) * 2 + (t & 1), xr = (t >> 1) % W;
+    const float* q = ab + ((long long)n * C + c8 * 8) * 2;
+    float a[8], b[8], acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = q[2 * e];
+      b[e] = q[2 * e + 1];
+      acc[e] = avg ? 0.f : -3.0e38f;
+    }
+    const long long goff = (long long)(c8 >> 1) * (W * 32) + xr * 32 + (c8 & 1) * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      char* xp = x + (((long long)n * 2 * D2 + 2 * zp + (k >> 1)) * 2 * H2 + 2 * yp + (k & 1)) * rowb + goff;
+      float f[8];
+      load8<T, 2>(xp, lo, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = act_fwd(f[e] * a[e] + b[e], ak);
+        if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v);
+        f[e] = v;
+        acc[e] = avg ? acc[e] + v : fmaxf(acc[e], v);
+      }
+      store8<T, 2>(xp, lo, f, c8, skip_lo != 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[e]), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+      acc[e] = avg ? (acc[e] + o) * 0.125f : fmaxf(acc[e], o);
+    }
+    if (!(xr & 1)) {
+      char* pp = pooled + (((long long)n * D2 + zp) * H2 + yp) * prowb + (long long)(c8 >> 1) * (W2 * 32) + (xr >> 1) * 32 + (c8 & 1) * 16;
+      store8<T, 2>(pp, plo, acc, c8, pool_skip_lo != 0);
+    }
+  }
+  if (RangeCheck<T>::on) raise_flag(oflow, bad);
+}
+
 // out [N][2D][2H][2W][C] <- in [N][D][H][W][C].  Cell formulation: the 2 x 2 x 2 outputs (2z+1..2z+2, 2y+1..2y+2,
 // 2x+1..2x+2) all interpolate the SAME eight inputs (z..z+1, y..y+1, x..x+1), so a thread loads those eight 8-channel
 // vectors once and writes eight outputs -- cache reads equal the output bytes instead of 8x (the per-output version was
@@ -577,6 +633,17 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
     default: return hipErrorInvalidValue;
   }
 #undef AMX_IN
+  return hipGetLastError();
+}
+
+// f16x2mx only: in-place norm apply + activation of x [N][D][H][W][C] (row-planar) and its 2x2x2 avg / max pooled copy
+bool in_apply_pool_eligible(int precision, int D, int H, int W, int C) {
+  return precision == 4 && !(D & 1) && !(H & 1) && !(W & 1) && C % 16 == 0 && ((long long)W * (C / 8)) % 64 == 0 && !getenv("AMX_NO_APPLY_POOL");
+}
+hipError_t launch_in_apply_pool(void* x, const float* ab, void* pooled, int N, int D, int H, int W, int C, int act, float slope, int avg,
+                                int skip_lo, int pool_skip_lo, int* oflow, hipStream_t st) {
+  hipLaunchKernelGGL(in_apply_pool_kernel<f16>, dim3((unsigned)((long long)N * (D / 2) * (H / 2))), dim3(256), 0, st, (char*)x, ab,
+                     (char*)pooled, D / 2, H / 2, W, C, act, slope, avg, skip_lo, pool_skip_lo, oflow);
   return hipGetLastError();
 }
 
