@@ -31,7 +31,7 @@ hipError_t launch_pool2(const void* in, void* out, int N, int Do, int Ho, int Wo
 hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long long voxels, hipStream_t st);
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
-int conv_pick_q(int Cout, int W);
+int conv_pick_q(int Cout, int W, int precision);
 hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st);
 hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st, int CoutReal = 0);
 const char* last_conv_stem_kernel_name();
@@ -67,7 +67,8 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, cons
                             float* out, void* scratch, hipStream_t st);
 hipError_t launch_poison_if_flag(const int* flag, int* host_flag, float* y, long long count, hipStream_t st);
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
-                                      hipStream_t st, int skip_lo = 0);
+                                      hipStream_t st, int skip_lo = 0, const float* ab = nullptr, int act = 0, float slope = 0.f,
+                                      int* oflow = nullptr);
 hipError_t launch_affine_act(void* x, const float* scale, const float* shift, int N, long long vox, int C, int act,
                              float slope, int precision, hipStream_t st, int* oflow = nullptr);
 hipError_t launch_export_ncdhw(const void* src0, int C0, const void* src1, int C1, int up_shift, int N, int D, int H, int W,
@@ -409,6 +410,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
     int level = 0, slot = -1, C = 0, Cr = 0;
     bool planar = false;
     const float* ab = nullptr;                      // non-null: the tensor is RAW, its norm + activation pending: y = act(a x + b)
+    int ab_act = AMX_ACT_NONE;                      //   ... with this activation
   };
   float* ab_buf[2] = {(float*)((char*)in_scratch + in_scratch_bytes(h, n, d, hh, w) - 2 * kPendingAbBytes(n)),
                       (float*)((char*)in_scratch + in_scratch_bytes(h, n, d, hh, w) - kPendingAbBytes(n))};
@@ -620,7 +622,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       auto launch_one = [&](const amx::ConvParams& q) -> hipError_t {
         if (q.src0_f32c1) return amx::launch_conv_stem(q, stem_precision(c.precision), st);
         if (use_upcat) return amx::launch_conv_upcat16(q, c.precision, st);
-        if (use_zx) return amx::launch_conv_zx(q, cur.ab, c.activation, c.act_slope, L.wx, st);
+        if (use_zx) return amx::launch_conv_zx(q, cur.ab, cur.ab_act, c.act_slope, L.wx, st);
         return amx::launch_conv(q, c.precision, L.q, st);
       };
       // pipelined windows (two batches in flight on two streams): the accumulating launches of this batch wait for the other
@@ -696,6 +698,12 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         const size_t nxt_mod = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);
         const bool apply_pool = !defer && mx && !taps && !x_offs && act_on == L.has_act && nxt_mod < h->kinds.size() && h->kinds[nxt_mod] == K_POOL &&
                                 !have_fused_pool && amx::in_apply_pool_eligible(c.precision, dd, dh, dw, L.cout_p);
+        // trilinear upsample right after this group (decoder): the upsample pass normalises its eight inputs on the way in
+        static int up_env = -1;
+        if (up_env < 0) up_env = getenv("AMX_NO_APPLY_UP") ? 0 : 1;
+        const bool defer_up = up_env && !defer && !apply_pool && !taps && !x_offs && act_on == L.has_act && nxt_mod < h->kinds.size() &&
+                              h->kinds[nxt_mod] == K_UP && c.interp == AMX_INTERP_TRILINEAR;
+        if (defer_up) defer = true;
         const int slots = !fuse_stats ? 0 : p.src0_f32c1 ? stem_slots : use_zx ? amx::conv_zx_stats_slots(dh, dw) : amx::last_conv_stats_slots();
         float* abo = (defer || apply_pool) ? ab_buf[ab_next] : nullptr;
         AMX_HIP(amx::launch_instnorm(A.slot[lv][out.slot], L.in_gamma, L.in_beta, c.norm_eps, n, (long long)dd * dh * dw,
@@ -713,8 +721,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         }
         if (defer) {
           out.ab = abo;
+          out.ab_act = act_on ? c.activation : AMX_ACT_NONE;
           ab_next ^= 1;
-          if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "instnorm statistics only (apply fused into the next conv)");
+          if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "instnorm statistics only (apply fused into the next %s)", defer_up ? "upsample" : "conv");
         }
       }
       if (final_via_export)
@@ -794,7 +803,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
           if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
         }
         AMX_HIP(amx::launch_upsample2_trilinear(A.slot[cur.level][cur.slot], A.slot[lv][up.slot], n, d >> cur.level,
-                                                hh >> cur.level, w >> cur.level, cur.C, c.precision, st, conv_only(i + 1)));
+                                                hh >> cur.level, w >> cur.level, cur.C, c.precision, st, conv_only(i + 1), cur.ab,
+                                                cur.ab_act, c.act_slope, h->d_flag));
         A.used[cur.level][cur.slot] = false;
         cur = up;
         cur_is_full_up = true;
@@ -915,7 +925,7 @@ int amx_unet_create(amx_unet_t** out, const amx_unet_cfg* cfg) {
     }
     // Q is chosen for the reference operating point (128^3 windows): level l runs at W = 128>>l.
     const int w_at = h->pack_w >> L.level;
-    L.q = amx::conv_pick_q(L.cout_p, w_at > 0 ? w_at : 1);
+    L.q = amx::conv_pick_q(L.cout_p, w_at > 0 ? w_at : 1, cfg->precision);
     const size_t wbytes = (size_t)L.cout_p * L.cin_pad * 28 * 2 * (is_split(cfg->precision) ? 2 : 1);   // strict: [Wh | Wl]
     hipError_t e = hipMalloc(&L.wpk, wbytes);
     if (e == hipSuccess && !is_split(cfg->precision) && L.cin == 48 && L.cout == 16 && cfg->use_skip && cfg->interp == AMX_INTERP_NEAREST)
@@ -1190,7 +1200,7 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
   // strict precision: x0 / x1 / out16 voxels hold [hi(C) | lo(C)]; f16x2mx: [hi(C) | lo(C) | e4m3 copies (2C bytes)] -- the INPUT
   // voxels must carry valid copies (tests/_util.py to_ndhwc_mx), the output's copy section is left untouched
   const long long eb = elem_bytes(precision);
-  const int q = amx::conv_pick_q(cout, w);
+  const int q = amx::conv_pick_q(cout, w, precision);
   if (d_out32 && (q > 2 || w < 32)) return fail(AMX_ERR_INVALID, "fp32 planar output needs cout <= 32 and w >= 32");
   if (cin_real < 1 || cin_real > c0 + c1 || cout_real < 1 || cout_real > cout || (weight_mode != 0 && weight_mode != 1))
     return fail(AMX_ERR_INVALID, "bad weight description (mode %d, cin_real %d, cout_real %d)", weight_mode, cin_real, cout_real);
@@ -1267,7 +1277,7 @@ int amx_conv3d_upcat_merged(const void* d_x0, int c0, const void* d_x1, int c1, 
     return fail(AMX_ERR_INVALID, "merged concat conv needs c0 == cout >= 32 (16 in the strict precisions), c1 %% 32 == 0, w >= 16, even dims "
                 "(c0=%d c1=%d cout=%d dims %d,%d,%d)", c0, c1, cout, d, hh, w);
   hipStream_t st = (hipStream_t)stream;
-  const int q = amx::conv_pick_q(cout, w);
+  const int q = amx::conv_pick_q(cout, w, precision);
   char* wmerge = (char*)d_wpk + align_up((size_t)cout * c0 * 28 * 2 * (split ? 2 : 1), 256);
   AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, c0, c0, cout, q, precision, st, 0, 0, c0 + c1));
   AMX_HIP(amx::launch_pack_upmerge(d_weight, d_scale, wmerge, c0, c0 + c1, c1, cout, precision, st));

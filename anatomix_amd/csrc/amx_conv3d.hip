@@ -242,10 +242,17 @@ const char* last_conv_kernel_name() { return g_kernel_name; }
 
 // Tile-shape heuristic.  Returns the Q (16-channel MFMA tiles per workgroup) a layer will be
 // launched with; the packed-weight layout depends on it.
-int conv_pick_q(int Cout, int W) {
+int conv_pick_q(int Cout, int W, int precision) {
   if (Cout == 16) return 1;
   if (Cout == 32) return 2;
   int q = W >= 32 ? 4 : 2;    // Cout >= 64 at 32^3 and larger: 4; 16^3 and below: more cout groups to fill the chip
+  // f16x2mx keeps Q = 2 (brick 4x4x32) at every width: its sweep holds the f16 AND the fp8 fragments, and four column tiles left
+  // the 64^3 / 32^3 layers of anatomix-dev at 310-430 TF against 400-550 with two (batch 4, same box: 64 -> 64 @64^3 629 -> 482 us,
+  // 192 -> 64 @64^3 1664 -> 1264, 384 -> 128 @32^3 809 -> 631; Q = 1: 536 / 1479 / 733).  The single 16-bit and the bf16x2 / f16x2
+  // kernels measured 0-7 % SLOWER with two (6 M forward 64 -> 64 @32^3 45.5 -> 46.9 us; strict 192 -> 64 @64^3 2045 -> 2197).
+  if (precision == 4) q = 2;
+  if (W >= 32 && getenv("AMX_Q_WIDE")) q = atoi(getenv("AMX_Q_WIDE"));     // experiment switches
+  if (W <= 8 && getenv("AMX_Q_DEEP")) q = atoi(getenv("AMX_Q_DEEP"));
   // (round 4, same box, batch 4: Q = 1 or 4 instead of 2 at the 8^3 level: 128 -> 256 22.2 -> 22.8 / 27.9 us, 256 -> 256 32.8 -> 34.7 / 44.9;
   //  at the 16^3 level Q = 1 / 4: 128 -> 128 28.1 -> 52.1 / 39.2 us -- more or fewer cout groups do not help: profiles/r04_deep_level_q.txt)
   while (Cout % (16 * q)) q >>= 1;   // 48 / 96 / 192 output channels (data gradients of the concat convs): 1 / 2 / 4

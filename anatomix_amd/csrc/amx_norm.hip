@@ -338,8 +338,11 @@ __global__ __launch_bounds__(256) void in_apply_pool_kernel(char* __restrict__ x
 // L1-bound at 2.0 TB/s on the 537 MB level-0 tensor of anatomix-dev).  Cells run from -1 to L-1 per axis with clamped
 // inputs, which reproduces the border rows (output 0 and 2L-1) of align_corners=False.  One block per (n, cz, cy).
 template <typename T, int FMT>
+// ab != null: `in` is a RAW conv output whose InstanceNorm + activation is pending -- act(a x + b) is applied to the eight inputs on
+// the way in (the separate apply pass over the low-resolution tensor disappears; nothing else reads that tensor).
 __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __restrict__ in, char* __restrict__ out, int N,
-                                                                  int D, int H, int W, int C, int skip_lo) {
+                                                                  int D, int H, int W, int C, int skip_lo,
+                                                                  const float* __restrict__ ab, int act, float slope, int* oflow) {
   constexpr int M = Fmt<FMT>::M;
   const int c8n = C >> 3;
   int r = blockIdx.x;
@@ -364,6 +367,21 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       load8<T, FMT>(rows[k >> 1] + Fmt<FMT>::group_rx(0, (k & 1 ? x1 : x0), C, W, c8), Fmt<FMT>::lo_off(C, W), v[k]);
+    if (ab) {
+      const float* q = ab + ((long long)n * C + c8 * 8) * 2;
+      const float ak = act_k(act, slope);
+      bool bad = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = q[2 * e], b = q[2 * e + 1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k][e] = act_fwd(v[k][e] * a + b, ak);
+          if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v[k][e]);
+        }
+      }
+      if (RangeCheck<T>::on) raise_flag(oflow, bad);
+    }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {                          // output (pz, py, px): 0 = odd position 2c+1, 1 = even position 2c+2
       const int pz = o >> 2, py = (o >> 1) & 1, px = o & 1;
@@ -598,14 +616,10 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
   float* ab_in = partial + in_coeff_offset(N, vox, C, fused_slots);
   float* ab = ab_out ? ab_out : ab_in;
   int nblk = fused_slots > 0 ? fused_slots : in_num_blocks(vox, C);
-  if (fused_slots > 4096) {
-    // fold the slots into kPreChunks chunks first (the chunk sums live behind the coefficients: N * kPreChunks * C * 2 floats, which
-    // fit the 65536-entry floor of the scratch of the separate statistics pass only when C * 64 <= 65536 -- true for C <= 1024)
-    float* partial2 = ab_in + (size_t)N * C * 2;
-    hipLaunchKernelGGL(in_prereduce_kernel, dim3(C / 8, N, kPreChunks), dim3(256), 0, st, partial, partial2, C, nblk);
-    partial = partial2;
-    nblk = kPreChunks;
-  }
+  const bool prereduce = nblk > 512;      // (in_finalize walks the slots 32 at a time with dependent adds: 4096 slots took 55 us, 64 chunks take 5)
+  // prereduce: fold the slots into kPreChunks chunks first (the chunk sums live behind the coefficients: N * kPreChunks * C * 2 floats,
+  // instnorm_scratch_bytes reserves them)
+  float* partial2 = ab_in + (size_t)N * C * 2;
   const int c8n = C / 8;
   if (c8n > 256) return hipErrorInvalidValue;          // C <= 2048
   const int nrow = 256 / c8n;
@@ -615,6 +629,11 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
 #define AMX_IN(T, S)                                                                                                   \
   if (fused_slots <= 0)                                                                                                \
     hipLaunchKernelGGL((in_stats_kernel<T, S>), dim3(nblk, N), dim3(256), lds, st, (const char*)x, partial, vox, C, W);   \
+  if (prereduce) {                                                                                                     \
+    hipLaunchKernelGGL(in_prereduce_kernel, dim3(C / 8, N, kPreChunks), dim3(256), 0, st, partial, partial2, C, nblk);    \
+    partial = partial2;                                                                                                \
+    nblk = kPreChunks;                                                                                                 \
+  }                                                                                                                    \
   hipLaunchKernelGGL((in_finalize_kernel<T, S>), dim3(C / 8, N), dim3(256), 0, st, (const char*)x, partial, gamma, beta, eps, vox, C, \
                      nblk, ab, kshift, fused_slots > 0 ? 1 : 0, W);                                               \
   if (!apply) {                                                                                                  \
@@ -648,9 +667,10 @@ hipError_t launch_in_apply_pool(void* x, const float* ab, void* pooled, int N, i
 }
 
 hipError_t launch_upsample2_trilinear(const void* in, void* out, int N, int D, int H, int W, int C, int precision,
-                                      hipStream_t st, int skip_lo = 0) {
+                                      hipStream_t st, int skip_lo = 0, const float* ab = nullptr, int act = 0, float slope = 0.f,
+                                      int* oflow = nullptr) {
   const unsigned blocks = (unsigned)((long long)N * (D + 1) * (H + 1));
-#define AMX_UP(T, S) hipLaunchKernelGGL((upsample2_trilinear_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C, skip_lo)
+#define AMX_UP(T, S) hipLaunchKernelGGL((upsample2_trilinear_kernel<T, S>), dim3(blocks), dim3(256), 0, st, (const char*)in, (char*)out, N, D, H, W, C, skip_lo, ab, act, slope, oflow)
   switch (precision) {
     case 0: AMX_UP(f16, false); break;
     case 1: AMX_UP(bf16, false); break;
