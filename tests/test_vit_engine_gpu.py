@@ -179,5 +179,7 @@ def test_engine_refuses_what_it_cannot_run(device):
         m(torch.zeros(1, 1, 64, 64, 64, device=device))
     kw2 = dict(kw, input_shape=(24, 24, 24))                        # 27 tokens: not a multiple of 64
     m2 = PrimusV2(**kw2).to(device).eval()
-    with torch.no_grad(), pytest.raises(_lib.AmxError, match="token grid"):
+    # outside the engine's envelope: a RuntimeError that carries the engine's reason and names the switch to the torch composition
+    with torch.no_grad(), pytest.raises(RuntimeError, match="token grid") as ei:
         m2(torch.zeros(1, 1, 24, 24, 24, device=device))
+    assert "use_engine" in str(ei.value)
