@@ -22,12 +22,25 @@ def friendly(mangled):
         return f"conv3d_upcat16<{'f16' if m.group(1) == 'DF16_' else 'bf16'},2x8x32,c8+l3,r10/6,o{m.group(2)}>"
     m = re.match(r"_ZN3amx18conv3d_stem_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
     if m:
-        return f"conv3d_stem<{'f16' if m.group(1) == 'DF16_' else 'bf16'},q{m.group(2)},2x8x32,c8+l1,r10>"
-    m = re.match(r"_ZN3amx19conv3d_k3_v2_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
-    if m:
-        t, wz, wy, wx, nwz, nwy, q, nch, o = m.groups()
-        return (f"conv3d_k3_v2<{'f16' if t == 'DF16_' else 'bf16'},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},"
-                f"w{int(nwz)*int(nwy)},q{q},nch{nch},o{o}>")
+        split = re.search(r"Lb1EEEv", mangled) is not None      # <T, Q, TY, TX, TZ, NC, R, SPLIT>
+        return f"conv3d_stem<{'f16' if m.group(1) == 'DF16_' else 'bf16'}{'x2' if split else ''},q{m.group(2)},2x8x32,c8+l1,r10>"
+    m = re.match(r"_ZN3amx19conv3d_k3_v2_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E"
+                 r"(?:Li(\d+)ELi(\d+)ELb(\d)E(?:Lb(\d)E)?)?", mangled)
+    if m:   # <T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF, SPLIT, MX>; same text as the launcher prints
+        t, wz, wy, wx, nwz, nwy, q, nch, o, nlw, nbuf, split, mx = m.groups()
+        name = "f16" if t == "DF16_" else "bf16"
+        if mx == "1":
+            name += "x2mx"
+        elif split == "1":
+            name += "x2"
+        waves = f"w{int(nwz)*int(nwy)}" + (f"+l{nlw},b{nbuf}" if nlw and int(nlw) > 0 else "")
+        return f"conv3d_k3_v2<{name},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},{waves},q{q},nch{nch},o{o}>"
+    if "conv3d_k3_zx_kernel" in mangled:
+        return "conv3d_k3_zx<f16x2mx,32->32,2x2x32,m4+x4+cv4,r6>"
+    for k in ("in_apply_pool_kernel", "in_apply_fast_kernel", "in_apply_kernel", "upsample2_trilinear_kernel", "in_finalize_kernel",
+              "in_prereduce_kernel", "in_stats_kernel", "conv3d_stem2_kernel"):
+        if k in mangled:
+            return k
     m = re.match(r"_ZN3amx21conv3d_upmerge_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E", mangled)
     if m:   # <T, Q, TZ, TY, NBUF, KS, SPLIT, LXT>
         t, q, tz, ty, nbuf, ks, split, lxt = m.groups()
