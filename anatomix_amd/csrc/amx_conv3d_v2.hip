@@ -820,6 +820,9 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
     if (nch % 2 == 0) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 1, 2, 0>(p, st);
     return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 1, 1, 0>(p, st);
   }
+  // 4-wide levels: half bricks (4x2x8, 4 waves) -- twice the workgroups (1024 -> 1024 @4^3, batch 4: 128 -> 256 on 256 CUs) and half as
+  // many waves streaming the same weight fragments from L2
+  if (Q == 2 && p.W <= 4 && !getenv("AMX_V2_NO_HALF_BRICK")) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 2, 1, 0>(p, st);
   if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
   if (Q == 4) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
@@ -837,7 +840,7 @@ int conv_v2_stats_slots(int D, int H, int W, int Q) {
     if (Q == 1) { ty = 2; tx = 16; nw = 4; }
     else { ty = 4; tx = 16; nw = 8; }
   } else {
-    if (Q == 2) { ty = 4; tx = 8; nw = 8; }
+    if (Q == 2 && !(W <= 4 && !getenv("AMX_V2_NO_HALF_BRICK"))) { ty = 4; tx = 8; nw = 8; }
     else { ty = 2; tx = 8; nw = 4; }
   }
   return ((D + tz - 1) / tz) * ((H + ty - 1) / ty) * ((W + tx - 1) / tx) * nw;

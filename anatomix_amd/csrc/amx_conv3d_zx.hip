@@ -204,6 +204,11 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         const i32x4 bq = *(const i32x4*)(e.wx + (((S0 + i) * 2 + wq) * 2 + 1) * 1024 + lane * 16);
         wreg[i] = __builtin_shufflevector(a, bq, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+      // ... and the f16 A fragments of tap steps 12 / 13 (the (., 2, 2) taps) of channel half mh: those 2 x 8 MFMAs per x half run here
+      // instead of in the main waves, whose sweep + epilogue chain is the longer one (ablations: mx sweeps -119 us, main sweeps -254)
+      typedef Ops<f16>::vec8 hvec8;
+      const hvec8 wf12 = *(const hvec8*)(p.wpk + ((mh * kSteps + 12) * 2 + wq) * 1024 + lane * 16);
+      const hvec8 wf13 = *(const hvec8*)(p.wpk + ((mh * kSteps + 13) * 2 + wq) * 1024 + lane * 16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       auto mine = [](const int step) { return step >= S0 && step < S0 + 7; };
       for (int s = 0; s < nsteps; ++s) {
@@ -276,6 +281,20 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
               }
             }
           }
+          {
+            const int koff = mh * 2 * PPL;                      // hi planes 2 mh, 2 mh + 1
+#pragma unroll
+            for (int tz = 0; tz < 2; ++tz) {
+              const int sl0 = ((s * TZ + tz) % R) * PLSZ, sl1 = ((s * TZ + tz + 1) % R) * PLSZ, sl2 = ((s * TZ + tz + 2) % R) * PLSZ;
+              const int bz = lanebase + (hi ? sl1 : sl0) + koff + (2 * HX + 2) * 16;
+              const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
+#pragma unroll
+              for (int cy = 0; cy < 2; ++cy) {
+                acc[tz][cy] = Ops<f16>::mfma(wf12, *(const hvec8*)(smem + bz + (cy * HX) * 16), acc[tz][cy]);
+                acc[tz][cy] = Ops<f16>::mfma(wf13, *(const hvec8*)(smem + b0 + (cy * HX) * 16), acc[tz][cy]);
+              }
+            }
+          }
 #pragma unroll
           for (int tz = 0; tz < 2; ++tz)
 #pragma unroll
@@ -299,11 +318,11 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
   const int base_dx = lanebase + hi * 16 * HX;
   // ---------------- main wave: Wh * xh of cout tile wq, + the mx partial, bias, statistics, store ----------------
   typedef Ops<f16>::vec8 vec8;
-  vec8 wreg[2][kSteps];
+  vec8 wreg[2][12];                                        // tap steps 0 .. 11 (12 / 13: the mx waves)
 #pragma unroll
   for (int k = 0; k < 2; ++k)
 #pragma unroll
-    for (int s = 0; s < kSteps; ++s) wreg[k][s] = *(const vec8*)(p.wpk + ((k * kSteps + s) * 2 + wq) * 1024 + lane * 16);
+    for (int s = 0; s < 12; ++s) wreg[k][s] = *(const vec8*)(p.wpk + ((k * kSteps + s) * 2 + wq) * 1024 + lane * 16);
   const int cbc = g * 8 + wq * 4;                           // lane holds output channels cbc .. cbc + 3 (Q = 2 packing)
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *(const f32x4*)(p.bias + cbc);
@@ -354,17 +373,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
           for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = Ops<f16>::mfma(wreg[k][9 + kz], H[cy], acc[tz][cy]);
         }
       }
-#pragma unroll
-      for (int tz = 0; tz < 2; ++tz) {
-        const int sl0 = ((s * TZ + tz) % R) * PLSZ, sl1 = ((s * TZ + tz + 1) % R) * PLSZ, sl2 = ((s * TZ + tz + 2) % R) * PLSZ;
-        const int bz = lanebase + (hi ? sl1 : sl0) + koff + (2 * HX + 2) * 16;
-        const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy) {
-          acc[tz][cy] = Ops<f16>::mfma(wreg[k][12], *(const vec8*)(smem + bz + (cy * HX) * 16), acc[tz][cy]);
-          acc[tz][cy] = Ops<f16>::mfma(wreg[k][13], *(const vec8*)(smem + b0 + (cy * HX) * 16), acc[tz][cy]);
-        }
-      }
+      // (tap steps 12 / 13 run in the mx waves)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);

@@ -383,6 +383,8 @@ __global__ __launch_bounds__(256) void upsample2_trilinear_kernel(const char* __
       if (RangeCheck<T>::on) raise_flag(oflow, bad);
     }
 #pragma unroll
+    // (A separable form -- x, y in place, then z: 36 instead of 64 operations per channel -- was measured SLOWER on the same box:
+    //  64 -> 64 into 128^3 646 -> 726 us, 128 -> 128 into 64^3 162 -> 182; the eight independent weighted sums schedule better.)
     for (int o = 0; o < 8; ++o) {                          // output (pz, py, px): 0 = odd position 2c+1, 1 = even position 2c+2
       const int pz = o >> 2, py = (o >> 1) & 1, px = o & 1;
       const int oz = 2 * cz + 1 + pz, oy = 2 * cy + 1 + py, ox = 2 * cx + 1 + px;
