@@ -203,6 +203,12 @@ def test_dev_mx_golden_probes_and_taps_from_the_reference(device):
           norm_eps=1e-2, activation="lrelu"), (32, 48, 32)),                                  # nearest upsample: the gather path
     (dict(dimension=3, input_nc=1, output_nc=24, num_downs=2, ngf=24, norm="instance", interp="trilinear", pooling="Avg"),
      (16, 16, 32)),                                                                           # padded widths, output through the export pass
+    # 32-wide level 0 at whole 2x32 tiles: the normalise-on-load kernel (pending norms, its fp32 planar output conv), statistics in the
+    # stem, apply + MAX pool in one pass, pending norm inside the trilinear upsample
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=32, norm="instance", interp="trilinear", pooling="Max", norm_eps=1e-2),
+     (32, 64, 64)),
+    (dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=32, norm="instance_affine", interp="nearest", pooling="Avg",
+          activation="lrelu"), (16, 36, 32)),                                                 # H = 36: 18 tiles of 2 rows
 ])
 def test_mx_other_instance_norm_networks(device, kw, size):
     m, sd, _ = _model(device, kw, 3)
