@@ -26,8 +26,13 @@
 
 namespace amx {
 
-struct ZxCfg {
-  static constexpr int TY = 2, TX = 32, TZ = 2, R = 6;
+// Tile (y, x): 2 x 32 (two 16-voxel column tiles side by side) or 4 x 16 (two row pairs on top of each other) -- the second form halos
+// 6 x 18 instead of 4 x 34 voxels per plane for the same 64 outputs (1.69 instead of 2.13 converted voxels per output voxel, two
+// converter passes per plane instead of three).  HALF = byte offset of a wave's half tile inside a plane.
+template <int TY_, int TX_>
+struct ZxCfgT {
+  static constexpr int TY = TY_, TX = TX_, TZ = 2, R = 6;
+  static_assert((TY == 2 && TX == 32) || (TY == 4 && TX == 16), "two half tiles of 2 rows x 16 voxels");
   static constexpr int NCV = 4, NMAIN = 4, NMX = 4, NC = NMAIN + NMX;     // converter / consumer waves
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;           // halo voxels of one z-plane
   static constexpr int PPL = ((HVP * 16 + 255) / 256) * 256;              // one 16-byte-per-voxel plane
@@ -37,8 +42,10 @@ struct ZxCfg {
   static constexpr int XCHOFF = FLAGOFF + 128;                            // mailboxes [mx wave 4][x half 2][tile 4][1 KiB]
   static constexpr int LDS_BYTES = XCHOFF + 4 * 8192;
   static constexpr int NJ = (HVP + 63) / 64;                              // converter passes per plane
+  static constexpr int HALF = TX == 32 ? 256 : 2 * HX * 16;
   static_assert(LDS_BYTES <= 160 * 1024, "ring + mailboxes must fit the LDS");
 };
+typedef ZxCfgT<2, 32> ZxCfg;
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
@@ -50,9 +57,8 @@ struct ZxExtra {
   const char* wx;         // fp8 fragments of pack_weights_zx_kernel
 };
 
-template <int DUMMY>
+template <typename C>
 __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_kernel(const ConvParams p, const ZxExtra e) {
-  typedef ZxCfg C;
   constexpr int HX = C::HX, PPL = C::PPL, PLSZ = C::PLSZ, R = C::R, TZ = C::TZ, NJ = C::NJ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -223,7 +229,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         // registers inside the 168 of three waves per SIMD; 97 registers, none spilled, this way)
 #pragma unroll 1
         for (int xh = 0; xh < ((p.dbg & (2 | 32)) ? 0 : 2); ++xh) {   // (AMX_ZX_DBG 2 / 32: timing ablation without the sweeps)
-          const int lanebase = vbase + xh * 256;
+          const int lanebase = vbase + xh * C::HALF;
           f32x4 acc[2][2];
 #pragma unroll
           for (int tz = 0; tz < 2; ++tz)
@@ -313,7 +319,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
 
   const int cwv = wave;
   const int wq = cwv >> 1, wcx = cwv & 1;
-  const int lanebase = vbase + wcx * 256;
+  const int lanebase = vbase + wcx * C::HALF;
   const int base_d1 = lanebase + hi * 16;
   const int base_dx = lanebase + hi * 16 * HX;
   // ---------------- main wave: Wh * xh of cout tile wq, + the mx partial, bias, statistics, store ----------------
@@ -328,7 +334,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
   if (p.bias) bias = *(const f32x4*)(p.bias + cbc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int ocs = p.ocs ? p.ocs : 32;
-  const int yl = y0, xl = x0 + wcx * 16 + li;
+  const int yl = y0 + (C::TX == 32 ? 0 : wcx * 2), xl = x0 + (C::TX == 32 ? wcx * 16 : 0) + li;
   char* out_l = p.out + (long long)n * p.on + (long long)yl * p.oy + (long long)xl * p.ox + (long long)(cbc >> 4) * ocs + (cbc & 15) * 2;
   const long long out_lo = (long long)(p.Cout >> 4) * ocs;
   // the network's output conv: fp32 [n][c][z][y][x] -- per channel j of the lane a 64-byte run of the 16 voxel lanes
@@ -505,20 +511,20 @@ bool conv_zx_eligible(const ConvParams& p) {
   static int off = -1;
   if (off < 0) off = getenv("AMX_NO_ZX") ? 1 : 0;
   const bool out_ok = p.out32 ? (!p.wmap && p.act == ACT_NONE && !p.stats) : (p.out && p.ox == 32);
-  return !off && !p.src0_f32c1 && p.C0 == 32 && p.C1 == 0 && p.Cout == 32 && out_ok && p.mxs && p.W % 32 == 0 && p.H % 2 == 0 &&
-         p.D % 2 == 0 && p.D >= 4 && p.s0x == 32;
+  return !off && !p.src0_f32c1 && p.C0 == 32 && p.C1 == 0 && p.Cout == 32 && out_ok && p.mxs &&
+         ((p.W % 32 == 0 && p.H % 2 == 0) || (p.W % 16 == 0 && p.H % 4 == 0)) && p.D % 2 == 0 && p.D >= 4 && p.s0x == 32;
 }
-int conv_zx_stats_slots(int H, int W) { return (H / 2) * (W / 32) * 2; }
+int conv_zx_stats_slots(int H, int W) { return H * W / 32; }       // one per (tile, half tile), whichever tile shape runs
 
 static thread_local char g_kernel_name_zx[64] = "";
 const char* last_conv_zx_kernel_name() { return g_kernel_name_zx; }
 
-hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
-  typedef ZxCfg C;
+template <typename C>
+static hipError_t launch_conv_zx_t(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
   snprintf(g_kernel_name_zx, sizeof g_kernel_name_zx, "conv3d_k3_zx<f16x2mx,32->32,%dx%dx%d,m4+x4+cv4,r%d%s%s>", C::TZ, C::TY, C::TX, C::R,
            in_ab ? ",norm-in" : "", p.out32 ? ",o1" : "");
   static bool attr_done = false;
-  auto kern = conv3d_k3_zx_kernel<0>;
+  auto kern = conv3d_k3_zx_kernel<C>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -533,6 +539,14 @@ hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in
   e.in_ab = in_ab; e.in_act = in_act; e.in_slope = in_slope; e.wx = (const char*)wx;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nby * p.nbx * p.N)), dim3((C::NC + C::NCV) * 64), C::LDS_BYTES, st, p, e);
   return hipGetLastError();
+}
+
+hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
+  static int tile = -1;                 // AMX_ZX_TILE = 0: 2x32 tiles wherever they fit, 1 (default): 4x16 tiles wherever they fit
+  if (tile < 0) tile = getenv("AMX_ZX_TILE") ? atoi(getenv("AMX_ZX_TILE")) : 1;
+  const bool wide_ok = p.W % 32 == 0 && p.H % 2 == 0, tall_ok = p.W % 16 == 0 && p.H % 4 == 0;
+  if (tall_ok && (tile == 1 || !wide_ok)) return launch_conv_zx_t<ZxCfgT<4, 16>>(p, in_ab, in_act, in_slope, wx, st);
+  return launch_conv_zx_t<ZxCfgT<2, 32>>(p, in_ab, in_act, in_slope, wx, st);
 }
 
 }  // namespace amx
