@@ -29,9 +29,10 @@ namespace amx {
 // Tile (y, x): 2 x 32 (two 16-voxel column tiles side by side) or 4 x 16 (two row pairs on top of each other) -- the second form halos
 // 6 x 18 instead of 4 x 34 voxels per plane for the same 64 outputs (1.69 instead of 2.13 converted voxels per output voxel, two
 // converter passes per plane instead of three).  HALF = byte offset of a wave's half tile inside a plane.
-template <int TY_, int TX_>
+// NBOX: mailbox sets (2: an mx wave may run one step ahead of the main waves that take its partial sums).
+template <int TY_, int TX_, int R_ = 6, int NBOX_ = 1>
 struct ZxCfgT {
-  static constexpr int TY = TY_, TX = TX_, TZ = 2, R = 6;
+  static constexpr int TY = TY_, TX = TX_, TZ = 2, R = R_, NBOX = NBOX_;
   static_assert((TY == 2 && TX == 32) || (TY == 4 && TX == 16), "two half tiles of 2 rows x 16 voxels");
   static constexpr int NCV = 4, NMAIN = 4, NMX = 4, NC = NMAIN + NMX;     // converter / consumer waves
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;           // halo voxels of one z-plane
@@ -40,7 +41,7 @@ struct ZxCfgT {
   static constexpr int PLSZ = 8 * PPL;
   static constexpr int FLAGOFF = R * PLSZ;                                // ready[4] +0, done[8] +32, mxdone[4] +64, mainfree[4] +96
   static constexpr int XCHOFF = FLAGOFF + 128;                            // mailboxes [mx wave 4][x half 2][tile 4][1 KiB]
-  static constexpr int LDS_BYTES = XCHOFF + 4 * 8192;
+  static constexpr int LDS_BYTES = XCHOFF + NBOX * 4 * 8192;
   static constexpr int NJ = (HVP + 63) / 64;                              // converter passes per plane
   static constexpr int HALF = TX == 32 ? 256 : 2 * HX * 16;
   static_assert(LDS_BYTES <= 160 * 1024, "ring + mailboxes must fit the LDS");
@@ -48,6 +49,14 @@ struct ZxCfgT {
 typedef ZxCfgT<2, 32> ZxCfg;
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Timing ablations (tools/zx_ablate.sh, env AMX_ZX_DBG) exist only in a build with -DAMX_ZX_ABLATE: even as never-taken run-time branches
+// they cost (two further switches of this kind slowed the kernel by 10 %: conditional loads are not scheduled ahead).
+#ifdef AMX_ZX_ABLATE
+#define ZX_DBG(bits) (p.dbg & (bits))
+#else
+#define ZX_DBG(bits) false
+#endif
 
 // Parameters beyond ConvParams: the pending norm of the input (null: the input is stored already activated)
 struct ZxExtra {
@@ -136,7 +145,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
 #pragma unroll
         for (int k = 0; k < 4; ++k) hp[k] = (unsigned)to_bits<f16>(v[2 * k]) | ((unsigned)to_bits<f16>(v[2 * k + 1]) << 16);
         uint2 xl8, xh8;
-        mx_split8(v, xl8, xh8);
+        mx_split8_direct(v, xl8, xh8);
         if (slot[j] >= 0) {
           *(uint4*)(dstp + cw * PPL + slot[j]) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
           char* x8 = dstp + C::X8OFF + (cw >> 1) * 2 * PPL + slot[j] + (cw & 1) * 8;       // chunk cw >> 1: [xl8 plane | xh8 plane]
@@ -155,7 +164,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         if (qq < nplanes) {
           // ring slot qq % R is free once every consumer is done with plane qq - R: planes < TZ * min(done) are dead
           while (qq >= R + TZ * __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done))) __builtin_amdgcn_s_sleep(1);
-          if (!(p.dbg & 16) || qq < R) convert_plane(qq, h);      // (AMX_ZX_DBG 16: timing ablation, the ring is only filled once)
+          if (!ZX_DBG(16) || qq < R) convert_plane(qq, h);      // (AMX_ZX_DBG 16: timing ablation, the ring is only filled once)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS is in-order per CU: the flag lands after the plane's data
           flag_store(ready + cw, qq + 1);
         }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
     const int mw = wave - C::NMAIN, wq = mw >> 1, mh = mw & 1;
     const int mx_sa = __builtin_amdgcn_readfirstlane(*p.mxs);
     const int sb = 0x7f7f7f7f;
-    char* box = smem + C::XCHOFF + mw * 8192 + lane * 16;
+    char* box0 = smem + C::XCHOFF + mw * 8192 + lane * 16;
     auto frag = [&](int addr) -> i32x8 {                    // chunk 0 plane | chunk 1 plane (2 PPL further on), same voxel
       const i32x4 a = *(const i32x4*)(smem + addr);
       const i32x4 bq = *(const i32x4*)(smem + addr + 2 * PPL);
@@ -219,8 +228,9 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
       auto mine = [](const int step) { return step >= S0 && step < S0 + 7; };
       for (int s = 0; s < nsteps; ++s) {
         wait_planes(s);
-        // the mailbox is free once BOTH main waves of this cout tile have taken step s - 1
-        while (flag_load(mainfree + wq * 2) < s || flag_load(mainfree + wq * 2 + 1) < s) __builtin_amdgcn_s_sleep(1);
+        // the mailbox (set s % NBOX) is free once BOTH main waves of this cout tile have taken step s - NBOX
+        char* box = box0 + (C::NBOX == 2 ? (s & 1) * 32768 : 0);
+        while (flag_load(mainfree + wq * 2) < s + 1 - C::NBOX || flag_load(mainfree + wq * 2 + 1) < s + 1 - C::NBOX) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         auto mm = [&](const int step, const i32x8& f, f32x4 a) {
           return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wreg[step - S0], f, a, 0, 0, 0, mx_sa, 0, sb);
@@ -228,7 +238,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         // the two x halves as a RUN-TIME loop: unrolled, hipcc kept the whole step's fragments and addresses alive (447 spilled
         // registers inside the 168 of three waves per SIMD; 97 registers, none spilled, this way)
 #pragma unroll 1
-        for (int xh = 0; xh < ((p.dbg & (2 | 32)) ? 0 : 2); ++xh) {   // (AMX_ZX_DBG 2 / 32: timing ablation without the sweeps)
+        for (int xh = 0; xh < (ZX_DBG(2 | 32) ? 0 : 2); ++xh) {   // (AMX_ZX_DBG 2 / 32: timing ablation without the sweeps)
           const int lanebase = vbase + xh * C::HALF;
           f32x4 acc[2][2];
 #pragma unroll
@@ -358,7 +368,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
       for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = bias;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      if (p.dbg & (2 | 64)) break;
+      if (ZX_DBG(2 | 64)) break;
       const int koff = k * 2 * PPL;                          // channel planes 2k, 2k + 1
 #pragma unroll
       for (int pl = 0; pl < 4; ++pl) {
@@ -390,7 +400,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
     {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
-        const char* box = smem + C::XCHOFF + (wq * 2 + mh) * 8192 + lane * 16 + wcx * 4096;
+        const char* box = smem + C::XCHOFF + (wq * 2 + mh) * 8192 + lane * 16 + wcx * 4096 + (C::NBOX == 2 ? (s & 1) * 32768 : 0);
 #pragma unroll
         for (int tz = 0; tz < 2; ++tz)
 #pragma unroll
@@ -414,7 +424,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
           s1[j] += d;
           s2[j] += d * d;
         }
-        if (p.dbg & 4) continue;
+        if (ZX_DBG(4)) continue;
         if (out32_l) {
           float* d32 = out32_l + (long long)(s * TZ + tz) * p.pz + cy * p.py;
 #pragma unroll
@@ -545,6 +555,8 @@ hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in
   static int tile = -1;                 // AMX_ZX_TILE = 0: 2x32 tiles wherever they fit, 1 (default): 4x16 tiles wherever they fit
   if (tile < 0) tile = getenv("AMX_ZX_TILE") ? atoi(getenv("AMX_ZX_TILE")) : 1;
   const bool wide_ok = p.W % 32 == 0 && p.H % 2 == 0, tall_ok = p.W % 16 == 0 && p.H % 4 == 0;
+  // (a ring of 8 planes instead of 6 for the 4x16 tiles: 1016 / 1067 -> 1015 / 1037 us, inside the noise -- not instantiated)
+  // (two mailbox sets -- NBOX = 2, an mx wave one step ahead of its main waves: 1030 / 1014 -> 1036 / 1015 us, nothing -- not instantiated)
   if (tall_ok && (tile == 1 || !wide_ok)) return launch_conv_zx_t<ZxCfgT<4, 16>>(p, in_ab, in_act, in_slope, wx, st);
   return launch_conv_zx_t<ZxCfgT<2, 32>>(p, in_ab, in_act, in_slope, wx, st);
 }

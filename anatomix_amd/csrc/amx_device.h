@@ -70,6 +70,19 @@ __device__ __forceinline__ void mx_split8(const float (&f)[8], uint2& xl8, uint2
   xh8 = make_uint2(e4m3_pk4(h[0], h[1], h[2], h[3]), e4m3_pk4(h[4], h[5], h[6], h[7]));
 }
 
+// The same for a value that is NOT stored as a pair (the normalise-on-load converters): the lo part goes to e4m3 without the detour
+// through f16 (two conversions per value less; at least as close to the fp32 value)
+__device__ __forceinline__ void mx_split8_direct(const float (&f)[8], uint2& xl8, uint2& xh8) {
+  float h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (float)(_Float16)f[e];
+    l[e] = (f[e] - h[e]) * kMxLoScale;
+  }
+  xl8 = make_uint2(e4m3_pk4(l[0], l[1], l[2], l[3]), e4m3_pk4(l[4], l[5], l[6], l[7]));
+  xh8 = make_uint2(e4m3_pk4(h[0], h[1], h[2], h[3]), e4m3_pk4(h[4], h[5], h[6], h[7]));
+}
+
 // Store the copies of one 8-channel group.  The lanes (2k, 2k + 1) of a wave hold the two groups of ONE 16-channel chunk of one voxel
 // (every pass maps consecutive threads to consecutive groups and C / 8 is even): they exchange halves (DPP quad_perm [1,0,3,2]) so
 // that the even lane writes the chunk's 16 xl8 bytes and the odd lane its 16 xh8 bytes -- two 16-byte stores per 32-byte chunk
