@@ -805,6 +805,8 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
       static int narrow = -1;
       if (narrow < 0) narrow = getenv("AMX_V2_NARROW") ? 1 : 0;
       if (OUTMODE == 0 && narrow) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);
+      // (brick 4x8x16 instead -- 12 % less halo, 84 % instead of 53 % of the DMA lanes used -- measured on f16x2mx, batch 4: 64 -> 64 @64^3
+      //  506 -> 508 us, 192 -> 64 @64^3 1337 -> 1377, 96 -> 32 @128^3 2815 -> 2854: these layers are not fill-bound)
       return launch_pick<T, SPLIT, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
     }
     if (OUTMODE == 0 && Q == 4) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 4, 1, 0>(p, st);  // brick 4x4x16, 8 waves
