@@ -36,7 +36,7 @@ def friendly(mangled):
         waves = f"w{int(nwz)*int(nwy)}" + (f"+l{nlw},b{nbuf}" if nlw and int(nlw) > 0 else "")
         return f"conv3d_k3_v2<{name},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},{waves},q{q},nch{nch},o{o}>"
     if "conv3d_k3_zx_kernel" in mangled:
-        m = re.search(r"ZxCfgTILi(\d+)ELi(\d+)E", mangled)
+        m = re.search(r"ZxCfgT(?:ILi|<)(\d+)(?:ELi|, )(\d+)", mangled)
         return f"conv3d_k3_zx<f16x2mx,32->32,2x{m.group(1)}x{m.group(2)},m4+x4+cv4,r6>" if m else "conv3d_k3_zx<f16x2mx,32->32,m4+x4+cv4,r6>"
     for k in ("in_apply_pool_kernel", "in_apply_fast_kernel", "in_apply_kernel", "upsample2_trilinear_kernel", "in_finalize_kernel",
               "in_prereduce_kernel", "in_stats_kernel", "conv3d_stem2_kernel"):
