@@ -566,7 +566,9 @@ static void stem_segments(const ConvParams& p, int TY, int TX, int TZ, int* zseg
 // InstanceNorm statistics in the epilogue (ConvParams::stats): the tap-gather kernel of the split precisions, whole tiles only.
 // Returns the slots per sample ([n][slot][Cout][2] partial sums), 0 when the layer must keep its separate statistics pass.
 int conv_stem_stats_slots(const ConvParams& p, int precision) {
-  if (precision < 2 || getenv("AMX_NO_FUSED_STATS")) return 0;
+  static int off = -1;
+  if (off < 0) off = getenv("AMX_NO_FUSED_STATS") ? 1 : 0;
+  if (precision < 2 || off) return 0;
   constexpr int TY = 8, TX = 32, TZ = 2, NC = 8;
   if (p.H % TY || p.W % TX || p.D % TZ) return 0;
   int zseg, nseg;

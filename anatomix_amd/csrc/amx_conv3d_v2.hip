@@ -793,6 +793,18 @@ static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
   return launch_cfg2<T, SPLIT, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE>(p, st);
 }
 
+// environment switches of the brick choice, read once (the statistics-slot count below must see the same values as the dispatch)
+static bool v2_narrow() {
+  static int v = -1;
+  if (v < 0) v = getenv("AMX_V2_NARROW") ? 1 : 0;
+  return v != 0;
+}
+static bool v2_half_brick() {
+  static int v = -1;
+  if (v < 0) v = getenv("AMX_V2_NO_HALF_BRICK") ? 0 : 1;
+  return v != 0;
+}
+
 template <typename T, int OUTMODE, int SPLIT>
 static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   const int nch = (p.C0 + p.C1) / 16;
@@ -802,9 +814,7 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
       // AMX_V2_NARROW: brick 4x4x16 instead -- three stage buffers fit the LDS, so the loader-wave pipeline applies.  Measured on
       // 96 -> 32 @64^3, batch 4: 206 -> 197 us (+5 %); not the default: the same instantiation also serves the 16^3 layers, and one
       // kernel name per layer class keeps the per-kernel tables of bench.py and rocprofv3 comparable.
-      static int narrow = -1;
-      if (narrow < 0) narrow = getenv("AMX_V2_NARROW") ? 1 : 0;
-      if (OUTMODE == 0 && narrow) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);
+      if (OUTMODE == 0 && v2_narrow()) return launch_pick<T, SPLIT, 1, 2, 16, 4, 2, 2, 1, 0>(p, st);
       // (brick 4x8x16 instead -- 12 % less halo, 84 % instead of 53 % of the DMA lanes used -- measured on f16x2mx, batch 4: 64 -> 64 @64^3
       //  506 -> 508 us, 192 -> 64 @64^3 1337 -> 1377, 96 -> 32 @128^3 2815 -> 2854: these layers are not fill-bound)
       return launch_pick<T, SPLIT, 1, 2, 32, 4, 2, 2, 1, OUTMODE>(p, st);       // brick 4x4x32, 8 waves
@@ -824,7 +834,7 @@ static hipError_t launch_conv2_t(const ConvParams& p, int Q, hipStream_t st) {
   }
   // 4-wide levels: half bricks (4x2x8, 4 waves) -- twice the workgroups (1024 -> 1024 @4^3, batch 4: 128 -> 256 on 256 CUs) and half as
   // many waves streaming the same weight fragments from L2
-  if (Q == 2 && p.W <= 4 && !getenv("AMX_V2_NO_HALF_BRICK")) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 2, 1, 0>(p, st);
+  if (Q == 2 && p.W <= 4 && v2_half_brick()) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 2, 1, 0>(p, st);
   if (Q == 2) return launch_pick<T, SPLIT, 1, 2, 8, 4, 2, 2, 1, 0>(p, st);           // brick 4x4x8, 8 waves
   if (Q == 4) return launch_pick<T, SPLIT, 1, 2, 8, 4, 1, 4, 1, 0>(p, st);
   return hipErrorInvalidValue;
@@ -836,13 +846,13 @@ int conv_v2_stats_slots(int D, int H, int W, int Q) {
   int tz = 4, ty, tx, nw;
   if (W >= 32) {
     if (Q == 1) { ty = 8; tx = 32; nw = 8; }
-    else if (Q == 2) { ty = 4; tx = getenv("AMX_V2_NARROW") ? 16 : 32; nw = 8; }
+    else if (Q == 2) { ty = 4; tx = v2_narrow() ? 16 : 32; nw = 8; }
     else { ty = 4; tx = 16; nw = 8; }
   } else if (W >= 16) {
     if (Q == 1) { ty = 2; tx = 16; nw = 4; }
     else { ty = 4; tx = 16; nw = 8; }
   } else {
-    if (Q == 2 && !(W <= 4 && !getenv("AMX_V2_NO_HALF_BRICK"))) { ty = 4; tx = 8; nw = 8; }
+    if (Q == 2 && !(W <= 4 && v2_half_brick())) { ty = 4; tx = 8; nw = 8; }
     else { ty = 2; tx = 8; nw = 4; }
   }
   return ((D + tz - 1) / tz) * ((H + ty - 1) / ty) * ((W + tx - 1) / tx) * nw;

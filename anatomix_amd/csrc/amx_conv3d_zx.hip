@@ -119,6 +119,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
     const unsigned a_done = lds_addr(done);
     constexpr int PF = 1;                                    // planes in flight ahead of the one being converted
     uint4 rh[PF + 1][NJ], rl[PF + 1][NJ];
+    float vmax = 0.f;                                        // largest |normalised value| this wave turned into an f16 hi part
     auto load_plane = [&](int q, int set) {                  // unconditional (clamped) loads: PF planes ahead in registers
       const int qq = q < nplanes ? q : nplanes - 1;
       const char* plane = src_n + (long long)reflect_clamp(qq - 1, p.D) * p.s0z;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
           const float x = (float)__builtin_bit_cast(f16, (unsigned short)(wh[k >> 1] >> ((k & 1) * 16))) +
                           (float)__builtin_bit_cast(f16, (unsigned short)(wl[k >> 1] >> ((k & 1) * 16)));
           v[k] = act_fwd(x * ca[k] + cb[k], ak);
+          vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v[k]));
         }
         unsigned hp[4];
 #pragma unroll
@@ -170,6 +172,9 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         }
       }
     }
+    // the f16 range of the operand the normalisation produced (what the separate apply pass checks before it stores; a NaN input
+    // surfaces in the main waves' check of the outputs)
+    raise_flag(p.oflow, !(vmax <= 65504.f));
     return;
   }
 

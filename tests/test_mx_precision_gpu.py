@@ -234,3 +234,20 @@ def test_mx_determinism_and_batch_independence(device):
     with torch.no_grad():
         y2, y0, y1, y2b = m(x), m(x[:1]), m(x[1:]), m(x)
     assert torch.equal(y2[:1], y0) and torch.equal(y2[1:], y1) and torch.equal(y2, y2b)
+
+
+@pytest.mark.parametrize("key,gain", [("model.3.weight", 1e6),      # raw conv output of the normalise-on-load kernel beyond f16
+                                      ("model.1.weight", 1e6)])     # InstanceNorm gain: the value its converters normalise to
+def test_mx_f16_range_is_guarded_in_the_fused_kernels(device, key, gain):
+    kw = dict(dimension=3, input_nc=1, output_nc=32, num_downs=2, ngf=32, norm="instance_affine", interp="trilinear", pooling="Avg")
+    sd = R.synthetic_state_dict(kw, 2)
+    sd[key] = sd[key] * gain
+    m = anatomix_amd.Unet(**kw)
+    m.load_state_dict(sd)
+    m.precision = P
+    m = m.to(device).eval()
+    with torch.no_grad():
+        y = m(R.synthetic_input(4, 1, (16, 32, 32)).to(device))
+        with pytest.raises(_lib.AmxOverflowError):
+            m.check_numerics()
+    assert torch.isnan(y).all()
