@@ -509,11 +509,11 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false>
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false, int TX = 32>
 static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   if constexpr (OUTMODE == 0 && NS == 0 && !POOL)
-    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true, SPLIT>(p, st);
-  constexpr int TX = 32, TZ = 2;
+    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true, SPLIT, TX>(p, st);
+  constexpr int TZ = 2;
   typedef ZmCfg<SPLIT ? 2 : NCK, QT, TY, TX, R> C;
   constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
   snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
@@ -637,6 +637,9 @@ hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st
     if (precision == 0) return planar ? launch_zm<f16, 1, 1, 8, 10, 1>(p, st) : launch_zm<f16, 1, 1, 8, 10, 0>(p, st);
     return planar ? launch_zm<bf16, 1, 1, 8, 10, 1>(p, st) : launch_zm<bf16, 1, 1, 8, 10, 0>(p, st);
   }
+  // (8 x 16 instead of 4 x 32 (y, x) tiles for the 32-cout layers -- halo 1.41 instead of 1.59 loaded voxels per output, the re-tiling
+  //  that gave the normalise-on-load kernel 15 % -- runs (launch_zm_ns<..., TX = 16>) and was measured at batch 4: 32 -> 32 @64^3
+  //  722 -> 730 TF, 16 -> 32 unchanged: these layers do not pay for their halo)
   if (p.C0 == 16) return precision == 0 ? launch_zm<f16, 1, 2, 4, 10, 0>(p, st) : launch_zm<bf16, 1, 2, 4, 10, 0>(p, st);
   return precision == 0 ? launch_zm<f16, 2, 2, 4, 10, 0>(p, st) : launch_zm<bf16, 2, 2, 4, 10, 0>(p, st);
 }
