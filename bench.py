@@ -758,6 +758,9 @@ def main():
         dist.all_gather_object(names, f"rank {rank}: {dev_name} (uuid {uuid})")
         ctx.devices = names
 
+    # `--precision` left at its default: the 6 M variant runs f16 (the headline), the InstanceNorm variant its own default (f16x2mx)
+    if args.variant == "anatomix-dev" and "--precision" not in sys.argv:
+        args.precision = None
     result = run_workload(ctx, variant=args.variant, workload=args.workload, sw_volume=args.sw_volume, precision=args.precision,
                           steps=args.steps, warmup=args.warmup, batch=args.batch, size=args.size, no_graph=args.no_graph,
                           with_cpu=not args.no_cpu_baseline, cpu_forwards=args.cpu_forwards, with_parity=not args.no_parity,
