@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libanatomix_amd.so")
+# AMX_LIB_PATH (read here, by the Python loader, never by the library): another build of the same sources, e.g. the
+# -DAMX_EXPERIMENT library of `make exp` whose ablation switches tools/ drives through the environment
+LIB_PATH = os.environ.get("AMX_LIB_PATH") or os.path.join(_HERE, "csrc", "libanatomix_amd.so")
 
 NORM = {"none": 0, "batch": 1, "instance": 2, "instance_affine": 3}
 ACT = {"none": 0, "relu": 1, "lrelu": 2}
@@ -74,6 +76,8 @@ SYMBOLS = {
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
     "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_conv3d_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "amx_conv3d_k3_reflect_ws": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P, C.c_size_t, _P]),
     "amx_conv3d_upcat_merged_packed_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_conv3d_upcat_merged": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "amx_conv3d_k3_reflect_ex": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),

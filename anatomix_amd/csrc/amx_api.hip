@@ -32,6 +32,7 @@ hipError_t launch_sw_normalize(float* acc, const float* cnt, int channels, long 
 hipError_t launch_sw_count(float* cnt, int vd, int vh, int vw, int oz, int oy, int ox, int rd, int rh,
                            int rw, const float* wmap, hipStream_t st);
 int conv_pick_q(int Cout, int W, int precision);
+size_t conv_ks_part_bytes(int C0, int Cout, int N, int D, int H, int W, int precision, int Q);
 hipError_t launch_conv_stem(const ConvParams& p, int precision, hipStream_t st);
 hipError_t launch_pack_stem(const float* w, const float* scale, void* wpk, int Cout, int precision, hipStream_t st, int CoutReal = 0);
 const char* last_conv_stem_kernel_name();
@@ -341,6 +342,17 @@ size_t in_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
   return align_up(amx::instnorm_scratch_bytes(n, h->cfg.ngf << h->cfg.num_downs, worst), 256) + 2 * kPendingAbBytes(n);
 }
 
+// fp32 partial tensors of the layers that split K across workgroups (conv3d_k3_ks, the deepest levels): the largest one
+size_t ks_scratch_bytes(const amx_unet* h, int n, int d, int hh, int w) {
+  size_t worst = 0;
+  for (const ConvLayer& L : h->convs) {
+    if (L.after_up || L.is_final || L.level == 0) continue;
+    const size_t b = amx::conv_ks_part_bytes(L.cin_pad, L.cout_p, n, d >> L.level, hh >> L.level, w >> L.level, h->cfg.precision, L.q);
+    worst = b > worst ? b : worst;
+  }
+  return align_up(worst, 256);
+}
+
 int check_shape(const amx_unet* h, int n, int d, int hh, int w) {
   const int L = h->cfg.num_downs;
   if (n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
@@ -382,6 +394,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
   for (int l = 0; l < NL; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
   void* in_scratch = (char*)ws + need;                 // instance-norm partial sums + (a, b) pairs
   need += in_scratch_bytes(h, n, d, hh, w);
+  const size_t ks_bytes = ks_scratch_bytes(h, n, d, hh, w);
+  float* ks_scratch = ks_bytes ? (float*)((char*)ws + need) : nullptr;
+  need += ks_bytes;
   if (ws_bytes < need || ((uintptr_t)ws & 255))
     return fail(AMX_ERR_WORKSPACE, "workspace needs %zu bytes, 256-byte aligned (got %zu)", need, ws_bytes);
 
@@ -416,7 +431,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
                       (float*)((char*)in_scratch + in_scratch_bytes(h, n, d, hh, w) - kPendingAbBytes(n))};
   int ab_next = 0;
   static int zx_env = -1;
-  if (zx_env < 0) zx_env = getenv("AMX_NO_ZX") ? 0 : 1;
+  if (zx_env < 0) zx_env = amx::exp_env("AMX_NO_ZX") ? 0 : 1;
   // Row-planar storage (amx_common.h, layouts FMT 2 / 3) of the tensors the generic kernel gathers 32 bytes per voxel from: every
   // tensor of f16x2mx; in the single 16-bit precisions the WIDE ones (>= 64 channels: the 32^3 .. 8^3 levels of the 6 M network),
   // whose channels-last voxels of 128 .. 512 bytes left the LDS-DMA at 11-15 B/clk/CU (profiles/r03_dma_stride_ubench.txt).  Their
@@ -427,7 +442,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
   // 128 -> 128 @16^3 27.6 -> 26.7, 8^3 unchanged; 2743 -> 2772 volumes/s (+1 %, inside the box-to-box noise).  f16x2mx, whose
   // 192-byte voxels sit at 128^3, gained 28 % per layer from the same layout and always uses it.
   static int planar_env = -1;
-  if (planar_env < 0) planar_env = getenv("AMX_PLANAR16") ? 1 : 0;
+  if (planar_env < 0) planar_env = amx::exp_env("AMX_PLANAR16") ? 1 : 0;
   const bool planar16 = planar_env && !split && !taps && c.interp == AMX_INTERP_NEAREST &&
                         (c.norm == AMX_NORM_NONE || c.norm == AMX_NORM_BATCH_EVAL);
   Tensor cur;              // current activation (slot -1: the fp32 network input)
@@ -615,6 +630,9 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       const bool fuse_stats = inorm && !use_merge && !use_upcat && !L.is_final && !x_offs &&
                               (p.src0_f32c1 ? stem_slots > 0 : (zx_shape || amx::conv_fuses_stats(p, c.precision, L.q)));
       if (fuse_stats) p.stats = (float*)in_scratch;
+      if (ks_scratch && !have_cur_up && !L.is_final && cur.slot >= 0 && !raw_bn && !use_merge &&
+          amx::conv_ks_part_bytes(p.C0, p.Cout, n, dd, dh, dw, c.precision, L.q) <= ks_bytes)
+        p.part = ks_scratch;
       // f16x2mx 32 -> 32 at whole tiles: the normalise-on-load z-march kernel (amx_conv3d_zx.hip).  It is the ONLY consumer of a
       // tensor whose norm was left pending (below), and takes already-normalised inputs too.
       const bool use_zx = zx_shape;
@@ -700,7 +718,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
                                 !have_fused_pool && amx::in_apply_pool_eligible(c.precision, dd, dh, dw, L.cout_p);
         // trilinear upsample right after this group (decoder): the upsample pass normalises its eight inputs on the way in
         static int up_env = -1;
-        if (up_env < 0) up_env = getenv("AMX_NO_APPLY_UP") ? 0 : 1;
+        if (up_env < 0) up_env = amx::exp_env("AMX_NO_APPLY_UP") ? 0 : 1;
         const bool defer_up = up_env && !defer && !apply_pool && !taps && !x_offs && act_on == L.has_act && nxt_mod < h->kinds.size() &&
                               h->kinds[nxt_mod] == K_UP && c.interp == AMX_INTERP_TRILINEAR;
         if (defer_up) defer = true;
@@ -1051,6 +1069,7 @@ size_t amx_unet_workspace_bytes(const amx_unet_t* h, int n, int d, int hh, int w
   size_t need = 0;
   for (int l = 0; l <= h->cfg.num_downs; ++l) need += 3 * level_bytes(h, l, n, d, hh, w);
   need += in_scratch_bytes(h, n, d, hh, w);
+  need += ks_scratch_bytes(h, n, d, hh, w);
   return need;
 }
 
@@ -1188,7 +1207,7 @@ size_t amx_conv3d_packed_bytes(int cin, int cout) {
 static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight, int weight_mode,
                          int cin_real, int cout_real, const float* d_scale, const float* d_shift, int cout, int n, int d,
                          int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
-                         void* stream) {
+                         void* stream, void* d_scratch = nullptr, size_t scratch_bytes = 0) {
   if (!d_x0 || !d_weight || !d_wpk || (!d_out16 == !d_out32)) return fail(AMX_ERR_INVALID, "bad pointer arguments");
   if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16)
     return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
@@ -1242,8 +1261,28 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     AMX_HIP(amx::launch_conv_upcat16(p, precision, st));
     return AMX_OK;
   }
+  // split-K scratch offered by the caller (amx_conv3d_k3_reflect_ws): deep layers with few voxels split K across workgroups
+  if (d_scratch && !c1 && d_out16) {
+    const size_t need = amx::conv_ks_part_bytes(c0, cout, n, d, hh, w, precision, q);
+    if (need && (scratch_bytes < need || ((uintptr_t)d_scratch & 15)))
+      return fail(AMX_ERR_WORKSPACE, "split-K scratch needs %zu bytes, 16-byte aligned (got %zu)", need, scratch_bytes);
+    if (need) p.part = (float*)d_scratch;
+  }
   AMX_HIP(amx::launch_conv(p, precision, q, st));
   return AMX_OK;
+}
+
+size_t amx_conv3d_scratch_bytes(int c0, int c1, int cout, int n, int d, int hh, int w, int precision) {
+  if (c1 || c0 % 16 || cout % 16 || precision < AMX_PREC_F16 || precision > AMX_PREC_F16X2_MX) return 0;
+  return amx::conv_ks_part_bytes(c0, cout, n, d, hh, w, precision, amx::conv_pick_q(cout, w, precision));
+}
+
+int amx_conv3d_k3_reflect_ws(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
+                             const float* d_scale, const float* d_shift, int cout, int n, int d, int hh, int w,
+                             int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
+                             void* d_scratch, size_t scratch_bytes, void* stream) {
+  return conv3d_single(d_x0, c0, d_x1, c1, d_weight, 0, c0 + c1, cout, d_scale, d_shift, cout, n, d, hh, w, act, slope,
+                       precision, d_wpk, d_out16, d_out32, stream, d_scratch, scratch_bytes);
 }
 
 int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,

@@ -2,8 +2,8 @@
 //   per-head LayerNorm of q and k (the reference wrapper's ``qk_norm``, anatomix/model/vit3d/architectures.py:108-115)
 //   -> rotary position embedding on the patch tokens (timm apply_rot_embed_cat: x*cos + rot(x)*sin, register tokens untouched)
 //   -> softmax(q k^T / sqrt(d)) v, flash-style (scores never leave registers), for 4104 tokens x 6 heads x head_dim 66.
-// This is 63 % of the model's FLOPs (2 * 2 * 4104^2 * 396 per layer x 12 layers); the plain linears around it stay on the
-// vendor GEMM (torch -> hipBLASLt), as the brief allows for plain library GEMMs.
+// This is 63 % of the model's FLOPs (2 * 2 * 4104^2 * 396 per layer x 12 layers); the linears around it run on this library's own
+// weight-stationary MFMA product kernel (amx_gemm.hip) -- no vendor GEMM anywhere in the forward (amx_vit.hip).
 //
 // Two kernels:
 //   attn_prep   fp32 [b][n][heads*hd] q / k / v -> f16 operands: Qp [b][h][n_pad][104], q pre-multiplied by log2(e) / sqrt(hd);

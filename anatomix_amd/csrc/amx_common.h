@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace amx {
 
@@ -30,6 +31,14 @@ __host__ __device__ constexpr int tapB_index(int s) {           // -1: no tap (z
 }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+// Experiment / ablation switches are environment variables ONLY in a -DAMX_EXPERIMENT build (make EXTRA=-DAMX_EXPERIMENT); the
+// product library reads no environment on any path: every switch is a compile-time "unset".
+#ifdef AMX_EXPERIMENT
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 // Parameters of one 3x3x3 reflect-padded convolution launch.  All tensors are channels-last
 // (N, D, H, W, C) 16-bit unless noted.  Strides are in BYTES.
@@ -60,6 +69,8 @@ struct ConvParams {
                                //   f16 range (|v| > 65504) or NaN -- see amx_unet_numerics_status (include/anatomix_amd.h)
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
   const int* mxs;              // AMX_PREC_F16X2_MX: device word holding the E8M0 block-scale byte (x4) of this layer's fp8 weights
+  float* part;                 // conv3d_k3_ks: fp32 partial tensors [slice][voxel][Cout] of a cross-workgroup K split (scratch offered by the caller; null: no split)
+  int kslices;                 //   ... and the number of K slices of this launch (set by the launcher)
   int cs0, cs1, ocs;           // byte stride between the 32-byte pieces (16-channel chunks) of one voxel in src0 / src1 / out; 0 = 32
                                //   (channels-last voxels).  Voxel layout FMT 2 keeps a ROW's pieces of one chunk together: W * 32.
 };

@@ -251,8 +251,12 @@ int conv_pick_q(int Cout, int W, int precision) {
   // 192 -> 64 @64^3 1664 -> 1264, 384 -> 128 @32^3 809 -> 631; Q = 1: 536 / 1479 / 733).  The single 16-bit and the bf16x2 / f16x2
   // kernels measured 0-7 % SLOWER with two (6 M forward 64 -> 64 @32^3 45.5 -> 46.9 us; strict 192 -> 64 @64^3 2045 -> 2197).
   if (precision == 4) q = 2;
-  if (W >= 32 && getenv("AMX_Q_WIDE")) q = atoi(getenv("AMX_Q_WIDE"));     // experiment switches
-  if (W <= 8 && getenv("AMX_Q_DEEP")) q = atoi(getenv("AMX_Q_DEEP"));
+  // experiment switches (-DAMX_EXPERIMENT builds only): read ONCE -- the packing at create time and the launch must see the same Q --
+  // and only the values the kernels are instantiated for
+  static const int q_wide = [] { const char* e = exp_env("AMX_Q_WIDE"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+  static const int q_deep = [] { const char* e = exp_env("AMX_Q_DEEP"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+  if (W >= 32 && q_wide) q = q_wide;
+  if (W <= 8 && q_deep) q = q_deep;
   // (round 4, same box, batch 4: Q = 1 or 4 instead of 2 at the 8^3 level: 128 -> 256 22.2 -> 22.8 / 27.9 us, 256 -> 256 32.8 -> 34.7 / 44.9;
   //  at the 16^3 level Q = 1 / 4: 128 -> 128 28.1 -> 52.1 / 39.2 us -- more or fewer cout groups do not help: profiles/r04_deep_level_q.txt)
   while (Cout % (16 * q)) q >>= 1;   // 48 / 96 / 192 output channels (data gradients of the concat convs): 1 / 2 / 4
@@ -262,6 +266,9 @@ int conv_pick_q(int Cout, int W, int precision) {
 hipError_t launch_conv_v2(const ConvParams& p, int precision, int Q, hipStream_t st);
 const char* last_conv_v2_kernel_name();
 int last_conv_v2_stats_slots();
+bool conv_ks_eligible(const ConvParams& p, int precision, int Q);
+hipError_t launch_conv_ks(const ConvParams& p, int precision, int Q, hipStream_t st);
+const char* last_conv_ks_kernel_name();
 bool conv_zmarch_eligible(const ConvParams& p);
 bool conv_zmarch_eligible_split(const ConvParams& p);
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st);
@@ -270,7 +277,7 @@ const char* last_conv_zm_kernel_name();
 // true when launch_conv runs the generic kernel for this layer -- the one whose epilogue can write InstanceNorm partial sums
 bool conv_fuses_stats(const ConvParams& p, int precision, int Q) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_FUSED_STATS") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_FUSED_STATS") ? 1 : 0;
   if (off || p.src0_f32c1 || p.out32) return false;
   return !((((precision < 2 && conv_zmarch_eligible(p)) || ((precision == 2 || precision == 3) && conv_zmarch_eligible_split(p))) && Q == p.Cout / 16));
 }
@@ -286,6 +293,11 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
   }
   if (p.src0_f32c1) return hipErrorInvalidValue;   // the fp32 stem has its own kernel (amx_conv3d_stem.hip)
   (void)planar;
+  if (conv_ks_eligible(p, precision, Q)) {           // deep levels: register-stationary weights, K split over the waves
+    hipError_t e = launch_conv_ks(p, precision, Q, st);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_ks_kernel_name());
+    return e;
+  }
   hipError_t e = launch_conv_v2(p, precision, Q, st);   // generic path: persistent double-buffered DMA kernel
   snprintf(g_kernel_name, sizeof g_kernel_name, "%s", last_conv_v2_kernel_name());
   return e;

@@ -553,7 +553,7 @@ const char* last_conv_stem_kernel_name() { return g_kernel_name4; }
 static void stem_segments(const ConvParams& p, int TY, int TX, int TZ, int* zseg_out, int* nseg_out) {
   const int tiles = ((p.H + TY - 1) / TY) * ((p.W + TX - 1) / TX) * p.N;
   static int wgs = -1;
-  if (wgs < 0) wgs = getenv("AMX_STEM_WGS") ? atoi(getenv("AMX_STEM_WGS")) : 512;
+  if (wgs < 0) wgs = exp_env("AMX_STEM_WGS") ? atoi(exp_env("AMX_STEM_WGS")) : 512;
   int nseg = (wgs + tiles - 1) / tiles;
   if (nseg < 1) nseg = 1;
   int zseg = (p.D + nseg - 1) / nseg;
@@ -567,7 +567,7 @@ static void stem_segments(const ConvParams& p, int TY, int TX, int TZ, int* zseg
 // Returns the slots per sample ([n][slot][Cout][2] partial sums), 0 when the layer must keep its separate statistics pass.
 int conv_stem_stats_slots(const ConvParams& p, int precision) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_FUSED_STATS") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_FUSED_STATS") ? 1 : 0;
   if (precision < 2 || off) return 0;
   constexpr int TY = 8, TX = 32, TZ = 2, NC = 8;
   if (p.H % TY || p.W % TX || p.D % TZ) return 0;
@@ -586,7 +586,7 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
            TZ, TY, TX, NC, R);
   static int dbg = -1;
   if (dbg < 0) {
-    const char* e = getenv("AMX_DBG");
+    const char* e = exp_env("AMX_DBG");
     dbg = e ? atoi(e) : 0;
   }
   p.dbg = dbg;
@@ -599,7 +599,7 @@ static hipError_t launch_stem_t(ConvParams p, hipStream_t st) {
   // 135.3 -> 91.5 us).  In the split precisions the layer writes twice the bytes and is store-bound either way (tap-gather
   // 220 / 145 us vs rows 235 / 152 us for 32 / 16 channels): those keep the tap-gather kernel.  AMX_STEM_GATHER=1 / =0 force one.
   static int gather = -1;
-  if (gather < 0) gather = getenv("AMX_STEM_GATHER") ? atoi(getenv("AMX_STEM_GATHER")) : 2;
+  if (gather < 0) gather = exp_env("AMX_STEM_GATHER") ? atoi(exp_env("AMX_STEM_GATHER")) : 2;
   if (!p.stats && (gather == 0 || (gather == 2 && !SPLIT))) {
     if (p.dbg & 2) p.dbg |= 4;
     typedef Stem2Cfg<TY, TX, TZ, NC, R, SPLIT> C2;

@@ -370,7 +370,7 @@ size_t conv_upcat16_packed_bytes() { return (size_t)(kSteps + 64) * 1024; }
 
 bool conv_upcat16_eligible(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_UPCAT") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_UPCAT") ? 1 : 0;
   return !off && !p.src0_f32c1 && p.up_shift == 1 && p.C0 == 16 && p.C1 == 32 && p.Cout == 16 && p.W >= 32 && p.H >= 8 && p.D >= 4 &&
          !(p.D & 1) && !(p.H & 1) && !(p.W & 1);
 }
@@ -389,7 +389,7 @@ static hipError_t launch_upcat_t(ConvParams p, hipStream_t st) {
   }
   static int dbg = -1;
   if (dbg < 0) {
-    const char* e = getenv("AMX_DBG");
+    const char* e = exp_env("AMX_DBG");
     dbg = e ? atoi(e) : 0;
   }
   p.dbg = dbg;

@@ -382,7 +382,7 @@ int conv_upmerge_q(int Cout, int split) { return (!split && Cout % 32 == 0) ? 2 
 // (the 48 -> 16 layer has its own fused kernel in the 16-bit precisions, amx_conv3d_upcat.hip; in strict precision it comes here)
 bool conv_upmerge_eligible(int C0, int C1, int Cout, int D, int H, int W, int up_shift, int split) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_UPMERGE") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_UPMERGE") ? 1 : 0;
   return !off && up_shift == 1 && C0 >= 16 && C1 >= 32 && C1 % 32 == 0 && Cout >= (split ? 16 : 32) && Cout % 16 == 0 && W >= 16 && !(D & 1) && !(H & 1) &&
          !(W & 1) && D >= 4 && H >= 4;
 }
@@ -412,7 +412,7 @@ static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
   p.nbx = (p.LW + LXT - 1) / LXT;
   static int dbg = -1;
   if (dbg < 0) {
-    const char* e = getenv("AMX_DBG");
+    const char* e = exp_env("AMX_DBG");
     dbg = e ? atoi(e) : 0;
   }
   p.dbg = dbg;

@@ -746,9 +746,9 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
   static int dbg = -1;
   static unsigned long long* trace_buf = nullptr;
   if (dbg < 0) {
-    const char* e = getenv("AMX_DBG");
+    const char* e = exp_env("AMX_DBG");
     dbg = e ? atoi(e) : 0;
-    if (getenv("AMX_TRACE")) dbg |= 8;
+    if (exp_env("AMX_TRACE")) dbg |= 8;
   }
   p.dbg = dbg;
   const long long items = (long long)p.nbz * p.nby * p.nbx * p.N * (p.Cout / (16 * Q));
@@ -784,7 +784,7 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
 template <typename T, int SPLIT, int WZ, int WY, int WX, int NWZ, int NWY, int Q, int NCH, int OUTMODE>
 static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
   static int classic = -1;
-  if (classic < 0) classic = getenv("AMX_V2_CLASSIC") ? 1 : 0;
+  if (classic < 0) classic = exp_env("AMX_V2_CLASSIC") ? 1 : 0;
   typedef Conv2Cfg<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE> C0;
   constexpr bool can = 3 * C0::BUF + 64 <= 160 * 1024 && NWZ * NWY <= 8;
   if constexpr (can) {
@@ -796,12 +796,12 @@ static hipError_t launch_pick(const ConvParams& p, hipStream_t st) {
 // environment switches of the brick choice, read once (the statistics-slot count below must see the same values as the dispatch)
 static bool v2_narrow() {
   static int v = -1;
-  if (v < 0) v = getenv("AMX_V2_NARROW") ? 1 : 0;
+  if (v < 0) v = exp_env("AMX_V2_NARROW") ? 1 : 0;
   return v != 0;
 }
 static bool v2_half_brick() {
   static int v = -1;
-  if (v < 0) v = getenv("AMX_V2_NO_HALF_BRICK") ? 0 : 1;
+  if (v < 0) v = exp_env("AMX_V2_NO_HALF_BRICK") ? 0 : 1;
   return v != 0;
 }
 

@@ -528,9 +528,9 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   }
   static int dbg = -1;
   if (dbg < 0) {
-    const char* e = getenv("AMX_DBG");
+    const char* e = exp_env("AMX_DBG");
     dbg = e ? atoi(e) : 0;
-    if (getenv("AMX_TRACE")) dbg |= 8;
+    if (exp_env("AMX_TRACE")) dbg |= 8;
   }
   p.dbg = dbg;
   p.nby = (p.H + TY - 1) / TY;
@@ -574,7 +574,7 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
 template <int QT, int TY, int OUTMODE>
 static bool zm_can_stage(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_STORERS") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_STORERS") ? 1 : 0;
   if (off || p.H % TY || p.W % 32) return false;
   if (OUTMODE == 0)
     return p.ox == 32 * QT && !((size_t)p.out & 15) && !(p.oy & 15) && !(p.oz & 15) && !(p.on & 15);
@@ -582,7 +582,7 @@ static bool zm_can_stage(const ConvParams& p) {
   // starts at an odd x of the accumulation volume (sliding-window starts 25, 75, 125 ...) is staged too -- its pieces just
   // straddle 16-byte boundaries.  (Unstaged, those windows took the scattered 4-byte read-modify-write path: 197 vs 83 us.)
   static int aligned_only = -1;
-  if (aligned_only < 0) aligned_only = getenv("AMX_STAGE_ALIGNED_ONLY") ? 1 : 0;
+  if (aligned_only < 0) aligned_only = exp_env("AMX_STAGE_ALIGNED_ONLY") ? 1 : 0;
   if (aligned_only) return !(p.py & 3) && !(p.pz & 3) && !(p.pc & 3) && !(p.pn & 3) && !((size_t)p.out32 & 15) && !((size_t)p.wmap & 15);
   return !((size_t)p.out32 & 3) && !((size_t)p.wmap & 3);
 }
@@ -594,7 +594,7 @@ static hipError_t launch_zm(const ConvParams& p, hipStream_t st) {
   // rows per store instruction, instead of 64-byte pieces from the MFMA lanes); 16-bit NDHWC output 130 -> 155 us
   // (its direct stores are already 512-byte runs; the staging round trip only adds LDS traffic) -- so planar only.
   static int stage16 = -1;
-  if (stage16 < 0) stage16 = getenv("AMX_STAGE16") ? 1 : 0;
+  if (stage16 < 0) stage16 = exp_env("AMX_STAGE16") ? 1 : 0;
   if constexpr (NCK == 1)
     if ((OUTMODE == 1 || (stage16 && !p.out2)) && zm_can_stage<QT, TY, OUTMODE>(p)) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 2>(p, st);
   return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, 0>(p, st);
@@ -604,7 +604,7 @@ static hipError_t launch_zm(const ConvParams& p, hipStream_t st) {
 // (not 32 -> 16), W >= 32; the packed weights must use Q = Cout/16 tiles per group (conv_pick_q does).
 bool conv_zmarch_eligible(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_ZMARCH") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_ZMARCH") ? 1 : 0;
   if (off || p.src0_f32c1 || p.C1 != 0 || p.W < 32 || p.H < 8 || p.D < 8) return false;
   if (p.C0 == 16 && p.Cout == 16) return true;
   if (p.out32) return false;                                // planar epilogue only instantiated for 16 -> 16
@@ -614,14 +614,14 @@ bool conv_zmarch_eligible(const ConvParams& p) {
 // The fused max-pool needs even extents (every 2x2x2 window inside one wave's block).
 bool conv_zmarch_can_pool(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_POOLFUSE") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_POOLFUSE") ? 1 : 0;
   return !off && conv_zmarch_eligible(p) && !p.out32 && !(p.D & 1) && !(p.H & 1) && !(p.W & 1);
 }
 
 // Strict precision: the 16 -> 16 layers (all of level 0 in the 6M network) have a z-march variant too.
 bool conv_zmarch_eligible_split(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_ZMARCH_SPLIT") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_ZMARCH_SPLIT") ? 1 : 0;
   return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16;
 }
 bool conv_zmarch_can_pool_split(const ConvParams& p) { return conv_zmarch_can_pool(p) && conv_zmarch_eligible_split(p); }

@@ -524,7 +524,7 @@ hipError_t launch_pack_weights_zx(const float* w, const float* scale, void* wx, 
 // fp32 planar output (no importance map, no activation of its own)
 bool conv_zx_eligible(const ConvParams& p) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_ZX") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_ZX") ? 1 : 0;
   const bool out_ok = p.out32 ? (!p.wmap && p.act == ACT_NONE && !p.stats) : (p.out && p.ox == 32);
   return !off && !p.src0_f32c1 && p.C0 == 32 && p.C1 == 0 && p.Cout == 32 && out_ok && p.mxs &&
          ((p.W % 32 == 0 && p.H % 2 == 0) || (p.W % 16 == 0 && p.H % 4 == 0)) && p.D % 2 == 0 && p.D >= 4 && p.s0x == 32;
@@ -546,7 +546,7 @@ static hipError_t launch_conv_zx_t(ConvParams p, const float* in_ab, int in_act,
     attr_done = true;
   }
   static int dbg = -1;
-  if (dbg < 0) dbg = getenv("AMX_ZX_DBG") ? atoi(getenv("AMX_ZX_DBG")) : 0;
+  if (dbg < 0) dbg = exp_env("AMX_ZX_DBG") ? atoi(exp_env("AMX_ZX_DBG")) : 0;
   p.dbg = dbg;
   p.nby = p.H / C::TY;
   p.nbx = p.W / C::TX;
@@ -558,7 +558,7 @@ static hipError_t launch_conv_zx_t(ConvParams p, const float* in_ab, int in_act,
 
 hipError_t launch_conv_zx(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
   static int tile = -1;                 // AMX_ZX_TILE = 0: 2x32 tiles wherever they fit, 1 (default): 4x16 tiles wherever they fit
-  if (tile < 0) tile = getenv("AMX_ZX_TILE") ? atoi(getenv("AMX_ZX_TILE")) : 1;
+  if (tile < 0) tile = exp_env("AMX_ZX_TILE") ? atoi(exp_env("AMX_ZX_TILE")) : 1;
   const bool wide_ok = p.W % 32 == 0 && p.H % 2 == 0, tall_ok = p.W % 16 == 0 && p.H % 4 == 0;
   // (a ring of 8 planes instead of 6 for the 4x16 tiles: 1016 / 1067 -> 1015 / 1037 us, inside the noise -- not instantiated)
   // (two mailbox sets -- NBOX = 2, an mx wave one step ahead of its main waves: 1030 / 1014 -> 1036 / 1015 us, nothing -- not instantiated)

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // K chunk of KC steps) are requested before the current unit is multiplied, so a wave always has KC * MT (x2 when split)
 // 1-KiB loads in flight; accumulators stay in registers across the chunks of a row group.
 static int gemm_env(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = exp_env(name);
   return e ? atoi(e) : dflt;
 }
 

@@ -660,7 +660,7 @@ hipError_t launch_instnorm(void* x, const float* gamma, const float* beta, float
 // f16x2mx only: in-place norm apply + activation of x [N][D][H][W][C] (row-planar) and its 2x2x2 avg / max pooled copy
 bool in_apply_pool_eligible(int precision, int D, int H, int W, int C) {
   static int off = -1;
-  if (off < 0) off = getenv("AMX_NO_APPLY_POOL") ? 1 : 0;
+  if (off < 0) off = exp_env("AMX_NO_APPLY_POOL") ? 1 : 0;
   return !off && precision == 4 && !(D & 1) && !(H & 1) && !(W & 1) && C % 16 == 0 && ((long long)W * (C / 8)) % 64 == 0;
 }
 hipError_t launch_in_apply_pool(void* x, const float* ab, void* pooled, int N, int D, int H, int W, int C, int act, float slope, int avg,

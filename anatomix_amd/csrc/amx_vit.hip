@@ -447,7 +447,7 @@ int amx_vit_forward(amx_vit_t* h, const float* d_x, float* d_y, int n, void* d_w
   const int M = n * T;
   const int D0 = c.grid_d * 8, H0 = c.grid_h * 8, W0 = c.grid_w * 8;
 #ifdef AMX_VIT_DEBUG_STOP    // debugging aid of tools/vit_bisect.py (build with -DAMX_VIT_DEBUG_STOP): return after a stage.  Compiled OUT of the product.
-  static const int dbg_stop = getenv("AMX_VIT_STOP") ? atoi(getenv("AMX_VIT_STOP")) : 0;
+  static const int dbg_stop = exp_env("AMX_VIT_STOP") ? atoi(exp_env("AMX_VIT_STOP")) : 0;
 #else
   constexpr int dbg_stop = 0;
 #endif

@@ -321,7 +321,7 @@ static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* ni
   // partial sums) measured 135 us on 16 -> 16 @128^3 x 2 views against 99 us for 256, 99 -> 58 us on 32 -> 32 @64^3, 68 -> 38 us
   // on 64 -> 64 @32^3; 257 .. 320 workgroups (a second, nearly empty round) are the worst case (tools/wgrad_time.py).
   static int target = -1;
-  if (target < 0) target = getenv("AMX_WGRAD_WGS") ? atoi(getenv("AMX_WGRAD_WGS")) : 256;
+  if (target < 0) target = exp_env("AMX_WGRAD_WGS") ? atoi(exp_env("AMX_WGRAD_WGS")) : 256;
   int nc = target / npairs;                    // floor: never spill into a second round
   if (nc > *nitems) nc = *nitems;
   if (nc < 1) nc = 1;

@@ -208,6 +208,15 @@ int amx_conv3d_k3_reflect(const void* d_x0, int c0, const void* d_x1, int c1, co
                           int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
                           float* d_out32, void* stream);
 
+/* The same call with caller-owned scratch for the layers that split K across workgroups (deep levels with few voxels:
+ * conv3d_k3_ks writes fp32 partial tensors per K slice, a second kernel sums them in slice order -- deterministic).
+ * amx_conv3d_scratch_bytes returns 0 when the shape does not split; d_scratch may then be NULL. */
+size_t amx_conv3d_scratch_bytes(int c0, int c1, int cout, int n, int d, int hh, int w, int precision);
+int amx_conv3d_k3_reflect_ws(const void* d_x0, int c0, const void* d_x1, int c1, const float* d_weight,
+                             const float* d_scale, const float* d_shift, int cout, int n, int d, int hh,
+                             int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
+                             float* d_out32, void* d_scratch, size_t scratch_bytes, void* stream);
+
 /* The same convolution with a described weight tensor, so that callers need no host-side reshuffling:
  *   weight_mode 0: d_weight fp32 [cout_real][cin_real][27]; input channels cin_real .. c0+c1-1 and output channels
  *                  cout_real .. cout-1 are zero padding (the stem: one real input channel in a 16-channel tensor);

@@ -103,7 +103,7 @@ def max_rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slope=0.3):
+def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slope=0.3, no_scratch=False):
     """Calls amx_conv3d_k3_reflect.  x0/x1: NCDHW float CPU tensors (x1 half resolution or None)."""
     lib = _lib.load()
     tdt = TORCH_T[precision]
@@ -128,9 +128,12 @@ def run_conv(device, x0, x1, w, scale, shift, act, precision, planar=False, slop
             out = torch.full((n, d, h, 3 * cout // 16, ww, 32), 0x7f, dtype=torch.uint8, device=device)
         o16, o32 = out, None
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc),
-                                         _lib.ptr(dsh), cout, n, d, h, ww, act, slope, _lib.PRECISION[precision],
-                                         _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), st))
+    # split-K scratch (conv3d_k3_ks, deep levels with few voxels): offered whenever the shape asks for it, poisoned first
+    sb = 0 if no_scratch else lib.amx_conv3d_scratch_bytes(c0, c1, cout, n, d, h, ww, _lib.PRECISION[precision])
+    scratch = torch.full((max(sb, 4) // 4,), float("nan"), dtype=torch.float32, device=device) if sb else None
+    _lib.check(lib.amx_conv3d_k3_reflect_ws(_lib.ptr(dx0), c0, _lib.ptr(dx1), c1, _lib.ptr(dw), _lib.ptr(dsc),
+                                            _lib.ptr(dsh), cout, n, d, h, ww, act, slope, _lib.PRECISION[precision],
+                                            _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), _lib.ptr(scratch), sb, st))
     torch.cuda.synchronize(device)
     out = out.cpu()
     if planar:

@@ -16,9 +16,11 @@ wpk = torch.empty(lib.amx_conv3d_packed_bytes(c0 + c1, cout), dtype=torch.uint8,
 o16 = None if planar else torch.empty(n, S, S, S, cout, device=dev, dtype=torch.half)
 o32 = torch.empty(n, cout, S, S, S, device=dev) if planar else None
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+sb = lib.amx_conv3d_scratch_bytes(c0, c1, cout, n, S, S, S, 0)
+scratch = torch.empty(max(sb, 4) // 4, device=dev) if sb else None
 def run():
-    _lib.check(lib.amx_conv3d_k3_reflect(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(w), None, _lib.ptr(sh), cout, n, S, S, S,
-                                         1, 0.3, 0, _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), st))
+    _lib.check(lib.amx_conv3d_k3_reflect_ws(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(w), None, _lib.ptr(sh), cout, n, S, S, S,
+                                            1, 0.3, 0, _lib.ptr(wpk), _lib.ptr(o16), _lib.ptr(o32), _lib.ptr(scratch), sb, st))
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
