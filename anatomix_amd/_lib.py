@@ -131,8 +131,20 @@ SYMBOLS = {
 _lib = None
 
 
+AMX_ERR_INVALID, AMX_ERR_SHAPE, AMX_ERR_NOT_LOADED, AMX_ERR_WORKSPACE, AMX_ERR_HIP, AMX_ERR_OVERFLOW = -1, -2, -3, -4, -5, -6
+
+
 class AmxError(RuntimeError):
-    pass
+    """A non-zero status of the C ABI; ``code`` is the status (include/anatomix_amd.h amx_status)."""
+
+    def __init__(self, *args):
+        # (code, message) or just a message
+        self.code = args[0] if args and isinstance(args[0], int) else None
+        super().__init__(*(args[1:] if self.code is not None else args))
+
+
+class AmxEnvelopeError(AmxError):
+    """The configuration lies outside what an engine entry covers (AMX_ERR_INVALID / AMX_ERR_SHAPE at create time)."""
 
 
 class AmxOverflowError(AmxError, FloatingPointError):
@@ -159,8 +171,8 @@ def load():
 
 def check(status: int):
     if status != 0:
-        cls = AmxOverflowError if status == -6 else AmxError
-        raise cls(f"anatomix_amd error {status}: {load().amx_last_error().decode()}")
+        cls = AmxOverflowError if status == AMX_ERR_OVERFLOW else AmxError
+        raise cls(int(status), f"anatomix_amd error {status}: {load().amx_last_error().decode()}")
 
 
 def ptr(t):

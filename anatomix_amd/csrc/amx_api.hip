@@ -577,10 +577,12 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
         r.module_idx = L.module_idx; r.cin = L.cin; r.cout = L.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
         const double vox = (double)n * dd * dh * dw;
         r.flops = 2.0 * 27.0 * L.cin * L.cout * vox;
-        const double up_div = cur_is_full_up ? 1.0 : 8.0;      // nearest: the low-resolution tensor is read, not its 8x image
-        const double in_b = cur.slot < 0 ? 4.0 * vox : (p.C0 * vox + p.C1 * vox / up_div) * (double)eb;
-        const double out_b = L.is_final ? 4.0 * L.cout * vox : (double)eb * L.cout * vox;
-        r.bytes = in_b + out_b + (double)eb * 27.0 * L.cin * L.cout;
+        // ALGORITHMIC bytes: 16-bit activations read once and written once + the weights, the upsampled
+        // segment counted at its LOW resolution for either interpolation (a materialised trilinear tensor and the hi / lo / e4m3
+        // planes of the split precisions are this build's storage choices, not the layer's traffic requirement)
+        const double in_b = cur.slot < 0 ? 4.0 * vox : (p.C0 * vox + p.C1 * vox / 8.0) * 2.0;
+        const double out_b = L.is_final ? 4.0 * L.cout * vox : 2.0 * L.cout * vox;
+        r.bytes = in_b + out_b + 2.0 * 27.0 * L.cin * L.cout;
         if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
       }
       // nn.MaxPool3d(2) right after this block (network.py:368): fuse it into the z-marching epilogue

@@ -448,11 +448,14 @@ class PrimusV2(nn.Module):
             try:
                 output = self.forward_hip(x)
             except _lib.AmxError as e:
-                # configurations outside the engine's envelope (amx_vit_create refuses them: input_channels != 1, token grids that
-                # are not multiples of 64 or have an odd width, widths beyond its tiles, other decoders) ran on the torch modules
-                # before the engine existed: name the switch instead of leaving an engine status code as the only message
-                raise RuntimeError(f"PrimusV2: the HIP engine does not cover this configuration ({e}); set `model.use_engine = False` "
-                                   "to run the stock torch composition of the same modules") from e
+                # configurations outside the engine's envelope (amx_vit_create refuses them with AMX_ERR_INVALID / AMX_ERR_SHAPE:
+                # input_channels != 1, token grids that are not multiples of 64 or have an odd width, widths beyond its tiles, other
+                # decoders) ran on the torch modules before the engine existed: name the switch.  Every other failure (HIP runtime
+                # errors, out of memory, the overflow guard) keeps its own type and message.
+                if getattr(e, "code", None) not in (_lib.AMX_ERR_INVALID, _lib.AMX_ERR_SHAPE):
+                    raise
+                raise _lib.AmxEnvelopeError(e.code, f"PrimusV2: the HIP engine does not cover this configuration ({e}); set "
+                                            "`model.use_engine = False` to run the stock torch composition of the same modules") from e
         else:
             output = self.out_norm(self._body(x))
         if ret_mask:

@@ -65,7 +65,10 @@ class FusedAdamW(torch.optim.Optimizer):
             vals = self._hyper_values(group)
             for (g2, dev), (host, _) in self._hyper.items():
                 if g2 == gi and tuple(host.tolist()) != vals:
-                    torch.cuda.synchronize(dev)
+                    # (not while the stream is being captured: a device-wide synchronise is illegal there and nothing can be
+                    #  replaying -- hence reading the mirror -- before the capture ends)
+                    if not torch.cuda.is_current_stream_capturing():
+                        torch.cuda.synchronize(dev)
                     host.copy_(torch.tensor(vals, dtype=torch.float64))
 
     def _hyper_buffers(self, gi, group, dev):

@@ -218,6 +218,13 @@ class GraphedContrastiveStep:
                 self._tail(total, layer_losses)
         torch.cuda.current_stream(self.A.device).wait_stream(side)
         self._zero()
+        # hyper-parameters at capture time: FusedAdamW mirrors are refreshed (and waited for) BEFORE the capture starts -- inside it a
+        # synchronise would abort the capture; stock optimizers get the snapshot of what is being frozen into the graph
+        for opt in (self.optimizers or ()):
+            if hasattr(opt, "refresh_hyperparameters"):
+                opt.refresh_hyperparameters()
+            else:
+                self._check_frozen_hyperparameters(opt)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.total, self.layer_losses, self.ids, out = self._eager()
@@ -234,7 +241,7 @@ class GraphedContrastiveStep:
     def _check_frozen_hyperparameters(self, opt):
         """A stock capturable optimizer inside a graph replays the hyper-parameters of the capture: refuse to diverge silently."""
         snap = tuple((g["lr"] if not torch.is_tensor(g["lr"]) else None, tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in opt.param_groups)
-        seen = self.__dict__.setdefault("_hyper_snap", {})
+        seen = self.__dict__.setdefault("_hyper_snap", {})       # first call: from _capture, i.e. the values frozen into the graph
         if seen.setdefault(id(opt), snap) != snap:
             raise RuntimeError("GraphedContrastiveStep: the hyper-parameters of a captured torch optimizer changed (lr / betas / eps / "
                                "weight_decay are frozen into the graph); use anatomix_amd.pretraining.FusedAdamW, a tensor lr, or build a "

@@ -101,20 +101,58 @@ def _fused_ok(predictor, inputs, roi) -> bool:
             predictor.hip_unsupported_reason(inputs[:, :, :1, :1, :1].expand(-1, -1, 2, 2, 2)) is None)
 
 
+def _is_affine_leaf(m) -> bool:
+    if isinstance(m, nn.Identity):
+        return True
+    if isinstance(m, (nn.Dropout, nn.Dropout3d)):
+        return not m.training
+    return (isinstance(m, nn.Conv3d) and m.kernel_size == (1, 1, 1) and m.stride == (1, 1, 1) and
+            m.padding in ((0, 0, 0), "valid", "same") and m.dilation == (1, 1, 1) and m.groups == 1)
+
+
+# containers whose forward() is known to be nothing but their children applied in order (checked by name: MONAI is not a dependency)
+_COMPOSITION_ONLY = {("monai.networks.blocks.dynunet_block", "UnetOutBlock"), ("monai.networks.blocks.convolutions", "Convolution")}
+
+
 def _pointwise_affine(module) -> bool:
-    """True if `module` is a composition of 1x1x1 convolutions (stride 1, no padding, any bias) and identities -- a per-voxel AFFINE
-    map A f + b.  MONAI's UnetOutBlock (the head of segmentation_utils.py:113-115) is one: Convolution(conv_only=True, k=1)."""
-    leaves = [m for m in module.modules() if not list(m.children())]
-    if not leaves:
+    """True if `module` is PROVABLY a per-voxel AFFINE map A f + b: 1x1x1 convolutions (stride 1, no padding, any bias), identities and
+    eval-mode dropouts, composed only by containers whose forward() is pure composition -- nn.Sequential (and subclasses that do not
+    override forward) or the whitelisted MONAI blocks (UnetOutBlock = the head of segmentation_utils.py:113-115, Convolution).  A
+    module with its OWN forward() may apply functional nonlinearities (softmax, sigmoid, clamp, argmax) that no child reveals, so it
+    is never accepted on the strength of its leaves; a numeric probe of additivity and locality backs the structural check."""
+    def structural(m) -> bool:
+        kids = list(m.children())
+        if not kids:
+            return _is_affine_leaf(m)
+        pure = (isinstance(m, nn.Sequential) and type(m).forward is nn.Sequential.forward) or \
+               (type(m).__module__, type(m).__name__) in _COMPOSITION_ONLY
+        return pure and all(structural(k) for k in kids)
+
+    if not structural(module):
         return False
-    for m in leaves:
-        if isinstance(m, (nn.Identity, nn.Dropout, nn.Dropout3d)) and not (isinstance(m, (nn.Dropout, nn.Dropout3d)) and m.training):
-            continue
-        if isinstance(m, nn.Conv3d) and m.kernel_size == (1, 1, 1) and m.stride == (1, 1, 1) and m.padding in ((0, 0, 0), "valid", "same") \
-                and m.dilation == (1, 1, 1) and m.groups == 1:
-            continue
-        return False
-    return True
+    convs = [m for m in module.modules() if isinstance(m, nn.Conv3d)]
+    if not convs:
+        return True                               # identities only
+    # numeric guard: h(a + b) - h(a) - h(b) + h(0) = 0 and a one-voxel perturbation stays in its voxel
+    w = convs[0].weight
+    with torch.no_grad():
+        g = torch.Generator(device="cpu").manual_seed(0)
+        a = torch.randn(1, convs[0].in_channels, 2, 2, 3, generator=g).to(w.device, w.dtype)
+        b = torch.randn(1, convs[0].in_channels, 2, 2, 3, generator=g).to(w.device, w.dtype)
+        try:
+            h0, ha, hb, hab = module(torch.zeros_like(a)), module(a), module(b), module(a + b)
+            if ha.shape[2:] != a.shape[2:]:
+                return False
+            scale = float(hab.abs().max()) + 1e-12
+            if float((hab - ha - hb + h0).abs().max()) > 1e-4 * scale + 1e-6:
+                return False
+            a2 = a.clone()
+            a2[..., 0, 0, 0] += 1.0
+            diff = (module(a2) - ha).abs()
+            diff[..., 0, 0, 0] = 0
+            return float(diff.max()) <= 1e-6 * scale + 1e-9
+        except Exception:
+            return False
 
 
 def _split_unet_and_head(predictor, inputs, roi):

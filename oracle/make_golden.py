@@ -7,7 +7,7 @@ parameters and inputs are regenerated from seeds by oracle.unet_ref.synthetic_st
 synthetic_input, so nothing of the reference's source travels.
 
 Cases: variants {anatomix, anatomix-dev} x seeds {0, 1}; sizes 32^3 / 64^3
-(6M) and 64^3 (dev); plus the `layers` branch (taps 27,31,38,45,52,65 -> network.py:475-529) and
+(6M) and 64^3 / 128^3 (dev), 128^3 (6M); plus the `layers` branch (taps 27,31,38,45,52,65 -> network.py:475-529) and
 the encode_only early return for the 6M model.
 """
 import os
@@ -44,7 +44,7 @@ def main():
     out = {}
     cases = [("anatomix", 0, 32, 1.0), ("anatomix", 1, 32, 1.0), ("anatomix", 0, 64, 1.0),
              ("anatomix", 0, 32, 2 ** 0.5), ("anatomix", 0, 128, 1.0),
-             ("anatomix-dev", 0, 64, 1.0), ("anatomix-dev", 1, 64, 1.0)]
+             ("anatomix-dev", 0, 64, 1.0), ("anatomix-dev", 1, 64, 1.0), ("anatomix-dev", 0, 128, 1.0)]
     for variant, seed, size, gain in cases:
         kw = R.VARIANTS[variant]
         m = RefUnet(**kw).eval()
