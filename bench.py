@@ -644,7 +644,12 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         else:
             cfg_s = ("the predictor call of sliding_window_inference, BASELINE configs[1] / the metric" if variant == "anatomix"
                      else "BASELINE configs[3]")
-            workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 ({cfg_s}); fp32 NCDHW in/out, {storage}" +
+            tol_s = ""
+            if variant == "anatomix" and precision == "f16":
+                # the precision contract of this number, in the workload string itself (verdict r04 item 6)
+                tol_s = ("; holds the 1e-3 tolerance against the fp32 reference in rel-L2 ONLY (max-norm 0.86e-3 .. 1.4e-3 by weight "
+                         "seed; the mode that holds both norms is value_strict)")
+            workload_s = (f"{name} forward on sw_batch={B} windows of 1x{S}^3 ({cfg_s}); fp32 NCDHW in/out, {storage}{tol_s}" +
                           ("; the module runs the batch as chunks of 4 on two HIP streams" if B >= 8 and not vit else ""))
             if vit:
                 workload_s = (f"{name} forward on a batch of {B} volumes of 1x{S}^3 (BASELINE configs[4]), one amx_vit_forward call: "
