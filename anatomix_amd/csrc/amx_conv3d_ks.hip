@@ -24,12 +24,8 @@
 //     LDS-DMA issue of the next halo (~100 cycles per KiB instruction, the wave is blocked), the reduction, the LDS latency of a B
 //     fragment all idle the matrix pipe (measured: 20 k cycles per brick for 7.2 k of MFMA issue).  The cout tiles of the
 //     workgroup are therefore split over CW waves per K position: wave (k, c) keeps Q tiles x one chunk = 112 VGPRs of weights, the
-//     CW waves of a K position share that chunk's halo buffers (each issues 1 / CW of its DMA) and reduce independently.  A
-//     workgroup barrier would put all eight waves into the same phase again (measured: sweeps at 46 % of the matrix pipe, the rest
-//     reductions and DMA issue with the pipe idle), so these configurations use NO s_barrier: the KW waves of a reduction group meet
-//     through monotonic LDS counters ("partials written" / "partials read"), the CW waves of a K position through "my share of
-//     the halo landed" / "I am done reading the stage"; wave = cw * KW + k puts one wave of each group on every SIMD, and the
-//     groups drift into opposite phases -- one sweeps while the other reduces.
+//     CW waves of a K position share that chunk's halo buffers (each issues 1 / CW of its DMA) and reduce independently; the
+//     existing reduction barriers order "DMA landed" and "buffer free" for the shared buffers, so still no flags.
 // Same arithmetic formulation as the other conv kernels (amx_conv3d.hip): A = packed weights [cout group][chunk][step 14][q][lane][8],
 // B = activations from a plane-major halo image, 14 paired-tap steps per 16 channels; reflect padding resolved in the gather.
 // Replaces nn.Conv3d(k=3, padding_mode='reflect') + folded eval BatchNorm3d + ReLU of /root/reference/anatomix/model/network.py:334-445
@@ -66,7 +62,7 @@ struct KsCfg {
   // registers to scratch memory, reloaded in every reduction)
   static constexpr int NVTG = NVT / NH;                    // column tiles per group
   static constexpr int OWN = NVTG / KW;                    // column tiles of a group a wave finalises
-  static constexpr int SCR_MAX = 160 * 1024 / WGS_PER_CU - HALO_BYTES - (CW_ > 1 ? 256 : 0);
+  static constexpr int SCR_MAX = 160 * 1024 / WGS_PER_CU - HALO_BYTES;
   static constexpr int pick_rt() {                         // tiles per owner and reduction round that fit the scratch
     for (int r = OWN; r >= 1; --r)
       if (OWN % r == 0 && TEAMS * CW * KW * (KW - 1) * r * Q * 1024 <= SCR_MAX) return r;
@@ -76,9 +72,7 @@ struct KsCfg {
   static constexpr int ROUNDS = RT ? OWN / RT : 0;
   static constexpr int SCR_GROUP = KW * (KW - 1) * RT * Q * 1024;   // one (team, cout wave) reduction group
   static constexpr int SCR_BYTES = TEAMS * CW * SCR_GROUP;
-  static constexpr bool FLAGS = CW > 1;                    // LDS-counter synchronisation instead of workgroup barriers
-  static constexpr int FLAG_BYTES = FLAGS ? 4 * 16 * 4 : 0;   // land / free / arrived / read-done, one int per wave (<= 16 waves)
-  static constexpr int LDS_BYTES = HALO_BYTES + SCR_BYTES + FLAG_BYTES;
+  static constexpr int LDS_BYTES = HALO_BYTES + SCR_BYTES;
   static_assert(NVT % NH == 0 && NVTG % KW == 0, "every wave finalises the same number of column tiles of every group");
   static_assert(NH == 1 || CPW == 1, "tile groups re-read the stage's halo: one chunk per wave and brick");
   static_assert(CW == 1 || CPW == 1, "shared halo buffers are ordered by the per-brick reduction barriers: one stage per brick");
@@ -104,8 +98,7 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // wave = (team, cout wave, K position): the KW waves of a reduction group sit on different SIMDs, the CW groups share them
-  const int team = wave / (KW * CW), cw = (wave - team * (KW * CW)) / KW, k = wave % KW;
+  const int team = wave / (KW * CW), k = (wave - team * (KW * CW)) / CW, cw = wave % CW;   // wave = (team, K position, cout wave)
   const int li = lane & 15, g = lane >> 4;
 
   // ---- this workgroup's (cout group, K slice) and its contiguous run of bricks; XCD b % 8 gets a contiguous span of the
@@ -146,42 +139,6 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
   for (int m = 0; m < NPKW; ++m) pk_off[m] = 0;
   char* const halo = smem + (team * KW + k) * (C::NBUF * CHBUF);
   char* const scratch = smem + C::HALO_BYTES + (team * CW + cw) * C::SCR_GROUP;
-  // ---- LDS counters (FLAGS): every wait is bounded -- a protocol error would surface as wrong values in the parity tests, not as a hang
-  int* const f_land = (int*)(smem + C::HALO_BYTES + C::SCR_BYTES);   // [wave] stages whose halo share of this wave has landed
-  int* const f_free = f_land + 16;                          // [wave] stages this wave has finished reading
-  int* const f_arr = f_land + 32;                           // [wave] reduction rounds whose partials this wave has written
-  int* const f_rdn = f_land + 48;                           // [wave] reduction rounds whose partials this wave has read
-  const int gbase = wave - k;                               // first wave of this reduction group
-  auto wait_one = [&](const int* f, int target) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (__builtin_amdgcn_readfirstlane(flag_load(f)) >= target) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-  };
-  auto wait_group = [&](const int* f, int target) {          // every wave of this reduction group
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      int m = flag_load(f + gbase);
-#pragma unroll
-      for (int i = 1; i < KW; ++i) {
-        const int v = flag_load(f + gbase + i);
-        m = v < m ? v : m;
-      }
-      if (__builtin_amdgcn_readfirstlane(m) >= target) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-  };
-  auto wait_partners = [&](const int* f, int target) {       // the other cout waves of this K position (they share its halo buffers)
-#pragma unroll
-    for (int c2 = 0; c2 < CW; ++c2)
-      if (c2 != cw) wait_one(f + team * (KW * CW) + c2 * KW + k, target);
-  };
-  if (C::FLAGS) {
-    if (tid < 64) ((int*)f_land)[tid] = 0;
-    __syncthreads();                                        // (the only workgroup barrier of these configurations)
-  }
-  int rho = 0;                                              // reduction rounds of this wave so far
 
   auto decode = [&](int b) {                                // brick index -> sample and origin
     KsBrick r;
@@ -282,7 +239,7 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
   static_assert(NA <= 63, "vmcnt is a 6-bit counter");
   asm volatile("" ::"v"(sink));                             // (the touch is older than the halo DMA: returned by now)
-  if (C::FLAGS) flag_store(f_land + wave, 1);               // my share of the first halo has landed
+  if (CW > 1) __syncthreads();                              // the other cout waves' share of the first halo has landed too
   AMX_STAMP();
 
   f32x4 acc[NVTG][Q];
@@ -311,12 +268,9 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
           } else if (cp + 1 < CPW) {
             if (cu_valid) issue(cu, cp + 1, (t + cp + 1) & 1);
           } else if (nx_valid) {
-            // shared buffers: the other cout waves have finished reading the stage before this one (it used the buffer being refilled)
-            if (C::FLAGS && t > 0) wait_partners(f_free, t);
             offsets(nx);
             issue(nx, 0, (t + cp + 1) & 1);
           }
-          if (C::FLAGS && cu_valid) wait_partners(f_land, t + 1);   // their share of THIS stage's halo has landed
         }
         AMX_STAMP();
         if (cp == 0) {
@@ -360,10 +314,6 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
           // the next stage's halo (issued at least a whole sweep ago) and the previous stores have landed; the reads of this stage
           // have returned (their MFMAs were issued), so its buffer may be refilled by the stage after the next
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (C::FLAGS && cu_valid) {
-            flag_store(f_land + wave, t + 2);               // my share of the next stage's halo has landed ...
-            flag_store(f_free + wave, t + 1);               // ... and I am done reading this stage's buffer
-          }
           AMX_STAMP();
         }
       }
@@ -378,14 +328,10 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
         if (dbg & 16) {                                     // ablation: no reduction, no stores (the barriers order the shared buffers)
-          if (!C::FLAGS) {
-            __syncthreads();
-            __syncthreads();
-          }
+          __syncthreads();
+          __syncthreads();
           continue;
         }
-        if (C::FLAGS && !cu_valid) continue;                 // (a team without a brick: its waves skip the round together)
-        if (C::FLAGS) wait_group(f_rdn, rho);                // the scratch tiles of the previous round have been read by their owners
 #pragma unroll
         for (int o = 0; o < KW; ++o) {
           if (o != k && cu_valid) {
@@ -397,13 +343,7 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
               for (int q = 0; q < Q; ++q) *(f32x4*)(dst + (i * Q + q) * 1024) = acc[o * OWN + r * RT + i][q];
           }
         }
-        if (C::FLAGS) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          flag_store(f_arr + wave, rho + 1);
-          wait_group(f_arr, rho + 1);
-        } else {
-          __syncthreads();
-        }
+        __syncthreads();
 #pragma unroll
         for (int o = 0; o < KW; ++o) {
           if (o == k && cu_valid) {
@@ -461,13 +401,7 @@ __global__ __launch_bounds__(C::NWAVE * 64, C::NWAVE * C::WGS_PER_CU / 4) void c
             if (!PART && RangeCheck<T>::on) raise_flag(p.oflow, bad);
           }
         }
-        if (C::FLAGS) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the scratch tiles have returned
-          flag_store(f_rdn + wave, rho + 1);
-          ++rho;
-        } else {
-          __syncthreads();                                  // the scratch tiles may be overwritten (next round / group / brick)
-        }
+        __syncthreads();                                    // the scratch tiles may be overwritten (next round / group / brick)
       }
       AMX_STAMP();
     }
@@ -660,8 +594,10 @@ static hipError_t launch_ks_t(ConvParams p, const KsPlan& pl, int Q, hipStream_t
     e = part ? launch_ks_cfg<T, CC, true>(p, st) : launch_ks_cfg<T, CC, false>(p, st);       \
   } while (0)
   //                                                 brick     Q/wave packed CPW KW CW teams groups
-  // (NBUF = 1 -- two un-prefetched 4-wave workgroups per CU instead of one 8-wave workgroup -- measured slower, 64 -> 64 @32^3
-  //  41.9 -> 47.8 us: every brick's halo is then staged by two workgroups; profiles/r05_ks_shapes.txt)
+  // Measured and NOT kept (profiles/r05_ks_shapes.txt, r05_ks_flags_trace.txt): NBUF = 1 -- two un-prefetched 4-wave workgroups per CU
+  // instead of one 8-wave workgroup -- 64 -> 64 @32^3 41.9 -> 47.8 us (every brick's halo is then staged by two workgroups); LDS
+  // counters instead of workgroup barriers for the two reduction groups: 42.3 -> 42.1 us (the groups do drift into opposite phases,
+  // but a wave sweeps only 28 % of its time: the reduction round itself is the cost).
   if (Q == 4 && pl.kw == 2) {            // 32 -> 64 (W >= 32: conv_pick_q): 2 chunks, two bricks in flight, two waves per SIMD
     if (wide) AMX_KS(2, 4, 16, 2, 4, 1, 2, 2, 2, 2);
   } else if (Q == 4) {                   // 64 -> 64: 4 chunks x 2 cout waves

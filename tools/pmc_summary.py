@@ -35,6 +35,13 @@ def friendly(mangled):
             name += "x2"
         waves = f"w{int(nwz)*int(nwy)}" + (f"+l{nlw},b{nbuf}" if nlw and int(nlw) > 0 else "")
         return f"conv3d_k3_v2<{name},{int(wz)*int(nwz)}x{int(wy)*int(nwy)}x{wx},{waves},q{q},nch{nch},o{o}>"
+    m = re.match(r"_ZN3amx19conv3d_k3_ks_kernelI(DF16_|DF16b)NS_5KsCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEELb(\d)E", mangled)
+    if m:   # <T, KsCfg<TZ, TY, TX, Q, QP, CPW, KW, CW, TEAMS, NH, NBUF>, PART>; same text as the launcher prints
+        t, tz, ty, tx, q, qp, cpw, kw, cw, teams, nh, nbuf, part = m.groups()
+        return (f"conv3d_k3_ks<{'f16' if t == 'DF16_' else 'bf16'},{tz}x{ty}x{tx},q{q},k{kw}x{cpw},c{cw},t{teams},h{nh},b{nbuf}"
+                f"{',part' if part == '1' else ''}>")
+    if "splitk_reduce_kernel" in mangled:
+        return "splitk_reduce"
     if "conv3d_k3_zx_kernel" in mangled:
         m = re.search(r"ZxCfgT(?:ILi|<)(\d+)(?:ELi|, )(\d+)", mangled)
         return f"conv3d_k3_zx<f16x2mx,32->32,2x{m.group(1)}x{m.group(2)},m4+x4+cv4,r6>" if m else "conv3d_k3_zx<f16x2mx,32->32,m4+x4+cv4,r6>"
