@@ -109,6 +109,10 @@ hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D,
 hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
                                                hipStream_t st);
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
+hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long long sz, long long sy, long long sx, long long sc,
+                              const long long* coords, int N, int P, int C, float* rows, hipStream_t st);
+hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
+                               long long dx, int N, int P, int C, int accumulate, hipStream_t st);
 size_t mindssc_scratch_bytes(int H, int W, int D);
 hipError_t launch_mindssc(const float* img, int H, int W, int D, int radius, int dilation, float* out, void* scratch,
                           hipStream_t st);
@@ -1616,6 +1620,21 @@ int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, in
   if (num < 1 || n_draws < num || n_draws > 4096) return fail(AMX_ERR_INVALID, "1 <= num <= n_draws <= 4096 (got %d, %d)", num, n_draws);
   if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
   AMX_HIP(amx::launch_sample_coords(d_draws, n_draws, num, d0, d1, d2, d_coords, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_gather_rows(const void* d_src, int dtype, long long src_sn, long long src_sz, long long src_sy, long long src_sx, long long src_sc,
+                    const long long* d_coords, int n, int p, int c, float* d_rows, void* stream) {
+  if (!d_src || !d_coords || !d_rows || n < 1 || p < 1 || c < 1 || dtype < 0 || dtype > 2) return fail(AMX_ERR_INVALID, "gather_rows: bad arguments");
+  AMX_HIP(amx::launch_gather_rows(d_src, dtype, src_sn, src_sz, src_sy, src_sx, src_sc, d_coords, n, p, c, d_rows, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_scatter_rows(const float* d_rows, const long long* d_coords, void* d_dst, int precision, long long dst_sn, long long dst_sz,
+                     long long dst_sy, long long dst_sx, int n, int p, int c, int accumulate, void* stream) {
+  if (!d_rows || !d_coords || !d_dst || n < 1 || p < 1 || c < 1 || (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16))
+    return fail(AMX_ERR_INVALID, "scatter_rows: bad arguments");
+  AMX_HIP(amx::launch_scatter_rows(d_rows, d_coords, d_dst, precision, dst_sn, dst_sz, dst_sy, dst_sx, n, p, c, accumulate, (hipStream_t)stream));
   return AMX_OK;
 }
 

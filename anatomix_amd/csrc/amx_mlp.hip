@@ -259,7 +259,11 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ Cm, int M, int N, int R, int r_per_split,
                                                          float scale) {
-  __shared__ float As[16][36], Bs[16][36];
+  // KC = 64 reduction rows per stage (four 16-row sub-chunks): a stage is one global fetch -> LDS -> two barriers round trip, and
+  // with 16-row stages a 1024 x 256 x 256 product was 16 such round trips of ~1 us around 64 FMAs per thread (18 us per launch,
+  // 72 launches per contrastive step: profiles/r05 step kernel stats).  Same products added in the same order: bit-identical.
+  constexpr int KC = 64;
+  __shared__ float As[KC][36], Bs[KC][36];
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int rbeg = blockIdx.z * r_per_split, rend = min(R, rbeg + r_per_split);
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict
   const float* P = isb ? B : A;
   const bool T = isb ? TB : TA;
   const int o0 = isb ? n0 : m0, O = isb ? N : M;
-  auto fetch = [&](int r0) -> float4 {
+  auto fetch = [&](int r0) -> float4 {                        // one 16-row sub-chunk
     if (!T) {                                                 // storage [R][O]
       const int r = r0 + (t >> 3), o = o0 + (t & 7) * 4;
       return (r < rend && o < O) ? *(const float4*)(P + (size_t)r * O + o) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict
     if (r + 3 >= rend) v.w = 0.f;
     return v;
   };
-  auto stash = [&](float4 v) {
-    float(*S)[36] = isb ? Bs : As;
+  auto stash = [&](int sub, float4 v) {
+    float(*S)[36] = (isb ? Bs : As) + sub * 16;
     if (!T) {
       *(float4*)&S[t >> 3][(t & 7) * 4] = v;
     } else {
@@ -294,14 +298,21 @@ __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict
     }
   };
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  float4 pv = fetch(rbeg);
-  for (int r0 = rbeg; r0 < rend; r0 += 16) {
-    __syncthreads();
-    stash(pv);
-    __syncthreads();
-    if (r0 + 16 < rend) pv = fetch(r0 + 16);
+  float4 pv[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+  for (int u = 0; u < 4; ++u) pv[u] = fetch(rbeg + 16 * u);
+  for (int r0 = rbeg; r0 < rend; r0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stash(u, pv[u]);
+    __syncthreads();
+    if (r0 + KC < rend) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pv[u] = fetch(r0 + KC + 16 * u);
+    }
+    const int nr = min(KC, rend - r0);                        // (rows past rend were stashed as zeros: adding them changes nothing,
+#pragma unroll 16                                             //  but a short tail need not be walked)
+    for (int r = 0; r < nr; ++r) {
       const float2 a = *(const float2*)&As[r][ty * 2];
       const float2 b = *(const float2*)&Bs[r][tx * 2];
       acc[0][0] += a.x * b.x;

@@ -69,6 +69,68 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
   }
 }
 
+// ---- sampled feature taps (the contrastive step reads 512 voxels of each tapped feature map: supcl_model.py:801-843 calls
+// netF(feat_k, num_patches, ids), pretraining_networks.py:472-480 gathers feat[:, :, x, y, z]).  Going through a dense fp32 NCDHW
+// copy of every tapped tensor costs an export pass forward and, backward, a dense zero tensor + index_put + an import pass per
+// layer -- 268 MB each way at the 128^3 tap -- for 1024 rows.  These two kernels read / write the rows in place instead.
+//
+// gather : rows[n][p][c] (fp32) = src[n][coords[p]][c];  src is a 16-bit channels-last tensor (dtype 0 f16 / 1 bf16) or fp32
+//          (dtype 2: the network output, NCDHW) through element strides (sn, sz, sy, sx, sc)
+// scatter: dst[n][coords[p]][c] (16-bit, byte strides) = or += rows[n][p][c], fp32 add then ONE rounding -- the arithmetic of
+//          import_ncdhw(accumulate) restricted to the sampled voxels.  The coordinates of a layer are distinct (sampling without
+//          replacement), so no two threads touch one element: deterministic.
+template <int DT>
+__global__ void gather_rows_kernel(const char* __restrict__ src, long long sn, long long sz, long long sy, long long sx, long long sc,
+                                   const long long* __restrict__ coords, int N, int P, int C, float* __restrict__ rows) {
+  const long long total = (long long)N * P * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int pi = (int)(r % P), n = (int)(r / P);
+    const long long e = n * sn + coords[3 * pi] * sz + coords[3 * pi + 1] * sy + coords[3 * pi + 2] * sx + c * sc;
+    float v;
+    if (DT == 2) v = ((const float*)src)[e];
+    else if (DT == 0) v = (float)((const f16*)src)[e];
+    else v = (float)((const bf16*)src)[e];
+    rows[i] = v;
+  }
+}
+
+template <typename T>
+__global__ void scatter_rows_kernel(const float* __restrict__ rows, const long long* __restrict__ coords, char* __restrict__ dst,
+                                    long long dn, long long dz, long long dy, long long dx, int N, int P, int C, int accumulate) {
+  const long long total = (long long)N * P * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int pi = (int)(r % P), n = (int)(r / P);
+    T* d = (T*)(dst + n * dn + coords[3 * pi] * dz + coords[3 * pi + 1] * dy + coords[3 * pi + 2] * dx) + c;
+    const float v = rows[i];
+    *d = accumulate ? (T)((float)*d + v) : (T)v;
+  }
+}
+
+hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long long sz, long long sy, long long sx, long long sc,
+                              const long long* coords, int N, int P, int C, float* rows, hipStream_t st) {
+  const long long total = (long long)N * P * C;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == 0) gather_rows_kernel<0><<<blocks, 256, 0, st>>>((const char*)src, sn, sz, sy, sx, sc, coords, N, P, C, rows);
+  else if (dtype == 1) gather_rows_kernel<1><<<blocks, 256, 0, st>>>((const char*)src, sn, sz, sy, sx, sc, coords, N, P, C, rows);
+  else if (dtype == 2) gather_rows_kernel<2><<<blocks, 256, 0, st>>>((const char*)src, sn, sz, sy, sx, sc, coords, N, P, C, rows);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
+                               long long dx, int N, int P, int C, int accumulate, hipStream_t st) {
+  const long long total = (long long)N * P * C;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == 0) scatter_rows_kernel<f16><<<blocks, 256, 0, st>>>(rows, coords, (char*)dst, dn, dz, dy, dx, N, P, C, accumulate);
+  else if (dtype == 1) scatter_rows_kernel<bf16><<<blocks, 256, 0, st>>>(rows, coords, (char*)dst, dn, dz, dy, dx, N, P, C, accumulate);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st) {
   (void)d0;
   const size_t lds = (size_t)n * 2 * sizeof(long long);

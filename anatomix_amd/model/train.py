@@ -109,8 +109,15 @@ def _to_ncdhw(t):             # 16-bit NDHWC -> fp32 NCDHW
 
 class _UnetTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, layers, *params):
+    def forward(ctx, model, x, layers, sampler, *params):
+        # sampler (None: dense taps): callable (module id, (d, h, w)) -> int64 coords [P, 3]; the taps then come back as the P sampled
+        # rows [N, P, C] fp32 of each tapped tensor (gathered in place from the 16-bit channels-last storage) instead of dense fp32
+        # NCDHW copies, and the backward scatters the row gradients straight into the framed gradient buffers
         dt = _DT[model.train_precision]
+        coords_of = {}
+        # an output nobody differentiates (the network output next to sampled taps: 268 MB at 128^3) arrives as None in backward, not as a
+        # dense zero tensor that would then be imported
+        ctx.set_materialize_grads(False)
         act = model._cfg["activation"]
         trilinear = model._cfg["interp"] == "trilinear"
         kinds = _module_kinds(model)
@@ -165,6 +172,8 @@ class _UnetTrainFn(torch.autograd.Function):
                                        shift=b.contiguous())
                     blk.update(bn=bn, frozen=True, a=a, Y=Y, act=act if has_act else "none")
                     tensors[blk["name"]] = Y
+                    if sampler is not None and (i in layers or any(j in layers for j in blk["alias_ids"])):
+                        raise NotImplementedError("sampled taps at a frozen-statistics block")
                     if i in layers:                                      # pre-norm tap: the raw convolution, computed only when asked for
                         taps[i] = _to_ncdhw(T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias))
                     for j in blk["alias_ids"]:
@@ -192,15 +201,24 @@ class _UnetTrainFn(torch.autograd.Function):
                     blk.update(bn=bn, X=X, Y=Y, mean=mean, rstd=rstd, act=act if has_act else "none")
                     tensors[blk["name"]] = Y
                     if i in layers:
-                        taps[i] = _to_ncdhw(X)                           # pre-norm conv output
+                        if sampler is not None:
+                            coords_of[i] = sampler(i, tuple(X.shape[1:4]))
+                            taps[i] = T.gather_rows(X, coords_of[i])[..., : blk["cout"]]
+                        else:
+                            taps[i] = _to_ncdhw(X)                       # pre-norm conv output
                     for j in blk["alias_ids"]:
                         if j in layers:
+                            if sampler is not None:
+                                raise NotImplementedError("sampled taps are implemented at conv ids (pre-norm outputs) and the output conv")
                             taps[j] = _to_ncdhw(Y)                       # in-place activation aliases the norm output
                     i += 1 + int(has_act)
                 else:                                                    # the bare output conv
                     out = T.conv_forward(tensors[in0], None, conv.weight, out32=True, shift=bias)
                     blk.update(bn=None, final=True)
                     tensors[blk["name"]] = out
+                    if sampler is not None and i in layers:
+                        coords_of[i] = sampler(i, tuple(out.shape[2:]))
+                        taps[i] = T.gather_rows(out, coords_of[i], channels_last=False)
                 blocks.append(blk)
                 ops.append(("conv", blk))
                 cur = blk["name"]
@@ -213,9 +231,13 @@ class _UnetTrainFn(torch.autograd.Function):
                 ops.append(("pool", cur, dst, avg, i))
                 cur = dst
                 if i in layers:
+                    if sampler is not None:
+                        raise NotImplementedError("sampled taps are implemented at conv ids (pre-norm outputs) and the output conv")
                     taps[i] = _to_ncdhw(tensors[dst])
             elif k == "up":
                 pending_low = cur
+                if i in layers and sampler is not None:
+                    raise NotImplementedError("sampled taps are implemented at conv ids (pre-norm outputs) and the output conv")
                 if i in layers:
                     # the reference takes this tap AFTER torch.cat((skip, upsampled), 1) (network.py:500-502): materialised
                     # only when asked for -- the convolution that follows still reads skip and low-resolution tensor directly
@@ -232,6 +254,7 @@ class _UnetTrainFn(torch.autograd.Function):
             i += 1
         if tracked:
             torch._foreach_add_(tracked, 1)
+        ctx.coords_of = coords_of
         ctx.up_taps, ctx.trilinear = up_taps, trilinear
         ctx.model, ctx.tensors, ctx.ops, ctx.layers, ctx.dt = model, tensors, ops, sorted(taps), dt
         ctx.param_ids = [id(p) for p in model.parameters()]
@@ -308,10 +331,16 @@ class _UnetTrainFn(torch.autograd.Function):
             n, d, h, w, c0 = x0.shape
             if blk.get("final"):
                 g = dout
-                if g is None:
+                rows = dtap.pop(idx, None) if idx in ctx.coords_of else None
+                if g is None and rows is None:
                     continue
                 fr = frame((n, d, h, w), blk["cout"])
-                T.import_ncdhw(g, T.interior(fr))
+                if g is not None:
+                    T.import_ncdhw(g, T.interior(fr))
+                else:
+                    T.interior(fr).zero_()
+                if rows is not None:                                    # sampled tap at the output conv: 2 x 512 rows of gradient
+                    T.scatter_rows(rows, ctx.coords_of[idx], T.interior(fr), accumulate=True)
             else:
                 name = blk["name"]
                 dy = grads.pop(name, None)
@@ -357,7 +386,10 @@ class _UnetTrainFn(torch.autograd.Function):
                 else:
                     T.interior(fr).zero_()
                 if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
-                    T.import_ncdhw(dtap.pop(idx), T.interior(fr), accumulate=True)
+                    if idx in ctx.coords_of:
+                        T.scatter_rows(dtap.pop(idx), ctx.coords_of[idx], T.interior(fr), accumulate=True)
+                    else:
+                        T.import_ncdhw(dtap.pop(idx), T.interior(fr), accumulate=True)
             # The weight gradient and the data gradient of a block both read `fr` and nothing else of each other: the weight
             # gradient goes to a side stream (result and scratch preallocated / cached on this one) and is joined before the next
             # block touches a framed buffer (they are shared per shape).  Letting it also run beside the next block's BatchNorm
@@ -426,7 +458,7 @@ class _UnetTrainFn(torch.autograd.Function):
                     add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))
         if wgrad_pending is not None:
             torch.cuda.current_stream(tensors["x"].device).wait_stream(wgrad_pending)
-        return (None, dx_in, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
+        return (None, dx_in, None, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
 
 
 def forward_train(model, x, layers):
@@ -434,9 +466,43 @@ def forward_train(model, x, layers):
     layers = [int(l) for l in layers]
     final_idx = max(i for i, m in enumerate(model.model) if isinstance(m, nn.Conv3d))
     want = sorted({l for l in layers if l != final_idx})
-    res = _UnetTrainFn.apply(model, x, tuple(want), *list(model.parameters()))
+    res = _UnetTrainFn.apply(model, x, tuple(want), None, *list(model.parameters()))
     out, taps = res[0], dict(zip(want, res[1:]))
     if not layers:
         return out
     feats = [out if l == final_idx else taps[l] for l in sorted(set(layers))]
     return out, feats
+
+
+def sampled_unsupported_reason(model, x, layers):
+    """None when ``forward_train_sampled`` covers the request: the HIP training path itself, and every tap at a convolution that is
+    followed by a norm in train mode (the pre-norm output) or at the output conv -- the ids the reference's launcher uses
+    (pretraining/scripts/pretrain_anatomix.py:385: 27, 31, 38, 45, 52, 65)."""
+    r = unsupported_reason(model, x, list(layers))
+    if r is not None:
+        return r
+    kinds = _module_kinds(model)
+    mods = list(model.model)
+    for l in layers:
+        if kinds[l] != "conv":
+            return "sampled taps are implemented at conv ids (pre-norm outputs) and the output conv"
+        if l + 1 < len(mods) and kinds[l + 1] == "norm" and isinstance(mods[l + 1], nn.BatchNorm3d) and not mods[l + 1].training:
+            return "sampled taps at a frozen-statistics block"
+    return None
+
+
+def forward_train_sampled(model, x, layers, sampler):
+    """The differentiable train-mode forward with SAMPLED taps: returns ``(out, rows, coords, dims)`` -- per tapped module id (ascending) the
+    fp32 rows [N, P, C] at the coordinates ``sampler(module id, (d, h, w))`` drew when the forward reached that tensor, those
+    coordinates, and the tensor's spatial size.  Same values as gathering from ``forward_train``'s dense taps; the dense fp32 copies, their
+    zero-filled gradients and the import passes are never made."""
+    layers = sorted({int(l) for l in layers})
+    dims, coords = {}, {}
+
+    def recording(i, shape):
+        dims[i] = tuple(shape)
+        coords[i] = sampler(i, shape)
+        return coords[i]
+
+    res = _UnetTrainFn.apply(model, x, tuple(layers), recording, *list(model.parameters()))
+    return res[0], list(res[1:]), [coords[l] for l in layers], [dims[l] for l in layers]

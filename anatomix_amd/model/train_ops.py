@@ -240,6 +240,44 @@ def export_ncdhw(x):
     return out
 
 
+def gather_rows(x, coords, channels_last=True):
+    """rows [N, P, C] fp32 = x[n, coords[p], :].  ``x``: 16-bit NDHWC [N, D, H, W, C'] (``channels_last``) or fp32 NCDHW [N, C, D, H, W];
+    ``coords``: int64 [P, 3] (z, y, x).  Reads the P voxels in place -- no dense fp32 copy of the tensor."""
+    lib = _lib.load()
+    coords = coords.contiguous()
+    p = coords.shape[0]
+    if channels_last:
+        n, c = x.shape[0], x.shape[4]
+        sn, sz, sy, sx, sc = x.stride()
+        dtype = _PREC[x.dtype]
+    else:
+        assert x.dtype == torch.float32
+        n, c = x.shape[0], x.shape[1]
+        sn, sc, sz, sy, sx = x.stride()
+        dtype = 2
+    rows = torch.empty((n, p, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.amx_gather_rows(ctypes.c_void_p(x.data_ptr()), dtype, sn, sz, sy, sx, sc, _lib.ptr(coords), n, p, c, _lib.ptr(rows),
+                                       _st(x.device)))
+    return rows
+
+
+def scatter_rows(rows, coords, dst, accumulate=False):
+    """Adjoint of ``gather_rows``: dst[n, coords[p], :C] (= or +=) rows[n, p, :] for a 16-bit NDHWC view ``dst`` (any strides, e.g. the
+    interior of a framed buffer); fp32 add, one rounding -- import_ncdhw(accumulate) restricted to the sampled voxels."""
+    lib = _lib.load()
+    rows = rows.contiguous() if rows.dtype == torch.float32 else rows.float().contiguous()
+    coords = coords.contiguous()
+    n, p, c = rows.shape
+    es = dst.element_size()
+    sn, sz, sy, sx, sc = [s * es for s in dst.stride()]
+    assert sc == es and dst.shape[0] == n and dst.shape[4] >= c and coords.shape == (p, 3)
+    with torch.cuda.device(rows.device):
+        _lib.check(lib.amx_scatter_rows(_lib.ptr(rows), _lib.ptr(coords), ctypes.c_void_p(dst.data_ptr()), _PREC[dst.dtype], sn, sz, sy, sx,
+                                        n, p, c, int(accumulate), _st(rows.device)))
+    return dst
+
+
 def import_ncdhw(g, dst, accumulate=False):
     """fp32 NCDHW gradient -> 16-bit NDHWC view ``dst`` [N, D, H, W, C'] (C' >= C channels per voxel; any strides that are
     multiples of 16 bytes, e.g. the interior of a framed buffer), optionally adding to it."""

@@ -99,39 +99,62 @@ class PatchSampleF(nn.Module):
             return_feats.append(x_sample)
         return return_feats, return_ids
 
+    def draw_coords(self, k, dims, num_patches, patch_ids, device):
+        """The no-mask sampling of feature map k (pretraining_networks.py:443-470): the given ids, or ``num_patches`` distinct
+        voxels of a grid of ``dims`` -- consumes torch's generator exactly as ``forward`` does for that layer."""
+        if patch_ids is not None:
+            return patch_ids[k].to(device)
+        # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
+        # unravelling of k (no host round trip anywhere on this path)
+        dims = [int(v) for v in dims]
+        ndims = len(dims)
+        nvox = 1
+        for v in dims:
+            nvox *= v
+        num = int(min(num_patches, nvox))
+        if device.type == "cuda" and nvox >= 8 * num and 2 * num <= 4096:
+            return self._sample_distinct(device, nvox, num, dims)
+        flat = torch.randperm(nvox, device=device)[:num]
+        cs = []
+        for a in range(ndims - 1, -1, -1):
+            cs.append(flat % dims[a])
+            flat = torch.div(flat, dims[a], rounding_mode="floor")
+        return torch.stack(cs[::-1], dim=1)
+
+    def forward_rows(self, rows, coords, streams=None):
+        """The heads on rows that were gathered elsewhere (``model.train.forward_train_sampled``): ``rows[k]`` [views, P, C] at
+        ``coords[k]`` -- what ``forward`` computes from the dense feature maps, without the dense feature maps."""
+        if self.use_mlp and not self.mlp_init:
+            self.create_mlp([torch.zeros((1, r.shape[2], 1, 1, 1), device=r.device) for r in rows])
+        ambient = torch.cuda.current_stream(rows[0].device) if streams is not None else None
+        out = []
+        for k, r in enumerate(rows):
+            if streams is not None:
+                streams[k].wait_stream(ambient)
+            with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
+                out.append(self._head(k, r.flatten(0, 1), r.shape[0], r.shape[1]))
+        return out, list(coords)
+
     def _one_layer(self, k, feat, num_patches, patch_ids, mask):
         """Sampling + gather + head of feature map k (pretraining_networks.py:432-511)."""
         ndims = feat.dim() - 2
         if num_patches > 0:
-            if patch_ids is not None:
-                coords = patch_ids[k].to(feat.device)
+            if patch_ids is None and mask is not None:
+                m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
+                fg = torch.where(m > 0)[2:]
+                perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
+                coords = torch.stack([f[perm] for f in fg], dim=1)
             else:
-                if mask is not None:
-                    m = F.interpolate(mask, size=feat.shape[2:], mode="nearest").to(feat.device)
-                    fg = torch.where(m > 0)[2:]
-                    perm = torch.randperm(fg[0].shape[0], device=feat.device)[: int(min(num_patches, fg[0].shape[0]))]
-                    coords = torch.stack([f[perm] for f in fg], dim=1)
-                else:
-                    # every voxel of the grid is a candidate: the k-th entry of torch.where(all-ones) is the C-order
-                    # unravelling of k (no host round trip anywhere on this path)
-                    nvox = feat[0, 0].numel()
-                    dims = list(feat.shape[2:])
-                    num = int(min(num_patches, nvox))
-                    if feat.is_cuda and nvox >= 8 * num and 2 * num <= 4096:
-                        coords = self._sample_distinct(feat.device, nvox, num, dims)
-                    else:
-                        flat = torch.randperm(nvox, device=feat.device)[:num]
-                        cs = []
-                        for a in range(ndims - 1, -1, -1):
-                            cs.append(flat % dims[a])
-                            flat = torch.div(flat, dims[a], rounding_mode="floor")
-                        coords = torch.stack(cs[::-1], dim=1)
+                coords = self.draw_coords(k, feat.shape[2:], num_patches, patch_ids, feat.device)
             idx = (slice(None), slice(None)) + tuple(coords[:, a] for a in range(ndims))
             x_sample = feat[idx]                                   # [views, C, P]
         else:
             x_sample, coords = feat.flatten(2), []
         nviews, nc, nsample = x_sample.size()
         x_sample = x_sample.permute(0, 2, 1).flatten(0, 1)         # [views * P, C]
+        return self._head(k, x_sample, nviews, nsample), coords
+
+    def _head(self, k, x_sample, nviews, nsample):
         if self.use_mlp:
             mlp = getattr(self, "mlp_%d" % k)
             # train-mode heads of the structure the reference builds run on the HIP kernels (one call per head and
@@ -140,4 +163,4 @@ class PatchSampleF(nn.Module):
                 x_sample = mlp_head.run_head(mlp, x_sample).view(nviews, nsample, -1)
             else:
                 x_sample = mlp(x_sample).view(nviews, nsample, -1)
-        return x_sample, coords
+        return x_sample

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 _PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
+_SAMPLED_TAPS = os.environ.get("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
 _STREAMS = {}
 
 
@@ -29,20 +30,35 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     if nce_weights is None:
         nce_weights = [1.0 / len(nce_layers)] * len(nce_layers)
     reals = torch.cat((real_A, real_B), dim=0) if real_B is not None else real_A
-    out, feat_kq = netG(reals, list(nce_layers), False)
+    sampled = _sampled_route(netG, netF, reals, nce_layers, num_patches)
+    if sampled is not None:
+        # netF only ever reads num_patches voxels of each tapped feature map (pretraining_networks.py:472-480): the network hands
+        # back those rows -- drawn with netF's own sampler when the forward reaches each tap, i.e. in netF's order, so the generator
+        # is consumed exactly as by netG(...) followed by netF(...) -- instead of dense fp32 copies of six tensors
+        from ..model import train as _train
+        out, rows, coords, dims = _train.forward_train_sampled(
+            netG, reals, list(nce_layers), lambda i, shape: netF.draw_coords(sampled[i], shape, num_patches, sample_ids, reals.device))
+        feat_sizes = dims
+        feat_kq = None
+    else:
+        out, feat_kq = netG(reals, list(nce_layers), False)
+        feat_sizes = [tuple(f.size()[2:]) for f in feat_kq]
     # The per-layer chains (sampling -> head -> loss, and their adjoints) are independent of each other and made of small
     # kernels that each occupy a fraction of the GPU: on CUDA they run on one stream per layer so they overlap -- autograd runs
     # a node's backward on the stream of its forward, so the adjoint chains overlap too -- and join before the sum.
     # (only while a HIP graph is being captured: launched eagerly, the extra stream switches cost the host more than the overlap
     # returns -- 16.9 vs 15.8 ms -- while a replayed graph gets the parallel branches for free: 12.6 -> 11.8 ms)
-    streams = _layer_streams(reals.device, len(feat_kq)) if (reals.is_cuda and _PARALLEL_HEADS and
-                                                             torch.cuda.is_current_stream_capturing()) else None
+    streams = _layer_streams(reals.device, len(feat_sizes)) if (reals.is_cuda and _PARALLEL_HEADS and
+                                                                torch.cuda.is_current_stream_capturing()) else None
     ambient = torch.cuda.current_stream(reals.device) if streams is not None else None
-    pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
+    if sampled is not None:
+        pooled, ids = netF.forward_rows(rows, coords, streams)
+    else:
+        pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
     parts, layer_losses = [], []
-    for k, (f_kq, sid, crit, layer, w, feat) in enumerate(zip(pooled, ids, criterions, nce_layers, nce_weights, feat_kq)):
+    for k, (f_kq, sid, crit, layer, w, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, nce_weights, feat_sizes)):
         with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
-            loss = crit(f_kq, seg_A, sid, feat.size()[2:])
+            loss = crit(f_kq, seg_A, sid, torch.Size(fsize))
             part = loss.mean() * w * lambda_nce
             det = loss.detach().mean()
         parts.append(part)                                    # (kept alive until after the backward: no cross-stream reuse)
@@ -56,6 +72,24 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     loss = total / grad_accum_iters
     (scaler.scale(loss) if scaler is not None else loss).backward()      # supcl_model.py:624-626
     return total, layer_losses, ids, out
+
+
+def _sampled_route(netG, netF, reals, nce_layers, num_patches):
+    """{module id: netF's layer index} when the step can take the sampled-tap route, else None: our Unet on its HIP training path
+    with every tap at a conv id, our PatchSampleF, ascending distinct layer ids (netF's feature order = the forward's order)."""
+    from ..model import train as _train
+    from ..model.network import Unet
+    from .patch_sample import PatchSampleF
+    layers = [int(l) for l in nce_layers]
+    if not (_SAMPLED_TAPS and isinstance(netG, Unet) and type(netF) is PatchSampleF and reals.is_cuda and num_patches > 0 and
+            torch.is_grad_enabled() and layers == sorted(set(layers)) and not getattr(netG, "allow_torch_path", False)):
+        return None
+    try:
+        if _train.sampled_unsupported_reason(netG, reals, layers) is not None:
+            return None
+    except Exception:
+        return None
+    return {l: k for k, l in enumerate(layers)}
 
 
 def _total_norm(net):

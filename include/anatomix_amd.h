@@ -435,6 +435,16 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
  * flat ids unravelled): d_draws int64 [n_draws], values in [0, d0*d1*d2) drawn WITH replacement by the caller's generator;
  * d_coords int64 [num][3] receives the C-order coordinates of the first `num` distinct draws in draw order -- the same
  * distribution as a random permutation's head, without sorting every voxel.  num <= n_draws <= 4096.  One launch. */
+/* Sampled feature taps of the contrastive step (pretraining_networks.py:472-480 gathers feat[:, :, x, y, z] at num_patches
+ * coordinates): rows[n][p][c] (fp32) = src[n][coords[p]][c] read in place -- src a 16-bit channels-last tensor (dtype = AMX_PREC_F16 /
+ * AMX_PREC_BF16) or an fp32 tensor (dtype 2, e.g. the NCDHW network output), ELEMENT strides -- and its adjoint
+ * dst[n][coords[p]][c] (= or +=) rows[n][p][c] into a 16-bit channels-last tensor (BYTE strides; fp32 add, one rounding; coords must
+ * be distinct).  d_coords: int64 [p][3] = (z, y, x). */
+int amx_gather_rows(const void* d_src, int dtype, long long src_sn, long long src_sz, long long src_sy, long long src_sx, long long src_sc,
+                    const long long* d_coords, int n, int p, int c, float* d_rows, void* stream);
+int amx_scatter_rows(const float* d_rows, const long long* d_coords, void* d_dst, int precision, long long dst_sn, long long dst_sz,
+                     long long dst_sy, long long dst_sx, int n, int p, int c, int accumulate, void* stream);
+
 int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, int d1, int d2, long long* d_coords, void* stream);
 
 /* The optimizer step of the contrastive step: torch.optim.AdamW as the reference builds it for netG and netF

@@ -491,3 +491,32 @@ def test_backward_code_paths_agree_parameter_by_parameter(device, switch, off, e
         # norm vectors <= 7.2e-2, cosines >= 0.998
         assert tot <= 2e-2, tot
         assert abs(float(ga.norm() / gb.norm()) - 1.0) <= 5e-3            # the recorded gradient norm: 0.5 %, not a 35 % band
+
+
+def test_sampled_tap_route_is_bit_identical_to_the_dense_tap_route(device, monkeypatch):
+    """contrastive_step hands netF the 512 sampled rows of each tapped tensor (gathered in place, gradients scattered in place:
+    model/train.py forward_train_sampled) instead of dense fp32 copies of six feature maps.  Same draws (the generator is consumed in the
+    same order), same values (a gather of the same 16-bit storage), same arithmetic in the adjoint (fp32 add, one rounding, at the
+    sampled voxels; + 0 elsewhere): losses, sample ids and EVERY parameter gradient must be bit-identical to the dense route."""
+    from anatomix_amd.pretraining import step as ST
+    res = {}
+    for route in ("sampled", "dense"):
+        monkeypatch.setattr(ST, "_SAMPLED_TAPS", route == "sampled")
+        netG, netF, crits, (vA, vB, seg) = _step_setup(device, "bf16", 64)
+        calls = []
+        if route == "sampled":
+            from anatomix_amd.model import train as TR
+            orig = TR.forward_train_sampled
+            monkeypatch.setattr(TR, "forward_train_sampled", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        torch.manual_seed(11)
+        r = contrastive_step(netG, netF, crits, vA, vB, seg, PI.NCE_LAYERS, num_patches=512)
+        assert bool(calls) == (route == "sampled")
+        res[route] = (r, {k: p.grad.detach().clone() for k, p in list(netG.named_parameters()) + list(netF.named_parameters())
+                          if p.grad is not None})
+    (ra, ga), (rb, gb) = res["sampled"], res["dense"]
+    assert ra["loss"] == rb["loss"] and ra["per_layer"] == rb["per_layer"]
+    for a, b in zip(ra["sample_ids"], rb["sample_ids"]):
+        assert torch.equal(a, b)
+    assert ga.keys() == gb.keys() and len(ga) > 60
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
