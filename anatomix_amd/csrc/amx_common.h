@@ -89,6 +89,43 @@ struct ConvParams {
 __host__ __device__ constexpr int fmt_of_precision(int precision) { return precision < 2 ? 0 : (precision == 4 ? 2 : 1); }
 __host__ __device__ constexpr int fmt_elem_bytes(int fmt) { return fmt == 0 ? 2 : (fmt == 1 ? 4 : 6); }
 
+// z segments of a z-marching launch.  Its workgroups are resident `slots` at a time (one per CU for the ring kernels), so a grid of
+// tiles * nseg workgroups runs in ceil(tiles * nseg / slots) ROUNDS of about (zseg + fill) plane-times each.  "Enough segments to reach
+// `slots` workgroups" (the rule until round 4) is right when tiles divides slots -- the inference shapes -- and bad otherwise: the data
+// gradient of a level-0 layer runs on the zero-framed 132^3 domain of two views = 170 tiles -> 2 segments = 340 workgroups = two
+// rounds of 66 planes, the second a third full (the time of ONE segment of 132), where 3 segments run as two full rounds of 44.
+// Picks the count that minimises rounds * (zseg + fill); `unit` = planes per march step (segments are multiples of it, >= 8 planes).
+inline void pick_z_segments(int tiles, int D, int unit, int slots, int* zseg_out, int* nseg_out) {
+  const int fill = 6;                                   // ring fill + first-step latency, in plane-times
+  long long best = -1;
+  int bz = D, bn = 1;
+  static const bool old_rule = exp_env("AMX_OLD_ZSEG") != nullptr;     // experiment builds: the rule until round 4, for A/B
+  if (old_rule) {
+    int n = (slots + tiles - 1) / tiles;
+    if (n < 1) n = 1;
+    int zs = ((D + n - 1) / n + unit - 1) / unit * unit;
+    if (zs < 8) zs = 8;
+    *zseg_out = zs;
+    *nseg_out = (D + zs - 1) / zs;
+    return;
+  }
+  for (int n = 1; n <= 32; ++n) {
+    int zs = (D + n - 1) / n;
+    zs = (zs + unit - 1) / unit * unit;
+    if (zs < 8) zs = 8;
+    const int ns = (D + zs - 1) / zs;
+    const long long rounds = ((long long)tiles * ns + slots - 1) / slots;
+    const long long score = rounds * (zs + fill);
+    if (best < 0 || score < best) {
+      best = score;
+      bz = zs;
+      bn = ns;
+    }
+  }
+  *zseg_out = bz;
+  *nseg_out = bn;
+}
+
 // Merged-tap convolution over the upsampled segment of a concat layer (amx_conv3d_upmerge.hip).
 struct UpmergeParams {
   const char* src;              // low-res tensor [N][LD][LH][LW][C1 (x2 when split)] 16-bit, byte strides below

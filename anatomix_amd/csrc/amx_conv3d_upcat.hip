@@ -396,12 +396,8 @@ static hipError_t launch_upcat_t(ConvParams p, hipStream_t st) {
   p.nby = (p.H + C::TY - 1) / C::TY;
   p.nbx = (p.W + C::TX - 1) / C::TX;
   const int tiles = p.nby * p.nbx * p.N;
-  int nseg = (256 + tiles - 1) / tiles;
-  if (nseg < 1) nseg = 1;
-  int zseg = (p.D + nseg - 1) / nseg;
-  zseg = (zseg + 1) / 2 * 2;
-  if (zseg < 8) zseg = 8;
-  nseg = (p.D + zseg - 1) / zseg;
+  int nseg, zseg;
+  pick_z_segments(tiles, p.D, 2, 256 * (C::LDS_BYTES <= 80 * 1024 ? 2 : 1), &zseg, &nseg);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((C::NC + C::NL) * 64), C::LDS_BYTES, st, p, zseg, nseg);
   return hipGetLastError();
 }

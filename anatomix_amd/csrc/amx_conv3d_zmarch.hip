@@ -537,12 +537,8 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
   p.nbx = (p.W + TX - 1) / TX;
   // z segments: enough workgroups to fill 256 CUs, each segment a multiple of TZ planes, >= 8 planes
   const int tiles = p.nby * p.nbx * p.N;
-  int nseg = (256 + tiles - 1) / tiles;
-  if (nseg < 1) nseg = 1;
-  int zseg = (p.D + nseg - 1) / nseg;
-  zseg = (zseg + TZ - 1) / TZ * TZ;
-  if (zseg < 8) zseg = 8;
-  nseg = (p.D + zseg - 1) / zseg;
+  int nseg, zseg;
+  pick_z_segments(tiles, p.D, TZ, 256 * (LDS <= 80 * 1024 ? 2 : 1), &zseg, &nseg);
   static unsigned long long* trace_buf = nullptr;
   if (p.dbg & 8) {   // debug only: per-phase cycle stamps of consumer waves 0 and 4, printed after a sync
     if (!trace_buf && hipMalloc((void**)&trace_buf, 1024 * 128 * 8) != hipSuccess) return hipErrorOutOfMemory;
