@@ -45,6 +45,14 @@ _P = C.c_void_p
 _I = C.c_int
 
 
+class PackReq(C.Structure):
+    _fields_ = [("d_weight", C.c_void_p), ("d_wpk", C.c_void_p), ("weight_mode", C.c_int32), ("cin_real", C.c_int32),
+                ("cin_pad", C.c_int32), ("cout_real", C.c_int32), ("cout", C.c_int32), ("w", C.c_int32)]
+
+
+WEIGHTS_PREPACKED = 16
+
+
 class LaunchRecord(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("module_idx", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("n", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ms", C.c_float),
@@ -76,6 +84,7 @@ SYMBOLS = {
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
     "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_conv3d_pack_batch": (_I, [C.POINTER(PackReq), _I, _I, _P]),
     "amx_conv3d_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "amx_conv3d_k3_reflect_ws": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P, C.c_size_t, _P]),
     "amx_conv3d_upcat_merged_packed_bytes": (C.c_size_t, [_I, _I, _I]),

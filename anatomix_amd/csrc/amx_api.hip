@@ -15,6 +15,8 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
 hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, int CinReal, int CinPad,
                                int Cout, int Q, int precision, hipStream_t st, int mode = 0, int CoutReal = 0, int CinStride = 0,
                                int C0Real = 0, int C0Phys = 0);
+hipError_t launch_pack_weights_batch(int count, const float* const* w, void* const* wpk, const int* CinReal, const int* CinPad, const int* Cout,
+                                     const int* Q, const int* mode, const int* CoutReal, int precision, hipStream_t st);
 hipError_t launch_pack_weights_mx(const float* w, const float* scale, void* wpk, int* mxs, int CinReal, int CinPad, int Cout, int Q,
                                   hipStream_t st, int CoutReal = 0, int CinStride = 0, int C0Real = 0, int C0Phys = 0);
 size_t conv_upmerge_packed_bytes(int C1, int Cout, int split);
@@ -1214,13 +1216,17 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
                          int cin_real, int cout_real, const float* d_scale, const float* d_shift, int cout, int n, int d,
                          int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16, float* d_out32,
                          void* stream, void* d_scratch = nullptr, size_t scratch_bytes = 0) {
-  if (!d_x0 || !d_weight || !d_wpk || (!d_out16 == !d_out32)) return fail(AMX_ERR_INVALID, "bad pointer arguments");
+  if (!d_x0 || (!d_weight && !(weight_mode & AMX_WEIGHTS_PREPACKED)) || !d_wpk || (!d_out16 == !d_out32)) return fail(AMX_ERR_INVALID, "bad pointer arguments");
   if (c0 % 16 || c1 % 16 || c0 + c1 < 16 || cout % 16 || cout < 16)
     return fail(AMX_ERR_INVALID, "channel counts must be multiples of 16 (c0=%d c1=%d cout=%d)", c0, c1, cout);
   if (c1 && (!d_x1 || (d & 1) || (hh & 1) || (w & 1))) return fail(AMX_ERR_SHAPE, "upsampled segment needs even dims");
   if (d < 2 || hh < 2 || w < 2) return fail(AMX_ERR_SHAPE, "reflect padding needs >= 2 voxels per axis");
   hipStream_t st = (hipStream_t)stream;
   if (precision < AMX_PREC_F16 || precision > AMX_PREC_F16X2_MX) return fail(AMX_ERR_INVALID, "unsupported precision %d", precision);
+  // weight_mode | AMX_WEIGHTS_PREPACKED: d_wpk already holds this layer's packing (amx_conv3d_pack_batch), nothing is packed here
+  const bool prepacked = (weight_mode & AMX_WEIGHTS_PREPACKED) != 0;
+  weight_mode &= ~AMX_WEIGHTS_PREPACKED;
+  if (prepacked && (is_split(precision) || d_scale)) return fail(AMX_ERR_INVALID, "prepacked weights: plain 16-bit precisions, no scale");
   if (is_mx(precision) && weight_mode != 0) return fail(AMX_ERR_INVALID, "f16x2mx packs forward weights only");
   // strict precision: x0 / x1 / out16 voxels hold [hi(C) | lo(C)]; f16x2mx: [hi(C) | lo(C) | e4m3 copies (2C bytes)] -- the INPUT
   // voxels must carry valid copies (tests/_util.py to_ndhwc_mx), the output's copy section is left untouched
@@ -1235,7 +1241,7 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     int* mxs = (int*)((char*)d_wpk + align_up((size_t)cout * (c0 + c1) * 28 * 2 * 2, 256));
     AMX_HIP(amx::launch_pack_weights_mx(d_weight, d_scale, d_wpk, mxs, cin_real, c0 + c1, cout, q, st, cout_real));
     p.mxs = mxs;
-  } else {
+  } else if (!prepacked) {
     AMX_HIP(amx::launch_pack_weights(d_weight, d_scale, d_wpk, cin_real, c0 + c1, cout, q, precision, st, weight_mode, cout_real));
   }
   p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout;
@@ -1260,6 +1266,8 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     p.out32 = d_out32;
     p.py = w; p.pz = (long long)hh * w; p.pc = p.pz * d; p.pn = p.pc * cout;
   }
+  if (prepacked && !is_split(precision) && weight_mode == 0 && cin_real == 48 && c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p))
+    return fail(AMX_ERR_INVALID, "prepacked weights: the 16 + up32 -> 16 merged-tap layer packs its own format (call without the flag)");
   if (!is_split(precision) && weight_mode == 0 && cin_real == 48 && c0 == 16 && c1 == 32 && cout == 16 && amx::conv_upcat16_eligible(p)) {
     char* up = (char*)d_wpk + ((size_t)cout * (c0 + c1) * 28 * 2 + 255) / 256 * 256;
     AMX_HIP(amx::launch_pack_upcat16(d_weight, d_scale, up, precision, st));
@@ -1275,6 +1283,25 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     if (need) p.part = (float*)d_scratch;
   }
   AMX_HIP(amx::launch_conv(p, precision, q, st));
+  return AMX_OK;
+}
+
+int amx_conv3d_pack_batch(const amx_pack_req* reqs, int count, int precision, void* stream) {
+  if (!reqs || count < 1 || count > 256 || (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16))
+    return fail(AMX_ERR_INVALID, "pack_batch: bad arguments");
+  std::vector<const float*> w(count);
+  std::vector<void*> wpk(count);
+  std::vector<int> cr(count), cp(count), co(count), q(count), md(count), cor(count);
+  for (int i = 0; i < count; ++i) {
+    const amx_pack_req& r = reqs[i];
+    if (!r.d_weight || !r.d_wpk || r.cin_pad % 16 || r.cin_pad < 16 || r.cout % 16 || r.cout < 16 || r.cin_real < 1 || r.cin_real > r.cin_pad ||
+        r.cout_real < 1 || r.cout_real > r.cout || (r.weight_mode != 0 && r.weight_mode != 1))
+      return fail(AMX_ERR_INVALID, "pack_batch: bad request %d", i);
+    w[i] = r.d_weight; wpk[i] = r.d_wpk; cr[i] = r.cin_real; cp[i] = r.cin_pad; co[i] = r.cout; md[i] = r.weight_mode; cor[i] = r.cout_real;
+    q[i] = amx::conv_pick_q(r.cout, r.w, precision);
+  }
+  AMX_HIP(amx::launch_pack_weights_batch(count, w.data(), wpk.data(), cr.data(), cp.data(), co.data(), q.data(), md.data(), cor.data(), precision,
+                                         (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -31,14 +31,13 @@ namespace amx {
 // split (strict precision): per cout group the chunk axis is doubled, [Wh chunks | Wl chunks], Wl = the residual of the
 // rounding of Wh (conv3d_k3_v2's SPLIT mode).
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
-                                    int split, int CinStride, int C0Real, int C0Phys) {
+__device__ __forceinline__ void pack_weights_range(const float* __restrict__ w, const float* __restrict__ scale,
+                                                   T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
+                                                   int split, int CinStride, int C0Real, int C0Phys, long long first, long long stride) {
   const int nchunk_phys = CinPad / 16 * (split ? 2 : 1);
   const long long total = (long long)(Cout / 16) * nchunk_phys * kSteps * 64 * 8;
   const int nchunk = CinPad / 16;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = first; idx < total; idx += stride) {
     const int e = idx & 7;
     const int lane = (idx >> 3) & 63;
     long long r = idx >> 9;
@@ -70,6 +69,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     }
     wpk[idx] = part ? (T)(v - (float)(T)v) : (T)v;
   }
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                    T* __restrict__ wpk, int CinReal, int CinPad, int Cout, int Q, int mode, int CoutReal,
+                                    int split, int CinStride, int C0Real, int C0Phys) {
+  pack_weights_range<T>(w, scale, wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride, C0Real, C0Phys,
+                        blockIdx.x * (long long)blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// Many layers in ONE launch (the training step packs every conv's forward weights, then every data-gradient packing, once per step:
+// 40 launches of 5-14 us each on the critical path became two).  The descriptors travel in the kernel arguments; a block finds its
+// layer from the block prefix table.
+struct PackBatch {
+  enum { kMax = 40 };
+  int count;
+  int first_block[kMax + 1];
+  const float* w[kMax];
+  void* wpk[kMax];
+  int CinReal[kMax], CinPad[kMax], Cout[kMax], Q[kMax], mode[kMax], CoutReal[kMax];
+};
+template <typename T>
+__global__ void pack_weights_batch_kernel(const PackBatch b) {
+  int l = 0;
+  while (l + 1 < b.count && (int)blockIdx.x >= b.first_block[l + 1]) ++l;
+  const int nb = b.first_block[l + 1] - b.first_block[l];
+  pack_weights_range<T>(b.w[l], nullptr, (T*)b.wpk[l], b.CinReal[l], b.CinPad[l], b.Cout[l], b.Q[l], b.mode[l], b.CoutReal[l], 0,
+                        b.CinReal[l], 0, 0, (blockIdx.x - b.first_block[l]) * (long long)blockDim.x + threadIdx.x,
+                        (long long)nb * blockDim.x);
 }
 
 // ---- AMX_PREC_F16X2_MX: the correction operands of a layer as fp8 A fragments of v_mfma_scale_f32_16x16x128_f8f6f4 -------------
@@ -317,6 +345,31 @@ hipError_t launch_pack_weights(const float* w, const float* scale, void* wpk, in
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, scale,
                        (bf16*)wpk, CinReal, CinPad, Cout, Q, mode, CoutReal, split, CinStride, C0Real, C0Phys);
+  return hipGetLastError();
+}
+
+// Batched packing of plain (un-split, un-scaled) layers: w[i] fp32, CinStride = CinReal; single 16-bit precisions only.
+hipError_t launch_pack_weights_batch(int count, const float* const* w, void* const* wpk, const int* CinReal, const int* CinPad, const int* Cout,
+                                     const int* Q, const int* mode, const int* CoutReal, int precision, hipStream_t st) {
+  if (precision > 1) return hipErrorInvalidValue;
+  for (int i0 = 0; i0 < count; i0 += PackBatch::kMax) {
+    PackBatch b;
+    b.count = count - i0 < PackBatch::kMax ? count - i0 : PackBatch::kMax;
+    int blocks = 0;
+    for (int i = 0; i < b.count; ++i) {
+      const int j = i0 + i;
+      const long long total = (long long)(Cout[j] / 16) * (CinPad[j] / 16) * kSteps * 64 * 8;
+      long long nb = (total + 255) / 256;
+      if (nb > 512) nb = 512;
+      b.first_block[i] = blocks;
+      blocks += (int)nb;
+      b.w[i] = w[j]; b.wpk[i] = wpk[j];
+      b.CinReal[i] = CinReal[j]; b.CinPad[i] = CinPad[j]; b.Cout[i] = Cout[j]; b.Q[i] = Q[j]; b.mode[i] = mode[j]; b.CoutReal[i] = CoutReal[j];
+    }
+    b.first_block[b.count] = blocks;
+    if ((precision & 1) == 0) hipLaunchKernelGGL(pack_weights_batch_kernel<f16>, dim3(blocks), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(pack_weights_batch_kernel<bf16>, dim3(blocks), dim3(256), 0, st, b);
+  }
   return hipGetLastError();
 }
 

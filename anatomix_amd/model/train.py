@@ -26,10 +26,11 @@ from . import train_ops as T
 _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
 
-OVERLAP_WGRAD = True           # weight gradients on a side stream, beside the data gradient of the same block
+OVERLAP_WGRAD = os.environ.get("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight gradients on a side stream, beside the data gradient of the same block
 RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
 SPLIT_CONCAT_DGRAD = int(os.environ.get("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
+BATCH_PACK = os.environ.get("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
 _SIDE = {}
 
 
@@ -132,6 +133,23 @@ class _UnetTrainFn(torch.autograd.Function):
         taps = {}
         up_taps = {}                                                     # upsample id -> (skip tensor, low-resolution tensor)
         tracked = []                                                     # num_batches_tracked of every BatchNorm: one foreach add
+        # Packed weights of every plain conv in ONE launch (T.pack_batch) instead of one small launch inside each conv call.  Which
+        # convs, with how many stored input channels and at which width, is recorded by the first forward of a given input shape
+        # (which packs per call) and replayed afterwards; a conv whose recorded shape does not match packs itself as before.
+        pkey = (tuple(x.shape), dt)
+        plan = getattr(model, "_pack_plan", {}).get(pkey) if BATCH_PACK else None
+        packs, rec = {}, {}
+        if plan:
+            ids = sorted(plan)
+            views = T.pack_batch([(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids], dt, dev)
+            packs = dict(zip(ids, views))
+
+        def packed(j, cin_pad, width, cout):
+            if (cin_pad, cout) == (48, 16):                              # the 16 + up32 -> 16 merged-tap layer packs its own format
+                return None
+            rec[j] = (cin_pad, width)
+            return packs.get(j) if plan and plan.get(j) == (cin_pad, width) else None
+
         i = 0
         while i < len(mods):
             k = kinds[i]
@@ -182,7 +200,9 @@ class _UnetTrainFn(torch.autograd.Function):
                     i += 1 + int(has_act)
                 elif has_bn:
                     bn = mods[i + 1]
-                    X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias)
+                    cin_pad = tensors[in0].shape[-1] + (0 if in1 is None else tensors[in1].shape[-1])
+                    X = T.conv_forward(tensors[in0], None if in1 is None else tensors[in1], conv.weight, shift=bias,
+                                       wpk=packed(i, cin_pad, tensors[in0].shape[3], (conv.out_channels + 15) // 16 * 16))
                     gam = None if bn.weight is None else bn.weight.detach()
                     bet = None if bn.bias is None else bn.bias.detach()
                     if isinstance(bn, nn.BatchNorm3d):
@@ -213,7 +233,8 @@ class _UnetTrainFn(torch.autograd.Function):
                             taps[j] = _to_ncdhw(Y)                       # in-place activation aliases the norm output
                     i += 1 + int(has_act)
                 else:                                                    # the bare output conv
-                    out = T.conv_forward(tensors[in0], None, conv.weight, out32=True, shift=bias)
+                    out = T.conv_forward(tensors[in0], None, conv.weight, out32=True, shift=bias,
+                                         wpk=packed(i, tensors[in0].shape[-1], tensors[in0].shape[3], (conv.out_channels + 15) // 16 * 16))
                     blk.update(bn=None, final=True)
                     tensors[blk["name"]] = out
                     if sampler is not None and i in layers:
@@ -252,6 +273,9 @@ class _UnetTrainFn(torch.autograd.Function):
             else:
                 raise NotImplementedError(f"module {i} ({type(mods[i]).__name__}) in the HIP training path")
             i += 1
+        if BATCH_PACK and not plan:
+            model.__dict__.setdefault("_pack_plan", {})[pkey] = rec
+        ctx.pkey = pkey
         if tracked:
             torch._foreach_add_(tracked, 1)
         ctx.coords_of = coords_of
@@ -299,6 +323,18 @@ class _UnetTrainFn(torch.autograd.Function):
             else:
                 n_, d_, h_, w_, c_ = low.shape
                 add_grad(low_name, gu.reshape(n_, d_, 2, h_, 2, w_, 2, c_).float().sum((2, 4, 6)).to(dt))
+        # data-gradient packings of the plain blocks in one launch (same record-and-replay as the forward)
+        bplan = getattr(model, "_pack_plan_bwd", {}).get(ctx.pkey) if BATCH_PACK else None
+        bpacks, brec = {}, {}
+        if bplan:
+            bids = sorted(bplan)
+            bviews = T.pack_batch([(T._as_weight(model.model[j].weight), 1, bplan[j][0], bplan[j][1]) for j in bids], dt, tensors["x"].device)
+            bpacks = dict(zip(bids, bviews))
+
+        def bpacked(j, cin_pad, width):
+            brec[j] = (cin_pad, width)
+            return bpacks.get(j) if bplan and bplan.get(j) == (cin_pad, width) else None
+
         wgrad_pending = None
         for op in reversed(ctx.ops):
             if wgrad_pending is not None:                               # the frames and the scratch are shared: one in flight
@@ -425,7 +461,7 @@ class _UnetTrainFn(torch.autograd.Function):
                 grads[blk["in0"]] = T.pad_fold(g_skip, grads.get(blk["in0"]))
                 add_grad(blk["in1"], T.upcat_split_backward_framed(g_up, 0, x1.shape[-1])[1])
                 continue
-            g_fr = T.conv_dgrad_framed(fr, conv.weight)
+            g_fr = T.conv_dgrad_framed(fr, conv.weight, wpk=bpacked(idx, fr.shape[-1], fr.shape[3]))
             if (x1 is not None and blk.get("cat_parts") is None and g_fr.shape[-1] == c0 + x1.shape[-1] and c0 % 8 == 0
                     and x1.shape[-1] % 8 == 0 and FUSED_FOLD_SPLIT):
                 # reflect-padding adjoint, channel split and the sum over the 8 children of every low-resolution voxel (adjoint of
@@ -458,6 +494,8 @@ class _UnetTrainFn(torch.autograd.Function):
                     add_grad(blk["in1"], up.float().sum((2, 4, 6)).to(dt))
         if wgrad_pending is not None:
             torch.cuda.current_stream(tensors["x"].device).wait_stream(wgrad_pending)
+        if BATCH_PACK and not bplan:
+            model.__dict__.setdefault("_pack_plan_bwd", {})[ctx.pkey] = brec
         return (None, dx_in, None, None) + tuple(pgrads.get(pid) for pid in ctx.param_ids)
 
 

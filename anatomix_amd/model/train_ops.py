@@ -40,7 +40,36 @@ def _as_weight(weight):
     return w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().contiguous()
 
 
-def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None, weight_mode=0):
+def pack_batch(reqs, dtype, device):
+    """One launch for many layers' packed weights.  ``reqs``: list of (weight fp32 contiguous, weight_mode, cin_pad, width): returns one
+    uint8 buffer per request (views of one allocation) to hand to ``conv_forward(..., wpk=)``."""
+    lib = _lib.load()
+    sizes, metas = [], []
+    for wt, mode, cin_pad, width in reqs:
+        if mode == 0:
+            cout_real, cin_real = wt.shape[0], wt.shape[1]
+        else:
+            cin_real, cout_real = wt.shape[0], wt.shape[1]
+        cout = (cout_real + 15) // 16 * 16
+        nb = (lib.amx_conv3d_packed_bytes(cin_pad, cout) + 255) // 256 * 256
+        sizes.append(nb)
+        metas.append((cin_real, cout_real, cout))
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=device)
+    arr = (_lib.PackReq * len(reqs))()
+    views, off = [], 0
+    for i, ((wt, mode, cin_pad, width), (cin_real, cout_real, cout), nb) in enumerate(zip(reqs, metas, sizes)):
+        v = buf[off: off + nb]
+        views.append(v)
+        arr[i].d_weight, arr[i].d_wpk = wt.data_ptr(), v.data_ptr()
+        arr[i].weight_mode, arr[i].cin_real, arr[i].cin_pad = mode, cin_real, cin_pad
+        arr[i].cout_real, arr[i].cout, arr[i].w = cout_real, cout, width
+        off += nb
+    with torch.cuda.device(device):
+        _lib.check(lib.amx_conv3d_pack_batch(arr, len(reqs), _PREC[dtype], _st(device)))
+    return views
+
+
+def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None, weight_mode=0, wpk=None):
     """nn.Conv3d(k3, reflect 'same') on cat(x0, nearest_up2(x1)).  weight_mode 0: weight fp32 [Cout, Cin, 3, 3, 3] with Cin <=
     channels of the inputs (the stem's single channel sits in a 16-channel tensor); weight_mode 1: the data-gradient
     convolution of the conv whose FORWARD weight is ``weight`` [Cin_of_x0, Cout_result, 3,3,3] (flip + transpose happen in
@@ -57,7 +86,11 @@ def conv_forward(x0, x1, weight, act="none", slope=0.3, out32=False, shift=None,
     cout = (cout_real + 15) // 16 * 16
     with torch.cuda.device(dev):
         nb = lib.amx_conv3d_packed_bytes(c0 + c1, cout)
-        wpk = _cached(("wpk", dev, nb), lambda: torch.empty(nb, dtype=torch.uint8, device=dev))
+        if wpk is not None:                                   # packed by pack_batch for exactly this call
+            assert wpk.numel() >= nb
+            weight_mode |= _lib.WEIGHTS_PREPACKED
+        else:
+            wpk = _cached(("wpk", dev, nb), lambda: torch.empty(nb, dtype=torch.uint8, device=dev))
         if out32:
             out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=dev)
             o16, o32 = None, out
@@ -135,9 +168,9 @@ def conv_dgrad(dx_framed, weight, cin_keep=None, accumulate_into=None):
     return pad_fold(conv_dgrad_framed(dx_framed, weight), accumulate_into)
 
 
-def conv_dgrad_framed(dx_framed, weight):
+def conv_dgrad_framed(dx_framed, weight, wpk=None):
     """First half of conv_dgrad: the raw result on the padded domain, 16-bit [N, D+4, H+4, W+4, Cin_pad16]."""
-    return conv_forward(dx_framed, None, weight, weight_mode=1)
+    return conv_forward(dx_framed, None, weight, weight_mode=1, wpk=wpk)
 
 
 def pad_fold(g, accumulate_into=None):

@@ -228,6 +228,20 @@ int amx_conv3d_k3_reflect_ex(const void* d_x0, int c0, const void* d_x1, int c1,
                              int d, int hh, int w, int act, float slope, int precision, void* d_wpk, void* d_out16,
                              float* d_out32, void* stream);
 
+/* Packing of MANY layers in one launch (the training step: every conv's weights change with every optimizer step, and packing each
+ * inside its conv call put 40 small launches on the step's critical path).  Request i packs d_weight (described as for
+ * amx_conv3d_k3_reflect_ex: weight_mode 0 / 1, cin_real of cin_pad stored input channels, cout_real of cout) into d_wpk
+ * (amx_conv3d_packed_bytes(cin_pad, cout) bytes) for a layer of spatial WIDTH w (the tile shape -- hence the packing -- depends on
+ * it).  The conv is then called with weight_mode | AMX_WEIGHTS_PREPACKED and that d_wpk (d_weight may be NULL).  Plain 16-bit
+ * precisions; not for the 16 + up32 -> 16 merged-tap layer. */
+#define AMX_WEIGHTS_PREPACKED 16
+typedef struct amx_pack_req {
+  const float* d_weight;
+  void* d_wpk;
+  int weight_mode, cin_real, cin_pad, cout_real, cout, w;
+} amx_pack_req;
+int amx_conv3d_pack_batch(const amx_pack_req* reqs, int count, int precision, void* stream);
+
 /* nn.MaxPool3d(2) / nn.AvgPool3d(2) on a 16-bit NDHWC tensor (network.py:297,368). */
 int amx_pool2(const void* d_in, void* d_out, int n, int d_out_, int h_out, int w_out, int c, int avg,
               int precision, void* stream);
