@@ -84,6 +84,10 @@ SYMBOLS = {
     "amx_sw_count": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_packed_bytes": (C.c_size_t, [_I, _I]),
     "amx_conv3d_k3_reflect": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "amx_conv3d_dgrad_interior_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "amx_conv3d_dgrad_interior": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "amx_conv3d_dgrad_shell_scratch_bytes": (C.c_size_t, []),
+    "amx_conv3d_dgrad_fold_shell": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "amx_conv3d_pack_batch": (_I, [C.POINTER(PackReq), _I, _I, _P]),
     "amx_conv3d_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "amx_conv3d_k3_reflect_ws": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -88,6 +88,11 @@ hipError_t launch_adamw(const long long* table, int count, double lr, double b1,
                         hipStream_t st, const double* d_hyper = nullptr);
 hipError_t launch_pad_fold(const void* g_framed, void* din, int N, int D, int H, int W, int C, int accumulate, int precision,
                            hipStream_t st);
+hipError_t launch_dgrad_fold_shell(const void* dy, long long yn, long long yz, long long yy, long long yx, int cdy, const float* w,
+                                   int co_real, int ci_real, void* dx, int cdx, int N, int D, int H, int W, int precision, void* scratch,
+                                   hipStream_t st);
+size_t dgrad_shell_scratch_bytes();
+bool conv_zmarch_eligible(const ConvParams& p);
 hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
                                      int accumulate, int precision, hipStream_t st);
 size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad);
@@ -1283,6 +1288,56 @@ static int conv3d_single(const void* d_x0, int c0, const void* d_x1, int c1, con
     if (need) p.part = (float*)d_scratch;
   }
   AMX_HIP(amx::launch_conv(p, precision, q, st));
+  return AMX_OK;
+}
+
+// ---- data gradient = interior launch of the forward kernel on the zero-framed gradient + shell terms (amx_train.hip)
+static bool dgrad_interior_shape_ok(int c_dy, int cout, int d, int hh, int w, int precision) {
+  if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return false;
+  amx::ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.C0 = c_dy; p.Cout = cout; p.D = d; p.H = hh; p.W = w; p.out = (char*)1;
+  return amx::conv_zmarch_eligible(p) && amx::conv_pick_q(cout, w, precision) == cout / 16 && (size_t)27 * c_dy * cout * 4 <= 150 * 1024;
+}
+
+int amx_conv3d_dgrad_interior_supported(int c_dy, int cout, int d, int hh, int w, int precision) {
+  return dgrad_interior_shape_ok(c_dy, cout, d, hh, w, precision) ? 1 : 0;
+}
+
+int amx_conv3d_dgrad_interior(const void* d_dy_framed, int c_dy, const float* d_weight, int weight_flags, int cin_real, int cout_real, int cout,
+                              int n, int d, int hh, int w, int precision, void* d_wpk, void* d_out16, void* stream) {
+  if (!d_dy_framed || !d_wpk || !d_out16 || (!d_weight && !(weight_flags & AMX_WEIGHTS_PREPACKED)))
+    return fail(AMX_ERR_INVALID, "dgrad_interior: bad pointer arguments");
+  if (!dgrad_interior_shape_ok(c_dy, cout, d, hh, w, precision))
+    return fail(AMX_ERR_INVALID, "dgrad_interior: shape outside the z-march kernels (ask amx_conv3d_dgrad_interior_supported)");
+  if (cin_real < 1 || cin_real > c_dy || cout_real < 1 || cout_real > cout) return fail(AMX_ERR_INVALID, "dgrad_interior: bad weight description");
+  hipStream_t st = (hipStream_t)stream;
+  const int q = cout / 16;
+  if (!(weight_flags & AMX_WEIGHTS_PREPACKED))
+    AMX_HIP(amx::launch_pack_weights(d_weight, nullptr, d_wpk, cin_real, c_dy, cout, q, precision, st, 1, cout_real));
+  amx::ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.N = n; p.D = d; p.H = hh; p.W = w; p.Cout = cout; p.C0 = c_dy;
+  p.s0x = (long long)c_dy * 2; p.s0y = p.s0x * (w + 4); p.s0z = p.s0y * (hh + 4); p.s0n = p.s0z * (d + 4);
+  p.src0 = (const char*)d_dy_framed + 2 * (p.s0z + p.s0y + p.s0x);       // the interior of [n][d+4][hh+4][w+4][c_dy]
+  p.raw_halo = 1;
+  p.wpk = (const char*)d_wpk;
+  p.act = AMX_ACT_NONE;
+  p.out = (char*)d_out16;
+  p.ox = (long long)cout * 2; p.oy = p.ox * w; p.oz = p.oy * hh; p.on = p.oz * d;
+  AMX_HIP(amx::launch_conv(p, precision, q, st));
+  return AMX_OK;
+}
+
+size_t amx_conv3d_dgrad_shell_scratch_bytes(void) { return amx::dgrad_shell_scratch_bytes(); }
+
+int amx_conv3d_dgrad_fold_shell(const void* d_dy_framed, int c_dy, const float* d_weight, int co_real, int ci_real, void* d_dx, int c_dx, int n,
+                                int d, int hh, int w, int precision, void* d_scratch, void* stream) {
+  if (!d_dy_framed || !d_weight || !d_dx || !d_scratch || ((uintptr_t)d_scratch & 15) || co_real < 1 || co_real > c_dy || ci_real < 1 || ci_real > c_dx || d < 2 || hh < 2 || w < 2)
+    return fail(AMX_ERR_INVALID, "dgrad_fold_shell: bad arguments");
+  const long long fx = (long long)c_dy * 2, fy = fx * (w + 4), fz = fy * (hh + 4), fn = fz * (d + 4);
+  AMX_HIP(amx::launch_dgrad_fold_shell((const char*)d_dy_framed + 2 * (fz + fy + fx), fn, fz, fy, fx, c_dy, d_weight, co_real, ci_real, d_dx, c_dx,
+                                       n, d, hh, w, precision, d_scratch, (hipStream_t)stream));
   return AMX_OK;
 }
 

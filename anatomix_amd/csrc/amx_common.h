@@ -69,6 +69,8 @@ struct ConvParams {
                                //   f16 range (|v| > 65504) or NaN -- see amx_unet_numerics_status (include/anatomix_amd.h)
   int dbg;                     // ablation switches (env AMX_DBG; 0 in production): 1 no DMA after the first, 2 no MFMA sweep, 4 no stores
   const int* mxs;              // AMX_PREC_F16X2_MX: device word holding the E8M0 block-scale byte (x4) of this layer's fp8 weights
+  int raw_halo;                // 1: src0 is the INTERIOR of a zero-framed buffer (frame >= 1 voxel): halo voxels are read from the frame at
+                               //   coordinates -1 / n instead of being reflected (the data gradient's interior part, amx_train.hip)
   float* part;                 // conv3d_k3_ks: fp32 partial tensors [slice][voxel][Cout] of a cross-workgroup K split (scratch offered by the caller; null: no split)
   int kslices;                 //   ... and the number of K slices of this launch (set by the launcher)
   int cs0, cs1, ocs;           // byte stride between the 32-byte pieces (16-channel chunks) of one voxel in src0 / src1 / out; 0 = 32

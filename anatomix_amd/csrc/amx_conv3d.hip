@@ -320,6 +320,7 @@ hipError_t launch_conv(const ConvParams& p, int precision, int Q, hipStream_t st
     return e;
   }
   if (p.src0_f32c1) return hipErrorInvalidValue;   // the fp32 stem has its own kernel (amx_conv3d_stem.hip)
+  if (p.raw_halo) return hipErrorInvalidValue;     // frame-reading sources: the z-march kernels only
   (void)planar;
   if (conv_ks_eligible(p, precision, Q)) {           // deep levels: register-stationary weights, K split over the waves
     hipError_t e = launch_conv_ks(p, precision, Q, st);

@@ -177,11 +177,11 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
       const int hv = j * 64 + lane;
       const int hy = hv / HX, hx = hv - hy * HX;
       valid[j] = hv < C::HVP;
-      off[j] = reflect_clamp(y0 + hy - 1, p.H) * (int)p.s0y + reflect_clamp(x0 + hx - 1, p.W) * (int)p.s0x + cp * 16;
+      off[j] = halo_coord(y0 + hy - 1, p.H, p.raw_halo) * (int)p.s0y + halo_coord(x0 + hx - 1, p.W, p.raw_halo) * (int)p.s0x + cp * 16;
     }
     const char* src_n = p.src0 + (long long)n * p.s0n;
     auto issue_plane = [&](int q) {
-      const char* plane = src_n + (long long)reflect_clamp(zs - 1 + q, p.D) * p.s0z;   // uniform
+      const char* plane = src_n + (long long)halo_coord(zs - 1 + q, p.D, p.raw_halo) * p.s0z;   // uniform
       char* dstp = smem + (q % R) * PLSZ + cp * PPL;                                    // uniform
 #pragma unroll
       for (int j = 0; j < NDMA; ++j)

@@ -40,6 +40,13 @@ __device__ __forceinline__ int reflect_clamp(int g, int n) {
   return g >= n ? n - 1 : g;
 }
 
+// source coordinate of a halo voxel: reflected, or (raw: the source is the interior of a zero-framed buffer) the neighbour itself,
+// kept inside the one-voxel frame for the out-of-volume voxels of partial tiles
+__device__ __forceinline__ int halo_coord(int g, int n, int raw) {
+  if (raw) return g < -1 ? -1 : (g > n ? n : g);
+  return reflect_clamp(g, n);
+}
+
 // ---- fp8 side of precision AMX_PREC_F16X2_MX (include/anatomix_amd.h) ---------------------------------------------------------
 // A stored value v = hi + lo (f16 pair).  The conv multiplies Wh * hi on the f16 MFMA and forms the two correction products
 // Wh * lo + Wl * hi on the block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, twice the f16 rate) from OCP e4m3 copies

@@ -533,6 +533,198 @@ __global__ void pool2_max_bwd_kernel(const char* __restrict__ dp, const char* __
   }
 }
 
+// ---------------------------------------------------------------- data gradient without the padded-domain detour: the shell terms
+// The adjoint of y = conv_valid(reflect_pad(x)) is dx = P^T g with g = the zero-padded correlation of dy with the flipped, transposed
+// weights on [-1, n]^3 and P^T the fold dx[1] += g[-1], dx[n-2] += g[n] per axis.  Computing g on the zero-FRAMED (n+4)^3 domain and
+// folding it afterwards (pad_fold above) costs, for the level-0 layers of a two-view step, a 132^3 convolution whose 170 tiles run as
+// two rounds (97 us against 64 us for the 128^3 forward) plus a 70 us fold pass.  Instead:
+//   * g on the INTERIOR [0, n)^3 is an ordinary launch of the forward kernel that reads its halo from the zero frame instead of
+//     reflecting (ConvParams::raw_halo) -- the forward's tiles, the forward's time -- written straight into dx;
+//   * the SHELL values only ever reach the voxels with a coordinate equal to 1 or n-2, and a shell value has few taps (dy is zero
+//     outside the volume).  Per destination m and shell source s (m with one or more coordinates 1 -> -1, n-2 -> n):
+//         dx[m][ci] += sum over taps t with s - t inside the volume, over co, of  w[co][ci][t] dy[s - t][co]      (w: the FORWARD weights)
+//     A pure face voxel (one such coordinate) has one source with one tap along its axis -- a 3x3 correlation of the dy face plane --
+//     the rim voxels of the six near-face planes (edges / corners of the inner box) up to 7 sources of 9, 3 or 1 taps.  All of it runs
+//     on the MFMA in dgrad_shell_kernel: a wave owns a tile of 16 voxels of one plane x 16 (32) channels, K = 2 taps x 16 or 1 tap x 32
+//     channels per step, the B fragment is one 16-byte global load per lane (no LDS), the A fragments of the plane's own face source
+//     stay in registers, those of the rare other sources are gathered from the fp32 weights when a tile needs them.  (A VALU version of
+//     the shell took 65 us per 16 -> 16 layer at 128^3 x 2 -- 12 M wave instructions for 0.9 GFLOP; rim voxels as chains of dependent
+//     gathers another 38 us.)
+//   Every destination is owned by exactly one lane (a voxel belongs to the FIRST of the six planes that contains it), sums in
+//   fp32, one read-modify-write of the 16-bit dx: deterministic, no atomics.
+// dy: interior view of the framed gradient (byte strides); w fp32 [co_real][ci_real][27]; dx dense [N][D][H][W][CDX] 16-bit.
+// Shell sources are numbered in ABSOLUTE axes, combo = 9 oz + 3 oy + ox in 1 .. 26 (per axis 0 keep: taps -1, 0, +1; 1 low: the source
+// sits at -1 and only tap -1 reaches the volume; 2 high: only tap +1); tap k of a source enumerates the kept axes' taps, x fastest.
+// Its MFMA A fragments -- rows = output channels, K = TPS taps x CDY channels per step -- live in one table per layer,
+// [step][m tile][lane][8], built by dgrad_shell_pack_kernel (gathering them from the fp32 [co][ci][27] weights inside the main kernel
+// cost 8 strided loads per lane and step: 80 us for a 16 -> 16 layer).
+__host__ __device__ constexpr int shell_ntap(int combo) { return (combo / 9 ? 1 : 3) * ((combo / 3) % 3 ? 1 : 3) * (combo % 3 ? 1 : 3); }
+__host__ __device__ constexpr int shell_steps(int combo, int tps) { return (shell_ntap(combo) + tps - 1) / tps; }
+__host__ __device__ constexpr int shell_base(int combo, int tps) {      // steps of the combos before this one
+  int b = 0;
+  for (int c = 1; c < combo; ++c) b += shell_steps(c, tps);
+  return b;
+}
+__host__ __device__ inline int shell_tap(int combo, int k) {            // -> (tz << 8) | (ty << 4) | tx, each in 0 .. 2
+  const int oz = combo / 9, oy = (combo / 3) % 3, ox = combo % 3;
+  const int cx = ox ? 1 : 3, cy = oy ? 1 : 3;
+  const int ix = k % cx, iy = (k / cx) % cy, iz = k / (cx * cy);
+  return ((oz == 0 ? iz : (oz == 1 ? 0 : 2)) << 8) | ((oy == 0 ? iy : (oy == 1 ? 0 : 2)) << 4) | (ox == 0 ? ix : (ox == 1 ? 0 : 2));
+}
+
+template <typename T, int CDY, int CDX>
+__global__ __launch_bounds__(64) void dgrad_shell_pack_kernel(const float* __restrict__ w, int co_real, int ci_real, T* __restrict__ tab) {
+  constexpr int TPS = 32 / CDY, MT = CDX / 16;
+  const int step = blockIdx.x / MT, mt = blockIdx.x % MT;
+  int combo = 1, base = 0;
+  while (combo < 26 && base + shell_steps(combo, TPS) <= step) base += shell_steps(combo++, TPS);
+  const int j = step - base, lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const int k = TPS == 2 ? 2 * j + (g >> 1) : j, ntap = shell_ntap(combo);
+  const int co0 = TPS == 2 ? (g & 1) * 8 : g * 8, ci = mt * 16 + li;
+  const int tp = shell_tap(combo, k < ntap ? k : 0);
+  const int tap = ((tp >> 8) * 3 + ((tp >> 4) & 15)) * 3 + (tp & 15);
+  T* o = tab + ((long long)blockIdx.x * 64 + lane) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int co = co0 + e;
+    o[e] = (T)((k < ntap && co < co_real && ci < ci_real) ? w[((long long)co * ci_real + ci) * 27 + tap] : 0.f);
+  }
+}
+
+template <typename T, int CDY, int CDX>
+__global__ __launch_bounds__(256) void dgrad_shell_kernel(const char* __restrict__ dy, long long yn, long long yz, long long yy, long long yx,
+                                                          const T* __restrict__ tab, char* __restrict__ dx, int D, int H, int W) {
+  typedef typename Ops<T>::vec8 vec8;
+  constexpr int TPS = 32 / CDY;                       // taps per MFMA step: K = 32 = TPS taps x CDY channels
+  constexpr int NSTEP = (9 + TPS - 1) / TPS;          // steps of a nine-tap source
+  constexpr int MT = CDX / 16;
+  // grid: x = chunks of the plane's 16-voxel tiles, y = near-face plane (axis a = y >> 1, coordinate 1 or n_a - 2), z = sample.
+  // A voxel is owned by the FIRST plane of that order containing it.
+  const int pl = blockIdx.y, a = pl >> 1, side = pl & 1, n = blockIdx.z;
+  const int dims[3] = {D, H, W};
+  const int b0 = a == 0 ? 1 : 0, b1 = a == 2 ? 1 : 2;
+  const int n0 = dims[b0], n1 = dims[b1], na = dims[a];
+  const int ma = side ? na - 2 : 1;
+  if (ma < 0 || ma >= na || (side && na - 2 == 1)) return;       // (n_a = 3: both sides are the same plane, visited once)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int co0 = TPS == 2 ? (g & 1) * 8 : g * 8;
+  const long long ystr[3] = {yz, yy, yx};
+  const long long dstr[3] = {(long long)H * W * CDX * 2, (long long)W * CDX * 2, (long long)CDX * 2};
+  const vec8* ftab = (const vec8*)tab + lane;
+  auto combo_of = [&](int oa, int o0, int o1) {
+    int o3[3];
+    o3[a] = oa; o3[b0] = o0; o3[b1] = o1;
+    return o3[0] * 9 + o3[1] * 3 + o3[2];
+  };
+  // the plane's own face source (s_a = -1 or n_a, the other axes kept): the only source of all but its rim voxels -- kept in registers
+  const int oa_face = side ? 2 : 1;
+  const int face_combo = combo_of(oa_face, 0, 0), face_base = shell_base(face_combo, TPS);
+  vec8 fa_face[NSTEP][MT];
+#pragma unroll
+  for (int j = 0; j < NSTEP; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fa_face[j][mt] = ftab[((face_base + j) * MT + mt) * 64];
+
+  const int tpr = (n1 + 15) >> 4, ntile = n0 * tpr;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+    const int m0 = tile / tpr, m1 = (tile - m0 * tpr) * 16 + li;
+    int m[3];
+    m[a] = ma; m[b0] = m0; m[b1] = m1;
+    bool own = m1 < n1;
+    for (int q = 0; q < pl; ++q) own &= !(m[q >> 1] == ((q & 1) ? dims[q >> 1] - 2 : 1));   // an earlier plane owns it
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the destination's current value is requested now, next to the fragments (a tile is two memory round trips otherwise)
+    char* d = dx + (((long long)n * D * H * W) * CDX * 2) + ma * dstr[a] + m0 * dstr[b0] + (own ? m1 : 0) * dstr[b1] + g * 8;   // channels 4 g .. 4 g + 3
+    uint2 oldv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) oldv[mt] = own ? *(const uint2*)(d + mt * 32) : make_uint2(0, 0);
+    // every shell source: per axis keep / low (m == 1) / high (m == n - 2), not all three "keep"
+    for (int oa = 0; oa < 3; ++oa) {
+      if ((oa == 1 && ma != 1) || (oa == 2 && ma != na - 2)) continue;
+      for (int o0 = 0; o0 < 3; ++o0) {
+        if ((o0 == 1 && m0 != 1) || (o0 == 2 && m0 != n0 - 2)) continue;
+        for (int o1 = 0; o1 < 3; ++o1) {
+          if (oa == 0 && o0 == 0 && o1 == 0) continue;
+          const bool lv = own && (o1 == 0 || (o1 == 1 ? m1 == 1 : m1 == n1 - 2));
+          if (!__any(lv)) continue;                            // wave-uniform
+          const int combo = combo_of(oa, o0, o1), ntap = shell_ntap(combo);
+          const int sa = oa == 0 ? ma : (oa == 1 ? -1 : na), s0 = o0 == 0 ? m0 : (o0 == 1 ? -1 : n0), s1 = o1 == 0 ? m1 : (o1 == 1 ? -1 : n1);
+          const bool face = combo == face_combo;
+          const int nstep = (ntap + TPS - 1) / TPS, base = face ? 0 : shell_base(combo, TPS);
+          // all of the source's fragments are requested before the first MFMA (a load -> MFMA chain per step made every tile a
+          // string of memory latencies)
+          vec8 fbs[NSTEP], fas[NSTEP][MT];
+#pragma unroll
+          for (int j = 0; j < NSTEP; ++j) {
+            const int k = TPS == 2 ? 2 * j + (g >> 1) : j;
+            const int tp = shell_tap(combo, k < ntap ? k : 0);
+            const int t3[3] = {tp >> 8, (tp >> 4) & 15, tp & 15};
+            const int qa = sa - (t3[a] - 1), q0 = s0 - (t3[b0] - 1), q1 = s1 - (t3[b1] - 1);
+            const bool ok = lv && j < nstep && k < ntap && qa >= 0 && qa < na && q0 >= 0 && q0 < n0 && q1 >= 0 && q1 < n1;
+            const char* src = dy + (long long)n * yn + (ok ? qa : 0) * ystr[a] + (ok ? q0 : 0) * ystr[b0] + (ok ? q1 : 0) * ystr[b1] + co0 * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fbs[j][e] = (T)0.f;
+            if (ok) fbs[j] = *(const vec8*)src;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fas[j][mt] = face ? fa_face[j][mt] : ftab[((base + (j < nstep ? j : 0)) * MT + mt) * 64];
+          }
+#pragma unroll
+          for (int j = 0; j < NSTEP; ++j) {          // (steps past the source's last one multiply zero B fragments)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = Ops<T>::mfma(fas[j][mt], fbs[j], acc[mt]);
+          }
+        }
+      }
+    }
+    if (!own) continue;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      uint2* p2 = (uint2*)(d + mt * 32);
+      const uint2 old = oldv[mt];
+      const float a0 = (float)__builtin_bit_cast(T, (unsigned short)(old.x & 0xffff)) + acc[mt][0];
+      const float a1 = (float)__builtin_bit_cast(T, (unsigned short)(old.x >> 16)) + acc[mt][1];
+      const float a2 = (float)__builtin_bit_cast(T, (unsigned short)(old.y & 0xffff)) + acc[mt][2];
+      const float a3 = (float)__builtin_bit_cast(T, (unsigned short)(old.y >> 16)) + acc[mt][3];
+      *p2 = make_uint2((unsigned)to_bits<T>(a0) | ((unsigned)to_bits<T>(a1) << 16), (unsigned)to_bits<T>(a2) | ((unsigned)to_bits<T>(a3) << 16));
+    }
+  }
+}
+
+size_t dgrad_shell_scratch_bytes() { return (size_t)shell_base(27, 1) * 2 * 1024; }     // the largest fragment table (one tap per step, two m tiles)
+
+hipError_t launch_dgrad_fold_shell(const void* dy, long long yn, long long yz, long long yy, long long yx, int cdy, const float* w,
+                                   int co_real, int ci_real, void* dx, int cdx, int N, int D, int H, int W, int precision, void* scratch,
+                                   hipStream_t st) {
+  if ((cdy != 16 && cdy != 32) || (cdx != 16 && cdx != 32) || precision > 1 || !scratch) return hipErrorInvalidValue;
+  long long mx = (long long)H * W;
+  if ((long long)D * W > mx) mx = (long long)D * W;
+  if ((long long)D * H > mx) mx = (long long)D * H;
+  long long bx = ((mx + 15) / 16 + 3) / 4;                   // four waves per block, ONE 16-voxel tile per wave: a tile is a latency chain
+  if (bx < 1) bx = 1;                                        // (fragments + old value -> MFMAs -> store), so they all go in flight at once
+  if (bx > 1024) bx = 1024;
+  const dim3 gf((unsigned)bx, 6, (unsigned)N);
+  const int nsteps = shell_base(27, 32 / cdy), mt = cdx / 16;
+#define AMX_SHELL(T, CDY, CDX)                                                                                                \
+  {                                                                                                                           \
+    hipLaunchKernelGGL((dgrad_shell_pack_kernel<T, CDY, CDX>), dim3(nsteps * mt), dim3(64), 0, st, w, co_real, ci_real, (T*)scratch);        \
+    hipLaunchKernelGGL((dgrad_shell_kernel<T, CDY, CDX>), gf, dim3(256), 0, st, (const char*)dy, yn, yz, yy, yx, (const T*)scratch, (char*)dx, \
+                       D, H, W);                                                                                              \
+  }
+#define AMX_SHELL_T(T)                                                                                                        \
+  {                                                                                                                           \
+    if (cdy == 16 && cdx == 16) AMX_SHELL(T, 16, 16)                                                                          \
+    else if (cdy == 16) AMX_SHELL(T, 16, 32)                                                                                  \
+    else if (cdx == 16) AMX_SHELL(T, 32, 16)                                                                                  \
+    else AMX_SHELL(T, 32, 32)                                                                                                 \
+  }
+  if (precision == 0) AMX_SHELL_T(f16) else AMX_SHELL_T(bf16)
+#undef AMX_SHELL_T
+#undef AMX_SHELL
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------- launchers
 size_t train_scratch_bytes(int C) { return ((size_t)65536 * 2 + (size_t)C * 2) * sizeof(float); }
 

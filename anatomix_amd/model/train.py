@@ -30,6 +30,7 @@ OVERLAP_WGRAD = os.environ.get("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight gr
 RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
 SPLIT_CONCAT_DGRAD = int(os.environ.get("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
+DIRECT_DGRAD = os.environ.get("AMX_NO_DIRECT_DGRAD", "0") != "1"   # data gradient: interior launch + shell terms instead of the framed domain + pad_fold
 BATCH_PACK = os.environ.get("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
 _SIDE = {}
 
@@ -456,10 +457,18 @@ class _UnetTrainFn(torch.autograd.Function):
                 # generic kernel takes as one launch (415 us at 128^3 x 2 views); as a 16 -> 16 (skip channels) and a 16 -> 32
                 # (upsampled channels) launch both halves run on the z-marching kernels, and the halves feed different consumers anyway
                 w = conv.weight.detach()
-                g_skip = T.conv_dgrad_framed(fr, w[:, :c0].contiguous())
+                w_skip = w[:, :c0].contiguous()
                 g_up = T.conv_dgrad_framed(fr, w[:, c0:].contiguous())
-                grads[blk["in0"]] = T.pad_fold(g_skip, grads.get(blk["in0"]))
+                if DIRECT_DGRAD and T.dgrad_direct_supported(fr, w_skip):
+                    add_grad(blk["in0"], T.conv_dgrad_direct(fr, w_skip))
+                else:
+                    grads[blk["in0"]] = T.pad_fold(T.conv_dgrad_framed(fr, w_skip), grads.get(blk["in0"]))
                 add_grad(blk["in1"], T.upcat_split_backward_framed(g_up, 0, x1.shape[-1])[1])
+                continue
+            if x1 is None and blk.get("cat_parts") is None and DIRECT_DGRAD and T.dgrad_direct_supported(fr, conv.weight):
+                # the forward kernel on the interior of the framed gradient + the folded shell terms: no (n + 4)^3 domain, no fold pass
+                g = T.conv_dgrad_direct(fr, conv.weight, wpk=bpacked(idx, fr.shape[-1], fr.shape[3] - 4))
+                add_grad(blk["in0"], g[..., : x0.shape[-1]] if g.shape[-1] != x0.shape[-1] else g)
                 continue
             g_fr = T.conv_dgrad_framed(fr, conv.weight, wpk=bpacked(idx, fr.shape[-1], fr.shape[3]))
             if (x1 is not None and blk.get("cat_parts") is None and g_fr.shape[-1] == c0 + x1.shape[-1] and c0 % 8 == 0

@@ -173,6 +173,44 @@ def conv_dgrad_framed(dx_framed, weight, wpk=None):
     return conv_forward(dx_framed, None, weight, weight_mode=1, wpk=wpk)
 
 
+def dgrad_direct_supported(dx_framed, weight):
+    """True when ``conv_dgrad_direct`` covers this block (the shapes of the z-march kernels, plain 16-bit storage)."""
+    lib = _lib.load()
+    n, df, hf, wf, c = dx_framed.shape
+    cout = (weight.shape[1] + 15) // 16 * 16
+    return bool(lib.amx_conv3d_dgrad_interior_supported(c, cout, df - 4, hf - 4, wf - 4, _PREC[dx_framed.dtype]))
+
+
+def conv_dgrad_direct(dx_framed, weight, wpk=None):
+    """The data gradient [N, D, H, W, Cin_pad16] of the conv whose forward weight is ``weight`` from the zero-framed output gradient, WITHOUT
+    computing it on the padded domain: the forward kernel on the interior (halo read from the frame) + the folded shell terms.
+    Equals ``pad_fold(conv_dgrad_framed(dx_framed, weight))`` up to the rounding of 16-bit intermediates."""
+    lib = _lib.load()
+    dev = dx_framed.device
+    n, df, hf, wf, c = dx_framed.shape
+    d, h, w = df - 4, hf - 4, wf - 4
+    wt = _as_weight(weight)
+    co_f, ci_f = wt.shape[0], wt.shape[1]
+    cout = (ci_f + 15) // 16 * 16
+    out = torch.empty((n, d, h, w, cout), dtype=dx_framed.dtype, device=dev)
+    with torch.cuda.device(dev):
+        nb = lib.amx_conv3d_packed_bytes(c, cout)
+        flags = 0
+        if wpk is not None:
+            assert wpk.numel() >= nb
+            flags = _lib.WEIGHTS_PREPACKED
+        else:
+            wpk = _cached(("wpk", dev, nb), lambda: torch.empty(nb, dtype=torch.uint8, device=dev))
+        prec = _PREC[dx_framed.dtype]
+        _lib.check(lib.amx_conv3d_dgrad_interior(_lib.ptr(dx_framed), c, _lib.ptr(wt), flags, co_f, ci_f, cout, n, d, h, w, prec,
+                                                 _lib.ptr(wpk), _lib.ptr(out), _st(dev)))
+        # (one fragment table per call site would be needed if calls of DIFFERENT layers could overlap: they are stream-ordered)
+        tab = _cached(("shell_tab", dev), lambda: torch.empty(lib.amx_conv3d_dgrad_shell_scratch_bytes(), dtype=torch.uint8, device=dev))
+        _lib.check(lib.amx_conv3d_dgrad_fold_shell(_lib.ptr(dx_framed), c, _lib.ptr(wt), co_f, ci_f, _lib.ptr(out), cout, n, d, h, w, prec,
+                                                   _lib.ptr(tab), _st(dev)))
+    return out
+
+
 def pad_fold(g, accumulate_into=None):
     """Second half: the reflect-padding adjoint, [N, D+4, H+4, W+4, C] -> [N, D, H, W, C]."""
     lib = _lib.load()

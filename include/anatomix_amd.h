@@ -242,6 +242,21 @@ typedef struct amx_pack_req {
 } amx_pack_req;
 int amx_conv3d_pack_batch(const amx_pack_req* reqs, int count, int precision, void* stream);
 
+/* Data gradient of the reflect-padded conv WITHOUT the padded-domain detour (amx_train.hip): d_dy_framed is the zero-framed output
+ * gradient [n][d+4][hh+4][w+4][c_dy] (the buffer amx_bn_act_backward writes); amx_conv3d_dgrad_interior runs the forward kernel on its
+ * interior with the halo read from the frame (the zero-padded correlation with the flipped, transposed FORWARD weights d_weight
+ * fp32 [cin_real = forward Cout][cout_real = forward Cin][27]; weight_flags 0 or AMX_WEIGHTS_PREPACKED with a weight_mode-1 packing)
+ * into the dense 16-bit d_out16 [n][d][hh][w][cout]; amx_conv3d_dgrad_fold_shell then adds the folded shell terms of the reflect
+ * adjoint to the voxels with a coordinate 1 or size - 2.  Together = amx_conv3d_k3_reflect_ex(weight_mode 1) on the framed domain
+ * followed by amx_pad_fold.  Shapes: what the z-march kernels take (16 / 32 channels in, 16 / 32 out, not 32 -> 16, w >= 32, d, hh >= 8):
+ * amx_conv3d_dgrad_interior_supported returns 1. */
+int amx_conv3d_dgrad_interior_supported(int c_dy, int cout, int d, int hh, int w, int precision);
+int amx_conv3d_dgrad_interior(const void* d_dy_framed, int c_dy, const float* d_weight, int weight_flags, int cin_real, int cout_real, int cout,
+                              int n, int d, int hh, int w, int precision, void* d_wpk, void* d_out16, void* stream);
+size_t amx_conv3d_dgrad_shell_scratch_bytes(void);     /* d_scratch of amx_conv3d_dgrad_fold_shell: the shell sources' MFMA fragment table */
+int amx_conv3d_dgrad_fold_shell(const void* d_dy_framed, int c_dy, const float* d_weight, int co_real, int ci_real, void* d_dx, int c_dx, int n,
+                                int d, int hh, int w, int precision, void* d_scratch, void* stream);
+
 /* nn.MaxPool3d(2) / nn.AvgPool3d(2) on a 16-bit NDHWC tensor (network.py:297,368). */
 int amx_pool2(const void* d_in, void* d_out, int n, int d_out_, int h_out, int w_out, int c, int avg,
               int precision, void* stream);

@@ -247,3 +247,44 @@ def _fold64(gd, d, h, w):
         core.narrow(ax, L - 2, 1).add_(out.narrow(ax, L + 2, 1))
         out = core
     return out
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,size", [(16, 16, (8, 8, 32)), (16, 16, (16, 24, 64)), (32, 32, (8, 12, 32)), (16, 32, (8, 8, 40)),
+                                           (16, 16, (9, 10, 35)), (32, 16, (8, 8, 32))])
+def test_direct_data_gradient_equals_the_framed_route(device, prec, cin, cout, size):
+    """conv_dgrad_direct = the forward kernel on the interior of the zero-framed gradient (halo read from the frame) + the folded shell
+    terms of the reflect adjoint, against (a) autograd of the fp64 reflect-padded conv on the same rounded operands and (b) the
+    framed-domain route (conv on (n+4)^3 + pad_fold) it replaces.  Shapes: every z-march class (16 -> 16, 32 -> 32, and the two halves
+    of the split concat gradient), partial tiles, and one the direct route does not take (asks ``dgrad_direct_supported``)."""
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(7)
+    n = 2
+    x = torch.randn(n, cin, *size, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    dy = torch.randn(n, cout, *size, generator=g)
+    xq, dyq, wq = x.to(dt).double().requires_grad_(True), dy.to(dt).double(), w.to(dt).double()
+    F.conv3d(F.pad(xq, (1,) * 6, mode="reflect"), wq).backward(dyq)
+    framed = T.new_framed(n, *size, cout, dt, device)
+    T.interior(framed).copy_(cl(dy, dt, device))
+    wd = w.to(device)
+    ok = T.dgrad_direct_supported(framed, wd)
+    assert ok == (cin in (16, 32) and cout in (16, 32) and not (cout == 32 and cin == 16) and size[2] >= 32 and size[0] >= 8 and size[1] >= 8)
+    if not ok:
+        return
+    old = T.pad_fold(T.conv_dgrad_framed(framed, wd))
+    new = T.conv_dgrad_direct(framed, wd)
+    assert new.shape == old.shape
+    assert not framed[:, :2].any() and not framed[:, -2:].any() and not framed[:, :, :2].any() and not framed[..., :2, :].any()
+    e_new, e_old = rel_l2(ncdhw(new)[:, :cin], xq.grad), rel_l2(ncdhw(old)[:, :cin], xq.grad)
+    assert e_new < 2 * ULP[prec], (e_new, e_old)
+    # the near-face voxels are where the two routes differ in arithmetic: check them on their own
+    face = torch.zeros(size, dtype=torch.bool)
+    for a, s in enumerate(size):
+        idx = [slice(None)] * 3
+        for v in (1, s - 2):
+            idx[a] = v
+            face[tuple(idx)] = True
+    ref = xq.grad[:, :, face]
+    assert rel_l2(ncdhw(new)[:, :cin][:, :, face], ref) < 3 * ULP[prec]
+    assert torch.equal(T.conv_dgrad_direct(framed, wd), new)          # deterministic
