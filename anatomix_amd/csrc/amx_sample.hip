@@ -26,8 +26,18 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
     const int i = i0 + k;
     if (i >= n) break;
     const long long mine = v[i];
+    // (one value per iteration was a chain of dependent LDS round trips: 25 us for 1024 draws; eight independent broadcast reads
+    //  per iteration are paced by the LDS pipe instead)
     bool dup = false;
-    for (int j = 0; j < i; ++j) dup |= (v[j] == mine);
+    int j = 0;
+    for (; j + 8 <= i; j += 8) {
+      long long t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = v[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dup |= (t[u] == mine);
+    }
+    for (; j < i; ++j) dup |= (v[j] == mine);
     if (!dup) {
       keep_mask |= 1 << k;
       ++cnt;

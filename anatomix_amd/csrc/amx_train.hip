@@ -566,11 +566,23 @@ __host__ __device__ constexpr int shell_base(int combo, int tps) {      // steps
   return b;
 }
 __host__ __device__ inline int shell_tap(int combo, int k) {            // -> (tz << 8) | (ty << 4) | tx, each in 0 .. 2
+  // divisions by the constant 3 only: with run-time divisors (1 or 3 taps per axis) the three divisions per step were most of the
+  // shell kernel's VALU work
   const int oz = combo / 9, oy = (combo / 3) % 3, ox = combo % 3;
-  const int cx = ox ? 1 : 3, cy = oy ? 1 : 3;
-  const int ix = k % cx, iy = (k / cx) % cy, iz = k / (cx * cy);
+  const int k3 = k / 3;
+  const int ix = ox ? 0 : k - 3 * k3, k1 = ox ? k : k3;
+  const int k13 = k1 / 3;
+  const int iy = oy ? 0 : k1 - 3 * k13, iz = oy ? k1 : k13;
   return ((oz == 0 ? iz : (oz == 1 ? 0 : 2)) << 8) | ((oy == 0 ? iy : (oy == 1 ? 0 : 2)) << 4) | (ox == 0 ? ix : (ox == 1 ? 0 : 2));
 }
+struct ShellBaseTab {                      // shell_base for both step widths, built at compile time
+  unsigned char v[2][28];
+  constexpr ShellBaseTab() : v() {
+    for (int t = 0; t < 2; ++t)
+      for (int c = 0; c < 28; ++c) v[t][c] = (unsigned char)shell_base(c, t + 1);
+  }
+};
+__device__ constexpr ShellBaseTab kShellBase{};
 
 template <typename T, int CDY, int CDX>
 __global__ __launch_bounds__(64) void dgrad_shell_pack_kernel(const float* __restrict__ w, int co_real, int ci_real, T* __restrict__ tab) {
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(256) void dgrad_shell_kernel(const char* __restrict
   };
   // the plane's own face source (s_a = -1 or n_a, the other axes kept): the only source of all but its rim voxels -- kept in registers
   const int oa_face = side ? 2 : 1;
-  const int face_combo = combo_of(oa_face, 0, 0), face_base = shell_base(face_combo, TPS);
+  const int face_combo = combo_of(oa_face, 0, 0), face_base = kShellBase.v[TPS - 1][face_combo];
   vec8 fa_face[NSTEP][MT];
 #pragma unroll
   for (int j = 0; j < NSTEP; ++j)
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(256) void dgrad_shell_kernel(const char* __restrict
           const int combo = combo_of(oa, o0, o1), ntap = shell_ntap(combo);
           const int sa = oa == 0 ? ma : (oa == 1 ? -1 : na), s0 = o0 == 0 ? m0 : (o0 == 1 ? -1 : n0), s1 = o1 == 0 ? m1 : (o1 == 1 ? -1 : n1);
           const bool face = combo == face_combo;
-          const int nstep = (ntap + TPS - 1) / TPS, base = face ? 0 : shell_base(combo, TPS);
+          const int nstep = (ntap + TPS - 1) / TPS, base = kShellBase.v[TPS - 1][combo];
           // all of the source's fragments are requested before the first MFMA (a load -> MFMA chain per step made every tile a
           // string of memory latencies)
           vec8 fbs[NSTEP], fas[NSTEP][MT];

@@ -75,3 +75,8 @@ for k in queues[mainq]:
 print("main queue by kernel:")
 for n, t in agg.most_common(25):
     print(f"  {t / 1e3:8.1f} us  {n}")
+# full ordered listing of the last step (offset us, duration us, queue, kernel) beside the summary
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as f:
+        for k in ev:
+            f.write(f"{(k[0] - t0) / 1e3:9.1f} {(k[1] - k[0]) / 1e3:8.1f} q{k[3]:>3s} {short(k[2])}\n")
