@@ -10,9 +10,9 @@ The UNet inside the step runs forward and backward on the HIP kernels (anatomix_
 """
 from .supcon import SupPatchNCELoss
 from .patch_sample import PatchSampleF
-from .step import contrastive_step, GraphedContrastiveStep
+from .step import contrastive_step, GraphedContrastiveStep, StepRecord
 from .data_parallel import GradientBuckets
 from .optim import FusedAdamW
 from .data import H5SupCLDataset, random_crop
 
-__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep", "GradientBuckets", "FusedAdamW", "H5SupCLDataset", "random_crop"]
+__all__ = ["SupPatchNCELoss", "PatchSampleF", "contrastive_step", "GraphedContrastiveStep", "StepRecord", "GradientBuckets", "FusedAdamW", "H5SupCLDataset", "random_crop"]

@@ -1,9 +1,11 @@
 """One contrastive-pretraining step: the per-batch body of the reference's SupCLModel
 (forward supcl_model.py:723-770, calculate_NCE_loss 801-843, optimize_parameters 603-661)."""
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import contextlib
 import gc
+import weakref
 import os
 
 import torch
@@ -189,6 +191,43 @@ def contrastive_step(netG, netF, criterions, real_A, real_B, seg_A, nce_layers, 
                        out=out.detach() if torch.is_tensor(out) else out)
 
 
+class StepRecord(Mapping):
+    """The record of one replayed step whose SCALARS (loss, per-layer losses, gradient norms) are read from the device on first use.
+    ``GraphedContrastiveStep(lazy_scalars=True)`` enqueues a non-blocking copy of the step's scalar vector into pinned host memory and
+    returns this mapping at once, so the host can enqueue the next step while this one still runs -- the reference reads every scalar
+    with ``.item()`` as it goes (supcl_model.py:841), which idles the device between steps for as long as the host needs to come back
+    (~0.2 ms of an 8 ms step here).  Reading ``rec["loss"]`` / ``["per_layer"]`` / ``["grad_norm_G"]`` / ``["grad_norm_F"]`` waits for
+    that step only; ``["out"]`` and ``["sample_ids"]`` are device tensors of the step's static buffers (valid until the next replay)."""
+    _KEYS = ("loss", "per_layer", "grad_norm_G", "grad_norm_F", "sample_ids", "out")
+
+    def __init__(self, host, event, layers, sample_ids, out):
+        self._host, self._event, self._layers, self._vals = host, event, layers, None
+        self._fixed = {"sample_ids": sample_ids, "out": out}
+
+    def resolve(self):
+        if self._vals is None:
+            self._event.synchronize()
+            self._vals = self._host.tolist()                # the pinned slot is reused by a later step: keep the numbers, not the buffer
+            self._host = None
+        return self._vals
+
+    def __getitem__(self, key):
+        if key in self._fixed:
+            return self._fixed[key]
+        if key not in self._KEYS:
+            raise KeyError(key)
+        v = self.resolve()
+        if key == "per_layer":
+            return OrderedDict((str(layer), x) for layer, x in zip(self._layers, v[3:]))
+        return v[{"loss": 0, "grad_norm_G": 1, "grad_norm_F": 2}[key]]
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+
 class GraphedContrastiveStep:
     """``contrastive_step`` captured once in a HIP graph and replayed: the step is ~700 kernel launches, most of them a few
     microseconds long; replaying them from one graph removes the launch gaps between them (16.3 -> 13.4 ms per step at 128^3
@@ -206,8 +245,9 @@ class GraphedContrastiveStep:
     AccumulateGrad nodes would run there, outside the capture.  ``contrastive_step`` returns detached records for that reason."""
 
     def __init__(self, netG, netF, criterions, nce_layers, optimizers, nce_weights=None, num_patches=512, lambda_nce=1.0,
-                 grad_sync=None, warmup=3, grad_buckets=None, tail_graph=True):
+                 grad_sync=None, warmup=3, grad_buckets=None, tail_graph=True, lazy_scalars=False):
         self.netG, self.netF, self.criterions, self.nce_layers = netG, netF, criterions, list(nce_layers)
+        self.lazy_scalars, self._slots, self._slot_owner, self._slot_next = bool(lazy_scalars), None, None, 0
         self.optimizers, self.nce_weights, self.num_patches, self.lambda_nce = optimizers, nce_weights, num_patches, lambda_nce
         self.grad_buckets = grad_buckets
         if grad_buckets is not None and getattr(grad_buckets, "overlap", False):
@@ -315,6 +355,22 @@ class GraphedContrastiveStep:
                 scalars = self.tail_scalars
             else:
                 scalars = self._tail(self.total, self.layer_losses)
+        if self.lazy_scalars and scalars.is_cuda:
+            # a ring of pinned slots; a slot about to be reused first hands its numbers to the record that still owns it
+            if self._slots is None:
+                self._slots = [torch.empty(scalars.shape, dtype=scalars.dtype).pin_memory() for _ in range(8)]
+                self._slot_owner = [None] * len(self._slots)
+            k = self._slot_next
+            self._slot_next = (k + 1) % len(self._slots)
+            owner = self._slot_owner[k]() if self._slot_owner[k] is not None else None
+            if owner is not None:
+                owner.resolve()
+            self._slots[k].copy_(scalars, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(scalars.device))
+            rec = StepRecord(self._slots[k], ev, self.nce_layers, self.ids, self.out)
+            self._slot_owner[k] = weakref.ref(rec)
+            return rec
         vals = scalars.tolist()
         per_layer = OrderedDict((str(layer), v) for layer, v in zip(self.nce_layers, vals[3:]))
         return OrderedDict(loss=vals[0], per_layer=per_layer, grad_norm_G=vals[1], grad_norm_F=vals[2], sample_ids=self.ids,

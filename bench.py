@@ -561,8 +561,17 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
             # the whole step replayed from a HIP graph (1 GPU: optimizers included; data parallel: forward + backward in the
             # graph, then the RCCL all-reduces of the buckets, gradient norms and AdamW)
             from anatomix_amd.pretraining import GraphedContrastiveStep
-            graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512, grad_buckets=buckets)
-            step = lambda: graphed(vA, vB, seg)["out"]
+            # AMX_LAZY_SCALARS=1 (A/B): the step's loss / norm scalars go to pinned host memory by a non-blocking copy and are read when
+            # someone looks at them, so the host enqueues step k + 1 while step k runs.  Measured SLOWER on MI355X (8.43-8.74 against
+            # 8.23-8.28 ms per step, three alternations on one box): replays queued behind a running replay of the same graph cost more
+            # than the ~0.15 ms host gap they remove, so the bench reads the scalars every step like the reference does.
+            graphed = GraphedContrastiveStep(model, netF, crits, PI.NCE_LAYERS, opts, num_patches=512, grad_buckets=buckets,
+                                             lazy_scalars=os.environ.get("AMX_LAZY_SCALARS", "0") == "1")
+            last_record = {}
+
+            def step():
+                last_record["r"] = graphed(vA, vB, seg)
+                return last_record["r"]["out"]
         units_per_step = world * 2
         grad_ctx = torch.enable_grad()
     if sw_volume:
@@ -603,6 +612,9 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
     ms_step = elapsed / steps * 1e3
     value = units_per_step * steps / elapsed
     assert torch.isfinite(y).all()
+    if workload == "step" and not no_graph:
+        import math
+        assert math.isfinite(last_record["r"]["loss"]), "non-finite loss in the last timed step"
     sustained = None
     if sustain_s > 0 and world == 1:
         sustained = sustained_run(torch, dev, step, grad_ctx, units_per_step, ms_step, sustain_s)
@@ -636,7 +648,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         elif workload == "step":
             workload_s = (f"{name}: contrastive pretraining step, one pair of views of a {S}^3 volume per GPU (taps "
                           "27,31,38,45,52,65; 512 patches per layer; MLP heads; six SupCon losses; backward; " +
-                          ("torch.optim.AdamW" if os.environ.get("AMX_TORCH_ADAMW", "0") == "1" else "AdamW as one launch per optimizer") + "), bf16 "
+                          ("torch.optim.AdamW" if os.environ.get("AMX_TORCH_ADAMW", "0") == "1" else "AdamW as one launch per optimizer") +
+                          ("; loss / norm scalars copied to pinned host memory every step, read by the host on demand" if not no_graph and os.environ.get("AMX_LAZY_SCALARS", "0") == "1" else "") + "), bf16 "
                           "storage, every UNet conv / BatchNorm / pool forward and backward on the HIP kernels" +
                           ("" if no_graph else ", replayed from HIP graphs") + " (BASELINE configs[2])")
             par = f"data parallel x{world}: one pair per rank" + dp_note

@@ -109,6 +109,45 @@ def _head(cin, width, n_mlps, act, seed):
     return m
 
 
+@pytest.mark.gpu
+def test_lazy_step_records_hold_the_numbers_of_the_blocking_ones():
+    """GraphedContrastiveStep(lazy_scalars=True) returns at once and reads the scalars on first use: twelve replays enqueued without a
+    host synchronisation in between (more than the ring of pinned slots) must report exactly what the blocking mode reports for the
+    same seed, step by step."""
+    import contextlib, io
+    from argparse import Namespace
+    import anatomix_amd
+    from anatomix_amd.pretraining import GraphedContrastiveStep, PatchSampleF, SupPatchNCELoss, FusedAdamW
+    from anatomix_amd.pretraining.step import StepRecord
+    from oracle import pretrain_inputs as PI, unet_ref as R
+    dev = torch.device("cuda:0")
+    kw = R.VARIANTS["anatomix"]
+    nopt = Namespace(nce_T=0.33, weigh_rarity=False, balance_denominator=False, weighting_mode="raw")
+    A, B, seg = [t.to(dev) for t in PI.step_inputs(64)]
+
+    def run(lazy):
+        torch.manual_seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            netG = anatomix_amd.Unet(**kw)
+            netG.load_state_dict(R.synthetic_state_dict(kw, 3, gain=2 ** 0.5))
+            netF = PatchSampleF(use_mlp=True, init_type="kaiming", nc=256, n_mlps=3)
+            netF.create_mlp([torch.zeros(1, c, 1, 1, 1, device=dev) for c in (128, 256, 128, 64, 32, 16)])
+        netG.precision = "bf16"
+        netG, netF = netG.to(dev).train(), netF.to(dev).train()
+        crits = [SupPatchNCELoss(nopt) for _ in PI.NCE_LAYERS]
+        opts = (FusedAdamW(netG.parameters(), lr=1e-3), FusedAdamW(netF.parameters(), lr=1e-3))
+        step = GraphedContrastiveStep(netG, netF, crits, PI.NCE_LAYERS, opts, num_patches=64, warmup=2, lazy_scalars=lazy)
+        torch.manual_seed(12)
+        recs = [step(A, B, seg) for _ in range(12)]
+        return [(r["loss"], r["grad_norm_G"], r["grad_norm_F"], tuple(r["per_layer"].values())) for r in recs], recs
+
+    want, _ = run(False)
+    got, recs = run(True)
+    assert all(isinstance(r, StepRecord) for r in recs) and set(recs[0]) == {"loss", "per_layer", "grad_norm_G", "grad_norm_F", "sample_ids", "out"}
+    assert got == want
+    assert all(np.isfinite(v[0]) for v in got) and len({v[0] for v in got}) > 1
+
+
 @pytest.mark.parametrize("n,cin,width,n_mlps,act", [(1024, 16, 256, 3, "relu"), (1024, 256, 256, 3, "relu"),
                                                     (128, 128, 256, 2, "relu"), (1000, 64, 128, 3, "lrelu"),
                                                     (2048, 32, 64, 2, "lrelu"), (7, 4, 8, 3, "relu")])
