@@ -294,73 +294,139 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     // work is doubled / tripled at unchanged traffic -- the lower bound of a conv -> conv chain through the ring
     for (int rep = (p.dbg >> 10) & 7; rep >= 0; --rep)
     if (!(p.dbg & 2)) {
+      if constexpr (NCKP > 1 && !SPLIT) {
+        // Two (or, SPLIT, two passes over) channel chunks: 28 resident weight fragments leave room for ONE set of six ring fragments, and
+        // "read a plane's six, then its 16 MFMAs" (the first form) exposed the LDS round trip eight times per step -- a wave's sweep
+        // took ~4100 cycles for 1792 cycles of MFMAs, with or without the other wave of its SIMD (profiles/r05_wgrad_probe.txt).  Rolling
+        // form: the step's fragment uses are one static sequence (per pass: 4 planes x [4 row fragments, 2 x+2 fragments], then the 8
+        // fragments of the taps (0,2,2)|(1,2,2) and (2,2,2)); use i sits in slot i mod NSLOT, and the read for use i + NSLOT is issued
+        // right after the MFMAs of use i -- about 9 MFMAs ahead of its first use, in fewer registers than the one-plane set.
+        constexpr int PER = 4 * 6 + 8, NU = NCKP * PER, NSLOT = 4;
+        // addresses are formed per read from two lane bases and a wave-uniform ring offset (scalar registers): the eight per-plane
+        // address registers of the first form, next to 112 weight registers, pushed weight fragments into scratch memory
+        int slo[4];                                          // ring offsets of the step's four input planes (uniform)
 #pragma unroll
-      for (int ps = 0; ps < NCKP; ++ps) {
-        // SPLIT: pass 0 reads the hi planes and multiplies every fragment with Wh AND Wl (two MFMAs per fragment read),
-        // pass 1 reads the lo planes and multiplies with Wh.  Otherwise pass = chunk.
-        const int k = SPLIT ? 0 : ps;                        // (first) weight set of this pass
-        const bool both = SPLIT && ps == 0;                  // also the second weight set (Wl)
-        const int koff = ps * 2 * PPL;                       // channel planes 2 ps, 2 ps + 1
-        auto mm = [&](const int widx, const vec8& frag, f32x4 a) {
-          a = Ops<T>::mfma(wreg[k][widx], frag, a);
-          if (both) a = Ops<T>::mfma(wreg[NCKP - 1][widx], frag, a);
-          return a;
+        for (int pl = 0; pl < 4; ++pl) slo[pl] = __builtin_amdgcn_readfirstlane(((s * TZ + pl) % R) * PLSZ);
+        const int tail_lo = lanebase + (2 * HX + 2) * 16;   // taps (kz, 2, 2): low lanes plane tz (+ hi: tz + 1), and plane tz + 2
+        auto src = [&](int i) -> const vec8* {              // ring address of use i (i is a compile-time constant after unrolling)
+          const int ps = i / PER, j = i % PER, koff = ps * 2 * PPL;
+          if (j < 24) {
+            const int pl = j / 6, f = j % 6;
+            return f < 4 ? (const vec8*)(smem + base_d1 + (slo[pl] + koff + (f * HX) * 16))
+                         : (const vec8*)(smem + base_dx + (slo[pl] + koff + ((f - 4) * HX + 2) * 16));
+          }
+          const int t = j - 24, tz = t >> 2, cy = (t >> 1) & 1, which = t & 1;
+          if (which) return (const vec8*)(smem + tail_lo + (slo[tz + 2] + koff + (cy * HX) * 16));
+          return (const vec8*)(smem + tail_lo + ((hi ? slo[tz + 1] : slo[tz]) + koff + (cy * HX) * 16));
         };
-        // Per input plane pl: 4 row fragments of taps (kz,ky,0)|(kz,ky,1) and 2 fragments of taps
-        // (kz,0,2)|(kz,1,2); plane pl is tap plane kz = pl - tz of output plane tz.  Batches are double
-        // buffered one plane ahead of their MFMAs (sched_barrier pins the phases).
-        constexpr bool DB = NCKP == 1;     // two chunks: 28 resident weight fragments leave no room for a 2nd buffer
-        vec8 F[DB ? 2 : 1][4], H[DB ? 2 : 1][2];
-        auto load_plane = [&](int buf, int pl) {
+        auto use = [&](int i, const vec8& frag) {           // the MFMAs that consume use i
+          const int ps = i / PER, j = i % PER;
+          const int k = SPLIT ? 0 : ps;
+          const bool both = SPLIT && ps == 0;
+          auto mm = [&](const int widx, f32x4 a) {
+            a = Ops<T>::mfma(wreg[k][widx], frag, a);
+            if (both) a = Ops<T>::mfma(wreg[NCKP - 1][widx], frag, a);
+            return a;
+          };
+          if (j < 24) {
+            const int pl = j / 6, f = j % 6;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) F[buf][r] = *(const vec8*)(smem + b1[pl] + koff + (r * HX) * 16);
+            for (int tz = 0; tz < 2; ++tz) {
+              const int kz = pl - tz;
+              if (kz < 0 || kz > 2) continue;
+              if (f < 4) {
 #pragma unroll
-          for (int cy = 0; cy < 2; ++cy) H[buf][cy] = *(const vec8*)(smem + bx3[pl] + koff + (cy * HX + 2) * 16);
-        };
-        auto mma_plane = [&](int buf, int pl) {
-#pragma unroll
-          for (int tz = 0; tz < 2; ++tz) {
-            const int kz = pl - tz;
-            if (kz < 0 || kz > 2) continue;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-              for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(kz * 3 + ky, F[buf][cy + ky], acc[tz][cy]);
-#pragma unroll
-            for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(9 + kz, H[buf][cy], acc[tz][cy]);
+                for (int cy = 0; cy < 2; ++cy) {
+                  const int ky = f - cy;
+                  if (ky >= 0 && ky < 3) acc[tz][cy] = mm(kz * 3 + ky, acc[tz][cy]);
+                }
+              } else {
+                acc[tz][f - 4] = mm(9 + kz, acc[tz][f - 4]);
+              }
+            }
+          } else {
+            const int t = j - 24, tz = t >> 2, cy = (t >> 1) & 1, which = t & 1;
+            acc[tz][cy] = mm(12 + which, acc[tz][cy]);
           }
         };
-        if (DB) {
-          load_plane(0, 0);
+        vec8 S[NSLOT];
 #pragma unroll
-          for (int pl = 0; pl < 4; ++pl) {
-            if (pl + 1 < 4) load_plane((pl + 1) & 1, pl + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_plane(pl & 1, pl);
-          }
-        } else {
+        for (int i = 0; i < NSLOT; ++i) S[i] = *src(i);
 #pragma unroll
-          for (int pl = 0; pl < 4; ++pl) {
-            load_plane(0, pl);
-            mma_plane(0, pl);
-          }
+        for (int i = 0; i < NU; ++i) {
+          use(i, S[i % NSLOT]);
+          if (i + NSLOT < NU) S[i % NSLOT] = *src(i + NSLOT);
+          __builtin_amdgcn_sched_barrier(0);                 // (keeps every read behind the MFMAs of the use it replaces, and no further)
         }
-        // taps (0,2,2)|(1,2,2) (low lanes plane tz, high lanes plane tz+1) and (2,2,2) (plane tz+2)
+      } else {
 #pragma unroll
-        for (int tz = 0; tz < 2; ++tz) {
-          const int sl0 = ((s * TZ + tz) % R) * PLSZ, sl1 = ((s * TZ + tz + 1) % R) * PLSZ, sl2 = ((s * TZ + tz + 2) % R) * PLSZ;
-          const int bz = lanebase + (hi ? sl1 : sl0) + koff + (2 * HX + 2) * 16;
-          const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
-#pragma unroll
-          for (int cy = 0; cy < 2; ++cy) {
-            const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
-            const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
-            acc[tz][cy] = mm(12, s0, acc[tz][cy]);
-            acc[tz][cy] = mm(13, s1, acc[tz][cy]);
+        for (int ps = 0; ps < NCKP; ++ps) {
+          // SPLIT: pass 0 reads the hi planes and multiplies every fragment with Wh AND Wl (two MFMAs per fragment read),
+          // pass 1 reads the lo planes and multiplies with Wh.  Otherwise pass = chunk.
+          const int k = SPLIT ? 0 : ps;                        // (first) weight set of this pass
+          const bool both = SPLIT && ps == 0;                  // also the second weight set (Wl)
+          const int koff = ps * 2 * PPL;                       // channel planes 2 ps, 2 ps + 1
+          auto mm = [&](const int widx, const vec8& frag, f32x4 a) {
+            a = Ops<T>::mfma(wreg[k][widx], frag, a);
+            if (both) a = Ops<T>::mfma(wreg[NCKP - 1][widx], frag, a);
+            return a;
+          };
+          // Per input plane pl: 4 row fragments of taps (kz,ky,0)|(kz,ky,1) and 2 fragments of taps
+          // (kz,0,2)|(kz,1,2); plane pl is tap plane kz = pl - tz of output plane tz.  Batches are double
+          // buffered one plane ahead of their MFMAs (sched_barrier pins the phases).
+          constexpr bool DB = NCKP == 1;     // two chunks: 28 resident weight fragments leave no room for a 2nd buffer
+          vec8 F[DB ? 2 : 1][4], H[DB ? 2 : 1][2];
+          auto load_plane = [&](int buf, int pl) {
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) F[buf][r] = *(const vec8*)(smem + b1[pl] + koff + (r * HX) * 16);
+  #pragma unroll
+            for (int cy = 0; cy < 2; ++cy) H[buf][cy] = *(const vec8*)(smem + bx3[pl] + koff + (cy * HX + 2) * 16);
+          };
+          auto mma_plane = [&](int buf, int pl) {
+  #pragma unroll
+            for (int tz = 0; tz < 2; ++tz) {
+              const int kz = pl - tz;
+              if (kz < 0 || kz > 2) continue;
+  #pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+  #pragma unroll
+                for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(kz * 3 + ky, F[buf][cy + ky], acc[tz][cy]);
+  #pragma unroll
+              for (int cy = 0; cy < 2; ++cy) acc[tz][cy] = mm(9 + kz, H[buf][cy], acc[tz][cy]);
+            }
+          };
+          if (DB) {
+            load_plane(0, 0);
+  #pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+              if (pl + 1 < 4) load_plane((pl + 1) & 1, pl + 1);
+              __builtin_amdgcn_sched_barrier(0);
+              mma_plane(pl & 1, pl);
+            }
+          } else {
+  #pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+              load_plane(0, pl);
+              mma_plane(0, pl);
+            }
+          }
+          // taps (0,2,2)|(1,2,2) (low lanes plane tz, high lanes plane tz+1) and (2,2,2) (plane tz+2)
+  #pragma unroll
+          for (int tz = 0; tz < 2; ++tz) {
+            const int sl0 = ((s * TZ + tz) % R) * PLSZ, sl1 = ((s * TZ + tz + 1) % R) * PLSZ, sl2 = ((s * TZ + tz + 2) % R) * PLSZ;
+            const int bz = lanebase + (hi ? sl1 : sl0) + koff + (2 * HX + 2) * 16;
+            const int b0 = lanebase + sl2 + koff + (2 * HX + 2) * 16;
+  #pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+              const vec8 s0 = *(const vec8*)(smem + bz + (cy * HX) * 16);
+              const vec8 s1 = *(const vec8*)(smem + b0 + (cy * HX) * 16);
+              acc[tz][cy] = mm(12, s0, acc[tz][cy]);
+              acc[tz][cy] = mm(13, s1, acc[tz][cy]);
+            }
           }
         }
       }
-    }
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
     flag_store(done + wave, s + 1);
     AMX_ZSTAMP();                                            // [sweep done]
