@@ -220,49 +220,50 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
       asm volatile("" ::: "memory");
     }
     const int zo = zs + 2 * s + pz;
-    int sl[3];
+    // ring offsets of the three input planes and the two low-resolution planes: wave-uniform, kept in scalar registers
+    int slo[3], llo[2];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) sl[kz] = ((2 * s + pz + kz) % R) * PLSZ;
-    int b1[3], bx3[3];
+    for (int kz = 0; kz < 3; ++kz) slo[kz] = __builtin_amdgcn_readfirstlane(((2 * s + pz + kz) % R) * PLSZ);
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      b1[kz] = base_d1 + sl[kz];
-      bx3[kz] = base_dx + sl[kz];
-    }
-    const int bz = lanebase + (hi ? sl[1] : sl[0]);
-    const int b0 = lanebase + sl[2];
-    int lb[2];
-#pragma unroll
-    for (int ez = 0; ez < 2; ++ez) lb[ez] = lbase + ((s + pz + ez) % RL) * LPSZ;
+    for (int ez = 0; ez < 2; ++ez) llo[ez] = __builtin_amdgcn_readfirstlane(((s + pz + ez) % RL) * LPSZ);
+    const int bzv = lanebase + (hi ? slo[1] : slo[0]);      // taps (0,2,2)|(1,2,2): low lanes plane 0, high lanes plane 1
 
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = bias;
 
     if (!(p.dbg & 2)) {
-      // ---- skip part: 14 paired-tap steps; tile c = low row ly = c <-> output row y0 + 2c + py
-#pragma unroll
-      for (int st = 0; st < kSteps; ++st) {
-        const int kz = st < 9 ? st / 3 : (st < 12 ? st - 9 : (st == 12 ? 0 : 2));
-        const int ky = st < 9 ? st % 3 : (st < 12 ? 0 : 2);
-        const int kx2 = st < 9 ? 0 : 1;                         // kx = 2 is one slot right of kx = 0 in the split row
-        const int tapoff = (ky * HX + kx2) * 16;
-        const int bsel = st < 9 ? b1[kz] : (st < 12 ? bx3[kz] : (st == 12 ? bz : b0));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const vec8 bf = *(const vec8*)(smem + bsel + tapoff + (2 * c * HX) * 16);
-          acc[c] = Ops<T>::mfma(wsk[st], bf, acc[c]);
+      // The step's 88 fragment uses -- 14 paired-tap steps of the skip part (tile c = low row ly = c <-> output row y0 + 2c + py), then
+      // the 8 merged taps e = (ez, ey, ex) of the upsampled part on the low-resolution ring, 4 row tiles each, ONE MFMA per fragment --
+      // as one static sequence with rolling reads: use i sits in slot i mod NSLOT, the read for use i + NSLOT is issued right after the
+      // MFMA of use i.  (Left to the compiler the sequence was "2 ds_read, wait, MFMA, wait, MFMA": the LDS round trip in front of
+      // nearly every pair of MFMAs, in the largest kernel of the 6 M forward.)
+      constexpr int NSK = 4 * kSteps, NU = NSK + 4 * 8, NSLOT = 8;
+      auto src = [&](int i) -> const vec8* {                 // (i is a compile-time constant after unrolling)
+        if (i < NSK) {
+          const int st = i >> 2, c = i & 3;
+          const int kz = st < 9 ? st / 3 : (st < 12 ? st - 9 : (st == 12 ? 0 : 2));
+          const int ky = st < 9 ? st % 3 : (st < 12 ? 0 : 2);
+          const int kx2 = st < 9 ? 0 : 1;                     // kx = 2 is one slot right of kx = 0 in the split row
+          const int off = (ky * HX + kx2) * 16 + (2 * c * HX) * 16;
+          if (st < 9) return (const vec8*)(smem + base_d1 + (slo[kz] + off));
+          if (st < 12) return (const vec8*)(smem + base_dx + (slo[kz] + off));
+          if (st == 12) return (const vec8*)(smem + bzv + off);
+          return (const vec8*)(smem + lanebase + (slo[2] + off));
         }
-      }
-      // ---- upsampled part: 8 merged taps e = (ez, ey, ex) on the low-res ring
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+        const int e = (i - NSK) >> 2, c = (i - NSK) & 3;
         const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+        return (const vec8*)(smem + lbase + (llo[ez] + ((c + ey) * LX + ex) * 16));
+      };
+      vec8 S[NSLOT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const vec8 bf = *(const vec8*)(smem + lb[ez] + ((c + ey) * LX + ex) * 16);
-          acc[c] = Ops<T>::mfma(wup[e], bf, acc[c]);
-        }
+      for (int i = 0; i < NSLOT; ++i) S[i] = *src(i);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int c = i < NSK ? (i & 3) : ((i - NSK) & 3);
+        acc[c] = Ops<T>::mfma(i < NSK ? wsk[i >> 2] : wup[(i - NSK) >> 2], S[i % NSLOT], acc[c]);
+        if (i + NSLOT < NU) S[i % NSLOT] = *src(i + NSLOT);
+        __builtin_amdgcn_sched_barrier(0);                   // (keeps every read behind the MFMA of the use it replaces, and no further)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every ring read of this step has returned
