@@ -275,6 +275,11 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     }
 
     AMX_ZSTAMP();                                            // [planes landed]
+#ifdef AMX_EXPERIMENT
+    // (AMX_DBG bits 16..23 = n: the second consumer wave of every SIMD starts its first sweep n x 512 cycles late)
+    if (s == 0 && wave >= 4 && wave < 8)
+      for (int k = (p.dbg >> 16) & 255; k > 0; --k) __builtin_amdgcn_s_sleep(8);
+#endif
     // ring slots of the four input planes zs+2s-1 .. zs+2s+2  (q = 2s + pl)
     int b1[4], bx3[4];
 #pragma unroll
