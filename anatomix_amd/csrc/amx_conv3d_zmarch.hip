@@ -357,7 +357,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
         vec8 S[NSLOT];
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) S[i] = *src(i);
-#pragma unroll
+#pragma clang loop unroll(full)                              // (a partly unrolled loop indexes wreg[] dynamically: the weights go to scratch memory)
         for (int i = 0; i < NU; ++i) {
           use(i, S[i % NSLOT]);
           if (i + NSLOT < NU) S[i % NSLOT] = *src(i + NSLOT);
