@@ -213,8 +213,8 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
       need = need < nplanes ? need : nplanes;
       needl = needl < nlow ? needl : nlow;
       while (true) {
-        const int r0 = flag_load(ready), r1 = flag_load(ready + 1), r2 = flag_load(ready + 2);
-        if ((r0 < r1 ? r0 : r1) >= need && r2 >= needl) break;
+        const flag4_t r = flag_read4(ready);                  // (one 16-byte read instead of three relaxed loads per poll)
+        if ((r[0] < r[1] ? r[0] : r[1]) >= need && r[2] >= needl) break;
         __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");

@@ -424,16 +424,8 @@ __global__ __launch_bounds__((NWZ * NWY + NLW) * 64) void conv3d_k3_v2_kernel(co
   AMX_STAMP();
   for (int t = 0; t < T_total; ++t) {
     if (NLW) {
-      while (true) {                                   // every loader's share of step t has landed
-        int m = flag_load(ready);
-#pragma unroll
-        for (int i = 1; i < (NLW ? NLW : 1); ++i) {
-          const int r = flag_load(ready + i);
-          m = r < m ? r : m;
-        }
-        if (m >= t + 1) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+      static_assert(NLW <= 4 && C::FLAGOFF % 16 == 0, "the ready flags are polled with one 16-byte read");
+      while (flag_min4<(NLW ? NLW : 1)>(ready) < t + 1) __builtin_amdgcn_s_sleep(1);   // every loader's share of step t has landed
       asm volatile("" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(t) pieces (and older stores) are done

@@ -261,16 +261,8 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     {
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
       need = need < nplanes ? need : nplanes;
-      while (true) {
-        int m = flag_load(ready);
-#pragma unroll
-        for (int i = 1; i < NL; ++i) {
-          const int r = flag_load(ready + i);
-          m = r < m ? r : m;
-        }
-        if (m >= need) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+      static_assert(NL <= 4, "the ready flags are polled with one 16-byte read");
+      while (flag_min4<NL>(ready) < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
 

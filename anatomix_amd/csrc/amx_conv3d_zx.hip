@@ -190,16 +190,8 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
   auto wait_planes = [&](int s) {
     int need = TZ * s + TZ + 2;
     need = need < nplanes ? need : nplanes;
-    while (true) {
-      int m = flag_load(ready);
-#pragma unroll
-      for (int i = 1; i < C::NCV; ++i) {
-        const int r = flag_load(ready + i);
-        m = r < m ? r : m;
-      }
-      if (m >= need) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
+    static_assert(C::NCV <= 4 && C::FLAGOFF % 16 == 0, "the ready flags are polled with one 16-byte read");
+    while (flag_min4<C::NCV>(ready) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
   };
 

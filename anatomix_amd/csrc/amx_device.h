@@ -197,6 +197,26 @@ __device__ __forceinline__ int flag_load_asm(unsigned addr) {
   return r;
 }
 
+// min over the first N (<= 4) of four consecutive int flags (16-byte aligned) with one ds_read_b128: the consumer waves polled their
+// loaders' `ready` flags one relaxed load at a time -- four dependent LDS round trips per poll with four loaders (900-1100 cycles of
+// "wait" per z-march step even when the planes had landed, against 250 with two)
+typedef __attribute__((ext_vector_type(4))) int flag4_t;
+__device__ __forceinline__ flag4_t flag_read4(const int* p) {      // four consecutive flags, one LDS round trip
+  flag4_t a;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(lds_addr(p)) : "memory");
+  return a;
+}
+template <int N>
+__device__ __forceinline__ int flag_min4(const int* p) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  i32x4 a;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(lds_addr(p)) : "memory");
+  int m = a[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) m = a[i] < m ? a[i] : m;
+  return m;
+}
+
 // min over 8 consecutive int flags (32-byte aligned) with two ds_read_b128 and ONE wait
 __device__ __forceinline__ int flag_min8_asm(unsigned addr) {
   typedef __attribute__((ext_vector_type(4))) int i32x4;
