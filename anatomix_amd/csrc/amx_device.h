@@ -214,7 +214,7 @@ __device__ __forceinline__ int flag_min4(const int* p) {
   int m = a[0];
 #pragma unroll
   for (int i = 1; i < N; ++i) m = a[i] < m ? a[i] : m;
-  return m;
+  return __builtin_amdgcn_readfirstlane(m);                  // every lane read the same words: a scalar, so the poll loop is a scalar branch
 }
 
 // min over 8 consecutive int flags (32-byte aligned) with two ds_read_b128 and ONE wait
