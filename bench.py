@@ -720,7 +720,15 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         if workload == "step" and with_parity:
             # the step's parity lives in the tests (a 128^3 record of the reference's own step: tests/test_train_step_gpu.py); the
             # line carries what it can check in-process: a finite loss after `steps` optimiser updates
-            result["parity"] = {"finite_loss": bool(torch.isfinite(y).all()), "loss_after_timed_steps": float("%.4e" % float(y.float().mean())),
+            # (`y` is the network output of the last timed step; with the graphed step the loss itself is in `last_record`)
+            loss_last = None
+            if not no_graph:
+                try:
+                    loss_last = float("%.6g" % float(last_record["r"]["loss"]))
+                except Exception:
+                    loss_last = None
+            result["parity"] = {"finite_output": bool(torch.isfinite(y).all()), "mean_output_after_timed_steps": float("%.4e" % float(y.float().mean())),
+                                "loss_of_last_timed_step": loss_last,
                                 "against": "tests/test_train_step_gpu.py: losses / gradient norms of the reference's own fp32 step at 128^3 "
                                            "(tests/golden/pretrain_step128_golden.npz); no in-process oracle for a training step"}
     del model, x, y
