@@ -435,7 +435,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     }
     if constexpr (NS > 0) {   // the staging tile still holds step s-1 until both storers have read it into registers
       if (s >= SG::NB)
-        while (flag_load(stored) < s + 1 - SG::NB || flag_load(stored + 1) < s + 1 - SG::NB) __builtin_amdgcn_s_sleep(1);
+        while (flag_min2(stored) < s + 1 - SG::NB) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
     act_inplace<4>(&acc[0][0], p.act, p.slope);

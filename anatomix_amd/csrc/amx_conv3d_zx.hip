@@ -227,7 +227,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
         wait_planes(s);
         // the mailbox (set s % NBOX) is free once BOTH main waves of this cout tile have taken step s - NBOX
         char* box = box0 + (C::NBOX == 2 ? (s & 1) * 32768 : 0);
-        while (flag_load(mainfree + wq * 2) < s + 1 - C::NBOX || flag_load(mainfree + wq * 2 + 1) < s + 1 - C::NBOX) __builtin_amdgcn_s_sleep(1);
+        while (flag_min2(mainfree + wq * 2) < s + 1 - C::NBOX) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         auto mm = [&](const int step, const i32x8& f, f32x4 a) {
           return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wreg[step - S0], f, a, 0, 0, 0, mx_sa, 0, sb);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__((ZxCfg::NC + ZxCfg::NCV) * 64) void conv3d_k3_zx_ke
     flag_store(done + wave, s + 1);
 
     // ---- the correction products: the two mx waves of this cout tile (tap steps 0..6 / 7..13), this wave's x half
-    while (flag_load(mxdone + wq * 2) < s + 1 || flag_load(mxdone + wq * 2 + 1) < s + 1) __builtin_amdgcn_s_sleep(1);
+    while (flag_min2(mxdone + wq * 2) < s + 1) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
     {
 #pragma unroll

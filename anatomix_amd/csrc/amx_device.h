@@ -206,6 +206,12 @@ __device__ __forceinline__ flag4_t flag_read4(const int* p) {      // four conse
   asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(lds_addr(p)) : "memory");
   return a;
 }
+__device__ __forceinline__ int flag_min2(const int* p) {             // min of two consecutive flags (8-byte aligned), one LDS round trip
+  typedef __attribute__((ext_vector_type(2))) int i32x2;
+  i32x2 a;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(lds_addr(p)) : "memory");
+  return __builtin_amdgcn_readfirstlane(a[0] < a[1] ? a[0] : a[1]);
+}
 template <int N>
 __device__ __forceinline__ int flag_min4(const int* p) {
   typedef __attribute__((ext_vector_type(4))) int i32x4;
