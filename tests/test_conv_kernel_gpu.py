@@ -174,3 +174,40 @@ def test_merged_concat_conv_strict_precision_matches_fp64(device, case, precisio
     full = ref_conv_fp64(x0, x1, wgt, scale, shift, act)
     tol = 3e-5 if precision == "bf16x2" else 4e-6
     assert rel_l2(got, full) < tol and max_rel(got, full) < 4 * tol, (rel_l2(got, full), max_rel(got, full))
+
+
+@pytest.mark.parametrize("shape,limit_us", [((32, 0, 32, 64, 4), 350.0), ((16, 0, 16, 128, 2), 400.0), ((16, 32, 16, 64, 4), 300.0),
+                                            ((64, 0, 64, 32, 4), 250.0)])
+def test_hot_layers_are_not_pathologically_slow(device, shape, limit_us):
+    """A guard, not a benchmark: each of these layers takes 25-80 us on an MI355X, and the limit is ~5x that.  It exists because the
+    z-march kernels keep 14-28 weight fragments in registers and a change that makes hipcc index them dynamically (a loop left partly
+    rolled) or compile for the wrong occupancy moves them to scratch memory: the results stay bit-identical and the layer takes 10x
+    as long (seen twice in round 5: 70 -> 890 us)."""
+    import ctypes
+    from anatomix_amd import _lib
+    c0, c1, cout, S, n = shape
+    lib = _lib.load()
+    x0 = torch.randn(n, S, S, S, c0, device=device).half()
+    x1 = torch.randn(n, S // 2, S // 2, S // 2, c1, device=device).half() if c1 else None
+    w = (torch.randn(cout, c0 + c1, 27, device=device) / (27 * (c0 + c1)) ** 0.5).float()
+    sh = torch.zeros(cout, device=device)
+    wpk = torch.empty(lib.amx_conv3d_packed_bytes(c0 + c1, cout), dtype=torch.uint8, device=device)
+    out = torch.empty(n, S, S, S, cout, device=device, dtype=torch.half)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    sb = lib.amx_conv3d_scratch_bytes(c0, c1, cout, n, S, S, S, 0)
+    scratch = torch.empty(max(sb, 4) // 4, device=device) if sb else None
+
+    def run():
+        _lib.check(lib.amx_conv3d_k3_reflect_ws(_lib.ptr(x0), c0, _lib.ptr(x1), c1, _lib.ptr(w), None, _lib.ptr(sh), cout, n, S, S, S,
+                                                1, 0.3, 0, _lib.ptr(wpk), _lib.ptr(out), None, _lib.ptr(scratch), sb, st))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    assert us < limit_us, f"{shape}: {us:.0f} us per launch (limit {limit_us:.0f}): registers spilled to scratch memory?"
