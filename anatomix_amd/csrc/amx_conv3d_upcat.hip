@@ -213,6 +213,7 @@ __global__ __launch_bounds__((UpcatCfg::NC + UpcatCfg::NL) * 64) void conv3d_upc
       need = need < nplanes ? need : nplanes;
       needl = needl < nlow ? needl : nlow;
       while (true) {
+        static_assert(C::FLAGOFF % 16 == 0, "the ready flags are polled with one 16-byte read");
         const flag4_t r = flag_read4(ready);                  // (one 16-byte read instead of three relaxed loads per poll)
         if ((r[0] < r[1] ? r[0] : r[1]) >= need && r[2] >= needl) break;
         __builtin_amdgcn_s_sleep(1);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     {
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
       need = need < nplanes ? need : nplanes;
-      static_assert(NL <= 4, "the ready flags are polled with one 16-byte read");
+      static_assert(NL <= 4 && C::FLAGOFF % 16 == 0, "the ready flags are polled with one 16-byte read");
       while (flag_min4<NL>(ready) < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
