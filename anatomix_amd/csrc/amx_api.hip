@@ -1745,8 +1745,8 @@ int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int h
 
 int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0, int c1,
                              int accumulate_skip, int precision, void* stream) {
-  if (!d_dcat || !d_dskip || !d_dlow || n < 1 || dlow < 1 || hlow < 1 || wlow < 1 || c0 < 8 || c1 < 8 || c0 % 8 || c1 % 8)
-    return fail(AMX_ERR_INVALID, "bad argument");
+  if (!d_dcat || (!d_dskip && c0 > 0) || !d_dlow || n < 1 || dlow < 1 || hlow < 1 || wlow < 1 || c0 < 0 || c1 < 8 || c0 % 8 || c1 % 8)
+    return fail(AMX_ERR_INVALID, "bad argument");                       // c0 == 0: no skip part (the whole tensor is summed over children)
   AMX_HIP(amx::launch_upcat_split(d_dcat, d_dskip, d_dlow, n, dlow, hlow, wlow, c0, c1, accumulate_skip, 0, precision,
                                   (hipStream_t)stream));
   return AMX_OK;

@@ -813,7 +813,7 @@ hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, 
 
 hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
                               int acc_skip, int framed, int precision, hipStream_t st) {
-  if (c0 % 8 || c1 % 8 || c0 < (framed ? 0 : 8) || c1 < 8) return hipErrorInvalidValue;
+  if (c0 % 8 || c1 % 8 || c0 < 0 || c1 < 8) return hipErrorInvalidValue;       // c0 == 0: no skip part, everything is summed over children
   const int blocks = grid_for((long long)N * Dl * Hl * Wl * ((c0 + c1) / 8));
 #define AMX_UPS(T, F)                                                                                                            \
   hipLaunchKernelGGL((upcat_split_kernel<T, F>), dim3(blocks), dim3(256), 0, st, (const char*)dcat, (char*)dskip, (char*)dlow, N, Dl, \

@@ -384,7 +384,7 @@ def upcat_split_backward(dcat, c0, c1, skip_into=None):
     lib = _lib.load()
     n, d, h, w, c = dcat.shape
     assert c == c0 + c1 and dcat.is_contiguous()
-    dskip = skip_into if skip_into is not None else torch.empty((n, d, h, w, c0), dtype=dcat.dtype, device=dcat.device)
+    dskip = skip_into if skip_into is not None else (torch.empty((n, d, h, w, c0), dtype=dcat.dtype, device=dcat.device) if c0 else None)
     dlow = torch.empty((n, d // 2, h // 2, w // 2, c1), dtype=dcat.dtype, device=dcat.device)
     with torch.cuda.device(dcat.device):
         _lib.check(lib.amx_upcat_split_backward(_lib.ptr(dcat), _lib.ptr(dskip), _lib.ptr(dlow), n, d // 2, h // 2, w // 2, c0, c1,
