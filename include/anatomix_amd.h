@@ -276,7 +276,7 @@ int amx_upsample2_trilinear(const void* d_in, void* d_out, int n, int din, int h
 /* Adjoint of torch.cat((skip, nn.Upsample(2, 'nearest')(low)), 1) (network.py:500-502, 545) applied to the data gradient of the
  * concat conv: d_dcat 16-bit [n][2 dlow][2 hlow][2 wlow][c0 + c1] -> d_dskip [n][2 dlow][2 hlow][2 wlow][c0] (first c0
  * channels; added to the existing content when accumulate_skip) and d_dlow [n][dlow][hlow][wlow][c1] (sum of the 8 children of
- * every low-resolution voxel).  One pass over d_dcat. */
+ * every low-resolution voxel).  One pass over d_dcat.  c0 == 0 (d_dskip may be NULL): no skip part, c0 and c1 multiples of 8. */
 int amx_upcat_split_backward(const void* d_dcat, void* d_dskip, void* d_dlow, int n, int dlow, int hlow, int wlow, int c0, int c1,
                              int accumulate_skip, int precision, void* stream);
 /* The same with the reflect-padding adjoint (amx_pad_fold) applied while reading: d_g_framed is the data-gradient conv's raw result
