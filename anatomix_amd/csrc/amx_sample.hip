@@ -11,13 +11,17 @@ namespace amx {
 
 // draws [n] (values in [0, d0*d1*d2)) -> coords [num][3] int64, C-order unravel.  If fewer than `num` distinct values were
 // drawn (practically unreachable for n >= 2 num and >= 8 num voxels) the tail repeats the kept ones cyclically.
+// VT: the draws as 32-bit values in LDS when the volume has fewer than 2^31 voxels (every anatomix shape): the all-pairs comparison
+// is 524 k compares for 1024 draws and was paced by the VALU at three instructions per 64-bit compare (30 us per launch, five
+// launches on the main stream of a training step); one v_cmp per 32-bit value and 16-byte LDS reads bring it under 10 us.
+template <typename VT>
 __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __restrict__ draws, int n, int num, int d1, int d2,
                                                              long long* __restrict__ coords) {
   extern __shared__ long long sm[];
-  long long* v = sm;                      // [n]   the draws
-  long long* kept = sm + n;               // [n]   distinct values in draw order
+  VT* v = (VT*)sm;                        // [n (+ pad)]   the draws
+  VT* kept = v + ((n + 15) & ~15);        // [n]           distinct values in draw order
   __shared__ int wsum[16], total;
-  for (int i = threadIdx.x; i < n; i += 1024) v[i] = draws[i];
+  for (int i = threadIdx.x; i < n; i += 1024) v[i] = (VT)draws[i];
   __syncthreads();
   const int per = (n + 1023) / 1024;      // consecutive items per thread, so the prefix sum follows draw order
   const int i0 = threadIdx.x * per;
@@ -25,17 +29,18 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
   for (int k = 0; k < per; ++k) {
     const int i = i0 + k;
     if (i >= n) break;
-    const long long mine = v[i];
-    // (one value per iteration was a chain of dependent LDS round trips: 25 us for 1024 draws; eight independent broadcast reads
-    //  per iteration are paced by the LDS pipe instead)
+    const VT mine = v[i];
+    // (one value per iteration was a chain of dependent LDS round trips: 25 us for 1024 draws; independent broadcast reads of 16 / 8
+    //  values per iteration are paced by the LDS pipe and the compares instead)
     bool dup = false;
     int j = 0;
-    for (; j + 8 <= i; j += 8) {
-      long long t[8];
+    constexpr int UN = sizeof(VT) == 4 ? 16 : 8;
+    for (; j + UN <= i; j += UN) {
+      VT t[UN];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = v[j + u];
+      for (int u = 0; u < UN; ++u) t[u] = v[j + u];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) dup |= (t[u] == mine);
+      for (int u = 0; u < UN; ++u) dup |= (t[u] == mine);
     }
     for (; j < i; ++j) dup |= (v[j] == mine);
     if (!dup) {
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
   __syncthreads();
   const int have = total;
   for (int r = threadIdx.x; r < num; r += 1024) {
-    const long long f = kept[r < have ? r : (r - have) % have];
+    const long long f = (long long)kept[r < have ? r : (r - have) % have];
     coords[3 * r] = f / ((long long)d1 * d2);
     coords[3 * r + 1] = (f / d2) % d1;
     coords[3 * r + 2] = f % d2;
@@ -142,9 +147,11 @@ hipError_t launch_scatter_rows(const float* rows, const long long* coords, void*
 }
 
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st) {
-  (void)d0;
-  const size_t lds = (size_t)n * 2 * sizeof(long long);
-  sample_coords_kernel<<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords);
+  const size_t lds = (size_t)(((n + 15) & ~15) + n) * sizeof(long long);
+  if ((long long)d0 * d1 * d2 < (1ll << 31))
+    sample_coords_kernel<int><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords);
+  else
+    sample_coords_kernel<long long><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords);
   return hipGetLastError();
 }
 
