@@ -116,6 +116,7 @@ hipError_t launch_import_ncdhw(const float* src, void* dst, int N, int C, int D,
 hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int N, int D, int H, int W, int C, int precision,
                                                hipStream_t st);
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
+hipError_t launch_sample_perm(const long long* keys, int nvox, int num, int d1, int d2, long long* coords, hipStream_t st);
 hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long long sz, long long sy, long long sx, long long sc,
                               const long long* coords, int N, int P, int C, float* rows, hipStream_t st);
 hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
@@ -1702,6 +1703,15 @@ int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, in
   if (num < 1 || n_draws < num || n_draws > 4096) return fail(AMX_ERR_INVALID, "1 <= num <= n_draws <= 4096 (got %d, %d)", num, n_draws);
   if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
   AMX_HIP(amx::launch_sample_coords(d_draws, n_draws, num, d0, d1, d2, d_coords, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_sample_perm(const long long* d_keys, int d0, int d1, int d2, int num, long long* d_coords, void* stream) {
+  if (!d_keys || !d_coords) return fail(AMX_ERR_INVALID, "null argument");
+  if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");
+  const long long nvox = (long long)d0 * d1 * d2;
+  if (nvox > 4096 || num < 1 || num > nvox) return fail(AMX_ERR_INVALID, "sample_perm: 1 <= num <= d0 d1 d2 <= 4096 (got %d of %lld)", num, nvox);
+  AMX_HIP(amx::launch_sample_perm(d_keys, (int)nvox, num, d1, d2, d_coords, (hipStream_t)stream));
   return AMX_OK;
 }
 

@@ -11,39 +11,51 @@ namespace amx {
 
 // draws [n] (values in [0, d0*d1*d2)) -> coords [num][3] int64, C-order unravel.  If fewer than `num` distinct values were
 // drawn (practically unreachable for n >= 2 num and >= 8 num voxels) the tail repeats the kept ones cyclically.
-// VT: the draws as 32-bit values in LDS when the volume has fewer than 2^31 voxels (every anatomix shape): the all-pairs comparison
-// is 524 k compares for 1024 draws and was paced by the VALU at three instructions per 64-bit compare (30 us per launch, five
-// launches on the main stream of a training step); one v_cmp per 32-bit value and 16-byte LDS reads bring it under 10 us.
+// "The first occurrence of every value" through a hash table in LDS: every draw claims the slot of its VALUE (open addressing,
+// compare-and-swap on the key) and leaves the minimum of the draw indices there; a draw is kept when that minimum is its own index.
+// The result does not depend on the order in which the lanes get there.  (The first two forms compared every draw with all earlier
+// ones -- 524 k compares for 1024 draws, 25-30 us on the one compute unit this block runs on, five launches on the main stream of a
+// training step; 32-bit values did not change that.)  VT: 32-bit keys when the volume has fewer than 2^31 voxels.
 template <typename VT>
 __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __restrict__ draws, int n, int num, int d1, int d2,
-                                                             long long* __restrict__ coords) {
+                                                             long long* __restrict__ coords, int tsize) {
   extern __shared__ long long sm[];
   VT* v = (VT*)sm;                        // [n (+ pad)]   the draws
-  VT* kept = v + ((n + 15) & ~15);        // [n]           distinct values in draw order
+  VT* tkey = v + ((n + 15) & ~15);        // [tsize]       hash table: value of the slot (all ones: empty)
+  int* tidx = (int*)(tkey + tsize);       // [tsize]       ... and the smallest draw index that holds it
+  VT* kept = tkey;                        // [n]           distinct values in draw order -- the table's memory, once it is done with
   __shared__ int wsum[16], total;
   for (int i = threadIdx.x; i < n; i += 1024) v[i] = (VT)draws[i];
+  for (int i = threadIdx.x; i < tsize; i += 1024) {
+    tkey[i] = (VT)-1;
+    tidx[i] = 0x7fffffff;
+  }
   __syncthreads();
   const int per = (n + 1023) / 1024;      // consecutive items per thread, so the prefix sum follows draw order
   const int i0 = threadIdx.x * per;
+  auto slot_of = [&](VT key, bool claim) {                 // the slot that holds `key` (claiming an empty one on the way when asked)
+    unsigned h = ((unsigned)key * 2654435761u) >> 7;
+    for (;;) {
+      h &= (unsigned)(tsize - 1);
+      VT cur = tkey[h];
+      if (cur == key) return (int)h;
+      if (claim && cur == (VT)-1) {
+        const VT old = atomicCAS(&tkey[h], (VT)-1, key);
+        if (old == (VT)-1 || old == key) return (int)h;
+      }
+      ++h;
+    }
+  };
+  for (int k = 0; k < per; ++k) {
+    const int i = i0 + k;
+    if (i < n) atomicMin(&tidx[slot_of(v[i], true)], i);
+  }
+  __syncthreads();
   int keep_mask = 0, cnt = 0;
   for (int k = 0; k < per; ++k) {
     const int i = i0 + k;
     if (i >= n) break;
-    const VT mine = v[i];
-    // (one value per iteration was a chain of dependent LDS round trips: 25 us for 1024 draws; independent broadcast reads of 16 / 8
-    //  values per iteration are paced by the LDS pipe and the compares instead)
-    bool dup = false;
-    int j = 0;
-    constexpr int UN = sizeof(VT) == 4 ? 16 : 8;
-    for (; j + UN <= i; j += UN) {
-      VT t[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) t[u] = v[j + u];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) dup |= (t[u] == mine);
-    }
-    for (; j < i; ++j) dup |= (v[j] == mine);
-    if (!dup) {
+    if (tidx[slot_of(v[i], false)] == i) {
       keep_mask |= 1 << k;
       ++cnt;
     }
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
     total = run;
   }
   __syncthreads();
-  int p = wsum[wv] + inc - cnt;
+  int p = wsum[wv] + inc - cnt;            // (the barriers of the scan separate the last table read from the first write of `kept`)
   for (int k = 0; k < per; ++k) {
     const int i = i0 + k;
     if (i >= n) break;
@@ -82,6 +94,46 @@ __global__ __launch_bounds__(1024) void sample_coords_kernel(const long long* __
     coords[3 * r + 1] = (f / d2) % d1;
     coords[3 * r + 2] = f % d2;
   }
+}
+
+// ---- small grids: a uniformly random PERMUTATION prefix.  When the grid has fewer than 8 x num voxels (the 8^3 tap of a 128^3 step:
+// 512 voxels for 512 patches) the draw-and-keep-distinct kernel above cannot be used and PatchSampleF fell back to torch.randperm --
+// about a dozen small launches in the middle of the forward (~150 us of the main stream per training step).  Here: one random 62-bit key
+// per voxel (a single torch.randint launch, so torch's generator still seeds it), the voxel indices sorted by (key, index) with a
+// bitonic network in LDS by ONE block, the first `num` unravelled.  Every order is equally likely (ties between 62-bit keys: < 1e-12
+// for 4096 voxels, and then broken by index -- deterministic either way).
+__global__ __launch_bounds__(1024) void sample_perm_kernel(const long long* __restrict__ keys, int nvox, int num, int d1, int d2,
+                                                           long long* __restrict__ coords) {
+  __shared__ unsigned long long k[4096];                    // (key << 12) | index: one compare orders both
+  int np2 = 1;
+  while (np2 < nvox) np2 <<= 1;
+  for (int i = threadIdx.x; i < np2; i += 1024)
+    k[i] = i < nvox ? (((unsigned long long)keys[i] & ((1ull << 50) - 1)) << 12) | (unsigned)i : ~0ull;   // padding sorts last
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (np2 >> 1); t += 1024) {
+        const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = k[lo], b = k[hi];
+        if ((a > b) == up) {
+          k[lo] = b;
+          k[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int r = threadIdx.x; r < num; r += 1024) {
+    const long long f = (long long)(k[r] & 4095);
+    coords[3 * r] = f / ((long long)d1 * d2);
+    coords[3 * r + 1] = (f / d2) % d1;
+    coords[3 * r + 2] = f % d2;
+  }
+}
+
+hipError_t launch_sample_perm(const long long* keys, int nvox, int num, int d1, int d2, long long* coords, hipStream_t st) {
+  sample_perm_kernel<<<1, 1024, 0, st>>>(keys, nvox, num, d1, d2, coords);
+  return hipGetLastError();
 }
 
 // ---- sampled feature taps (the contrastive step reads 512 voxels of each tapped feature map: supcl_model.py:801-843 calls
@@ -147,11 +199,24 @@ hipError_t launch_scatter_rows(const float* rows, const long long* coords, void*
 }
 
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st) {
-  const size_t lds = (size_t)(((n + 15) & ~15) + n) * sizeof(long long);
-  if ((long long)d0 * d1 * d2 < (1ll << 31))
-    sample_coords_kernel<int><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords);
+  int tsize = 1024;
+  while (tsize < 2 * n) tsize <<= 1;                         // load factor <= 1/2 (n <= 4096: at most 8192 slots)
+  const bool small = (long long)d0 * d1 * d2 < (1ll << 31);
+  const size_t vb = small ? sizeof(int) : sizeof(long long);
+  const size_t lds = (size_t)(((n + 15) & ~15) + tsize) * vb + (size_t)tsize * sizeof(int);   // draws + table (the kept list re-uses the table)
+  static bool attr = false;
+  if (lds > 159 * 1024) return hipErrorInvalidValue;
+  if (!attr) {                                               // (the kernel also holds 68 bytes of static LDS)
+    hipError_t e = hipFuncSetAttribute((const void*)sample_coords_kernel<int>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)sample_coords_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  if (small)
+    sample_coords_kernel<int><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords, tsize);
   else
-    sample_coords_kernel<long long><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords);
+    sample_coords_kernel<unsigned long long><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords, tsize);
   return hipGetLastError();
 }
 

@@ -65,6 +65,21 @@ class PatchSampleF(nn.Module):
                     raise NotImplementedError("initialization method [%s] is not implemented" % self.init_type)
 
     @staticmethod
+    def _sample_perm(device, num, dims):
+        """``randperm(nvox)[:num]`` on a small grid (<= 4096 voxels): one random key per voxel from torch's generator, ordered and
+        unravelled by one HIP kernel (amx_sample_perm) instead of torch.randperm's dozen launches."""
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        d = [1] * (3 - len(dims)) + [int(v) for v in dims]
+        keys = torch.randint(1 << 62, (d[0] * d[1] * d[2],), device=device, dtype=torch.int64)
+        coords = torch.empty((num, 3), dtype=torch.int64, device=device)
+        with torch.cuda.device(device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.amx_sample_perm(_lib.ptr(keys), d[0], d[1], d[2], num, _lib.ptr(coords), st))
+        return coords[:, 3 - len(dims):]
+
+    @staticmethod
     def _sample_distinct(device, nvox, num, dims):
         """``randperm(nvox)[:num]`` without sorting every voxel: 2 * num draws with replacement from torch's generator, then
         the first ``num`` distinct ones in draw order (same distribution) unravelled by one HIP kernel (amx_sample_coords)."""
@@ -114,6 +129,8 @@ class PatchSampleF(nn.Module):
         num = int(min(num_patches, nvox))
         if device.type == "cuda" and nvox >= 8 * num and 2 * num <= 4096:
             return self._sample_distinct(device, nvox, num, dims)
+        if device.type == "cuda" and nvox <= 4096 and ndims <= 3:
+            return self._sample_perm(device, num, dims)
         flat = torch.randperm(nvox, device=device)[:num]
         cs = []
         for a in range(ndims - 1, -1, -1):

@@ -475,6 +475,11 @@ int amx_scatter_rows(const float* d_rows, const long long* d_coords, void* d_dst
                      long long dst_sy, long long dst_sx, int n, int p, int c, int accumulate, void* stream);
 
 int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, int d1, int d2, long long* d_coords, void* stream);
+/* The same branch on a SMALL grid (d0 d1 d2 <= 4096 voxels, e.g. 512 patches from an 8^3 map = all of it): d_keys holds one random
+ * non-negative 64-bit key per voxel (torch.randint: torch's generator seeds it); the voxels are ordered by key (ties by index) in one
+ * launch and the first `num` are unravelled to d_coords [num][3] -- a uniformly random permutation prefix, replacing
+ * torch.randperm(n)[:num] (pretraining_networks.py:443-470) and its dozen small launches. */
+int amx_sample_perm(const long long* d_keys, int d0, int d1, int d2, int num, long long* d_coords, void* stream);
 
 /* The optimizer step of the contrastive step: torch.optim.AdamW as the reference builds it for netG and netF
  * (pretraining/models/supcl_model.py:510-516, 584-590; stepped at :628-661), every parameter tensor of one optimizer in ONE

@@ -218,7 +218,9 @@ def test_distinct_coordinate_sampler():
     generator, uniform over the grid, and robust when the draws collide a lot."""
     from anatomix_amd.pretraining import PatchSampleF
     dev = torch.device("cuda:0")
-    for dims, num in (((128, 128, 128), 512), ((16, 16, 16), 512), ((20, 12, 18), 300), ((64, 48), 256)):
+    # (the last two: the largest draw count the entry takes, and a grid of more than 2^31 voxels -- 64-bit keys in the kernel's hash table)
+    for dims, num in (((128, 128, 128), 512), ((16, 16, 16), 512), ((20, 12, 18), 300), ((64, 48), 256), ((128, 128, 128), 2048),
+                      ((2048, 2048, 1024), 2048)):
         nvox = int(np.prod(dims))
         torch.manual_seed(5)
         c1 = PatchSampleF._sample_distinct(dev, nvox, num, list(dims))
@@ -240,7 +242,24 @@ def test_distinct_coordinate_sampler():
     octant = (allc >= 32) @ np.array([4, 2, 1])
     counts = np.bincount(octant, minlength=8) / len(allc)
     assert np.abs(counts - 0.125).max() < 0.02
-    # the sampler is what the module uses for large grids; small grids (a permutation of everything) keep randperm
+    # small grids (fewer than 8 x num voxels, <= 4096): a uniformly random permutation prefix from one key per voxel (amx_sample_perm)
+    for dims, num in (((8, 8, 8), 512), ((8, 8, 8), 100), ((16, 16, 16), 600), ((5, 7, 3), 105), ((12, 20), 64)):
+        torch.manual_seed(9)
+        p1 = PatchSampleF._sample_perm(dev, num, list(dims))
+        torch.manual_seed(9)
+        p2 = PatchSampleF._sample_perm(dev, num, list(dims))
+        assert p1.shape == (num, len(dims)) and p1.dtype == torch.int64 and torch.equal(p1, p2)
+        c = p1.cpu().numpy()
+        assert (c >= 0).all() and (c < np.array(dims)).all()
+        flat = np.ravel_multi_index(tuple(c.T), dims)
+        assert len(np.unique(flat)) == num
+        torch.manual_seed(9)                                             # the order is the order of the keys, ties by index
+        keys = torch.randint(1 << 62, (int(np.prod(dims)),), device=dev, dtype=torch.int64).cpu().numpy() & ((1 << 50) - 1)
+        assert (flat == np.lexsort((np.arange(len(keys)), keys))[:num]).all()
+    torch.manual_seed(1)                                                 # every voxel is equally likely to come first
+    firsts = torch.cat([PatchSampleF._sample_perm(dev, 1, [4, 4, 4]) for _ in range(640)]).cpu().numpy()
+    counts = np.bincount(np.ravel_multi_index(tuple(firsts.T), (4, 4, 4)), minlength=64)
+    assert counts.min() >= 1 and counts.max() <= 30                      # mean 10
     netF = PatchSampleF(use_mlp=False)
     feats = [torch.randn(2, 4, 32, 32, 32, device=dev), torch.randn(2, 4, 8, 8, 8, device=dev)]
     out, ids = netF(feats, 512, None, None)
