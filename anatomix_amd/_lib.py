@@ -136,6 +136,7 @@ SYMBOLS = {
     "amx_scatter_rows": (_I, [_P, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _I, _P]),
     "amx_sample_coords": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "amx_sample_perm": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "amx_import_input": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "amx_mindssc_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_mindssc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "amx_avg_pool3d_cat": (_I, [_P, _I, C.c_float, _P, _I, C.c_float, _I, _I, _I, _I, _P, _P]),

@@ -1706,6 +1706,14 @@ int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, in
   return AMX_OK;
 }
 
+int amx_import_input(const float* d_src, void* d_dst, int n, int cin, int d, int hh, int w, int precision, void* stream) {
+  if (!d_src || !d_dst || n < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_INVALID, "import_input: bad arguments");
+  if (cin < 1 || cin > 16) return fail(AMX_ERR_SHAPE, "import_input: 1 <= input channels <= 16 (got %d)", cin);
+  if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return fail(AMX_ERR_INVALID, "import_input: f16 / bf16 storage");
+  AMX_HIP(amx::launch_import_input(d_src, d_dst, n, cin, (long long)d * hh * w, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
 int amx_sample_perm(const long long* d_keys, int d0, int d1, int d2, int num, long long* d_coords, void* stream) {
   if (!d_keys || !d_coords) return fail(AMX_ERR_INVALID, "null argument");
   if (d0 < 1 || d1 < 1 || d2 < 1) return fail(AMX_ERR_SHAPE, "non-positive shape");

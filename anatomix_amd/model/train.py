@@ -126,8 +126,11 @@ class _UnetTrainFn(torch.autograd.Function):
         mods = list(model.model)
         dev = x.device
         n, _, d, h, w = x.shape
-        xin = torch.zeros((n, d, h, w, 16), dtype=dt, device=dev)        # the single input channel, padded to one MFMA chunk
-        xin[..., 0] = x.detach()[:, 0].to(dt)
+        # the single input channel, padded to one MFMA chunk: one pass (zero fill + cast + strided copy were three, 56 us at 128^3 x 2)
+        xin = T.import_input(x[:, :1], dt) if x.is_cuda else None
+        if xin is None:
+            xin = torch.zeros((n, d, h, w, 16), dtype=dt, device=dev)
+            xin[..., 0] = x.detach()[:, 0].to(dt)
         tensors = {"x": xin}
         blocks, ops, skips = [], [], []
         cur, pending_low = "x", None

@@ -349,6 +349,17 @@ def scatter_rows(rows, coords, dst, accumulate=False):
     return dst
 
 
+def import_input(x, dtype):
+    """fp32 [N, Cin <= 16, D, H, W] -> 16-bit channels-last [N, D, H, W, 16] (real channels first, the rest zero) in one pass."""
+    lib = _lib.load()
+    n, cin, d, h, w = x.shape
+    xs = x.detach().contiguous().float()
+    out = torch.empty((n, d, h, w, 16), dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.amx_import_input(_lib.ptr(xs), _lib.ptr(out), n, cin, d, h, w, _PREC[dtype], _st(x.device)))
+    return out
+
+
 def import_ncdhw(g, dst, accumulate=False):
     """fp32 NCDHW gradient -> 16-bit NDHWC view ``dst`` [N, D, H, W, C'] (C' >= C channels per voxel; any strides that are
     multiples of 16 bytes, e.g. the interior of a framed buffer), optionally adding to it."""

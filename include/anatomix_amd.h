@@ -290,6 +290,10 @@ int amx_upcat_split_backward_framed(const void* d_g_framed, void* d_dskip, void*
  * gradients coming back: export  d_src 16-bit [n][d][h][w][c] -> d_out fp32 [n][c][d][h][w];
  * import  d_src fp32 [n][c][d][h][w] -> d_dst 16-bit through byte strides (voxel pitch dst_sx >= 2 c; lets the interior of
  * a zero-framed gradient buffer be the destination), adding to the destination when accumulate != 0.  c % 8 == 0. */
+/* The network input for the training path: d_src fp32 [n][cin][d][hh][w] (1 <= cin <= 16) -> d_dst 16-bit channels-last
+ * [n][d][hh][w][16], the real channels first and the rest zero -- one pass (the differentiable forward pads the input to one
+ * 16-channel chunk so that its first conv is an ordinary 16 -> ngf layer, network.py:310-333 with input_nc = 1 or 2). */
+int amx_import_input(const float* d_src, void* d_dst, int n, int cin, int d, int hh, int w, int precision, void* stream);
 int amx_export_ncdhw(const void* d_src, int c, int n, int d, int hh, int w, float* d_out, int precision, void* stream);
 int amx_import_ncdhw(const float* d_src, void* d_dst, int n, int c, int d, int hh, int w, long long dst_sn, long long dst_sz,
                      long long dst_sy, long long dst_sx, int accumulate, int precision, void* stream);

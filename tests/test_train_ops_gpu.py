@@ -288,3 +288,15 @@ def test_direct_data_gradient_equals_the_framed_route(device, prec, cin, cout, s
     ref = xq.grad[:, :, face]
     assert rel_l2(ncdhw(new)[:, :cin][:, :, face], ref) < 3 * ULP[prec]
     assert torch.equal(T.conv_dgrad_direct(framed, wd), new)          # deterministic
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("cin", [1, 2, 16])
+def test_import_input_pads_to_sixteen_channels(device, prec, cin):
+    """amx_import_input: fp32 NCDHW -> 16-bit channels-last with 16 stored channels, bit for bit what zero-fill + cast + copy give."""
+    dt = DT[prec]
+    x = torch.randn(2, cin, 6, 10, 20, generator=torch.Generator().manual_seed(3)).to(device) * 3
+    got = T.import_input(x, dt)
+    want = torch.zeros(2, 6, 10, 20, 16, dtype=dt, device=device)
+    want[..., :cin] = x.permute(0, 2, 3, 4, 1).to(dt)
+    assert got.shape == want.shape and got.dtype == dt and torch.equal(got, want)
