@@ -14,6 +14,7 @@ import torch.nn as nn
 _PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
 _SAMPLED_TAPS = os.environ.get("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
 _STREAMS = {}
+_WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
 
 
 def _layer_streams(device, n):
@@ -57,21 +58,24 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         pooled, ids = netF.forward_rows(rows, coords, streams)
     else:
         pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
-    parts, layer_losses = [], []
-    for k, (f_kq, sid, crit, layer, w, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, nce_weights, feat_sizes)):
+    means, layer_losses = [], []
+    for k, (f_kq, sid, crit, layer, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, feat_sizes)):
         with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
-            loss = crit(f_kq, seg_A, sid, torch.Size(fsize))
-            part = loss.mean() * w * lambda_nce
-            det = loss.detach().mean()
-        parts.append(part)                                    # (kept alive until after the backward: no cross-stream reuse)
-        layer_losses.append(det)
+            m = crit(f_kq, seg_A, sid, torch.Size(fsize)).mean()
+        means.append(m)                                       # (kept alive until after the backward: no cross-stream reuse)
+        layer_losses.append(m.detach())                       # the recorded per-layer loss IS this mean (it was reduced a second time)
     if streams is not None:
         for s in streams:
             ambient.wait_stream(s)
-    total = 0.0
-    for part in parts:
-        total = total + part
-    loss = total / grad_accum_iters
+    # total = sum_k mean_k * w_k * lambda_nce (supcl_model.py:815-843) as ONE weighted sum of the stacked means: the chain of scalar
+    # multiplies and adds was a dozen 2-us launches on the main stream, forward and backward
+    wkey = (str(reals.device), tuple(float(w) for w in nce_weights), float(lambda_nce), float(grad_accum_iters))
+    wv = _WEIGHTS.get(wkey)
+    if wv is None:                                            # (first built in an eager warm-up step: a host copy cannot be captured)
+        wv = _WEIGHTS[wkey] = torch.tensor([w * lambda_nce / grad_accum_iters for w in nce_weights][: len(means)], dtype=torch.float32,
+                                           device=reals.device)
+    loss = (torch.stack(means) * wv).sum()
+    total = loss * grad_accum_iters if grad_accum_iters != 1 else loss
     (scaler.scale(loss) if scaler is not None else loss).backward()      # supcl_model.py:624-626
     return total, layer_losses, ids, out
 
