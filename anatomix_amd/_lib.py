@@ -137,6 +137,7 @@ SYMBOLS = {
     "amx_sample_coords": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "amx_sample_perm": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "amx_import_input": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "amx_gather_labels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "amx_mindssc_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "amx_mindssc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "amx_avg_pool3d_cat": (_I, [_P, _I, C.c_float, _P, _I, C.c_float, _I, _I, _I, _I, _P, _P]),

@@ -117,6 +117,8 @@ hipError_t launch_upsample2_trilinear_backward(const void* gout, void* gin, int 
                                                hipStream_t st);
 hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, int d1, int d2, long long* coords, hipStream_t st);
 hipError_t launch_sample_perm(const long long* keys, int nvox, int num, int d1, int d2, long long* coords, hipStream_t st);
+hipError_t launch_gather_labels(const float* seg, int D, int H, int W, const long long* coords, int P, int d, int h, int w, int views,
+                                int* out, hipStream_t st);
 hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long long sz, long long sy, long long sx, long long sc,
                               const long long* coords, int N, int P, int C, float* rows, hipStream_t st);
 hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
@@ -1711,6 +1713,14 @@ int amx_import_input(const float* d_src, void* d_dst, int n, int cin, int d, int
   if (cin < 1 || cin > 16) return fail(AMX_ERR_SHAPE, "import_input: 1 <= input channels <= 16 (got %d)", cin);
   if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return fail(AMX_ERR_INVALID, "import_input: f16 / bf16 storage");
   AMX_HIP(amx::launch_import_input(d_src, d_dst, n, cin, (long long)d * hh * w, precision, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_gather_labels(const float* d_seg, int sd, int sh, int sw, const long long* d_coords, int p, int d, int hh, int w, int views,
+                      int* d_labels, void* stream) {
+  if (!d_seg || !d_coords || !d_labels || p < 1 || views < 1) return fail(AMX_ERR_INVALID, "gather_labels: bad arguments");
+  if (sd < 1 || sh < 1 || sw < 1 || d < 1 || hh < 1 || w < 1) return fail(AMX_ERR_SHAPE, "gather_labels: non-positive shape");
+  AMX_HIP(amx::launch_gather_labels(d_seg, sd, sh, sw, d_coords, p, d, hh, w, views, d_labels, (hipStream_t)stream));
   return AMX_OK;
 }
 

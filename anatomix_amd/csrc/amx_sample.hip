@@ -136,6 +136,29 @@ hipError_t launch_sample_perm(const long long* keys, int nvox, int num, int d1, 
   return hipGetLastError();
 }
 
+// ---- class labels of the sampled patches (SupPatchNCELoss, supcl_model.py:100-123): F.interpolate(seg, size = feature map, 'nearest')
+// gathered at the patch coordinates, rounded to integer class ids and tiled over the views.  Six small torch launches per layer
+// (resize of the whole map, index, round, cast, repeat, contiguous); here the `views x P` ids are read straight from the
+// full-resolution segmentation: source index = min(floor(dst * float(in) / out), in - 1), ATen's nearest rule.
+__global__ void gather_labels_kernel(const float* __restrict__ seg, int D, int H, int W, const long long* __restrict__ coords, int P,
+                                     int d, int h, int w, int views, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float sz = (float)D / (float)d, sy = (float)H / (float)h, sx = (float)W / (float)w;
+  int z = (int)floorf((float)coords[3 * i] * sz), y = (int)floorf((float)coords[3 * i + 1] * sy), x = (int)floorf((float)coords[3 * i + 2] * sx);
+  z = z < D - 1 ? z : D - 1;
+  y = y < H - 1 ? y : H - 1;
+  x = x < W - 1 ? x : W - 1;
+  const int lab = (int)rintf(seg[((long long)z * H + y) * W + x]);   // torch.round: to nearest, ties to even
+  for (int v = 0; v < views; ++v) out[v * P + i] = lab;
+}
+
+hipError_t launch_gather_labels(const float* seg, int D, int H, int W, const long long* coords, int P, int d, int h, int w, int views,
+                                int* out, hipStream_t st) {
+  gather_labels_kernel<<<(P + 255) / 256, 256, 0, st>>>(seg, D, H, W, coords, P, d, h, w, views, out);
+  return hipGetLastError();
+}
+
 // ---- sampled feature taps (the contrastive step reads 512 voxels of each tapped feature map: supcl_model.py:801-843 calls
 // netF(feat_k, num_patches, ids), pretraining_networks.py:472-480 gathers feat[:, :, x, y, z]).  Going through a dense fp32 NCDHW
 // copy of every tapped tensor costs an export pass forward and, backward, a dense zero tensor + index_put + an import pass per

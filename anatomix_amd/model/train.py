@@ -378,7 +378,7 @@ class _UnetTrainFn(torch.autograd.Function):
                 if g is not None:
                     T.import_ncdhw(g, T.interior(fr))
                 else:
-                    T.interior(fr).zero_()
+                    fr.zero_()                                            # (the whole buffer: a contiguous fill is 3x faster than the strided interior)
                 if rows is not None:                                    # sampled tap at the output conv: 2 x 512 rows of gradient
                     T.scatter_rows(rows, ctx.coords_of[idx], T.interior(fr), accumulate=True)
             else:
@@ -424,7 +424,7 @@ class _UnetTrainFn(torch.autograd.Function):
                     if bn.weight is not None:
                         pgrads[id(bn.weight)], pgrads[id(bn.bias)] = torch.stack(dgs).sum(0), torch.stack(dbs).sum(0)
                 else:
-                    T.interior(fr).zero_()
+                    fr.zero_()                                            # (the whole buffer: a contiguous fill is 3x faster than the strided interior)
                 if idx in dtap:                                         # tap at the conv id: gradient of the PRE-norm output
                     if idx in ctx.coords_of:
                         T.scatter_rows(dtap.pop(idx), ctx.coords_of[idx], T.interior(fr), accumulate=True)

@@ -65,8 +65,23 @@ class SupPatchNCELoss(nn.Module):
 
     @torch.compiler.disable      # the reference compiles its criterion (supcl_model.py:477-489); the kernel call is opaque
     def forward(self, features, labels_seg, labels_coords, coords_range, debug=False):
-        labels = self.gather_labels(labels_seg, labels_coords, coords_range)        # [bs = 1, P]
         ntps, num_patches, nc = features.size()
+        if (features.is_cuda and len(coords_range) == 3 and labels_seg.is_cuda and labels_seg.dtype == torch.float32 and
+                labels_seg.dim() == 5 and labels_seg.shape[:2] == (1, 1) and labels_coords.dtype == torch.int64):
+            # the class ids of the views x P patches in one launch (amx_gather_labels) instead of resize + index + round + cast + repeat
+            import ctypes
+            from .. import _lib
+            lib = _lib.load()
+            seg = labels_seg.contiguous()
+            coords = labels_coords.contiguous()
+            lab = torch.empty(ntps * num_patches, dtype=torch.int32, device=features.device)
+            with torch.cuda.device(features.device):
+                st = ctypes.c_void_p(torch.cuda.current_stream(features.device).cuda_stream)
+                _lib.check(lib.amx_gather_labels(_lib.ptr(seg), seg.shape[2], seg.shape[3], seg.shape[4], _lib.ptr(coords), num_patches,
+                                                 int(coords_range[0]), int(coords_range[1]), int(coords_range[2]), ntps, _lib.ptr(lab), st))
+            return _SupConHip.apply(features.reshape(ntps * num_patches, nc), lab, self.temperature, self.weigh_rarity,
+                                    self.balance_denominator, self.weighting_mode == "sqrt")
+        labels = self.gather_labels(labels_seg, labels_coords, coords_range)        # [bs = 1, P]
         if labels.shape[0] != 1:
             raise NotImplementedError("one segmentation shared by the views (the reference's eq(labels, labels.T) needs bs == 1)")
         if features.is_cuda:

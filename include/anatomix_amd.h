@@ -484,6 +484,11 @@ int amx_sample_coords(const long long* d_draws, int n_draws, int num, int d0, in
  * launch and the first `num` are unravelled to d_coords [num][3] -- a uniformly random permutation prefix, replacing
  * torch.randperm(n)[:num] (pretraining_networks.py:443-470) and its dozen small launches. */
 int amx_sample_perm(const long long* d_keys, int d0, int d1, int d2, int num, long long* d_coords, void* stream);
+/* Class ids of the sampled patches for SupPatchNCELoss (supcl_model.py:100-123: F.interpolate(seg, size = the feature map, mode =
+ * 'nearest') gathered at the patch coordinates): d_seg fp32 [sd][sh][sw] (one label map shared by the views), d_coords int64
+ * [p][3] in the (d, hh, w) grid of the feature map -> d_labels int32 [views][p] (round to nearest, tiled over the views). */
+int amx_gather_labels(const float* d_seg, int sd, int sh, int sw, const long long* d_coords, int p, int d, int hh, int w, int views,
+                      int* d_labels, void* stream);
 
 /* The optimizer step of the contrastive step: torch.optim.AdamW as the reference builds it for netG and netF
  * (pretraining/models/supcl_model.py:510-516, 584-590; stepped at :628-661), every parameter tensor of one optimizer in ONE

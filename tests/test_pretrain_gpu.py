@@ -45,6 +45,25 @@ def test_hip_loss_forward_backward(device, case, wr, bal, mode):
     assert err.item() < 2e-5, err.item()
 
 
+@pytest.mark.parametrize("seg_shape,fsize", [((128, 128, 128), (64, 64, 64)), ((128, 128, 128), (8, 8, 8)), ((40, 52, 36), (13, 20, 36)),
+                                             ((30, 30, 30), (30, 30, 30)), ((17, 9, 33), (5, 4, 7))])
+def test_label_gather_kernel_equals_interpolate_and_index(device, seg_shape, fsize):
+    """amx_gather_labels (the criterion's one-launch label path) against F.interpolate(seg, size, 'nearest')[coords] -> round -> int ->
+    repeat, on divisible and non-divisible size ratios."""
+    import ctypes
+    from anatomix_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    seg = torch.randint(0, 9, (1, 1) + seg_shape, generator=g).float().to(device)
+    P = 300
+    coords = torch.stack([torch.randint(0, n, (P,), generator=g) for n in fsize], dim=1).to(device)
+    want = SupPatchNCELoss.gather_labels(seg, coords, fsize)[0].round().to(torch.int32).repeat(2)
+    lib = _lib.load()
+    got = torch.empty(2 * P, dtype=torch.int32, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.amx_gather_labels(_lib.ptr(seg), *seg_shape, _lib.ptr(coords), P, *fsize, 2, _lib.ptr(got), st))
+    assert torch.equal(got, want)
+
+
 def test_hip_loss_is_deterministic_and_forward_only_works(device):
     feats, seg, coords, size = PI.loss_inputs("p512c256")
     crit = SupPatchNCELoss(_opt(False, True, "raw"))
