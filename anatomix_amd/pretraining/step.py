@@ -109,6 +109,14 @@ def _grad_norms(netG, netF):
     # clip_grad_norm_(max_norm=inf) only measures (supcl_model.py:635-655): the norm is what is recorded; its second half -- every
     # gradient multiplied by clamp(inf / norm, max=1) = 1 -- is an identity pass over all gradients and is left out
     if hasattr(nn.utils, "get_total_norm"):
+        gG = [p.grad for p in netG.parameters() if p.grad is not None]
+        gF = [p.grad for p in netF.parameters() if p.grad is not None]
+        if gG and gF and hasattr(torch, "_foreach_norm") and all(g.is_cuda and g.dtype == torch.float32 and g.device == gG[0].device
+                                                                   for g in gG + gF):
+            # get_total_norm = vector_norm(stack(_foreach_norm(grads))) per network; the per-tensor norms of BOTH networks come from one
+            # multi-tensor launch here (the same numbers, four launches fewer at the end of every step)
+            norms = torch._foreach_norm(gG + gF, 2.0)
+            return torch.linalg.vector_norm(torch.stack(norms[: len(gG)]), 2.0), torch.linalg.vector_norm(torch.stack(norms[len(gG):]), 2.0)
         return _total_norm(netG), _total_norm(netF)
     # older torch: the norm of the per-tensor norms (clip_grad_norm_(max_norm=inf) would also multiply every gradient by
     # clamp(inf / norm) -- NaN when the norm itself is inf)
