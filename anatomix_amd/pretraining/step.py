@@ -14,7 +14,16 @@ import torch.nn as nn
 _PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
 _SAMPLED_TAPS = os.environ.get("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
 _STREAMS = {}
+_TAP_SHAPES = {}                                             # (network, input shape, tap ids, patches) -> {tap id: spatial shape}
+_PREDRAW = os.environ.get("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
 _WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
+
+
+def _draw_stream(device):
+    key = ("draw", device.type, device.index)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device)]
+    return _STREAMS[key][0]
 
 
 def _layer_streams(device, n):
@@ -39,8 +48,38 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         # back those rows -- drawn with netF's own sampler when the forward reaches each tap, i.e. in netF's order, so the generator
         # is consumed exactly as by netG(...) followed by netF(...) -- instead of dense fp32 copies of six tensors
         from ..model import train as _train
-        out, rows, coords, dims = _train.forward_train_sampled(
-            netG, reals, list(nce_layers), lambda i, shape: netF.draw_coords(sampled[i], shape, num_patches, sample_ids, reals.device))
+        # The coordinates do not depend on the features: once the tap shapes of this (network, input shape) are known from an earlier
+        # step they are all drawn up front, in netF's layer order (the generator is consumed exactly as before), on a side stream the
+        # forward joins at its first tap -- six draw + filter launches leave the main stream's critical path.
+        skey = (id(netG), tuple(reals.shape), tuple(int(l) for l in nce_layers), int(num_patches))
+        shapes = _TAP_SHAPES.get(skey)
+        pre = {}
+        if shapes is not None and sample_ids is None and _PREDRAW and torch.cuda.is_current_stream_capturing():   # (eagerly the stream switches cost more than they return)
+            side = _draw_stream(reals.device)
+            main = torch.cuda.current_stream(reals.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for l in sorted(sampled):
+                    pre[l] = netF.draw_coords(sampled[l], shapes[l], num_patches, None, reals.device)
+                    pre[l].record_stream(main)
+            joined = []
+
+            def sampler(i, shape):
+                if not joined:
+                    torch.cuda.current_stream(reals.device).wait_stream(side)
+                    joined.append(1)
+                if tuple(shape) != tuple(shapes[i]):
+                    raise RuntimeError("contrastive step: the tap shapes changed under a cached sampling plan")
+                return pre[i]
+        else:
+            seen = {}
+
+            def sampler(i, shape):
+                seen[i] = tuple(shape)
+                return netF.draw_coords(sampled[i], shape, num_patches, sample_ids, reals.device)
+        out, rows, coords, dims = _train.forward_train_sampled(netG, reals, list(nce_layers), sampler)
+        if shapes is None and sample_ids is None:
+            _TAP_SHAPES[skey] = dict(seen)
         feat_sizes = dims
         feat_kq = None
     else:
