@@ -31,6 +31,7 @@ RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm a
 SPLIT_CONCAT_DGRAD = int(os.environ.get("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
 DIRECT_DGRAD = os.environ.get("AMX_NO_DIRECT_DGRAD", "0") != "1"   # data gradient: interior launch + shell terms instead of the framed domain + pad_fold
+PACK_ASIDE = os.environ.get("AMX_NO_PACK_ASIDE", "0") != "1"     # A/B: both passes' weight packing on a side stream at the start of the forward
 BATCH_PACK = os.environ.get("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
 _SIDE = {}
 
@@ -126,8 +127,41 @@ class _UnetTrainFn(torch.autograd.Function):
         mods = list(model.model)
         dev = x.device
         n, _, d, h, w = x.shape
+        # Packed weights of every plain conv in ONE launch per pass (T.pack_batch) instead of one small launch inside each conv call.  Which
+        # convs, with how many stored input channels and at which width, is recorded by the first forward / backward of a given input
+        # shape (which pack per call) and replayed afterwards; a conv whose recorded shape does not match packs itself as before.
+        # While a HIP graph is being captured both launches go to a side stream here, beside the input import -- the backward's packing
+        # (the weights do not change in between) is then off the main stream altogether.
+        pkey = (tuple(x.shape), dt)
+        plan = getattr(model, "_pack_plan", {}).get(pkey) if BATCH_PACK else None
+        bplan0 = getattr(model, "_pack_plan_bwd", {}).get(pkey) if BATCH_PACK else None
+        packs, rec = {}, {}
+        ctx.bpacks_pre = None
+        pack_side = None
+        if plan:
+            ids = sorted(plan)
+            reqs = [(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids]
+            if x.is_cuda and PACK_ASIDE and torch.cuda.is_current_stream_capturing():
+                pack_side = _side_stream(dev)
+                main_s = torch.cuda.current_stream(dev)
+                pack_side.wait_stream(main_s)
+                with torch.cuda.stream(pack_side):
+                    views = T.pack_batch(reqs, dt, dev)
+                    for v in views:
+                        v.record_stream(main_s)
+                    if bplan0:
+                        bids = sorted(bplan0)
+                        bviews = T.pack_batch([(T._as_weight(mods[j].weight), 1, bplan0[j][0], bplan0[j][1]) for j in bids], dt, dev)
+                        for v in bviews:
+                            v.record_stream(main_s)
+                        ctx.bpacks_pre = (dict(bplan0), dict(zip(bids, bviews)))
+            else:
+                views = T.pack_batch(reqs, dt, dev)
+            packs = dict(zip(ids, views))
         # the single input channel, padded to one MFMA chunk: one pass (zero fill + cast + strided copy were three, 56 us at 128^3 x 2)
         xin = T.import_input(x[:, :1], dt) if x.is_cuda else None
+        if pack_side is not None:
+            torch.cuda.current_stream(dev).wait_stream(pack_side)
         if xin is None:
             xin = torch.zeros((n, d, h, w, 16), dtype=dt, device=dev)
             xin[..., 0] = x.detach()[:, 0].to(dt)
@@ -137,16 +171,6 @@ class _UnetTrainFn(torch.autograd.Function):
         taps = {}
         up_taps = {}                                                     # upsample id -> (skip tensor, low-resolution tensor)
         tracked = []                                                     # num_batches_tracked of every BatchNorm: one foreach add
-        # Packed weights of every plain conv in ONE launch (T.pack_batch) instead of one small launch inside each conv call.  Which
-        # convs, with how many stored input channels and at which width, is recorded by the first forward of a given input shape
-        # (which packs per call) and replayed afterwards; a conv whose recorded shape does not match packs itself as before.
-        pkey = (tuple(x.shape), dt)
-        plan = getattr(model, "_pack_plan", {}).get(pkey) if BATCH_PACK else None
-        packs, rec = {}, {}
-        if plan:
-            ids = sorted(plan)
-            views = T.pack_batch([(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids], dt, dev)
-            packs = dict(zip(ids, views))
 
         def packed(j, cin_pad, width, cout):
             if (cin_pad, cout) == (48, 16):                              # the 16 + up32 -> 16 merged-tap layer packs its own format
@@ -330,7 +354,10 @@ class _UnetTrainFn(torch.autograd.Function):
         # data-gradient packings of the plain blocks in one launch (same record-and-replay as the forward)
         bplan = getattr(model, "_pack_plan_bwd", {}).get(ctx.pkey) if BATCH_PACK else None
         bpacks, brec = {}, {}
-        if bplan:
+        pre = getattr(ctx, "bpacks_pre", None)
+        if bplan and pre is not None and pre[0] == bplan:            # packed beside the forward's input import (same weights)
+            bpacks = pre[1]
+        elif bplan:
             bids = sorted(bplan)
             bviews = T.pack_batch([(T._as_weight(model.model[j].weight), 1, bplan[j][0], bplan[j][1]) for j in bids], dt, tensors["x"].device)
             bpacks = dict(zip(bids, bviews))
