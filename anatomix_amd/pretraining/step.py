@@ -14,12 +14,18 @@ import torch.nn as nn
 _PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
 _SAMPLED_TAPS = os.environ.get("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
 _STREAMS = {}
+# Distinct side streams for the six per-layer head / loss chains.  One per layer (the first form) is NOT the fastest: HIP maps streams
+# onto four hardware queues and every cross-queue dependency of a replayed graph costs -- three streams (two layers each) measured
+# 7.45-7.50 ms per step against 7.74-7.77 with six, 7.53-7.55 with two, 7.68 with four (GPU_MAX_HW_QUEUES=8 instead: 14.4 ms).
+_HEAD_STREAMS = int(os.environ.get("AMX_HEAD_STREAMS", "3"))
 _TAP_SHAPES = {}                                             # (network, input shape, tap ids, patches) -> {tap id: spatial shape}
 _PREDRAW = os.environ.get("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
 _WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
 
 
 def _draw_stream(device):
+    if os.environ.get("AMX_OWN_DRAW_STREAM", "0") != "1":     # (A/B) the first head stream: it is idle until the heads start
+        return _layer_streams(device, 1)[0]
     key = ("draw", device.type, device.index)
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device=device)]
@@ -30,9 +36,10 @@ def _layer_streams(device, n):
     """One side stream per nce layer, created once per device."""
     key = (device.type, device.index)
     have = _STREAMS.setdefault(key, [])
-    while len(have) < n:
+    nuniq = min(n, _HEAD_STREAMS) if _HEAD_STREAMS > 0 else n
+    while len(have) < nuniq:
         have.append(torch.cuda.Stream(device=device))
-    return have[:n]
+    return [have[k % nuniq] for k in range(n)]
 
 
 
