@@ -24,12 +24,9 @@ _WEIGHTS = {}                                                # (device, nce weig
 
 
 def _draw_stream(device):
-    if os.environ.get("AMX_OWN_DRAW_STREAM", "0") != "1":     # (A/B) the first head stream: it is idle until the heads start
-        return _layer_streams(device, 1)[0]
-    key = ("draw", device.type, device.index)
-    if key not in _STREAMS:
-        _STREAMS[key] = [torch.cuda.Stream(device=device)]
-    return _STREAMS[key][0]
+    """The stream of the up-front coordinate draws: the first head stream (idle until the heads start; a stream of its own measured
+    the same, 7.38 vs 7.36 ms per step, and is one more stream on four hardware queues)."""
+    return _layer_streams(device, 1)[0]
 
 
 def _layer_streams(device, n):
