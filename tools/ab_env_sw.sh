@@ -1,0 +1,9 @@
+#!/bin/bash
+# sliding-window 256^3 with / without one environment switch on ONE box.  usage: tools/ab_env_sw.sh VAR=value
+cd ${GRAFT_REPO_ROOT:-.}
+KV=$1; shift
+run() { python bench.py --no-secondary --no-cpu-baseline --no-parity --sustain 0 --sw-volume 256 --steps 6 --warmup 2 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for rep in 1 2; do
+  echo "default  $(run "$@")"
+  echo "$KV $(env $KV bash -c "$(declare -f run); run $*")"
+done
