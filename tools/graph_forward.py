@@ -9,7 +9,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     m = anatomix_amd.Unet(**kw)
 m.load_state_dict(R.synthetic_state_dict(kw, 0))
 m = m.to(dev).eval()
-x = torch.rand(2, 1, 64, 64, 64, device=dev)
+x = torch.rand(4, 1, 128, 128, 128, device=dev)
 with torch.no_grad():
     y_ref = m(x).clone()
     s = torch.cuda.Stream()
@@ -32,4 +32,4 @@ with torch.no_grad():
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for _ in range(50): m(x)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"replay {1e3*(t1-t0)/50:.3f} ms, eager {1e3*(t2-t1)/50:.3f} ms per forward (2 x 64^3)")
+    print(f"replay {1e3*(t1-t0)/50:.3f} ms, eager {1e3*(t2-t1)/50:.3f} ms per forward (4 x 128^3)")
