@@ -145,9 +145,11 @@ class PatchSampleF(nn.Module):
             self.create_mlp([torch.zeros((1, r.shape[2], 1, 1, 1), device=r.device) for r in rows])
         ambient = torch.cuda.current_stream(rows[0].device) if streams is not None else None
         out = []
+        forked = set()
         for k, r in enumerate(rows):
-            if streams is not None:
+            if streams is not None and id(streams[k]) not in forked:      # (layers may share a stream: one fork per distinct stream)
                 streams[k].wait_stream(ambient)
+                forked.add(id(streams[k]))
             with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
                 out.append(self._head(k, r.flatten(0, 1), r.shape[0], r.shape[1]))
         return out, list(coords)

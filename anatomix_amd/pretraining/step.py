@@ -30,7 +30,7 @@ def _draw_stream(device):
 
 
 def _layer_streams(device, n):
-    """One side stream per nce layer, created once per device."""
+    """The side streams of the n per-layer chains (``_HEAD_STREAMS`` distinct ones, shared round-robin), created once per device."""
     key = (device.type, device.index)
     have = _STREAMS.setdefault(key, [])
     nuniq = min(n, _HEAD_STREAMS) if _HEAD_STREAMS > 0 else n
@@ -108,7 +108,7 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         means.append(m)                                       # (kept alive until after the backward: no cross-stream reuse)
         layer_losses.append(m.detach())                       # the recorded per-layer loss IS this mean (it was reduced a second time)
     if streams is not None:
-        for s in streams:
+        for s in dict.fromkeys(streams):                      # (each distinct stream once: layers share streams)
             ambient.wait_stream(s)
     # total = sum_k mean_k * w_k * lambda_nce (supcl_model.py:815-843) as ONE weighted sum of the stacked means: the chain of scalar
     # multiplies and adds was a dozen 2-us launches on the main stream, forward and backward
