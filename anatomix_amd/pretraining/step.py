@@ -104,7 +104,9 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     means, layer_losses = [], []
     for k, (f_kq, sid, crit, layer, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, feat_sizes)):
         with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
-            m = crit(f_kq, seg_A, sid, torch.Size(fsize)).mean()
+            m = crit(f_kq, seg_A, sid, torch.Size(fsize))
+            if m.dim() != 0:                                  # (the HIP criterion returns the scalar: a mean of it would be three more launches)
+                m = m.mean()
         means.append(m)                                       # (kept alive until after the backward: no cross-stream reuse)
         layer_losses.append(m.detach())                       # the recorded per-layer loss IS this mean (it was reduced a second time)
     if streams is not None:

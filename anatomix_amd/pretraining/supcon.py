@@ -29,7 +29,7 @@ class _SupConHip(torch.autograd.Function):
                                            int(sqrt_mode), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(scratch), nbytes, st))
         ctx.save_for_backward(grad)
         ctx.in_dtype = feat2d.dtype
-        return loss[0]
+        return loss.view(())
 
     @staticmethod
     def backward(ctx, gout):
