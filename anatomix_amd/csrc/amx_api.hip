@@ -93,6 +93,15 @@ hipError_t launch_dgrad_fold_shell(const void* dy, long long yn, long long yz, l
                                    hipStream_t st);
 size_t dgrad_shell_scratch_bytes();
 bool conv_zmarch_eligible(const ConvParams& p);
+bool conv_zmarch_stem_eligible(const ConvParams& p, int precision);
+const char* last_conv_zm_kernel_name();
+hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
+                                   void* prep, const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision,
+                                   hipStream_t st);
+size_t conv_zmarch_stem_prep_bytes(int N, int D, int H, int W);
+const char* last_conv_zm_kernel_name();
+hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const void* stem_wpk,
+                                   const float* stem_bias, int stem_act, float stem_slope, int precision, hipStream_t st);
 hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
                                      int accumulate, int precision, hipStream_t st);
 size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad);
@@ -496,6 +505,61 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       const ConvLayer& L = h->convs[conv_i++];
       const int lv = L.level;
       const int dd = d >> lv, dh = hh >> lv, dw = w >> lv;
+      // ---- stem + the 16 -> 16 layer behind it as ONE launch (amx_conv3d_zmarch.hip, STEM): the stem's output never reaches HBM.
+      // Plain forward only: no taps, folded (or no) norm on both layers, nothing else reads the stem's tensor.
+      if (cur.slot < 0 && !split && L.cout_p == 16 && L.cout == 16 && !L.is_final && conv_i < h->convs.size() &&
+          (!L.has_act || c.activation == AMX_ACT_RELU || c.activation == AMX_ACT_NONE) &&
+          !(L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE))) {
+        const ConvLayer& Nx = h->convs[conv_i];
+        const size_t g0 = i + 1 + (L.norm_idx >= 0 ? 1 : 0) + (L.has_act ? 1 : 0);       // module index of the next group
+        const size_t g1 = g0 + 1 + (Nx.norm_idx >= 0 ? 1 : 0) + (Nx.has_act ? 1 : 0);    // ... and of the one after it
+        bool ok = g0 < h->kinds.size() && h->kinds[g0] == K_CONV && Nx.level == 0 && !Nx.is_final && !Nx.after_up && Nx.cin_pad == 16 &&
+                  Nx.cout_p == 16 && Nx.cout == 16 && Nx.q == 1 && Nx.loaded;
+        for (int e : h->encoder_idx)
+          if (e >= (int)i && e < (int)g0) ok = false;                                     // the stem's tensor would be a skip connection
+        if (taps) {   // feature taps: only behind the pair (its activated output is module g1 - 1); the stem's tensor is never stored
+          for (int t = 0; t < taps->n; ++t)
+            if (taps->modules[t] + 1 < (int)g1) ok = false;
+          if (taps->stop >= 0 && taps->stop + 1 < (int)g1) ok = false;
+        }
+        amx::ConvParams p;
+        memset(&p, 0, sizeof p);
+        p.N = n; p.D = dd; p.H = dh; p.W = dw; p.Cout = Nx.cout_p; p.C0 = 16; p.C1 = 0;
+        p.wpk = (const char*)Nx.wpk; p.bias = Nx.shift; p.oflow = h->d_flag;
+        p.act = Nx.has_act ? c.activation : AMX_ACT_NONE; p.slope = c.act_slope;
+        p.ox = 16 * eb; p.oy = p.ox * dw; p.oz = p.oy * dh; p.on = p.oz * dd;
+        if (ok && amx::conv_zmarch_stem_eligible(p, c.precision)) {
+          Tensor out;
+          out.level = 0; out.C = Nx.cout_p; out.Cr = Nx.cout; out.slot = grab(0);
+          if (out.slot < 0) return fail(AMX_ERR_INVALID, "internal: arena exhausted at level 0");
+          p.out = A.slot[0][out.slot];
+          if (prof) {
+            amx_launch_record r;
+            memset(&r, 0, sizeof r);
+            r.module_idx = L.module_idx; r.cin = L.cin; r.cout = Nx.cout; r.n = n; r.d = dd; r.h = dh; r.w = dw;
+            const double vox = (double)n * dd * dh * dw;
+            r.flops = 2.0 * 27.0 * (L.cin * L.cout + Nx.cin * Nx.cout) * vox;
+            r.bytes = 4.0 * vox + 2.0 * Nx.cout * vox + 2.0 * 27.0 * (L.cin * L.cout + Nx.cin * Nx.cout);   // fp32 input once, 16-bit output once
+            if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
+          }
+          // the prepared input (two padded 16-bit copies, ~4.4 bytes per voxel) borrows a free level-0 slot for the duration of the launch
+          const int prep_slot = grab(0);
+          if (prep_slot < 0 || amx::conv_zmarch_stem_prep_bytes(n, dd, dh, dw) > level_bytes(h, 0, n, d, hh, w))
+            return fail(AMX_ERR_INVALID, "internal: no level-0 slot for the prepared stem input");
+          AMX_HIP(amx::launch_conv_zmarch_stem(p, x, xs_n, xs_z, xs_y, x_offs, A.slot[0][prep_slot], L.wpk, L.shift,
+                                               L.has_act ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st));
+          A.used[0][prep_slot] = false;                  // dead once its consumer is enqueued (stream order)
+          if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_zm_kernel_name());
+          ++conv_i;
+          cur = out;
+          i = g1 - 1;
+          if (float* t = tap_of((int)i)) AMX_HIP(export_slot(out, t));
+          for (int e : h->encoder_idx)
+            if (e == (int)i && c.use_skip) skips.push_back(cur);
+          if (stop == (int)i) return AMX_OK;
+          continue;
+        }
+      }
       amx::ConvParams p;
       memset(&p, 0, sizeof p);
       p.N = n; p.D = dd; p.H = dh; p.W = dw; p.Cout = L.cout_p;

@@ -64,6 +64,41 @@ struct ZmStage {
   static constexpr int TOTAL = NB * BYTES;
 };
 
+// STEM variant (round 6): the layer's INPUT is the single-channel stem convolution of the network input (network.py module 0 + folded
+// BatchNorm + ReLU), computed into the ring by the workgroup itself instead of being read from HBM -- the stem's 268 MB store and this
+// layer's 268 MB read (batch 4, 128^3) disappear; the stem costs one K = 32 MFMA pair per 16 voxels (amx_conv3d_stem.hip, row-fragment
+// formulation: same operands, same two MFMAs, same rounding -> the ring holds bit for bit what the stem kernel stores).
+//   * a small pass in front (stem_prep_kernel) rounds the fp32 input ONCE to the storage type and writes it reflect-padded (2 voxels in
+//     y and x) as the two shifted 16-bit row copies of the stem kernel -- copy A: value x at element x, copy B: value x + 1 at element x --
+//     so that the four consecutive values x - 1 .. x + 2 of ANY x start 4-byte aligned in one of the copies;
+//   * 16 waves of <= 128 registers: 8 consumers (unchanged sweep, rolling fragment reads) + 7 STEM waves + 1 LOADER wave;
+//   * the loader streams the 12 rows x 40 values of every input plane's two copies into an LDS ring of RC planes -- two 16-byte LDS-DMA
+//     instructions per plane, no register passes (`inready` counts landed planes);
+//   * stem wave w computes WHOLE ring planes q = w, w + 7, ...: a ring voxel OUTSIDE the volume is the reflection of the stem's OUTPUT, so
+//     its lane gathers the taps of the reflected voxel; it publishes ready[w] = the next plane it will publish.
+struct StemIn {
+  const char* srcA;             // prepared input, copy A: [N][D][H + 4][W + 8] 16-bit, value (y - 2, x - 2) reflected
+  const char* srcB;             //                 copy B: the same shifted by one element
+  long long sn, sz, sy;         // byte strides of both
+  const char* wpk;              // the stem's packed weights (pack_stem_kernel; the row-fragment tiles start at byte 4096)
+  const float* bias;            // [16] folded norm shift / conv bias or null
+  int act;                      // ACT_NONE or ACT_RELU
+  float slope;
+};
+
+template <int TY, int TX>
+struct ZmStemCfg {
+  static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
+  static constexpr int IY = HY + 2;                                   // input rows of a ring plane: one more voxel of halo
+  static constexpr int RS = (TX + 8) * 2;                             // bytes of a row copy: the values [x0 - 2, x0 + TX + 6) = five 16-byte pieces
+  static constexpr int CPSZ = IY * RS, IPLSZ = 2 * CPSZ;              // copies A | B of one input plane
+  static constexpr int RC = 16;                                       // input ring: the planes the <= 6 ring planes in production read + DMA lookahead
+  static constexpr int BYTES = RC * IPLSZ;
+  static constexpr int NSW = 7;                                       // stem waves (+ 1 loader wave = 8 producer waves; 16 waves of <= 128 registers)
+  static constexpr int NT = 2 * HY + (2 * HY + 15) / 16;              // tiles of one ring plane: (row, x 0..15), (row, x 16..31), the columns 32, 33 of 8 rows
+  static_assert(TX == 32 && IY * 5 <= 64 && RC * 2 <= 60 && IPLSZ % 64 == 0, "one DMA instruction per copy and plane (12 rows x five pieces); vmcnt range");
+};
+
 // One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
 // NS = 2 adds two STORER waves: the MFMA waves leave each step's outputs in an LDS staging tile and the storers
 // copy it out (storer w owns output plane w of every step).  A wave that issues global stores stalls while the
@@ -76,9 +111,10 @@ struct ZmStage {
 // 32-channel input -- and the step is swept twice: the hi planes against Wh and Wl (two MFMAs per fragment read), the lo planes
 // against Wh (Wh / Wl are the two packed "chunks" and stay in registers like the two chunks of the 32-channel kernel); the
 // epilogue splits the fp32 result again.
-template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL, bool SPLIT = false>
-__global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg) {
+template <typename T, int NCK, int QT, int TY, int TX, int R, int OUTMODE, int NS, bool POOL, bool SPLIT = false, bool STEM = false>
+__global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT ? 2 : NCK)) + NS) * 64) void conv3d_k3_zmarch_kernel(const ConvParams p, int zseg, int nseg, const StemIn si) {
   static_assert(!SPLIT || (NCK == 1 && QT == 1 && NS == 0), "strict z-march: 16 -> 16, direct stores");
+  static_assert(!STEM || (NCK == 1 && !SPLIT && NS == 0 && OUTMODE == 0), "stem-fed z-march: 16 input channels, direct 16-bit stores");
   constexpr int NCKP = SPLIT ? 2 : NCK;                             // chunk planes in the ring / weight sets in registers
   typedef ZmCfg<NCKP, QT, TY, TX, R> C;
   typedef ZmStage<QT, TY, TX, OUTMODE> SG;
@@ -113,7 +149,8 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
   int* done = (int*)(smem + C::FLAGOFF + 32);
   int* staged = (int*)(smem + C::FLAGOFF + 64);              // per consumer wave: steps whose outputs are in the staging tile
   int* stored = (int*)(smem + C::FLAGOFF + 96);              // per storer wave: steps it has read out of the staging tile
-  if (tid < (NS ? 32 : 16)) ((int*)(smem + C::FLAGOFF))[tid] = 0;
+  if (tid < ((NS || STEM) ? 32 : 16)) ((int*)(smem + C::FLAGOFF))[tid] = (STEM && tid < 8) ? (tid == 7 ? 0x7fffffff : tid) : 0;   // (STEM: ready[w] = the next plane stem wave w publishes; [7] belongs to no wave)
+  if constexpr (STEM) static_assert(STAGEOFF + ZmStemCfg<TY, TX>::BYTES <= 160 * 1024, "ring + input ring must fit the LDS");
   __syncthreads();
 
   if (NS && wave >= NC + NL) {
@@ -167,7 +204,232 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     return;
   }
 
-  if (wave >= NC) {
+  if constexpr (STEM) {
+    if (wave >= NC) {
+      typedef ZmStemCfg<TY, TX> SC;
+      constexpr int RS = SC::RS, CPSZ = SC::CPSZ, IPLSZ = SC::IPLSZ, RC = SC::RC;
+      constexpr int INOFF = STAGEOFF;
+      int* inready = staged;                                   // landed input planes (the storers' flag word is free: NS = 0)
+      // input planes the segment touches: ring plane q <-> z = zs - 1 + q, the stem voxel plane z1 = refl(z) reads z1 - 1 .. z1 + 1
+      const int zlo = zs >= 2 ? zs - 2 : 0;
+      const int zhi = ze + 1 <= p.D - 1 ? ze + 1 : p.D - 1;
+      if (wave == NC + SC::NSW) {
+        // =========================== loader wave ===========================
+        // lane -> (row pr of the twelve, piece pc of its five): the rows [y0 - 2, y0 + 10) = padded rows y0 .. y0 + 11, the values
+        // [x0 - 2, x0 + 38) = padded elements x0 .. x0 + 39.  One instruction per copy: 60 lanes x 16 bytes = CPSZ.
+        const int nin = zhi - zlo + 1;
+        const int pr = lane / 5, pc = lane - pr * 5;
+        const bool pvalid = lane < 60;
+        const int goff = pvalid ? (y0 + pr) * (int)si.sy + x0 * 2 + pc * 16 : 0;
+        const char* srcA = si.srcA + (long long)n * si.sn + goff;
+        const char* srcB = si.srcB + (long long)n * si.sn + goff;
+        auto issue_plane = [&](int k) {
+          const long long zo = (long long)(zlo + k) * si.sz;
+          char* dstp = smem + INOFF + ((zlo + k) % RC) * IPLSZ;
+          if (pvalid) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA + zo), (lptr_t)dstp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB + zo), (lptr_t)(dstp + CPSZ), 16, 0, 0);
+          }
+        };
+        int next_issue = 0, next_pub = 0, seen_ready = 0;
+        const unsigned a_in = lds_addr(inready);
+#ifdef AMX_EXPERIMENT
+        unsigned long long* ltr = (p.dbg & 8) && lane == 0 && blockIdx.x == 0 ? (unsigned long long*)p.stats + 1001 * 128 : nullptr;   // trace slot (wg 500, half 1)
+        int lcount = 0;
+#define AMX_LSTAMP() do { if (ltr && lcount < 128) ltr[lcount] = __builtin_readcyclecounter(); ++lcount; } while (0)
+        AMX_LSTAMP();
+#else
+#define AMX_LSTAMP() do {} while (0)
+#endif
+        while (next_pub < nin) {
+          // the ring slot of input plane zin held plane zin - RC, last read by ring plane z = zin - RC + 1 (q = z - zs + 1): every ring
+          // plane below zin - RC + 3 - zs must be done before the DMA may overwrite it
+          while (next_issue < nin) {
+            const int need_done = zlo + next_issue - RC + 3 - zs;
+            if (seen_ready < need_done) seen_ready = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(ready)));
+            if (seen_ready < need_done) break;
+            issue_plane(next_issue++);
+          }
+          if (next_issue == next_pub) {                         // ring full, everything published: wait for the stem waves
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+          }
+          AMX_LSTAMP();                                          // [issued what the ring allows]
+          WaitVm<2, RC - 1>::run(next_issue - next_pub - 1);    // the oldest unpublished plane has landed
+          AMX_LSTAMP();                                          // [landed]
+          flag_store_asm(a_in, ++next_pub);
+          AMX_LSTAMP();                                          // [published]
+        }
+        return;
+      }
+      // =========================== stem wave w: the ring planes q = w, w + NSW, ... ===========================
+      // A plane is a chain of LDS round trips (two polls, the operand reads, the dependent MFMA pair, the writes): ~2300 cycles however few
+      // tiles a wave computes -- with every stem wave on every plane (first form: tiles t = NSW i + w) the workgroup made one plane per
+      // 1.1 us whether it had three or seven stem waves.  So the waves take WHOLE planes, up to R - 4 = 6 of them in production at a time.
+      // ready[w] = the next plane wave w will publish (starts at w): min over the waves = every plane below it is in the ring.
+      // Ring plane = 10 rows of 34 voxels: tiles (row, x 0..15), (row, x 16..31), and the columns x = 32, 33 of eight rows per tile
+      // (lane -> row li / 2).  Row tiles reach their operands from one base register per read kind and x tile through immediate
+      // offsets; the reflected rows 0 / 9 (workgroups on the volume's y faces) add a uniform offset.
+      constexpr int NSW = SC::NSW;
+      const int w = wave - NC;
+      const int li = lane & 15, g = lane >> 4;
+      // (s_setprio 3 for these waves -- the consumers wait for their planes a third of the time -- measured SLOWER: 187 -> 201 us per launch)
+      const vec8 w0 = *(const vec8*)(si.wpk + 4096 + lane * 16);
+      // MFMA 1 carries row 8 only (lane group 0, k = 0 .. 2 of its K = 32 tile): run as the K = 16 product v_mfma_f32_16x16x16 (lane group g
+      // holds k = 4 g .. 4 g + 3) on the fragment's first two dwords -- half the matrix time, no zero registers in the B operand
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      u32x2 w1 = *(const u32x2*)(si.wpk + 4096 + 1024 + lane * 16);
+      if (g) w1 = u32x2{0u, 0u};
+      const f32x4 sbias = si.bias ? *(const f32x4*)(si.bias + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float lo_clip = si.act == ACT_RELU ? 0.f : -__builtin_inff();   // relu as max(v, 0); no activation: max(v, -inf)
+      // lane constants: rows (2g, 2g + 1) of MFMA 0, row 8 of MFMA 1; row r = 3 kz + ky
+      const int r0 = 2 * g, r1 = 2 * g + 1;
+      const int kz0 = r0 / 3, kz1 = r1 / 3;
+      auto xpart = [&](int hx) -> int {                        // row-copy offset of the four values x - 1 .. x + 2 of ring column hx (reflected)
+        const int v0 = reflect_clamp(x0 + hx - 1, p.W) - (x0 - 2) - 1;
+        return (v0 & 1) * CPSZ + (v0 & ~1) * 2;
+      };
+      auto ytop = [&](int hy) -> int { return reflect_clamp(y0 + hy - 1, p.H) - (y0 - 2) - 1; };   // region row of tap ky = 0 of ring row hy
+      const int xA = xpart(li), xB = xpart(16 + li);
+      const int d0 = __builtin_amdgcn_readfirstlane((ytop(0) - 0) * RS), d9 = __builtin_amdgcn_readfirstlane((ytop(9) - 9) * RS);   // 0 unless reflected
+      const int wlane = (g >> 1) * PPL + (g & 1) * 8 + li * 16;
+      int croff[2], cwoff[2];                                  // column tiles
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int crow = 8 * c + (li >> 1);
+        const bool cvalid = crow < C::HY;
+        const int crc = cvalid ? crow : 0;
+        croff[c] = ytop(crc) * RS + xpart(32 + (li & 1));
+        cwoff[c] = cvalid ? (g >> 1) * PPL + (g & 1) * 8 + (crow * HX + 32 + (li & 1)) * 16 : (g >> 1) * PPL + C::HVP * 16 + (g & 1) * 8;   // idle lanes: the plane's padding
+      }
+      constexpr int NB = 4;                                    // tiles per batch
+      float vmax = 0.f;
+      int seen_in = 0, seen_done = 0;
+#ifdef AMX_EXPERIMENT
+      unsigned long long* str = (p.dbg & 8) && lane == 0 && blockIdx.x == 0 && w == 0 ? (unsigned long long*)p.stats + 1000 * 128 : nullptr;   // trace slot (wg 500, half 0)
+      int scount = 0;
+#define AMX_SSTAMP() do { if (str && scount < 128) str[scount] = __builtin_readcyclecounter(); ++scount; } while (0)
+      AMX_SSTAMP();
+#else
+#define AMX_SSTAMP() do {} while (0)
+#endif
+      for (int q = w; q < nplanes; q += NSW) {
+        const int z1 = reflect_clamp(zs - 1 + q, p.D);
+        int zi[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) zi[kz] = reflect_clamp(z1 - 1 + kz, p.D);
+        int zmax = zi[0] > zi[1] ? zi[0] : zi[1];
+        zmax = zmax > zi[2] ? zmax : zi[2];
+        while (seen_in < zmax - zlo + 1) {                     // (polled only when the last value seen does not already allow it)
+          seen_in = flag_load(inready);
+          if (seen_in < zmax - zlo + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        while (q >= R + TZ * seen_done) {
+          seen_done = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(done)));
+          if (q >= R + TZ * seen_done) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        AMX_SSTAMP();                                            // [input landed, ring slot free]
+#ifdef AMX_EXPERIMENT
+        if (p.dbg & 64) { flag_store(ready + w, q + NSW); AMX_SSTAMP(); AMX_SSTAMP(); continue; }
+#endif
+        int ib[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) ib[kz] = INOFF + (zi[kz] % RC) * IPLSZ;
+        const int b0 = (kz0 == 0 ? ib[0] : (kz0 == 1 ? ib[1] : ib[2])) + (r0 % 3) * RS;
+        const int b1 = (kz1 == 0 ? ib[0] : (kz1 == 1 ? ib[1] : ib[2])) + (r1 % 3) * RS;
+        const int b8 = ib[2] + 2 * RS;
+        // bases (opaque to the compiler: the row offsets below then stay instruction immediates)
+        int a0 = b0 + xA, a1 = b1 + xA, a8 = b8 + xA, c0 = b0 + xB, c1 = b1 + xB, c8 = b8 + xB;
+        int wr = (q % R) * PLSZ + wlane;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a8), "+v"(c0), "+v"(c1), "+v"(c8), "+v"(wr));
+        auto rd = [&](int addr) -> u32x2 {                     // two dwords at a 4-byte aligned address (ds_read2_b32)
+          const unsigned* qq = (const unsigned*)(smem + addr);
+          return u32x2{qq[0], qq[1]};
+        };
+        // tile TI of the plane: its three read addresses / its write address
+        auto raddr = [&](int TI, int& r_0, int& r_1, int& r_8) {
+          if (TI < 2 * C::HY) {
+            const int row = TI >> 1, xt = TI & 1;
+            const int d = (row == 0 ? d0 : (row == C::HY - 1 ? d9 : 0)) + row * RS;
+            r_0 = (xt ? c0 : a0) + d; r_1 = (xt ? c1 : a1) + d; r_8 = (xt ? c8 : a8) + d;
+          } else {
+            const int c = TI - 2 * C::HY;
+            r_0 = b0 + croff[c]; r_1 = b1 + croff[c]; r_8 = b8 + croff[c];
+          }
+        };
+        auto waddr = [&](int TI) -> int {
+          if (TI < 2 * C::HY) return wr + ((TI >> 1) * HX + 16 * (TI & 1)) * 16;
+          return (q % R) * PLSZ + cwoff[TI - 2 * C::HY];
+        };
+        // Software pipeline over batches of NB tiles: iteration b issues the reads of batch b + 2, the products of batch b + 1 (its reads
+        // are an iteration old) and the epilogue of batch b (its products are an iteration old).  One batch at a time -- reads, wait,
+        // dependent MFMA pair, wait, epilogue -- took a stem wave ~8000 cycles per plane beside the consumers (6 batches x ~1300).
+        constexpr int NBT = (SC::NT + NB - 1) / NB;
+        u32x4 fa[2][NB];
+        u32x2 fe[2][NB];
+        f32x4 sacc[2][NB];
+        auto stage_a = [&](int bt) {
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            if (bt * NB + t >= SC::NT) continue;
+            int r_0, r_1, r_8;
+            raddr(bt * NB + t, r_0, r_1, r_8);
+            const u32x2 a = rd(r_0), bq = rd(r_1);
+            fa[bt & 1][t] = u32x4{a[0], a[1], bq[0], bq[1]};
+            fe[bt & 1][t] = rd(r_8);
+          }
+        };
+        auto stage_b = [&](int bt) {
+#pragma unroll
+          for (int t = 0; t < NB; ++t)
+            if (bt * NB + t < SC::NT) sacc[bt & 1][t] = Ops<T>::mfma(w0, __builtin_bit_cast(vec8, fa[bt & 1][t]), sbias);
+#pragma unroll
+          for (int t = 0; t < NB; ++t)
+            if (bt * NB + t < SC::NT) sacc[bt & 1][t] = Ops<T>::mfma16(w1, fe[bt & 1][t], sacc[bt & 1][t]);
+        };
+        auto stage_c = [&](int bt) {
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            if (bt * NB + t >= SC::NT) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(sacc[bt & 1][t][j], lo_clip, __builtin_inff());   // max(v, clip) in one VALU; NOT inline
+                                                                              // asm: hipcc must see the read of the MFMA result to pad its latency
+            if (RangeCheck<T>::on) {
+              asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[0]), "v"(v[1]));
+              asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[2]), "v"(v[3]));
+            }
+            *(uint2*)(smem + waddr(bt * NB + t)) = make_uint2(Ops<T>::pack2(v[0], v[1]), Ops<T>::pack2(v[2], v[3]));
+          }
+        };
+        stage_a(0);
+        if (NBT > 1) stage_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+          if (bt + 2 < NBT) stage_a(bt + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (bt + 1 < NBT) stage_b(bt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          stage_c(bt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        AMX_SSTAMP();                                            // [plane computed]
+        asm volatile("" ::: "memory");                         // (LDS serves a wave's accesses in order: the flag lands behind the plane)
+        flag_store(ready + w, q + NSW);
+        AMX_SSTAMP();                                            // [published]
+      }
+      if (RangeCheck<T>::on) raise_flag(p.oflow, !(vmax <= 65504.f));
+      return;
+    }
+  }
+
+  if (!STEM && wave >= NC) {
     // =========================== loader wave: channel plane cp = wave - NC ===========================
     const int cp = wave - NC;
     int off[NDMA];                     // per-lane source offset of halo voxel hv = 64*j + lane (fixed for the march)
@@ -248,7 +510,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 
   bool bad = false;
   // optional cycle trace (AMX_TRACE=1): consumer waves 0 and 4 of a few workgroups stamp s_memtime per phase
-  unsigned long long* trace = (p.dbg & 8) && (wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 512
+  unsigned long long* trace = (p.dbg & 8) && (wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 500
                                   ? (unsigned long long*)p.stats + ((long long)blockIdx.x * 2 + (wave >> 2)) * 128 : nullptr;
   int tcount = 0;
 #define AMX_ZSTAMP()                                                             \
@@ -262,7 +524,11 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
       int need = TZ * s + TZ + 2;                          // planes q <= TZ*s + TZ + 1 must have landed
       need = need < nplanes ? need : nplanes;
       static_assert(NL <= 4 && C::FLAGOFF % 16 == 0, "the ready flags are polled with one 16-byte read");
-      while (flag_min4<NL>(ready) < need) __builtin_amdgcn_s_sleep(1);
+      if constexpr (STEM) {
+        while (__builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(ready))) < need) __builtin_amdgcn_s_sleep(1);
+      } else {
+        while (flag_min4<NL>(ready) < need) __builtin_amdgcn_s_sleep(1);
+      }
       asm volatile("" ::: "memory");
     }
 
@@ -291,7 +557,7 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
     // work is doubled / tripled at unchanged traffic -- the lower bound of a conv -> conv chain through the ring
     for (int rep = (p.dbg >> 10) & 7; rep >= 0; --rep)
     if (!(p.dbg & 2)) {
-      if constexpr (NCKP > 1 && !SPLIT) {
+      if constexpr ((NCKP > 1 && !SPLIT) || STEM) {   // (STEM: 16 waves per workgroup leave each 128 registers -- no room for the double-buffered plane sets below)
         // Two (or, SPLIT, two passes over) channel chunks: 28 resident weight fragments leave room for ONE set of six ring fragments, and
         // "read a plane's six, then its 16 MFMAs" (the first form) exposed the LDS round trip eight times per step -- a wave's sweep
         // took ~4100 cycles for 1792 cycles of MFMAs, with or without the other wave of its SIMD (profiles/r05_wgrad_probe.txt).  Rolling
@@ -572,17 +838,21 @@ __global__ __launch_bounds__((8 + 2 * (SPLIT ? 2 : NCK) + NS) * 64) void conv3d_
 static thread_local char g_kernel_name3[64] = "";
 const char* last_conv_zm_kernel_name() { return g_kernel_name3; }
 
-template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false, int TX = 32>
-static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
-  if constexpr (OUTMODE == 0 && NS == 0 && !POOL)
-    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true, SPLIT, TX>(p, st);
+template <typename T, int NCK, int QT, int TY, int R, int OUTMODE, int NS, bool POOL = false, bool SPLIT = false, int TX = 32, bool STEM = false>
+static hipError_t launch_zm_ns(ConvParams p, hipStream_t st, const StemIn& si = StemIn{}) {
+  if constexpr (OUTMODE == 0 && NS == 0 && !POOL && !STEM)
+    if (p.out2) return launch_zm_ns<T, NCK, QT, TY, R, OUTMODE, NS, true, SPLIT, TX, STEM>(p, st, si);
   constexpr int TZ = 2;
   typedef ZmCfg<SPLIT ? 2 : NCK, QT, TY, TX, R> C;
-  constexpr int LDS = NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
+  constexpr int LDS = STEM ? C::FLAGOFF + 128 + ZmStemCfg<TY, TX>::BYTES : NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
+  if (STEM)
+    snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,stem1->16->16,%dx%dx%d,c8+st%d+cv1,r%d/%d%s>",
+             __is_same(T, f16) ? "f16" : "bf16", TZ, TY, TX, ZmStemCfg<TY, TX>::NSW, R, ZmStemCfg<TY, TX>::RC, p.out2 ? ",pool" : "");
+  else
   snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
            __is_same(T, f16) ? "f16" : "bf16", SPLIT ? "x2" : "", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE,
            p.out2 ? ",pool" : "");
-  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL, SPLIT>;
+  auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL, SPLIT, STEM>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -608,15 +878,15 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st) {
     (void)hipMemsetAsync(trace_buf, 0, 1024 * 128 * 8, st);
     p.stats = (float*)trace_buf;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + C::NL + NS) * 64), LDS, st, p, zseg, nseg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nseg)), dim3((8 + (STEM ? ZmStemCfg<TY, TX>::NSW + 1 : C::NL) + NS) * 64), LDS, st, p, zseg, nseg, si);
   if (p.dbg & 8) {
     static int printed = 0;
     (void)hipStreamSynchronize(st);
     if (printed++ == 3) {
       static unsigned long long hostbuf[1024 * 128];
       (void)hipMemcpy(hostbuf, trace_buf, sizeof hostbuf, hipMemcpyDeviceToHost);
-      const int wgs[3] = {0, 77, 255};
-      for (int wi = 0; wi < 3; ++wi)
+      const int wgs[4] = {0, 77, 255, 500};                     // (STEM: the slots of workgroup 500 hold stem wave 0 / the loader of workgroup 0)
+      for (int wi = 0; wi < (STEM ? 4 : 3); ++wi)
         for (int half = 0; half < 2; ++half) {
           const unsigned long long* tr = hostbuf + ((long long)wgs[wi] * 2 + half) * 128;
           fprintf(stderr, "[trace %s wg %d wave %d] wait/sweep/epilogue:", g_kernel_name3, wgs[wi], half * 4);
@@ -684,6 +954,76 @@ bool conv_zmarch_eligible_split(const ConvParams& p) {
   return !off && conv_zmarch_eligible(p) && p.C0 == 16 && p.Cout == 16;
 }
 bool conv_zmarch_can_pool_split(const ConvParams& p) { return conv_zmarch_can_pool(p) && conv_zmarch_eligible_split(p); }
+
+// The prepared input of the stem-fed layer (StemIn): per thread eight consecutive padded elements of one row of both copies.
+template <typename T>
+__global__ void stem_prep_kernel(const float* __restrict__ x, long long xs_n, long long xs_z, long long xs_y, char* __restrict__ A,
+                                 char* __restrict__ B, int N, int D, int H, int W, int* oflow) {
+  const int cpr = (W + 8) / 8;                                  // 16-byte chunks per padded row
+  const long long total = (long long)N * D * (H + 4) * cpr;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cpr);
+  long long r = idx / cpr;
+  const int yp = (int)(r % (H + 4));
+  r /= (H + 4);
+  const int z = (int)(r % D), n = (int)(r / D);
+  const float* row = (const float*)((const char*)x + n * xs_n + z * xs_z + (long long)reflect_clamp(yp - 2, H) * xs_y);
+  float v[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) v[e] = row[reflect_clamp(8 * c + e - 2, W)];
+  bool bad = false;
+  unsigned short h[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v[e]);     // an input beyond the storage range (or NaN) would reach the taps as Inf
+    h[e] = to_bits<T>(v[e]);
+  }
+  const long long o = idx * 16;                                 // both buffers are dense [N][D][H + 4][W + 8]
+  *(uint4*)(A + o) = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
+  *(uint4*)(B + o) = make_uint4(h[1] | (unsigned)h[2] << 16, h[3] | (unsigned)h[4] << 16, h[5] | (unsigned)h[6] << 16, h[7] | (unsigned)h[8] << 16);
+  if (RangeCheck<T>::on) raise_flag(oflow, bad);
+}
+
+size_t conv_zmarch_stem_prep_bytes(int N, int D, int H, int W) { return (size_t)2 * N * D * (H + 4) * (W + 8) * 2; }
+
+// Stem-fed 16 -> 16 layer (network.py modules 0..5 of the 6 M model as ONE launch): `p` describes the 16 -> 16 layer (its src0 is
+// ignored), the remaining arguments the stem in front of it.  Whole tiles only; single 16-bit precisions.
+bool conv_zmarch_stem_eligible(const ConvParams& p, int precision) {
+  static int off = -1;
+  if (off < 0) off = exp_env("AMX_NO_STEMFUSE") ? 1 : 0;
+  return !off && precision < 2 && p.C0 == 16 && p.C1 == 0 && p.Cout == 16 && !p.out32 && !p.raw_halo && p.W >= 32 && !(p.W % 32) && !(p.H % 8) &&
+         !(p.D & 1) && p.D >= 8 && p.ox == 32 && (p.ocs == 0 || p.ocs == 32);
+}
+// x_offs (host array of p.N element offsets, or null): sample i reads its volume at x + x_offs[i] (sliding-window batches).
+// `prep`: conv_zmarch_stem_prep_bytes(N, D, H, W) bytes of scratch (16-byte aligned) for the prepared input.
+hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
+                                   void* prep, const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision,
+                                   hipStream_t st) {
+  if (stem_act != ACT_NONE && stem_act != ACT_RELU) return hipErrorInvalidValue;   // the stem waves clip with one v_max
+  if (precision != 0 && precision != 1) return hipErrorInvalidValue;
+  const long long row = (long long)(p.W + 8) * 2, plane = row * (p.H + 4), vol = plane * p.D;
+  char* A = (char*)prep;
+  char* B = A + vol * p.N;
+  {
+    const int ns = x_offs ? p.N : 1;                             // one pass over the batch, or one per window
+    for (int i = 0; i < ns; ++i) {
+      const int nn = x_offs ? 1 : p.N;
+      const float* src = x_offs ? x + x_offs[i] : x;
+      const long long total = (long long)nn * p.D * (p.H + 4) * ((p.W + 8) / 8);
+      const unsigned blocks = (unsigned)((total + 255) / 256);
+      if (precision == 0)
+        hipLaunchKernelGGL(stem_prep_kernel<f16>, dim3(blocks), dim3(256), 0, st, src, xs_n, xs_z, xs_y, A + vol * i, B + vol * i, nn, p.D, p.H, p.W, p.oflow);
+      else
+        hipLaunchKernelGGL(stem_prep_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, xs_n, xs_z, xs_y, A + vol * i, B + vol * i, nn, p.D, p.H, p.W, p.oflow);
+    }
+  }
+  StemIn si;
+  si.srcA = A; si.srcB = B; si.sn = vol; si.sz = plane; si.sy = row;
+  si.wpk = (const char*)stem_wpk; si.bias = stem_bias; si.act = stem_act; si.slope = stem_slope;
+  if (precision == 0) return launch_zm_ns<f16, 1, 1, 8, 10, 0, 0, false, false, 32, true>(p, st, si);
+  return launch_zm_ns<bf16, 1, 1, 8, 10, 0, 0, false, false, 32, true>(p, st, si);
+}
 
 hipError_t launch_conv_zmarch(const ConvParams& p, int precision, hipStream_t st) {
   const bool planar = p.out32 != nullptr;

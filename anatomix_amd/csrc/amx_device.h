@@ -5,16 +5,36 @@
 namespace amx {
 
 template <typename T> struct Ops;
+typedef __attribute__((ext_vector_type(2))) unsigned amx_u32x2;
 template <> struct Ops<f16> {
   typedef f16x8 vec8;
   static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  // K = 16 form (lane group g holds k = 4 g .. 4 g + 3): operands as two dwords
+  static __device__ __forceinline__ f32x4 mfma16(amx_u32x2 a, amx_u32x2 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {      // round-to-nearest pair, a in the low half (v_cvt_pk_f16_f32)
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, h2));
   }
 };
 template <> struct Ops<bf16> {
   typedef bf16x8 vec8;
   static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(amx_u32x2 a, amx_u32x2 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, b2));
   }
 };
 
