@@ -11,6 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DAMX_EXPERIMENT library of `make exp` whose ablation switches tools/ drives through the environment
 LIB_PATH = os.environ.get("AMX_LIB_PATH") or os.path.join(_HERE, "csrc", "libanatomix_amd.so")
 
+
+def exp_env(name, default):
+    """A/B switches of the Python side (tools/ only): read from the environment ONLY under AMX_EXPERIMENT=1, like the C++ sources'
+    exp_env() behind -DAMX_EXPERIMENT; in a product run every switch is its default whatever the environment holds."""
+    if os.environ.get("AMX_EXPERIMENT", "0") != "1":
+        return default
+    return os.environ.get(name, default)
+
 NORM = {"none": 0, "batch": 1, "instance": 2, "instance_affine": 3}
 ACT = {"none": 0, "relu": 1, "lrelu": 2}
 POOL = {"Max": 0, "Avg": 1}

@@ -48,7 +48,7 @@ struct ZmCfg {
   static constexpr int NDMA = (HVP + 63) / 64;                     // DMA instructions per (z-plane, channel plane)
   static_assert(WPQ == (TY / 2) * XT, "each consumer wave owns a 2 x 2 x 16 voxel block per step");
   static_assert(R - 4 > TZ, "ring must hold more than one step of prefetch");
-  static_assert(R * NDMA <= 60, "loader wave must not exceed the 6-bit vmcnt range");
+  static constexpr bool VMCNT_OK = R * NDMA <= 60;                  // a loader wave must not exceed the 6-bit vmcnt range (checked where loaders run)
   static_assert(NL <= 8 && LDS_BYTES <= 160 * 1024, "ring must fit the LDS");
 };
 
@@ -431,6 +431,7 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
 
   if (!STEM && wave >= NC) {
     // =========================== loader wave: channel plane cp = wave - NC ===========================
+    static_assert(STEM || C::VMCNT_OK, "loader wave must not exceed the 6-bit vmcnt range");
     const int cp = wave - NC;
     int off[NDMA];                     // per-lane source offset of halo voxel hv = 64*j + lane (fixed for the march)
     bool valid[NDMA];

@@ -21,18 +21,19 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from . import train_ops as T
 
 _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
 
-OVERLAP_WGRAD = os.environ.get("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight gradients on a side stream, beside the data gradient of the same block
-RECOMPUTE_ACT = os.environ.get("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
-SPLIT_CONCAT_DGRAD = int(os.environ.get("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
-FUSED_FOLD_SPLIT = os.environ.get("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
-DIRECT_DGRAD = os.environ.get("AMX_NO_DIRECT_DGRAD", "0") != "1"   # data gradient: interior launch + shell terms instead of the framed domain + pad_fold
-PACK_ASIDE = os.environ.get("AMX_NO_PACK_ASIDE", "0") != "1"     # A/B: both passes' weight packing on a side stream at the start of the forward
-BATCH_PACK = os.environ.get("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
+OVERLAP_WGRAD = _lib.exp_env("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight gradients on a side stream, beside the data gradient of the same block
+RECOMPUTE_ACT = _lib.exp_env("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
+SPLIT_CONCAT_DGRAD = int(_lib.exp_env("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
+FUSED_FOLD_SPLIT = _lib.exp_env("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
+DIRECT_DGRAD = _lib.exp_env("AMX_NO_DIRECT_DGRAD", "0") != "1"   # data gradient: interior launch + shell terms instead of the framed domain + pad_fold
+PACK_ASIDE = _lib.exp_env("AMX_NO_PACK_ASIDE", "0") != "1"     # A/B: both passes' weight packing on a side stream at the start of the forward
+BATCH_PACK = _lib.exp_env("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
 _SIDE = {}
 
 

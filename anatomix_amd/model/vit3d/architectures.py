@@ -308,8 +308,8 @@ class PrimusV2(nn.Module):
                              grid_w=self.grid[2], hidden=int(embed_dim * mlp_ratio), dec1=0, dec2=0, qk_norm=int(bool(qk_norm)),
                              scale_attn_inner=int(bool(scale_attn_inner)), layer_scale=int(init_values is not None), in_eps=float(in_eps),
                              out_norm=int(isinstance(self.out_norm, ChannelDemean)),
-                             decoder_split=int(os.environ.get("AMX_VIT_DECODER_SPLIT", "1")),
-                             stem_split=int(os.environ.get("AMX_VIT_STEM_SPLIT", "1")))
+                             decoder_split=int(_lib.exp_env("AMX_VIT_DECODER_SPLIT", "1")),
+                             stem_split=int(_lib.exp_env("AMX_VIT_STEM_SPLIT", "1")))
         dec = [m for m in self.up_projection.decode.modules() if isinstance(m, nn.ConvTranspose3d)]
         self._vit_cfg["dec1"], self._vit_cfg["dec2"] = (dec[0].out_channels, dec[1].out_channels) if len(dec) == 3 else (0, 0)
         self.use_engine = True

@@ -57,7 +57,7 @@ def cached_spec(mlp):
 
 
 def unsupported_reason(mlp, x):
-    if os.environ.get("AMX_NO_MLP_HEAD", "0") == "1":
+    if _lib.exp_env("AMX_NO_MLP_HEAD", "0") == "1":
         return "disabled by AMX_NO_MLP_HEAD=1"
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
         return "expects a CUDA fp32 [rows, features] input"

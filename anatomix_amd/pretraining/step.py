@@ -11,15 +11,17 @@ import os
 import torch
 import torch.nn as nn
 
-_PARALLEL_HEADS = os.environ.get("AMX_SERIAL_HEADS", "0") != "1"
-_SAMPLED_TAPS = os.environ.get("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
+from .. import _lib
+
+_PARALLEL_HEADS = _lib.exp_env("AMX_SERIAL_HEADS", "0") != "1"
+_SAMPLED_TAPS = _lib.exp_env("AMX_DENSE_TAPS", "0") != "1"      # 0: the dense-tap route (A/B; same values)
 _STREAMS = {}
 # Distinct side streams for the six per-layer head / loss chains.  One per layer (the first form) is NOT the fastest: HIP maps streams
 # onto four hardware queues and every cross-queue dependency of a replayed graph costs -- three streams (two layers each) measured
 # 7.45-7.50 ms per step against 7.74-7.77 with six, 7.53-7.55 with two, 7.68 with four (GPU_MAX_HW_QUEUES=8 instead: 14.4 ms).
-_HEAD_STREAMS = int(os.environ.get("AMX_HEAD_STREAMS", "3"))
+_HEAD_STREAMS = int(_lib.exp_env("AMX_HEAD_STREAMS", "3"))
 _TAP_SHAPES = {}                                             # (network, input shape, tap ids, patches) -> {tap id: spatial shape}
-_PREDRAW = os.environ.get("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
+_PREDRAW = _lib.exp_env("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
 _WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
 
 

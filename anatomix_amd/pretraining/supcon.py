@@ -66,8 +66,12 @@ class SupPatchNCELoss(nn.Module):
     @torch.compiler.disable      # the reference compiles its criterion (supcl_model.py:477-489); the kernel call is opaque
     def forward(self, features, labels_seg, labels_coords, coords_range, debug=False):
         ntps, num_patches, nc = features.size()
+        # (the kernel takes raw device pointers: coordinates that are not an int64 [P, 3] tensor on the features' device -- a host tensor, a
+        #  list, fewer rows than patches -- keep the indexing route below, which raises or converts like the reference's torch ops)
         if (features.is_cuda and len(coords_range) == 3 and labels_seg.is_cuda and labels_seg.dtype == torch.float32 and
-                labels_seg.dim() == 5 and labels_seg.shape[:2] == (1, 1) and labels_coords.dtype == torch.int64):
+                labels_seg.dim() == 5 and labels_seg.shape[:2] == (1, 1) and labels_seg.device == features.device and
+                torch.is_tensor(labels_coords) and labels_coords.dtype == torch.int64 and labels_coords.is_cuda and
+                labels_coords.device == features.device and tuple(labels_coords.shape) == (num_patches, 3)):
             # the class ids of the views x P patches in one launch (amx_gather_labels) instead of resize + index + round + cast + repeat
             import ctypes
             from .. import _lib

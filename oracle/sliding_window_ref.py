@@ -47,3 +47,48 @@ def sliding_window(vol, roi, predictor, overlap, mode="constant", sigma_scale=0.
                 acc[:, z:z + roi[0], y:y + roi[1], x:x + roi[2]] += w * pred
                 cnt[z:z + roi[0], y:y + roi[1], x:x + roi[2]] += w
     return acc / cnt
+
+
+def block_probe(y, vol, roi, variant="anatomix", overlap=0.8, sigma_scale=0.25, seed=0):
+    """Parity probe of a cubic sliding-window result at full schedule size without 343 CPU forwards: the block of output voxels
+    [s1, s2)^3 between the second and the third window start of every axis is covered by exactly the 8 windows with starts in
+    {s0, s1}^3, so its oracle value needs 8 forwards of the fp32 restatement (oracle/unet_ref.py, synthetic weights `seed`) blended
+    with gaussian_map.  y: [1, C, V, V, V] result (torch, any device), vol: [1, 1, V, V, V] input.  Returns the distances (dict) or
+    None when the schedule has fewer than three starts per axis."""
+    import os
+    import torch
+    from oracle import unet_ref as R
+    kw = R.VARIANTS[variant]
+    sd = R.synthetic_state_dict(kw, seed)
+    V, S = vol.shape[-1], roi
+    starts = starts_1d(V, S, overlap)
+    if len(starts) < 3 or starts[2] - starts[1] < 1:
+        return None
+    lo, hi = starts[1], starts[2]
+    # no other window may touch the block: the third start is its upper bound and every later start lies beyond it
+    assert all(st >= hi for st in starts[2:]) and starts[0] + S >= hi and starts[1] + S >= hi
+    w = torch.from_numpy(gaussian_map((S, S, S), sigma_scale))
+    volc = vol.detach().float().cpu()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(min(avail, 32))
+    acc, cnt = None, torch.zeros((hi - lo,) * 3)
+    with torch.no_grad():
+        for z in starts[:2]:
+            for yy in starts[:2]:
+                for x in starts[:2]:
+                    pred = R.forward(volc[:, :, z:z + S, yy:yy + S, x:x + S], sd, kw)[0]
+                    sl = (slice(lo - z, hi - z), slice(lo - yy, hi - yy), slice(lo - x, hi - x))
+                    wb = w[sl]
+                    acc = wb * pred[(slice(None),) + sl] if acc is None else acc + wb * pred[(slice(None),) + sl]
+                    cnt += wb
+    ref = (acc / cnt).double()
+    got = y.detach()[0, :, lo:hi, lo:hi, lo:hi].double().cpu()
+    d = got - ref
+    return {"rel_l2_vs_fp32_cpu_oracle": float("%.3e" % float(d.norm() / ref.norm())),
+            "max_rel_vs_fp32_cpu_oracle": float("%.3e" % float(d.abs().max() / ref.abs().max())),
+            "tolerance": 1e-3, "compliant": bool(float(d.norm() / ref.norm()) <= 1e-3),
+            "against": f"numpy sliding-window restatement over the fp32 CPU oracle on the {hi - lo}^3 output block [{lo}, {hi})^3 (covered by "
+                       f"exactly 8 of the {len(starts) ** 3} windows: 8 CPU forwards); MONAI itself is absent from the image -- parity with it unpinned"}

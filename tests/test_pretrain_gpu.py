@@ -64,6 +64,19 @@ def test_label_gather_kernel_equals_interpolate_and_index(device, seg_shape, fsi
     assert torch.equal(got, want)
 
 
+def test_criterion_with_host_coordinates_takes_the_indexing_route(device):
+    """The one-launch label path hands raw pointers to a kernel: coordinates on the host (what the old indexing route accepted) must
+    not reach it.  Same loss either way."""
+    feats, seg, coords, size = PI.loss_inputs("p512c256")
+    crit = SupPatchNCELoss(_opt(False, True, "raw"))
+    f = feats.to(device)
+    on_device = crit(f, seg.to(device), coords.to(device), size)
+    on_host = crit(f, seg.to(device), coords, size)                       # CPU int64 [P, 3]
+    assert torch.equal(on_device, on_host)
+    with pytest.raises((IndexError, RuntimeError)):
+        crit(f, seg.to(device), coords[:100].to(device), size)            # fewer rows than patches: a Python error, never an out-of-bounds read
+
+
 def test_hip_loss_is_deterministic_and_forward_only_works(device):
     feats, seg, coords, size = PI.loss_inputs("p512c256")
     crit = SupPatchNCELoss(_opt(False, True, "raw"))

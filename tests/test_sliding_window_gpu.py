@@ -98,6 +98,24 @@ def test_real_operating_point_roi128_overlap08_matches_cpu_oracle(device):
     assert rel_l2(got, torch.from_numpy(ref)) <= 1e-3
 
 
+def test_config2_full_schedule_256_cubed_343_windows(device):
+    """BASELINE configs[1] at its full size: one 256^3 volume, roi 128, overlap 0.8, gaussian 0.25 = 7 x 7 x 7 = 343 windows with
+    three-axis overlap, through extract_features' path (fused window batches, two batches in flight).  Checked on the output block
+    that exactly 8 windows cover (oracle/sliding_window_ref.block_probe: 8 CPU forwards of the fp32 oracle, ~15 s)."""
+    m, _ = _model(device)
+    vol = R.synthetic_input(77, 1, (256, 256, 256)).to(device)
+    assert len(window_starts((256, 256, 256), (128, 128, 128), 0.8)) == 343
+    with torch.no_grad():
+        assert _fused_ok(m, vol, (128, 128, 128))
+        y = sliding_window_inference(vol, (128, 128, 128), 4, m, overlap=0.8, mode="gaussian", sigma_scale=0.25)
+        torch.cuda.synchronize()
+    assert y.shape == (1, 16, 256, 256, 256) and torch.isfinite(y).all()
+    p = O.block_probe(y, vol, 128, "anatomix")
+    assert p is not None
+    assert p["rel_l2_vs_fp32_cpu_oracle"] <= 1e-3, p
+    assert p["max_rel_vs_fp32_cpu_oracle"] <= 1.5e-3, p
+
+
 def test_segmentation_validation_predictor_takes_the_fused_path(device):
     """train_segmentation.py:194-199: sliding_window_inference(val_images, roi, 4, nn.Sequential(Unet, UnetOutBlock), overlap=0.7),
     constant importance map.  The 1x1x1 head commutes with the window averaging, so the windows run fused up to the Unet's output

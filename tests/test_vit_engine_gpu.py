@@ -160,6 +160,7 @@ def test_engine_against_the_torch_composition_on_random_configurations(device, s
 def test_single_f16_stem_output_is_an_opt_in_within_tolerance(device, monkeypatch):
     """amx_vit_cfg.stem_split = 0 (env AMX_VIT_STEM_SPLIT=0): the stem's output without its lo plane -- faster, measured 3.7e-4 on
     its own; the default keeps the plane (fp32-grade tokens, test_tokenizer_tokens_match_the_oracle)."""
+    monkeypatch.setenv("AMX_EXPERIMENT", "1")                   # the Python A/B switches are only read under this gate (_lib.exp_env)
     monkeypatch.setenv("AMX_VIT_STEM_SPLIT", "0")
     kw = dict(V.VIT_VARIANTS["anatomix-dev-vit"], input_shape=(64, 64, 64), eva_depth=2)
     m, sd = _model(kw, 8, device)
