@@ -88,6 +88,8 @@ class SupPatchNCELoss(nn.Module):
         labels = self.gather_labels(labels_seg, labels_coords, coords_range)        # [bs = 1, P]
         if labels.shape[0] != 1:
             raise NotImplementedError("one segmentation shared by the views (the reference's eq(labels, labels.T) needs bs == 1)")
+        if labels.shape[1] != num_patches:     # (the reference's mask arithmetic fails on the shape mismatch; the kernel would read past the labels)
+            raise RuntimeError(f"labels_coords has {labels.shape[1]} rows, features have {num_patches} patches")
         if features.is_cuda:
             # class ids as int32, tiled over the views in (view, patch) order = features.view(ntps * P, nc)
             lab = labels[0].to(device=features.device).round().to(torch.int32).repeat(ntps).contiguous()
