@@ -243,8 +243,13 @@ def forward_roofline(torch, model, x, B):
     tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
     gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     total_ms = sum(v["ms"] for v in agg.values()) / reps
-    # the kernel's own roofline: algorithmic intensity against the ridge point of the two peaks
-    hbm_bound = flops_per_launch / bytes_per_launch < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    # the kernel's own roofline: intensity against the ridge point of the two peaks.  The merged-tap kernels (nearest-upsampled
+    # channels: the 27 taps of the reference's conv on the upsampled tensor coincide in 8 distinct low-resolution taps per output
+    # parity class) EXECUTE fewer products than the layer's algorithmic count, so their bound is decided by what they execute --
+    # conv3d_upcat16 (16 skip + 32 upsampled channels -> 16): (27 * 16 + 8 * 32) / (27 * 48) of the algorithmic FLOPs, which puts it
+    # on the HBM side of the ridge; pricing its algorithmic 348 GFLOP against the MFMA peak would read 0.85 of a peak it never uses
+    exec_flops = flops_per_launch * ((27 * 16 + 8 * 32) / (27.0 * 48) if dom.startswith("conv3d_upcat16") else 1.0)
+    hbm_bound = exec_flops / bytes_per_launch < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
     roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
                 "achieved": round(gbps if hbm_bound else tflops, 2),
                 "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
