@@ -71,6 +71,7 @@ _P = C.c_void_p
 _I = C.c_int
 SYMBOLS = {
     "amx_version": (_I, []),
+    "amx_debug_fill_lds": (_I, [C.c_uint, _P]),
     "amx_last_error": (C.c_char_p, []),
     "amx_unet_create": (_I, [C.POINTER(_P), C.POINTER(UnetCfg)]),
     "amx_unet_destroy": (None, [_P]),

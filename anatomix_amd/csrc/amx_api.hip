@@ -96,6 +96,9 @@ bool conv_zmarch_eligible(const ConvParams& p);
 bool conv_zmarch_stem_eligible(const ConvParams& p, int precision);
 const char* last_conv_zm_kernel_name();
 hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
+                                   const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision, hipStream_t st);
+const char* last_conv_zm_kernel_name();
+hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
                                    void* prep, const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision,
                                    hipStream_t st);
 size_t conv_zmarch_stem_prep_bytes(int N, int D, int H, int W);
@@ -507,7 +510,7 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
       const int dd = d >> lv, dh = hh >> lv, dw = w >> lv;
       // ---- stem + the 16 -> 16 layer behind it as ONE launch (amx_conv3d_zmarch.hip, STEM): the stem's output never reaches HBM.
       // Plain forward only: no taps, folded (or no) norm on both layers, nothing else reads the stem's tensor.
-      if (cur.slot < 0 && !split && L.cout_p == 16 && L.cout == 16 && !L.is_final && conv_i < h->convs.size() &&
+      if (cur.slot < 0 && !split && (!x_offs || n <= 16) && L.cout_p == 16 && L.cout == 16 && !L.is_final && conv_i < h->convs.size() &&
           (!L.has_act || c.activation == AMX_ACT_RELU || c.activation == AMX_ACT_NONE) &&
           !(L.norm_idx >= 0 && (c.norm == AMX_NORM_INSTANCE || c.norm == AMX_NORM_INSTANCE_AFFINE))) {
         const ConvLayer& Nx = h->convs[conv_i];
@@ -542,13 +545,8 @@ int run_forward_impl(amx_unet* h, const float* x, long long xs_n, long long xs_z
             r.bytes = 4.0 * vox + 2.0 * Nx.cout * vox + 2.0 * 27.0 * (L.cin * L.cout + Nx.cin * Nx.cout);   // fp32 input once, 16-bit output once
             if (prof->mark(r)) return fail(AMX_ERR_HIP, "hipEventRecord failed");
           }
-          // the prepared input (two padded 16-bit copies, ~4.4 bytes per voxel) borrows a free level-0 slot for the duration of the launch
-          const int prep_slot = grab(0);
-          if (prep_slot < 0 || amx::conv_zmarch_stem_prep_bytes(n, dd, dh, dw) > level_bytes(h, 0, n, d, hh, w))
-            return fail(AMX_ERR_INVALID, "internal: no level-0 slot for the prepared stem input");
-          AMX_HIP(amx::launch_conv_zmarch_stem(p, x, xs_n, xs_z, xs_y, x_offs, A.slot[0][prep_slot], L.wpk, L.shift,
-                                               L.has_act ? c.activation : AMX_ACT_NONE, c.act_slope, c.precision, st));
-          A.used[0][prep_slot] = false;                  // dead once its consumer is enqueued (stream order)
+          AMX_HIP(amx::launch_conv_zmarch_stem(p, x, xs_n, xs_z, xs_y, x_offs, L.wpk, L.shift, L.has_act ? c.activation : AMX_ACT_NONE,
+                                               c.act_slope, c.precision, st));
           if (prof) snprintf(prof->rec.back().kernel, sizeof prof->rec.back().kernel, "%s", amx::last_conv_zm_kernel_name());
           ++conv_i;
           cur = out;
@@ -972,6 +970,26 @@ int run_forward(amx_unet* h, const float* x, long long xs_n, long long xs_z, lon
 extern "C" {
 
 int amx_version(void) { return AMX_VERSION; }
+
+namespace {
+__global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  if (sink && lds_words[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern) *sink = 1;     // (keeps the stores alive)
+}
+}  // namespace
+
+int amx_debug_fill_lds(unsigned pattern, void* stream) {
+  static bool attr = false;
+  if (!attr) {
+    AMX_HIP(hipFuncSetAttribute((const void*)fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(fill_lds_kernel, dim3(512), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, (unsigned*)nullptr);
+  AMX_HIP(hipGetLastError());
+  return AMX_OK;
+}
 
 int amx_unet_numerics_status(amx_unet_t* h, int synchronize, void* stream) {
   if (!h) return fail(AMX_ERR_INVALID, "null handle");

@@ -26,6 +26,7 @@
 // Arithmetic is identical to the generic kernel (same packed-weight layout, same 14 paired-tap steps).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "amx_device.h"
 
@@ -77,9 +78,10 @@ struct ZmStage {
 //   * stem wave w computes WHOLE ring planes q = w, w + 7, ...: a ring voxel OUTSIDE the volume is the reflection of the stem's OUTPUT, so
 //     its lane gathers the taps of the reflected voxel; it publishes ready[w] = the next plane it will publish.
 struct StemIn {
-  const char* srcA;             // prepared input, copy A: [N][D][H + 4][W + 8] 16-bit, value (y - 2, x - 2) reflected
-  const char* srcB;             //                 copy B: the same shifted by one element
-  long long sn, sz, sy;         // byte strides of both
+  const char* src;              // fp32 network input [N][1][D][H][W] through byte strides (x contiguous)
+  long long sn, sz, sy;
+  long long offs[16];           // use_offs: sample i reads its volume at src + offs[i] bytes (sliding-window batches) instead of i * sn
+  int use_offs;
   const char* wpk;              // the stem's packed weights (pack_stem_kernel; the row-fragment tiles start at byte 4096)
   const float* bias;            // [16] folded norm shift / conv bias or null
   int act;                      // ACT_NONE or ACT_RELU
@@ -89,14 +91,21 @@ struct StemIn {
 template <int TY, int TX>
 struct ZmStemCfg {
   static constexpr int HY = TY + 2, HX = TX + 2, HVP = HY * HX;
-  static constexpr int IY = HY + 2;                                   // input rows of a ring plane: one more voxel of halo
-  static constexpr int RS = (TX + 8) * 2;                             // bytes of a row copy: the values [x0 - 2, x0 + TX + 6) = five 16-byte pieces
-  static constexpr int CPSZ = IY * RS, IPLSZ = 2 * CPSZ;              // copies A | B of one input plane
-  static constexpr int RC = 16;                                       // input ring: the planes the <= 6 ring planes in production read + DMA lookahead
-  static constexpr int BYTES = RC * IPLSZ;
+  static constexpr int IY = HY + 2, IX = HX + 2, IVP = IY * IX;       // input region of a ring plane: one more voxel of halo
+  static constexpr int RS = (TX + 8) * 2;                             // bytes of a row copy: the values [x0 - 2, x0 + TX + 6)
+  static constexpr int CPSZ = IY * RS;                                // copies A | B of one input plane
+  static constexpr int IPLSZ = ((2 * CPSZ + 8 + 63) / 64) * 64;       // + 8 bytes nobody reads (idle lanes of a conversion)
+  static constexpr int DUMMY = IPLSZ - 8;
+  static constexpr int RC = 16;                                       // input ring (row copies): what the <= 6 ring planes in production read + lookahead
+  static constexpr int SW = 40;                                       // staged fp32 row: the floats [x0 - 4, x0 + 36), ten 16-byte DMA pieces
+  static constexpr int STGSZ = ((IY * SW * 4 + 255) / 256) * 256;     // one staged fp32 plane (12 rows)
+  static constexpr int RSTG = 8;                                      // staging ring (DMA planes in flight)
+  static constexpr int NLD = (IVP + 63) / 64;                         // values per lane of a conversion
+  static constexpr int BYTES = RC * IPLSZ + RSTG * STGSZ;
   static constexpr int NSW = 7;                                       // stem waves (+ 1 loader wave = 8 producer waves; 16 waves of <= 128 registers)
+  static constexpr int LEAD = 3;                                      // a stem wave converts its input planes up to LEAD beyond the ring plane it starts
   static constexpr int NT = 2 * HY + (2 * HY + 15) / 16;              // tiles of one ring plane: (row, x 0..15), (row, x 16..31), the columns 32, 33 of 8 rows
-  static_assert(TX == 32 && IY * 5 <= 64 && RC * 2 <= 60 && IPLSZ % 64 == 0, "one DMA instruction per copy and plane (12 rows x five pieces); vmcnt range");
+  static constexpr bool OK = TX == 32 && IY == 12 && RSTG * 2 <= 60 && NLD == 7;   // two DMA instructions (6 rows x ten pieces) per input plane; vmcnt range
 };
 
 // One z-segment of one in-plane tile per workgroup.  OUTMODE 0: 16-bit NDHWC; 1: fp32 planar.
@@ -149,8 +158,17 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
   int* done = (int*)(smem + C::FLAGOFF + 32);
   int* staged = (int*)(smem + C::FLAGOFF + 64);              // per consumer wave: steps whose outputs are in the staging tile
   int* stored = (int*)(smem + C::FLAGOFF + 96);              // per storer wave: steps it has read out of the staging tile
-  if (tid < ((NS || STEM) ? 32 : 16)) ((int*)(smem + C::FLAGOFF))[tid] = (STEM && tid < 8) ? (tid == 7 ? 0x7fffffff : tid) : 0;   // (STEM: ready[w] = the next plane stem wave w publishes; [7] belongs to no wave)
-  if constexpr (STEM) static_assert(STAGEOFF + ZmStemCfg<TY, TX>::BYTES <= 160 * 1024, "ring + input ring must fit the LDS");
+  // (STEM: ready[w] = the next ring plane stem wave w publishes, stored[w] = inconv[w] = the next input plane it converts; [7] belongs to no wave)
+  if (tid < ((NS || STEM) ? 32 : 16))
+    ((int*)(smem + C::FLAGOFF))[tid] = (STEM && (tid < 8 || tid >= 24)) ? ((tid & 7) == 7 ? 0x7fffffff : (tid & 7)) : 0;
+  if constexpr (STEM) {
+    // The pad elements of every row copy (36 .. 39; the conversions write the 36 values of a row) are read as a fragment's fourth value
+    // against a zero weight: they must be FINITE, so the input ring starts as zeros -- whatever bit patterns the previous kernel left in
+    // this CU's LDS would otherwise turn 0 x Inf into NaN at a few voxels, on some boxes, sometimes (seen once in the registration test).
+    typedef ZmStemCfg<TY, TX> SC;
+    static_assert(SC::OK && STAGEOFF + SC::BYTES <= 160 * 1024, "stem-fed geometry; ring + input rings must fit the LDS");
+    for (int i = tid; i < SC::RC * SC::IPLSZ / 4; i += (NC + SC::NSW + 1) * 64) ((int*)(smem + STAGEOFF))[i] = 0;
+  }
   __syncthreads();
 
   if (NS && wave >= NC + NL) {
@@ -207,32 +225,40 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
   if constexpr (STEM) {
     if (wave >= NC) {
       typedef ZmStemCfg<TY, TX> SC;
-      constexpr int RS = SC::RS, CPSZ = SC::CPSZ, IPLSZ = SC::IPLSZ, RC = SC::RC;
-      constexpr int INOFF = STAGEOFF;
-      int* inready = staged;                                   // landed input planes (the storers' flag word is free: NS = 0)
+      constexpr int RS = SC::RS, CPSZ = SC::CPSZ, IPLSZ = SC::IPLSZ, RC = SC::RC, RSTG = SC::RSTG, NLD = SC::NLD, IX = SC::IX, SW = SC::SW;
+      constexpr int INOFF = STAGEOFF, STGOFF = STAGEOFF + RC * IPLSZ;
+      int* landed = staged;                                    // fp32 input planes landed in the staging ring (the storers' flag words are free: NS = 0)
+      int* inconv = stored;                                    // per stem wave: the next input plane (index from zlo) it will convert
       // input planes the segment touches: ring plane q <-> z = zs - 1 + q, the stem voxel plane z1 = refl(z) reads z1 - 1 .. z1 + 1
       const int zlo = zs >= 2 ? zs - 2 : 0;
       const int zhi = ze + 1 <= p.D - 1 ? ze + 1 : p.D - 1;
+      const int nin = zhi - zlo + 1;
+      const char* src_n = si.src + (si.use_offs ? si.offs[n & 15] : (long long)n * si.sn);
       if (wave == NC + SC::NSW) {
         // =========================== loader wave ===========================
-        // lane -> (row pr of the twelve, piece pc of its five): the rows [y0 - 2, y0 + 10) = padded rows y0 .. y0 + 11, the values
-        // [x0 - 2, x0 + 38) = padded elements x0 .. x0 + 39.  One instruction per copy: 60 lanes x 16 bytes = CPSZ.
-        const int nin = zhi - zlo + 1;
-        const int pr = lane / 5, pc = lane - pr * 5;
+        // The 12 rows x 40 floats [y0 - 2, y0 + 10) x [x0 - 4, x0 + 36) of an input plane as 120 16-byte pieces = TWO LDS-DMA instructions
+        // (lane -> row pr of six, piece pc of ten).  Rows / pieces outside the volume are clamped into it and never read: the reflection
+        // happens when a stem wave reads the staged plane back (conversion).
+        const int pr = lane / 10, pc = lane - pr * 10;
         const bool pvalid = lane < 60;
-        const int goff = pvalid ? (y0 + pr) * (int)si.sy + x0 * 2 + pc * 16 : 0;
-        const char* srcA = si.srcA + (long long)n * si.sn + goff;
-        const char* srcB = si.srcB + (long long)n * si.sn + goff;
+        int goff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int yy = y0 - 2 + pr + 6 * j, xx = x0 - 4 + 4 * pc;
+          yy = yy < 0 ? 0 : (yy > p.H - 1 ? p.H - 1 : yy);
+          xx = xx < 0 ? 0 : (xx > p.W - 4 ? p.W - 4 : xx);
+          goff[j] = pvalid ? yy * (int)si.sy + xx * 4 : 0;
+        }
         auto issue_plane = [&](int k) {
-          const long long zo = (long long)(zlo + k) * si.sz;
-          char* dstp = smem + INOFF + ((zlo + k) % RC) * IPLSZ;
+          const char* plane = src_n + (long long)(zlo + k) * si.sz;
+          char* dstp = smem + STGOFF + (k % RSTG) * SC::STGSZ;
           if (pvalid) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA + zo), (lptr_t)dstp, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcB + zo), (lptr_t)(dstp + CPSZ), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(plane + goff[0]), (lptr_t)dstp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(plane + goff[1]), (lptr_t)(dstp + 960), 16, 0, 0);
           }
         };
-        int next_issue = 0, next_pub = 0, seen_ready = 0;
-        const unsigned a_in = lds_addr(inready);
+        int next_issue = 0, next_pub = 0, seen_conv = 0;
+        const unsigned a_landed = lds_addr(landed);
 #ifdef AMX_EXPERIMENT
         unsigned long long* ltr = (p.dbg & 8) && lane == 0 && blockIdx.x == 0 ? (unsigned long long*)p.stats + 1001 * 128 : nullptr;   // trace slot (wg 500, half 1)
         int lcount = 0;
@@ -242,22 +268,21 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
 #define AMX_LSTAMP() do {} while (0)
 #endif
         while (next_pub < nin) {
-          // the ring slot of input plane zin held plane zin - RC, last read by ring plane z = zin - RC + 1 (q = z - zs + 1): every ring
-          // plane below zin - RC + 3 - zs must be done before the DMA may overwrite it
+          // staging slot k % RSTG held plane k - RSTG: every plane below k - RSTG + 1 must have been converted (min over the waves' inconv)
           while (next_issue < nin) {
-            const int need_done = zlo + next_issue - RC + 3 - zs;
-            if (seen_ready < need_done) seen_ready = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(ready)));
-            if (seen_ready < need_done) break;
+            const int need = next_issue - RSTG + 1;
+            if (seen_conv < need) seen_conv = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(inconv)));
+            if (seen_conv < need) break;
             issue_plane(next_issue++);
           }
-          if (next_issue == next_pub) {                         // ring full, everything published: wait for the stem waves
+          if (next_issue == next_pub) {                         // staging full, everything published: wait for the conversions
             __builtin_amdgcn_s_sleep(2);
             continue;
           }
-          AMX_LSTAMP();                                          // [issued what the ring allows]
-          WaitVm<2, RC - 1>::run(next_issue - next_pub - 1);    // the oldest unpublished plane has landed
+          AMX_LSTAMP();                                          // [issued what the staging ring allows]
+          WaitVm<2, RSTG - 1>::run(next_issue - next_pub - 1);  // the oldest unpublished plane has landed
           AMX_LSTAMP();                                          // [landed]
-          flag_store_asm(a_in, ++next_pub);
+          flag_store_asm(a_landed, ++next_pub);
           AMX_LSTAMP();                                          // [published]
         }
         return;
@@ -307,6 +332,47 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
       constexpr int NB = 4;                                    // tiles per batch
       float vmax = 0.f;
       int seen_in = 0, seen_done = 0;
+      // ---- conversion duty: this wave rounds the staged fp32 input planes k = w, w + NSW, ... (index from zlo) to the storage type and writes
+      // their two shifted row copies (copy A: value ix at element ix, copy B: value ix at element ix - 1; the stem kernel's layout).  The
+      // reflection of the input happens here: lane value (iy, ix) of the 12 x 36 region reads the staged row / column of the reflected voxel.
+      // (its per-value source / destination offsets are recomputed per conversion -- one plane in seven per wave -- rather than kept
+      //  in 21 registers next to the tile pipeline's: those spilled)
+      int myk = w, seen_landed = 0, seen_ready = 0;
+      bool ibad = false;
+      auto convert_plane = [&](int k) {
+        while (seen_landed < k + 1) {
+          seen_landed = flag_load(landed);
+          if (seen_landed < k + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        // the row-copy slot of input plane zin held plane zin - RC, last read by ring plane z = zin - RC + 1 (q = z - zs + 1): every ring
+        // plane below zin - RC + 3 - zs must be done before it is overwritten
+        const int need_done = zlo + k - RC + 3 - zs;
+        while (seen_ready < need_done) {
+          seen_ready = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(ready)));
+          if (seen_ready < need_done) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        const int so = (k % RSTG) * SC::STGSZ, dof = ((zlo + k) % RC) * IPLSZ;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));                       // (opaque: keeps hipcc from hoisting the seven offset sets out of the plane loop)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+          const int hv = j * 64 + lane_o;
+          const bool valid = hv < SC::IVP;
+          const int hvc = valid ? hv : SC::IVP - 1;
+          const int iy = hvc / IX, ix = hvc - iy * IX;
+          const int ry = reflect_clamp(y0 + iy - 2, p.H) - (y0 - 2), rx = reflect_clamp(x0 + ix - 2, p.W) - (x0 - 4);
+          const float f = *(const float*)(smem + STGOFF + so + (ry * SW + rx) * 4);
+          if (RangeCheck<T>::on) ibad |= RangeCheck<T>::bad(f);       // an input beyond the storage range (or NaN) would reach the taps as Inf
+          const unsigned short hb = to_bits<T>(f);
+          const int la = valid ? iy * RS + ix * 2 : SC::DUMMY;
+          const int lb = (valid && ix > 0) ? CPSZ + iy * RS + (ix - 1) * 2 : SC::DUMMY;
+          *(unsigned short*)(smem + INOFF + dof + la) = hb;
+          *(unsigned short*)(smem + INOFF + dof + lb) = hb;
+        }
+        asm volatile("" ::: "memory");                         // (LDS serves a wave's accesses in order: the flag lands behind the row copies)
+        flag_store(inconv + w, k + NSW);
+      };
 #ifdef AMX_EXPERIMENT
       unsigned long long* str = (p.dbg & 8) && lane == 0 && blockIdx.x == 0 && w == 0 ? (unsigned long long*)p.stats + 1000 * 128 : nullptr;   // trace slot (wg 500, half 0)
       int scount = 0;
@@ -322,8 +388,15 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
         for (int kz = 0; kz < 3; ++kz) zi[kz] = reflect_clamp(z1 - 1 + kz, p.D);
         int zmax = zi[0] > zi[1] ? zi[0] : zi[1];
         zmax = zmax > zi[2] ? zmax : zi[2];
+        // own conversions first, up to LEAD planes beyond what this ring plane reads: a wave never blocks on a ring slot while it owes an
+        // input plane that an older ring plane (another wave's) still waits for
+        {
+          int kmax = zs + q - zlo + SC::LEAD;
+          kmax = kmax < nin - 1 ? kmax : nin - 1;
+          for (; myk <= kmax; myk += NSW) convert_plane(myk);
+        }
         while (seen_in < zmax - zlo + 1) {                     // (polled only when the last value seen does not already allow it)
-          seen_in = flag_load(inready);
+          seen_in = __builtin_amdgcn_readfirstlane(flag_min8_asm(lds_addr(inconv)));
           if (seen_in < zmax - zlo + 1) __builtin_amdgcn_s_sleep(1);
         }
         while (q >= R + TZ * seen_done) {
@@ -424,7 +497,8 @@ __global__ __launch_bounds__((8 + (STEM ? ZmStemCfg<8, 32>::NSW + 1 : 2 * (SPLIT
         flag_store(ready + w, q + NSW);
         AMX_SSTAMP();                                            // [published]
       }
-      if (RangeCheck<T>::on) raise_flag(p.oflow, !(vmax <= 65504.f));
+      for (; myk < nin; myk += NSW) convert_plane(myk);       // input planes that only other waves' last ring planes read
+      if (RangeCheck<T>::on) raise_flag(p.oflow, ibad | !(vmax <= 65504.f));
       return;
     }
   }
@@ -847,7 +921,7 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st, const StemIn& si = 
   typedef ZmCfg<SPLIT ? 2 : NCK, QT, TY, TX, R> C;
   constexpr int LDS = STEM ? C::FLAGOFF + 128 + ZmStemCfg<TY, TX>::BYTES : NS ? C::FLAGOFF + 128 + ZmStage<QT, TY, TX, OUTMODE>::TOTAL : C::LDS_BYTES;
   if (STEM)
-    snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,stem1->16->16,%dx%dx%d,c8+st%d+cv1,r%d/%d%s>",
+    snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s,stem1->16->16,%dx%dx%d,c8+st%d+ld1,r%d/%d%s>",
              __is_same(T, f16) ? "f16" : "bf16", TZ, TY, TX, ZmStemCfg<TY, TX>::NSW, R, ZmStemCfg<TY, TX>::RC, p.out2 ? ",pool" : "");
   else
   snprintf(g_kernel_name3, sizeof g_kernel_name3, "conv3d_k3_zmarch<%s%s,%d->%d,%dx%dx%d,c8+l%d+s%d,r%d,o%d%s>",
@@ -956,38 +1030,6 @@ bool conv_zmarch_eligible_split(const ConvParams& p) {
 }
 bool conv_zmarch_can_pool_split(const ConvParams& p) { return conv_zmarch_can_pool(p) && conv_zmarch_eligible_split(p); }
 
-// The prepared input of the stem-fed layer (StemIn): per thread eight consecutive padded elements of one row of both copies.
-template <typename T>
-__global__ void stem_prep_kernel(const float* __restrict__ x, long long xs_n, long long xs_z, long long xs_y, char* __restrict__ A,
-                                 char* __restrict__ B, int N, int D, int H, int W, int* oflow) {
-  const int cpr = (W + 8) / 8;                                  // 16-byte chunks per padded row
-  const long long total = (long long)N * D * (H + 4) * cpr;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int c = (int)(idx % cpr);
-  long long r = idx / cpr;
-  const int yp = (int)(r % (H + 4));
-  r /= (H + 4);
-  const int z = (int)(r % D), n = (int)(r / D);
-  const float* row = (const float*)((const char*)x + n * xs_n + z * xs_z + (long long)reflect_clamp(yp - 2, H) * xs_y);
-  float v[9];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) v[e] = row[reflect_clamp(8 * c + e - 2, W)];
-  bool bad = false;
-  unsigned short h[9];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) {
-    if (RangeCheck<T>::on) bad |= RangeCheck<T>::bad(v[e]);     // an input beyond the storage range (or NaN) would reach the taps as Inf
-    h[e] = to_bits<T>(v[e]);
-  }
-  const long long o = idx * 16;                                 // both buffers are dense [N][D][H + 4][W + 8]
-  *(uint4*)(A + o) = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
-  *(uint4*)(B + o) = make_uint4(h[1] | (unsigned)h[2] << 16, h[3] | (unsigned)h[4] << 16, h[5] | (unsigned)h[6] << 16, h[7] | (unsigned)h[8] << 16);
-  if (RangeCheck<T>::on) raise_flag(oflow, bad);
-}
-
-size_t conv_zmarch_stem_prep_bytes(int N, int D, int H, int W) { return (size_t)2 * N * D * (H + 4) * (W + 8) * 2; }
-
 // Stem-fed 16 -> 16 layer (network.py modules 0..5 of the 6 M model as ONE launch): `p` describes the 16 -> 16 layer (its src0 is
 // ignored), the remaining arguments the stem in front of it.  Whole tiles only; single 16-bit precisions.
 bool conv_zmarch_stem_eligible(const ConvParams& p, int precision) {
@@ -996,31 +1038,19 @@ bool conv_zmarch_stem_eligible(const ConvParams& p, int precision) {
   return !off && precision < 2 && p.C0 == 16 && p.C1 == 0 && p.Cout == 16 && !p.out32 && !p.raw_halo && p.W >= 32 && !(p.W % 32) && !(p.H % 8) &&
          !(p.D & 1) && p.D >= 8 && p.ox == 32 && (p.ocs == 0 || p.ocs == 32);
 }
-// x_offs (host array of p.N element offsets, or null): sample i reads its volume at x + x_offs[i] (sliding-window batches).
-// `prep`: conv_zmarch_stem_prep_bytes(N, D, H, W) bytes of scratch (16-byte aligned) for the prepared input.
+// x_offs (host array of p.N element offsets, or null; at most 16 samples then): sample i reads its volume at x + x_offs[i]
+// (sliding-window batches: every window is reflect-padded as its own input).
 hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
-                                   void* prep, const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision,
-                                   hipStream_t st) {
-  if (stem_act != ACT_NONE && stem_act != ACT_RELU) return hipErrorInvalidValue;   // the stem waves clip with one v_max
-  if (precision != 0 && precision != 1) return hipErrorInvalidValue;
-  const long long row = (long long)(p.W + 8) * 2, plane = row * (p.H + 4), vol = plane * p.D;
-  char* A = (char*)prep;
-  char* B = A + vol * p.N;
-  {
-    const int ns = x_offs ? p.N : 1;                             // one pass over the batch, or one per window
-    for (int i = 0; i < ns; ++i) {
-      const int nn = x_offs ? 1 : p.N;
-      const float* src = x_offs ? x + x_offs[i] : x;
-      const long long total = (long long)nn * p.D * (p.H + 4) * ((p.W + 8) / 8);
-      const unsigned blocks = (unsigned)((total + 255) / 256);
-      if (precision == 0)
-        hipLaunchKernelGGL(stem_prep_kernel<f16>, dim3(blocks), dim3(256), 0, st, src, xs_n, xs_z, xs_y, A + vol * i, B + vol * i, nn, p.D, p.H, p.W, p.oflow);
-      else
-        hipLaunchKernelGGL(stem_prep_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, xs_n, xs_z, xs_y, A + vol * i, B + vol * i, nn, p.D, p.H, p.W, p.oflow);
-    }
-  }
+                                   const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision, hipStream_t st) {
+  if (stem_act != ACT_NONE && stem_act != ACT_RELU) return hipErrorInvalidValue;   // the stem waves clip with one v_med3
+  if ((precision != 0 && precision != 1) || (x_offs && p.N > 16)) return hipErrorInvalidValue;
   StemIn si;
-  si.srcA = A; si.srcB = B; si.sn = vol; si.sz = plane; si.sy = row;
+  memset(&si, 0, sizeof si);
+  si.src = (const char*)x; si.sn = xs_n; si.sz = xs_z; si.sy = xs_y;
+  if (x_offs) {
+    si.use_offs = 1;
+    for (int i = 0; i < p.N; ++i) si.offs[i] = x_offs[i] * 4;
+  }
   si.wpk = (const char*)stem_wpk; si.bias = stem_bias; si.act = stem_act; si.slope = stem_slope;
   if (precision == 0) return launch_zm_ns<f16, 1, 1, 8, 10, 0, 0, false, false, 32, true>(p, st, si);
   return launch_zm_ns<bf16, 1, 1, 8, 10, 0, 0, false, false, 32, true>(p, st, si);

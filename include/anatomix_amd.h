@@ -84,6 +84,10 @@ typedef struct amx_unet_cfg {
 typedef struct amx_unet amx_unet_t;
 
 int amx_version(void);
+
+/* Test aid (no reference counterpart): overwrites the LDS of every compute unit with `pattern` (one 160 KB workgroup per CU, twice over),
+ * so that a test can show that a kernel's results do not depend on what the previous kernel left there (tests/test_stem_fused_gpu.py). */
+int amx_debug_fill_lds(unsigned pattern, void* stream);
 const char* amx_last_error(void);
 
 /* Unet.__init__ (network.py:262-465): builds the layer plan (same module indices as the

@@ -86,6 +86,29 @@ def test_window_batches_are_padded_per_window(device):
     assert err < 1e-5, err                                        # (fp32 accumulation order of the weighted sums only)
 
 
+@pytest.mark.parametrize("pattern", [0x7E007E00, 0x7C00FC00, 0xFFFFFFFF])
+def test_results_do_not_depend_on_what_the_previous_kernel_left_in_lds(device, pattern):
+    """The pad elements of the input row copies are read against zero weights: with NaN / Inf bit patterns left in a CU's LDS by the
+    kernel before, 0 x Inf = NaN reached a few voxels of the fused launch's output on some boxes (once, in the registration test) until
+    the input ring was zero-filled at kernel start.  amx_debug_fill_lds writes the pattern into every CU's LDS right before the forward."""
+    import ctypes
+    from anatomix_amd import _lib
+    lib = _lib.load()
+    m = _model(device, "f16")
+    x = R.synthetic_input(21, 2, (64, 64, 64)).to(device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    with torch.no_grad():
+        want, _ = m.forward_hip_taps(x, [2])
+        for _ in range(3):
+            _lib.check(lib.amx_debug_fill_lds(pattern, st))
+            y = m(x)
+            assert torch.equal(y, want)
+            _lib.check(lib.amx_debug_fill_lds(pattern, st))
+            y2, _ = m.forward_hip_taps(x, [2])                  # (the two-launch route and every other kernel of the forward, too)
+            assert torch.equal(y2, want)
+    m.check_numerics()
+
+
 def test_input_beyond_f16_is_loud(device):
     """The fused path rounds the network input to the storage type in its preparation pass: a value beyond the f16 range must raise
     like an overflowing activation does (tests/test_range_safety_gpu.py covers the stem's own outputs through the fused launch)."""

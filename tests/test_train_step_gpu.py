@@ -442,6 +442,55 @@ def test_loss_trajectory_over_adamw_steps_follows_the_stock_modules(device):
     np.testing.assert_allclose(gh[2:], gr[2:], rtol=0.35)
 
 
+# One forward + backward of the HIP training path against oracle/train_lowp.py -- the SAME graph with the path's rounding points
+# (stored 16-bit activations and gradients, fp32 arithmetic in between) evaluated by torch on the CPU.  Unlike the fp32 records above,
+# whose 30-45 % bands are a property of 16-bit storage, this separates KERNEL correctness of the backward from storage precision the way
+# forward_lowp does for the forward: what remains is fp32 summation order and the 1-ulp storage flips it causes.  Bounds = measured x ~2.
+LOWP_BOUNDS = {"f16": dict(tap=2e-3, conv_w=4e-3, norm_v=3e-2, whole=3e-3), "bf16": dict(tap=1.5e-2, conv_w=3e-2, norm_v=0.2, whole=2.5e-2)}
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_backward_matches_the_rounding_point_emulation(device, precision):
+    from oracle import train_lowp as TL
+    layers = [27, 31, 38, 45, 52]
+    size = 64
+    hip, _ = _pair(device, precision)
+    sd = {k: v.detach().cpu().clone() for k, v in hip.state_dict().items()}
+    x = torch.from_numpy(np.random.RandomState(3).rand(2, 1, size, size, size).astype(np.float32))
+    scale = 1024.0 if precision == "f16" else 1.0           # f16 gradients need loss scaling; the emulation applies the same factor
+    out, feats = hip(x.to(device), layers)
+    g = torch.Generator().manual_seed(5)
+    cots = [torch.randn(f.shape, generator=g) / f[0].numel() ** 0.5 for f in feats]
+    loss = 0.1 * out.square().mean()
+    for f, c in zip(feats, cots):
+        loss = loss + (f * c.to(device)).sum()
+    (loss * scale).backward()
+    dt = torch.float16 if precision == "f16" else torch.bfloat16
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 8 else 32))
+    ref, out_r, taps_r = TL.parameter_gradients(x, sd, KW, layers, [c * scale for c in cots], out_weight=0.1 * scale, lowp=dt)
+    lim = LOWP_BOUNDS[precision]
+    errs_t = [rel_l2(f.detach().cpu(), t) for f, t in zip(feats, taps_r)]
+    print(precision, "taps vs emulation", ["%.2e" % e for e in errs_t], "out %.2e" % rel_l2(out.detach().cpu(), out_r))
+    assert max(errs_t) <= lim["tap"], errs_t
+    worst_w, worst_v = ("", 0.0), ("", 0.0)
+    ga, gb = [], []
+    for k, p in hip.named_parameters():
+        a, b = p.grad.detach().double().cpu(), ref[k].double()
+        assert torch.isfinite(a).all(), k
+        e = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if a.dim() > 1:
+            worst_w = max(worst_w, (k, e), key=lambda t: t[1])
+        else:
+            worst_v = max(worst_v, (k, e), key=lambda t: t[1])
+        ga.append(a.flatten()); gb.append(b.flatten())
+    ga, gb = torch.cat(ga), torch.cat(gb)
+    whole = float((ga - gb).norm() / gb.norm())
+    print(precision, f"gradients vs emulation: whole {whole:.2e}, worst conv weight {worst_w}, worst norm vector {worst_v}")
+    assert worst_w[1] <= lim["conv_w"], worst_w
+    assert worst_v[1] <= lim["norm_v"], worst_v
+    assert whole <= lim["whole"], whole
+
+
 @pytest.mark.parametrize("switch,off,exact", [("RECOMPUTE_ACT", False, True), ("FUSED_FOLD_SPLIT", False, False),
                                              ("SPLIT_CONCAT_DGRAD", 0, False)])
 def test_backward_code_paths_agree_parameter_by_parameter(device, switch, off, exact, monkeypatch):
