@@ -60,10 +60,21 @@ class _RoundFwd(torch.autograd.Function):           # packed weights: 16-bit ope
         return g, None
 
 
-def forward_train_lowp(x, params, kwargs, layers=(), lowp=torch.bfloat16):
+def _force(t, forced, idx):
+    """Teacher forcing: the VALUE of a stored tensor is replaced by the one the HIP path stored (forced[idx], fp32 NCDHW), its gradient
+    keeps flowing into the emulated graph.  A random-weight train-mode BatchNorm network doubles any 1-ulp storage flip per layer
+    (7e-6 at the stem, 1.4e-2 at module 62 in f16, tools/train_lowp_debug.py): without forcing, the comparison of two correct
+    implementations reads like a bug at depth; with it every layer's adjoint is checked on the SAME stored operands."""
+    if forced is None or idx not in forced:
+        return t
+    return t + (forced[idx].to(t.dtype) - t).detach()
+
+
+def forward_train_lowp(x, params, kwargs, layers=(), lowp=torch.bfloat16, forced=None):
     """x [N, 1, D, H, W] fp32; params: {state-dict key: fp32 leaf tensor requiring grad} (conv weights, BatchNorm weight / bias);
     returns (out fp32, [taps in ascending module order]) -- taps at conv ids are the stored PRE-norm tensors, at norm / act ids the
-    stored activated tensors, like model/train.py."""
+    stored activated tensors, like model/train.py.  forced: {module id: tensor} values of stored tensors to substitute (conv id: X,
+    last id of its norm / act group: Y); see _force."""
     kw = dict(ngf=24, norm="batch", final_act="none", activation="relu", pooling="Max", interp="nearest",
               use_skip_connection=True, norm_eps=1e-5, doubleconv=True)
     kw.update(kwargs)
@@ -92,7 +103,7 @@ def forward_train_lowp(x, params, kwargs, layers=(), lowp=torch.bfloat16):
                     taps[i] = out
                 i += 1
                 continue
-            X = _RoundBoth.apply(z, lowp)
+            X = _force(_RoundBoth.apply(z, lowp), forced, i)
             if i in layers:
                 taps[i] = X
             j = i + 1
@@ -108,7 +119,7 @@ def forward_train_lowp(x, params, kwargs, layers=(), lowp=torch.bfloat16):
             if j < n and p.kinds[j] == "act":
                 y = torch.relu(y)
                 j += 1
-            Y = _RoundBoth.apply(y, lowp)
+            Y = _force(_RoundBoth.apply(y, lowp), forced, j - 1)
             for t in range(i + 1, j):
                 if t in layers:
                     taps[t] = Y
@@ -133,12 +144,12 @@ def forward_train_lowp(x, params, kwargs, layers=(), lowp=torch.bfloat16):
     return out, [taps[l] for l in sorted(taps)]
 
 
-def parameter_gradients(x, sd, kwargs, layers, cotangents, out_weight=0.1, lowp=torch.bfloat16):
+def parameter_gradients(x, sd, kwargs, layers, cotangents, out_weight=0.1, lowp=torch.bfloat16, forced=None):
     """Gradients of  out_weight * mean(out^2) + sum_i <tap_i, cotangent_i>  with respect to every conv weight and BatchNorm weight /
     bias of the state dict `sd` (fp32 tensors), through forward_train_lowp.  Returns ({key: gradient}, out, taps)."""
     params = {k: v.detach().clone().float().requires_grad_(True) for k, v in sd.items()
               if v.dtype.is_floating_point and ("running" not in k)}
-    out, taps = forward_train_lowp(x, params, kwargs, layers, lowp)
+    out, taps = forward_train_lowp(x, params, kwargs, layers, lowp, forced)
     loss = out_weight * out.square().mean()
     for t, c in zip(taps, cotangents):
         loss = loss + (t * c).sum()

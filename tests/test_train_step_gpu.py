@@ -445,33 +445,42 @@ def test_loss_trajectory_over_adamw_steps_follows_the_stock_modules(device):
 # One forward + backward of the HIP training path against oracle/train_lowp.py -- the SAME graph with the path's rounding points
 # (stored 16-bit activations and gradients, fp32 arithmetic in between) evaluated by torch on the CPU.  Unlike the fp32 records above,
 # whose 30-45 % bands are a property of 16-bit storage, this separates KERNEL correctness of the backward from storage precision the way
-# forward_lowp does for the forward: what remains is fp32 summation order and the 1-ulp storage flips it causes.  Bounds = measured x ~2.
-LOWP_BOUNDS = {"f16": dict(tap=2e-3, conv_w=4e-3, norm_v=3e-2, whole=3e-3), "bf16": dict(tap=1.5e-2, conv_w=3e-2, norm_v=0.2, whole=2.5e-2)}
+# forward_lowp does for the forward.  The emulated forward is teacher-forced with the tensors the HIP path stored (this network doubles
+# a 1-ulp storage flip per layer: un-forced, the forwards of two correct implementations are 1.4e-2 apart at module 62), so every
+# layer's adjoint runs on identical stored operands; what remains is fp32 summation order and the gradient flips it causes.
+LOWP_BOUNDS = {"f16": dict(fwd=2e-3, conv_w=2e-3, norm_v=2e-2, whole=2e-3), "bf16": dict(fwd=1.5e-2, conv_w=1.5e-2, norm_v=0.15, whole=1.5e-2)}
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
 def test_backward_matches_the_rounding_point_emulation(device, precision):
     from oracle import train_lowp as TL
-    layers = [27, 31, 38, 45, 52]
+    cot_layers = [27, 31, 38, 45, 52]
     size = 64
     hip, _ = _pair(device, precision)
     sd = {k: v.detach().cpu().clone() for k, v in hip.state_dict().items()}
+    plan = R.build_plan(**{k: v for k, v in KW.items() if k != "dimension"})
+    convs = [i for i, k in enumerate(plan.kinds) if k == "conv"][:-1]
+    acts = [i for i, k in enumerate(plan.kinds) if k == "act"]
+    layers = sorted(set(convs + acts))                      # every stored tensor: X at the conv ids, Y at the activation ids
     x = torch.from_numpy(np.random.RandomState(3).rand(2, 1, size, size, size).astype(np.float32))
     scale = 1024.0 if precision == "f16" else 1.0           # f16 gradients need loss scaling; the emulation applies the same factor
     out, feats = hip(x.to(device), layers)
+    stored = dict(zip(layers, feats))
     g = torch.Generator().manual_seed(5)
-    cots = [torch.randn(f.shape, generator=g) / f[0].numel() ** 0.5 for f in feats]
+    cots = {l: torch.randn(stored[l].shape, generator=g) / stored[l][0].numel() ** 0.5 for l in cot_layers}
     loss = 0.1 * out.square().mean()
-    for f, c in zip(feats, cots):
-        loss = loss + (f * c.to(device)).sum()
+    for l in cot_layers:
+        loss = loss + (stored[l] * cots[l].to(device)).sum()
     (loss * scale).backward()
     dt = torch.float16 if precision == "f16" else torch.bfloat16
-    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 8 else 32))
-    ref, out_r, taps_r = TL.parameter_gradients(x, sd, KW, layers, [c * scale for c in cots], out_weight=0.1 * scale, lowp=dt)
+    torch.set_num_threads(32)
+    forced = {l: t.detach().cpu() for l, t in stored.items()}
+    ref, out_r, taps_r = TL.parameter_gradients(x, sd, KW, cot_layers, [cots[l] * scale for l in cot_layers], out_weight=0.1 * scale,
+                                                lowp=dt, forced=forced)
     lim = LOWP_BOUNDS[precision]
-    errs_t = [rel_l2(f.detach().cpu(), t) for f, t in zip(feats, taps_r)]
-    print(precision, "taps vs emulation", ["%.2e" % e for e in errs_t], "out %.2e" % rel_l2(out.detach().cpu(), out_r))
-    assert max(errs_t) <= lim["tap"], errs_t
+    e_out = rel_l2(out.detach().cpu(), out_r)
+    print(precision, "output of the forced forward vs HIP %.2e" % e_out)
+    assert e_out <= lim["fwd"], e_out
     worst_w, worst_v = ("", 0.0), ("", 0.0)
     ga, gb = [], []
     for k, p in hip.named_parameters():
