@@ -553,6 +553,8 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
         grad_ctx = torch.enable_grad()
     if sw_volume:
         from anatomix_amd.registration.sliding_window import sliding_window_inference, window_starts
+        if not on_gpu:                                # --plumbing-cpu: the stock-module composition of the same network, generic window loop
+            model.allow_torch_path, model._warned = True, True
         V = sw_volume
         vol = R.synthetic_input(101, 1, (V, V, V)).to(dev)          # every rank holds the volume
         group = dist.group.WORLD if world > 1 else None
@@ -582,8 +584,11 @@ def run_workload(ctx, variant="anatomix", workload="forward", sw_volume=0, preci
                 "unit": "volumes/s", "n_gpus": world, "ranks_seen": getattr(ctx, "ranks_seen", 1), "devices": getattr(ctx, "devices", None),
                 "steps": steps, "warmup": warmup, "ms_per_step": round(float(t.item()) / steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "fp32 (stock torch modules on the CPU)", "data": "synthetic",
-                "config": {"workload": f"contrastive step at {size}^3 on the host, gloo, one pair per rank" + dp_note,
-                           "parallelism": f"data parallel x{world}"},
+                "config": {"workload": (f"sliding-window extraction of one {sw_volume}^3 volume (roi {size}, overlap 0.8, gaussian) on the host, gloo: "
+                                        f"{units_per_step} windows dealt to the ranks as z-ordered runs, neighbour slab exchange, every rank keeps "
+                                        "its normalised z-slab") if sw_volume else
+                                       f"contrastive step at {size}^3 on the host, gloo, one pair per rank" + dp_note,
+                           "parallelism": f"{'windows' if sw_volume else 'data parallel'} x{world}"},
                 "finite": bool(torch.isfinite(y).all())}
     elapsed = float(t.item())
     ms_step = elapsed / steps * 1e3
@@ -784,8 +789,8 @@ def main():
                               "steps": args.steps, "warmup": args.warmup}))
         return
     plumbing = bool(args.plumbing_cpu)
-    if plumbing and not (args.workload == "step" and args.no_graph):
-        print("bench.py: --plumbing-cpu runs `--workload step --no-graph` only", file=sys.stderr)
+    if plumbing and not ((args.workload == "step" and args.no_graph) or (args.workload == "forward" and args.sw_volume)):
+        print("bench.py: --plumbing-cpu runs `--workload step --no-graph` or `--sw-volume V` only", file=sys.stderr)
         sys.exit(2)
     if not plumbing:
         assert torch.cuda.is_available(), "bench.py needs a GPU"

@@ -46,3 +46,20 @@ def test_data_parallel_step_end_to_end_on_the_host():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2 and line["steps"] == 2
     assert line["finite"] and line["value"] > 0 and "flat buckets" in line["config"]["workload"]
+
+
+def test_sharded_sliding_window_end_to_end_on_the_host():
+    """the N-rank path of BASELINE configs[1] (`bench.py --sw-volume V --gpus N`) end to end where no GPU node is
+    available: self-launched at world size 2 on gloo, the windows of one volume dealt to the ranks as z-ordered runs, partial sums on
+    each rank's sub-volume, neighbour slab exchange, normalised z-slabs, max-over-ranks timing, ONE JSON line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sw-volume", "48", "--size", "32", "--plumbing-cpu",
+                        "--steps", "1", "--warmup", "0", "--sustain", "0"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2 and line["steps"] == 1
+    assert line["finite"] and line["value"] > 0 and "windows dealt to the ranks" in line["config"]["workload"]
