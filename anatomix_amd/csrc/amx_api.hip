@@ -981,10 +981,10 @@ __global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, unsigne
 }  // namespace
 
 int amx_debug_fill_lds(unsigned pattern, void* stream) {
-  static bool attr = false;
-  if (!attr) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     AMX_HIP(hipFuncSetAttribute((const void*)fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
+    attr_once.set();
   }
   hipLaunchKernelGGL(fill_lds_kernel, dim3(512), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, (unsigned*)nullptr);
   AMX_HIP(hipGetLastError());

@@ -414,12 +414,12 @@ void attention_operands(void* scratch, int b, int heads, int n, void** Qp, void*
 hipError_t launch_attention_fwd(const void* Qp, const void* Kp, const void* Vt, int b, int n, int heads, int hd, float* out, hipStream_t st) {
   const int npad = att_npad(n);
   constexpr int LDS = kAttNBUF * (kAttKFrag + kAttVFrag) * 1024 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   if (hd < kAttDV)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(npad / kAttBM, heads, b), dim3((4 + kAttNLW) * 64), LDS, st, (const f16*)Qp, (const f16*)Kp,

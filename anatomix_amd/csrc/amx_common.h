@@ -32,6 +32,21 @@ __host__ __device__ constexpr int tapB_index(int s) {           // -1: no tap (z
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 
+// "Set once" flags of launchers (hipFuncAttributeMaxDynamicSharedMemorySize, cached device properties) are per DEVICE: the attribute
+// belongs to the device's copy of the function, so a process that drives a second GPU must set it there too (advisor, round 5).
+// `mask`: one bit per device ordinal (devices >= 64 set the attribute on every launch).
+struct DeviceOnce {
+  unsigned long long mask = 0;
+  int dev = 0;
+  bool done() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    return dev < 64 && ((mask >> dev) & 1);
+  }
+  void set() {
+    if (dev < 64) mask |= 1ull << dev;
+  }
+};
+
 // Experiment / ablation switches are environment variables ONLY in a -DAMX_EXPERIMENT build (make EXTRA=-DAMX_EXPERIMENT); the
 // product library reads no environment on any path: every switch is a compile-time "unset".
 #ifdef AMX_EXPERIMENT

@@ -477,17 +477,22 @@ static hipError_t launch_ks_cfg(ConvParams p, hipStream_t st) {
   snprintf(g_kernel_name_ks, sizeof g_kernel_name_ks, "conv3d_k3_ks<%s,%dx%dx%d,q%d,k%dx%d,c%d,t%d,h%d,b%d%s>", __is_same(T, f16) ? "f16" : "bf16",
            C::TZ, C::TY, C::TX, C::Q, C::KW, C::CPW, C::CW, C::TEAMS, C::NH, C::NBUF, PART ? ",part" : "");
   auto kern = conv3d_k3_ks_kernel<T, C, PART>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
-  if (g_ks_cus == 0) {
+  static int ks_cus_dev = -1;                                 // (the CU count of the device it was read on)
+  {
     int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    g_ks_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorUnknown;
+    if (g_ks_cus == 0 || dev != ks_cus_dev) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+      g_ks_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      ks_cus_dev = dev;
+    }
   }
   p.nbz = (p.D + C::TZ - 1) / C::TZ;
   p.nby = (p.H + C::TY - 1) / C::TY;

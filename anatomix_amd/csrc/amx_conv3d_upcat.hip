@@ -383,11 +383,11 @@ static hipError_t launch_upcat_t(ConvParams p, hipStream_t st) {
   snprintf(g_kernel_name5, sizeof g_kernel_name5, "conv3d_upcat16<%s,2x8x32,c8+l3,r%d/%d,o%d>", __is_same(T, f16) ? "f16" : "bf16",
            C::R, C::RL, OUTMODE);
   auto kern = conv3d_upcat16_kernel<T, OUTMODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   static int dbg = -1;
   if (dbg < 0) {

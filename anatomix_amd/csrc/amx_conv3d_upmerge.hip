@@ -395,11 +395,11 @@ static hipError_t launch_upm(UpmergeParams p, hipStream_t st) {
   snprintf(g_kernel_name6, sizeof g_kernel_name6, "conv3d_upmerge<%s,q%d,%dx%dx%d,b%d,k%d>", __is_same(T, f16) ? (SPLIT ? "f16x2" : "f16") : (SPLIT ? "bf16x2" : "bf16"), Q,
            TZ, C::BY, LXT, NBUF, 32 * KS);
   auto kern = conv3d_upmerge_kernel<T, Q, TZ, TY, NBUF, KS, SPLIT, LXT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   if (g_num_cus6 == 0) {
     int dev = 0;

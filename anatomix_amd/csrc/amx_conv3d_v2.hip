@@ -717,11 +717,11 @@ static hipError_t launch_cfg2(ConvParams p, hipStream_t st) {
     snprintf(g_kernel_name2, sizeof g_kernel_name2, "conv3d_k3_v2<%s,%dx%dx%d,w%d,q%d,nch%d,o%d>",
              tn, C::TZ, C::TY, C::TX, C::NW, Q, NCH, OUTMODE);
   auto kern = conv3d_k3_v2_kernel<T, WZ, WY, WX, NWZ, NWY, Q, NCH, OUTMODE, NLW, NBUF, SPLIT, MX>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   if (g_num_cus == 0) {
     int dev = 0;

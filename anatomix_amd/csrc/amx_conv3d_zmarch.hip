@@ -928,11 +928,11 @@ static hipError_t launch_zm_ns(ConvParams p, hipStream_t st, const StemIn& si = 
            __is_same(T, f16) ? "f16" : "bf16", SPLIT ? "x2" : "", 16 * NCK, 16 * QT, TZ, TY, TX, C::NL, NS, R, OUTMODE,
            p.out2 ? ",pool" : "");
   auto kern = conv3d_k3_zmarch_kernel<T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL, SPLIT, STEM>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static amx::DeviceOnce attr_once;
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   static int dbg = -1;
   if (dbg < 0) {

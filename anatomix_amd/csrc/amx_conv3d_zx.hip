@@ -530,12 +530,12 @@ template <typename C>
 static hipError_t launch_conv_zx_t(ConvParams p, const float* in_ab, int in_act, float in_slope, const void* wx, hipStream_t st) {
   snprintf(g_kernel_name_zx, sizeof g_kernel_name_zx, "conv3d_k3_zx<f16x2mx,32->32,%dx%dx%d,m4+x4+cv4,r%d%s%s>", C::TZ, C::TY, C::TX, C::R,
            in_ab ? ",norm-in" : "", p.out32 ? ",o1" : "");
-  static bool attr_done = false;
+  static amx::DeviceOnce attr_once;
   auto kern = conv3d_k3_zx_kernel<C>;
-  if (!attr_done) {
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.set();
   }
   static int dbg = -1;
   if (dbg < 0) dbg = exp_env("AMX_ZX_DBG") ? atoi(exp_env("AMX_ZX_DBG")) : 0;

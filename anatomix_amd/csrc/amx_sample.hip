@@ -227,14 +227,15 @@ hipError_t launch_sample_coords(const long long* draws, int n, int num, int d0, 
   const bool small = (long long)d0 * d1 * d2 < (1ll << 31);
   const size_t vb = small ? sizeof(int) : sizeof(long long);
   const size_t lds = (size_t)(((n + 15) & ~15) + tsize) * vb + (size_t)tsize * sizeof(int);   // draws + table (the kept list re-uses the table)
-  static bool attr = false;
+  static amx::DeviceOnce attr_once;                          // per DEVICE: the attribute belongs to the device's copy of the function
+  const bool attr = attr_once.done();
   if (lds > 159 * 1024) return hipErrorInvalidValue;
   if (!attr) {                                               // (the kernel also holds 68 bytes of static LDS)
     hipError_t e = hipFuncSetAttribute((const void*)sample_coords_kernel<int>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)sample_coords_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr_once.set();
   }
   if (small)
     sample_coords_kernel<int><<<1, 1024, lds, st>>>(draws, n, num, d1, d2, coords, tsize);

@@ -16,7 +16,7 @@ def friendly(mangled):
     if m:   # <T, NCK, QT, TY, TX, R, OUTMODE, NS, POOL, SPLIT, STEM>; same text as the launcher prints
         t, nck, qt, ty, tx, r, o, ns, pool, split, stem = m.groups()
         if stem == "1":     # the stem-fed 16 -> 16 launch (7 stem waves + loader, input ring of 16 planes: ZmStemCfg)
-            return f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},stem1->16->16,2x{ty}x{tx},c8+st7+cv1,r{r}/16{',pool' if pool == '1' else ''}>"
+            return f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},stem1->16->16,2x{ty}x{tx},c8+st7+ld1,r{r}/16{',pool' if pool == '1' else ''}>"
         return (f"conv3d_k3_zmarch<{'f16' if t == 'DF16_' else 'bf16'},{16*int(nck)}->{16*int(qt)},2x{ty}x{tx},"
                 f"c8+l{2*int(nck)}+s{ns},r{r},o{o}{',pool' if pool == '1' else ''}>")
     m = re.match(r"_ZN3amx21conv3d_upcat16_kernelI(DF16_|DF16b)Li(\d+)E", mangled)
