@@ -141,12 +141,14 @@ class _UnetTrainFn(torch.autograd.Function):
         pack_side = None
         if plan:
             ids = sorted(plan)
-            reqs = [(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids]
             if x.is_cuda and PACK_ASIDE and torch.cuda.is_current_stream_capturing():
                 pack_side = _side_stream(dev)
                 main_s = torch.cuda.current_stream(dev)
                 pack_side.wait_stream(main_s)
                 with torch.cuda.stream(pack_side):
+                    # (the requests are formed ON the side stream: a parameter that is not fp32-contiguous gets a temporary copy there,
+                    #  which the allocator then only recycles behind the side stream's pack kernel)
+                    reqs = [(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids]
                     views = T.pack_batch(reqs, dt, dev)
                     for v in views:
                         v.record_stream(main_s)
@@ -157,6 +159,7 @@ class _UnetTrainFn(torch.autograd.Function):
                             v.record_stream(main_s)
                         ctx.bpacks_pre = (dict(bplan0), dict(zip(bids, bviews)))
             else:
+                reqs = [(T._as_weight(mods[j].weight), 0, plan[j][0], plan[j][1]) for j in ids]
                 views = T.pack_batch(reqs, dt, dev)
             packs = dict(zip(ids, views))
         # the single input channel, padded to one MFMA chunk: one pass (zero fill + cast + strided copy were three, 56 us at 128^3 x 2)

@@ -20,7 +20,6 @@ _STREAMS = {}
 # onto four hardware queues and every cross-queue dependency of a replayed graph costs -- three streams (two layers each) measured
 # 7.45-7.50 ms per step against 7.74-7.77 with six, 7.53-7.55 with two, 7.68 with four (GPU_MAX_HW_QUEUES=8 instead: 14.4 ms).
 _HEAD_STREAMS = int(_lib.exp_env("AMX_HEAD_STREAMS", "3"))
-_TAP_SHAPES = {}                                             # (network, input shape, tap ids, patches) -> {tap id: spatial shape}
 _PREDRAW = _lib.exp_env("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
 _WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
 
@@ -57,8 +56,10 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         # The coordinates do not depend on the features: once the tap shapes of this (network, input shape) are known from an earlier
         # step they are all drawn up front, in netF's layer order (the generator is consumed exactly as before), on a side stream the
         # forward joins at its first tap -- six draw + filter launches leave the main stream's critical path.
-        skey = (id(netG), tuple(reals.shape), tuple(int(l) for l in nce_layers), int(num_patches))
-        shapes = _TAP_SHAPES.get(skey)
+        # (the cache lives ON the module -- a dict keyed by id(netG) would hand a recycled id the plan of a dead network)
+        skey = (tuple(reals.shape), tuple(int(l) for l in nce_layers), int(num_patches))
+        tap_shapes = netG.__dict__.setdefault("_amx_tap_shapes", {})
+        shapes = tap_shapes.get(skey)
         pre = {}
         if shapes is not None and sample_ids is None and _PREDRAW and torch.cuda.is_current_stream_capturing():   # (eagerly the stream switches cost more than they return)
             side = _draw_stream(reals.device)
@@ -85,7 +86,7 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
                 return netF.draw_coords(sampled[i], shape, num_patches, sample_ids, reals.device)
         out, rows, coords, dims = _train.forward_train_sampled(netG, reals, list(nce_layers), sampler)
         if shapes is None and sample_ids is None:
-            _TAP_SHAPES[skey] = dict(seen)
+            tap_shapes[skey] = dict(seen)
         feat_sizes = dims
         feat_kq = None
     else:
