@@ -69,14 +69,16 @@ struct ZmStage {
 // BatchNorm + ReLU), computed into the ring by the workgroup itself instead of being read from HBM -- the stem's 268 MB store and this
 // layer's 268 MB read (batch 4, 128^3) disappear; the stem costs one K = 32 MFMA pair per 16 voxels (amx_conv3d_stem.hip, row-fragment
 // formulation: same operands, same two MFMAs, same rounding -> the ring holds bit for bit what the stem kernel stores).
-//   * a small pass in front (stem_prep_kernel) rounds the fp32 input ONCE to the storage type and writes it reflect-padded (2 voxels in
-//     y and x) as the two shifted 16-bit row copies of the stem kernel -- copy A: value x at element x, copy B: value x + 1 at element x --
-//     so that the four consecutive values x - 1 .. x + 2 of ANY x start 4-byte aligned in one of the copies;
 //   * 16 waves of <= 128 registers: 8 consumers (unchanged sweep, rolling fragment reads) + 7 STEM waves + 1 LOADER wave;
-//   * the loader streams the 12 rows x 40 values of every input plane's two copies into an LDS ring of RC planes -- two 16-byte LDS-DMA
-//     instructions per plane, no register passes (`inready` counts landed planes);
-//   * stem wave w computes WHOLE ring planes q = w, w + 7, ...: a ring voxel OUTSIDE the volume is the reflection of the stem's OUTPUT, so
+//   * the loader streams the 12 rows x 40 floats of every fp32 input plane into a staging ring -- two 16-byte LDS-DMA instructions per
+//     plane (`landed` counts them);
+//   * stem wave w owns the staged planes k = w, w + 7, ...: it rounds them ONCE to the storage type and writes the two shifted 16-bit
+//     row copies of the stem kernel into the input ring of RC planes -- copy A: value x at element x, copy B: value x + 1 at element
+//     x, so that the four consecutive values x - 1 .. x + 2 of ANY x start 4-byte aligned in one of the copies -- reflecting the INPUT
+//     through the staged row / column it reads (`inconv[w]` = the next plane it will convert);
+//   * and it computes WHOLE ring planes q = w, w + 7, ...: a ring voxel OUTSIDE the volume is the reflection of the stem's OUTPUT, so
 //     its lane gathers the taps of the reflected voxel; it publishes ready[w] = the next plane it will publish.
+// (the forms this went through and what each showed: section 0.)
 struct StemIn {
   const char* src;              // fp32 network input [N][1][D][H][W] through byte strides (x contiguous)
   long long sn, sz, sy;
