@@ -97,14 +97,6 @@ bool conv_zmarch_stem_eligible(const ConvParams& p, int precision);
 const char* last_conv_zm_kernel_name();
 hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
                                    const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision, hipStream_t st);
-const char* last_conv_zm_kernel_name();
-hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const long long* x_offs,
-                                   void* prep, const void* stem_wpk, const float* stem_bias, int stem_act, float stem_slope, int precision,
-                                   hipStream_t st);
-size_t conv_zmarch_stem_prep_bytes(int N, int D, int H, int W);
-const char* last_conv_zm_kernel_name();
-hipError_t launch_conv_zmarch_stem(const ConvParams& p, const float* x, long long xs_n, long long xs_z, long long xs_y, const void* stem_wpk,
-                                   const float* stem_bias, int stem_act, float stem_slope, int precision, hipStream_t st);
 hipError_t launch_pool2_max_backward(const void* dp, const void* in, void* din, int N, int Do, int Ho, int Wo, int C,
                                      int accumulate, int precision, hipStream_t st);
 size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad);
