@@ -174,6 +174,8 @@ struct WgradParams {
   int N, D, H, W, Cout;
   float* partial;                       // [nchunk][npairs][27][16][16]
   int nchunk, items_per_chunk, nitems, nyt;
+  int nxt, ppc, cpx, nplanes;            // transpose-read kernel: x tiles, planes per chunk, (chunk, pair) entries per XCD, tiles * D
+  int dbg;                               // experiment builds: 1 = no MFMA sweep, 2 = no DMA
 };
 
 }  // namespace amx

@@ -6,230 +6,289 @@
 //   (r = reflect; In may be the concatenation of a full-resolution segment and a nearest-upsampled half-resolution
 //    segment, exactly as the forward kernels read it).
 //
-// A GEMM whose reduction index is the VOXEL: D[co][ci] += A[co][k] B[k][ci] per tap with k = 32 consecutive x of
-// one row, v_mfma_f32_16x16x32.  A lane of an MFMA operand holds 8 consecutive k of ONE channel, but the tensors are
-// channels-last; the tiles are therefore TRANSPOSED when they are staged into LDS ([row][channel][x], two voxels per
-// 32-bit write), after which
-//   * an A fragment (dY) is one ds_read_b128;
-//   * the three x taps of one (kz, ky) come from TWO ds_read_b128 of the halo row (x-1+0 .. +15 in halo coordinates):
-//     kx = 0 is the first block itself, kx = 2 is a register renaming, kx = 1 four v_alignbit;
-//   * a row stride of 136 halves (272 B = 256 + 16) puts the 16 channel rows of a fragment read on 16 different
-//     16-byte bank groups: conflict-free.
-// (First version: channels-last tiles and 16-bit gathers, 98 LDS reads + ~140 VALU per 27 MFMAs -- LDS/VALU bound.)
-// Reflect padding and the nearest upsample of the concat convs are resolved when the tile is staged.
-// Work decomposition: grid (co-tile x ci-tile pairs, spatial chunks).  A workgroup walks its chunk of (n, 4-row tile, z)
-// items (z fastest): the 3 input z-planes of an item live in a ring of 4 LDS slots (slot = plane & 3), so a step stages
-// ONE new plane (+ the next dY rows), and those global loads are issued into registers BEFORE the item's MFMA sweep and
-// written to LDS after it (software prefetch; one barrier per item).  Its 8 waves split the item's K-blocks, keep 27
-// accumulators each for the whole chunk, and are summed through LDS at the end.  Partials [chunk][pair][27][16][16]
-// fp32 are then added by wgrad_reduce_kernel with a fixed summation tree: deterministic, no atomics.
+// A GEMM whose reduction index is the VOXEL: D[co][ci] += A[co][k] B[k][ci] per tap with k = 32 voxels, v_mfma_f32_16x16x32.
+// A lane of an MFMA operand holds 8 consecutive k of ONE channel, but the tensors are channels-last: the transposition is done by
+// the LDS read itself (gfx950 `ds_read_b64_tr_b16`), see below.  Reflect padding and the nearest upsample of the concat convs are
+// resolved when a tile is staged (per-lane source addresses of the LDS-DMA).  Partials [chunk][pair][27][16][16] fp32 are added by
+// wgrad_reduce_kernel with a fixed summation tree: deterministic, no atomics.
+// (History: channels-last tiles and 16-bit gathers, 98 LDS reads + ~140 VALU per 27 MFMAs; then tiles transposed at staging with
+// 32-bit LDS writes, a z-ring and a two-deep register prefetch -- 6000 cycles per 512-voxel item whatever the layer, because the
+// register copy of the prefetch forced `vmcnt(0)` every item and the transposed writes cost as much LDS time as the sweep.  The form
+// below: 1028 -> 764 us over the 13 conv shapes of the 6 M UNet's step, every shape faster, tools/wgrad_layers.py.)
 #include <stdlib.h>
 
 #include "amx_device.h"
 
 namespace amx {
 
-// Tile geometry by row width: TY rows of the padded width Wp per item, LDS row stride RS halves (>= Wp + 8; 2 * RS is an odd
-// multiple of 16 bytes mod 256, so the 16 channel rows of a fragment read hit 16 different 16-byte bank groups).  The item
-// always holds TY * Wp / 32 = 16 K-blocks, two per wave: narrow (deep) layers used to run with 4 rows like the wide ones and
-// kept only 4 (W <= 32) of the 8 waves busy.
-constexpr int wg_ty(int Wp) { return Wp <= 32 ? 16 : Wp <= 64 ? 8 : 4; }
-constexpr int wg_rs(int Wp) { return Wp <= 32 ? 40 : Wp <= 64 ? 72 : 136; }
-
-struct WgUnit {                       // staging unit: two adjacent voxels x 8 channels
-  uint4 a, b;
+// ---------------------------------------------------------------------------------------------------------------------
+// Transpose-read form (gfx950 `ds_read_b64_tr_b16`).  The tiles stay CHANNELS-LAST in LDS -- 32 bytes per voxel and channel
+// tile, exactly as they lie in memory -- so they are staged by LDS-DMA (global_load_lds_dwordx4, no registers, no VALU, no
+// ds_write) by two loader waves, and the MFMA operands (8 consecutive voxels of one channel per lane) are formed by the
+// LDS itself: a 16-lane group that points its lanes at the four 8-byte channel quads of four consecutive voxels (128
+// contiguous bytes) receives channel (lane & 15) of those four voxels (checked in tools/ubench/tr_read_check.hip).  Per
+// K-block (32 voxels x 27 taps): 2 reads for dY, 4 reads per (kz, ky) for the input, 27 MFMAs.
+//   * bank conflicts: the two groups served together (lanes 0-31) must lie in different 128-byte halves of the 256-byte
+//     bank row; with 8 voxels (256 B) per group they would not, so the 128-byte blocks of a row are stored swizzled,
+//     position = block ^ ((block >> 1) & 1) -- free: the DMA lane that fills a position simply fetches the swizzled source;
+//   * work: a workgroup owns one (cout tile, cin tile) pair and a contiguous range of the planes of the (n, y tile, x tile,
+//     z) sequence; 8 MFMA waves split the K-blocks of an item (G planes), keep their 27 accumulators for the whole range
+//     and are summed through LDS at the end (same partial layout / reduce kernels as before);
+//   * pipeline: ring of 3G + 2 input planes and 3G dY planes; the loaders run up to two items ahead of the MFMA waves,
+//     paced by counted vmcnt waits and two LDS counters (`ready` per loader, `done` per MFMA wave) -- no barrier in the march;
+//   * workgroup ids are dealt to the 8 XCDs round-robin: an XCD gets a CONTIGUOUS range of the (chunk, pair) list, so
+//     neighbouring tiles' shared halo rows and a chunk's dY (read once per cin tile) meet in one L2, and no XCD is handed
+//     more than its 32 workgroups (one per compute unit).
+// Geometry by row width: (TY, TX, G) = (8, 64, 1) for W > 32, (16, 32, 1), (16, 16, 2), (8, 8, 4) for W <= 8.
+// Measured (tools/wgrad_ab.sh, 16 -> 16 @128^3 x 2, 72 us): DMA alone 50 us, MFMA sweep alone 65 us, neither (launch, flags, the
+// cross-wave sum, the reduce launch) 22 us; the sweep runs at 54 % MFMA-busy, paced by the per-wave issue rate (7 instructions per
+// MFMA), zero bank conflicts (SQ_LDS_BANK_CONFLICT).
+template <int TY_, int TX_, int G_>
+struct WtCfg {
+  static constexpr int TY = TY_, TX = TX_, G = G_;
+  static constexpr int RSPAN = TX >= 32 ? 1 : 32 / TX;               // rows a K-block spans
+  static constexpr int XBN = TX >= 32 ? TX / 32 : 1;                 // K-blocks side by side in x
+  static constexpr int NKB = TY * TX / 32;                           // K-blocks per plane
+  static constexpr int KPW = (G * NKB + 7) / 8;                      // K-blocks per MFMA wave and item
+  static constexpr int IRB = TX == 8 ? 5 : TX / 4 + 1;               // 128-byte blocks per halo row (odd for TX = 8: groups in different rows)
+  static constexpr int DRB = TX == 8 ? 3 : TX / 4;
+  static constexpr int NDI = ((TY + 2) * IRB * 128 + 1023) / 1024;   // DMA instructions (1 KiB each) per input plane
+  static constexpr int NDD = (TY * DRB * 128 + 1023) / 1024;
+  static constexpr int ISZ = NDI * 1024, DSZ = NDD * 1024;
+  static constexpr int RI = 3 * G + 2, RD = 3 * G;
+  static constexpr int C = G == 1 ? 2 : 1;                           // load groups ahead of the first item (input planes z-1, z)
+  static constexpr int LAG = G == 1 ? 4 : G == 2 ? 3 : 2;            // group j may be issued once item j - LAG is done
+  static constexpr int NL = 2;                                       // loader waves
+  static constexpr int NTI = (NDI + NL - 1) / NL, NTD = (NDD + NL - 1) / NL;
+  static constexpr int FLAGS = RI * ISZ + RD * DSZ;
+  static constexpr int LDS = FLAGS + 64;
+  static constexpr int RED = 4 * 27 * 64 * 16;
+  static_assert(LDS <= 160 * 1024 && RED <= FLAGS, "LDS budget");
+  static_assert(G * NKB % 8 == 0 || G * NKB < 8, "K-blocks of an item split evenly over the 8 MFMA waves");
 };
 
-template <typename T, bool RING, int WG_TY, int WG_RS>
-__global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, int Wp) {
-  typedef typename Ops<T>::vec8 vec8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NDB = RING ? 2 : 1;
-  constexpr int RS = WG_RS;
-  constexpr int DY_BYTES = WG_TY * 16 * RS * 2, PLANE_BYTES = (WG_TY + 2) * 16 * RS * 2;
-  constexpr int NPL = 2, NDY = 1;                                   // prefetch units per thread (Wp <= 128)
-  char* dys = smem;                                                 // [NDB][WG_TY][16 co][RS]
-  char* ins = smem + NDB * DY_BYTES;                                // [RING ? 4 : 3][WG_TY + 2][16 ci][RS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, kg = lane >> 4;
+typedef __attribute__((ext_vector_type(4))) short amx_s16x4;
+__device__ __forceinline__ amx_u32x2 lds_read_tr16(unsigned addr) {
+  typedef __attribute__((address_space(3))) amx_s16x4* lp_t;
+  return __builtin_bit_cast(amx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)addr));
+}
 
-  const int ncit = (p.C0 + p.C1) / 16;
-  const int pair = blockIdx.x, cot = pair / ncit, cit = pair % ncit;
-  const int chunk = blockIdx.y;
+#ifdef AMX_EXPERIMENT
+#define AMX_WT_DBG p.dbg
+#else
+#define AMX_WT_DBG 0
+#endif
+template <typename T, typename C>
+__global__ __launch_bounds__(640) void conv3d_wgrad_tr_kernel(const WgradParams p) {
+  typedef typename Ops<T>::vec8 vec8;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int TY = C::TY, TX = C::TX, G = C::G, IRB = C::IRB, DRB = C::DRB, RI = C::RI, RD = C::RD, ISZ = C::ISZ, DSZ = C::DSZ;
+  char* ins = smem;
+  char* dys = smem + RI * ISZ;
+  int* ready = (int*)(smem + C::FLAGS);                             // [NL]
+  int* done = ready + 8;                                            // [8], 32-byte aligned
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int ncit = (p.C0 + p.C1) / 16, npairs = (p.Cout / 16) * ncit;
+  const int wq = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);       // XCD x works on entries [x * cpx, (x + 1) * cpx) of the (chunk, pair) list
+  if (wq >= p.nchunk * npairs) return;
+  const int chunk = wq / npairs, pair = wq - chunk * npairs;
+  const int cot = pair / ncit, cit = pair % ncit;
   const bool seg1 = cit * 16 >= p.C0;
   const int ci0 = seg1 ? cit * 16 - p.C0 : cit * 16;
   const int sh = seg1 ? p.up_shift : 0;
 
-  // two 16-byte global loads per unit, eight 32-bit LDS writes (transposed: channel rows, x along the row).
-  // A thread's units (u = tid + 512 k) keep their tile coordinates for the whole chunk: the decomposition of u (divisions by the
-  // run-time row width) and everything else that does not depend on the item is done ONCE here -- inside the item loop those
-  // divisions were ~500 VALU instructions per thread and item, more than the item's MFMA time.
-  const int hwp = Wp / 2, hwh = (Wp + 2) / 2;
-  const int ndy = WG_TY * hwp * 2, npl = (WG_TY + 2) * hwh * 2;
-  struct UnitDy { int row, lds; long long ga, gb; bool ok, oka, okb; } udy[NDY];
-  struct UnitPl { int hr, lds; long long ga, gb; bool ok, oka, okb; } upl[NPL];
-#pragma unroll
-  for (int k = 0; k < NDY; ++k) {
-    const int u = tid + k * 512, half = u & 1, xp = (u >> 1) % hwp, row = (u >> 1) / hwp, x = 2 * xp;
-    udy[k].ok = u < ndy; udy[k].row = row;
-    udy[k].lds = ((row * 16 + half * 8) * RS + x) * 2;
-    udy[k].ga = (long long)x * p.yx + cot * 32 + half * 16; udy[k].gb = udy[k].ga + p.yx;
-    udy[k].oka = x < p.W; udy[k].okb = x + 1 < p.W;
-  }
-  const long long sxs = seg1 ? p.s1x : p.s0x;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) {
-    const int u = tid + k * 512, half = u & 1, xp = (u >> 1) % hwh, hr = (u >> 1) / hwh, xh = 2 * xp;
-    upl[k].ok = u < npl; upl[k].hr = hr;
-    upl[k].lds = ((hr * 16 + half * 8) * RS + xh) * 2;
-    upl[k].ga = (long long)(reflect_clamp(xh - 1, p.W) >> sh) * sxs + ci0 * 2 + half * 16;
-    upl[k].gb = (long long)(reflect_clamp(xh, p.W) >> sh) * sxs + ci0 * 2 + half * 16;
-    upl[k].oka = xh <= p.W + 1; upl[k].okb = xh + 1 <= p.W + 1;
-  }
-  auto load_dy = [&](int k, int n, int z, int y0) -> WgUnit {
-    WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    if (udy[k].ok && y0 + udy[k].row < p.H) {
-      const char* b = p.dy + (long long)n * p.yn + (long long)z * p.yz + (long long)(y0 + udy[k].row) * p.yy;
-      if (udy[k].oka) r.a = *(const uint4*)(b + udy[k].ga);
-      if (udy[k].okb) r.b = *(const uint4*)(b + udy[k].gb);
-    }
-    return r;
-  };
-  auto load_pl = [&](int k, int n, int zz, int y0) -> WgUnit {      // zz: full-resolution plane index (already reflected)
-    WgUnit r{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    if (upl[k].ok) {
-      const int z2 = zz >> sh, yy = reflect_clamp(y0 + upl[k].hr - 1, p.H) >> sh;
-      const char* b = seg1 ? p.src1 + (long long)n * p.s1n + (long long)z2 * p.s1z + (long long)yy * p.s1y
-                           : p.src0 + (long long)n * p.s0n + (long long)z2 * p.s0z + (long long)yy * p.s0y;
-      if (upl[k].oka) r.a = *(const uint4*)(b + upl[k].ga);
-      if (upl[k].okb) r.b = *(const uint4*)(b + upl[k].gb);
-    }
-    return r;
-  };
-  auto store_unit = [&](char* at, const WgUnit& v) {                // at: LDS address of (channel row e = 0, even x)
-    const unsigned a[4] = {v.a.x, v.a.y, v.a.z, v.a.w}, b[4] = {v.b.x, v.b.y, v.b.z, v.b.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const unsigned lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (b[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-      *(unsigned*)(at + e * RS * 2) = lo | (hi << 16);
-    }
-  };
-  auto store_dy = [&](int k, int buf, const WgUnit& v) {
-    if (udy[k].ok) store_unit(dys + (size_t)buf * DY_BYTES + udy[k].lds, v);
-  };
-  auto store_pl = [&](int k, int slot, const WgUnit& v) {
-    if (upl[k].ok) store_unit(ins + (size_t)slot * PLANE_BYTES + upl[k].lds, v);
-  };
+  if (tid < 16) ready[tid] = 0;
+  __syncthreads();
 
   f32x4 acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nxb = Wp / 32;
-  const int item0 = chunk * p.items_per_chunk;
-  const int item1 = item0 + p.items_per_chunk < p.nitems ? item0 + p.items_per_chunk : p.nitems;
-  int db = 0;                                                       // dY buffer of the current item
-  WgUnit ra_dy[NDY], ra_pl[NPL];                                    // requested one item ago, stored after this item's sweep
-  bool ra_valid = false;
-  for (int item = item0; item < item1; ++item) {
-    const int z = item % p.D;                                       // z fastest: consecutive items march along z
-    const int r = item / p.D;
-    const int yt = r % p.nyt, n = r / p.nyt;
-    const int y0 = yt * WG_TY;
-    int slot[3];
+  const int P0 = chunk * p.ppc, P1 = P0 + p.ppc < p.nplanes ? P0 + p.ppc : p.nplanes;
+  int Jbase = 0, Sbase = 0;
+
+  if (wave >= 8) {
+    // =========================================== loader wave l ===========================================
+    const int l = wave - 8;
+    const unsigned a_ready = lds_addr(ready + l), a_done = lds_addr(done);
+    // every loader wave issues exactly NTI + NTD instructions per plane (an instruction index past the plane repeats the wave's
+    // last one: same source, same destination), so the counted waits are compile-time constants and the issue code is branch-free
+    constexpr int PER = G * (C::NTI + C::NTD);
+    int kki[C::NTI], kkd[C::NTD];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) slot[kz] = RING ? (reflect_clamp(z + kz - 1, p.D) & 3) : kz;
-    const bool cold = !RING || item == item0 || z == 0;
-    if (cold) {
-      __syncthreads();                                              // previous item's fragments are consumed
+    for (int t = 0; t < C::NTI; ++t) kki[t] = l + C::NL * t < C::NDI ? l + C::NL * t : l + C::NL * (t - 1);
 #pragma unroll
-      for (int k = 0; k < NDY; ++k) store_dy(k, db, load_dy(k, n, z, y0));
+    for (int t = 0; t < C::NTD; ++t) kkd[t] = l + C::NL * t < C::NDD ? l + C::NL * t : l + C::NL * (t - 1);
+    for (int P = P0; P < P1;) {
+      const int tile = P / p.D, za = P - tile * p.D;
+      const int zb = za + (P1 - P) < p.D ? za + (P1 - P) : p.D;
+      const int xt = tile % p.nxt, yt = (tile / p.nxt) % p.nyt, n = tile / (p.nxt * p.nyt);
+      const int y0 = yt * TY, x0 = xt * TX;
+      const int nz = zb - za, ni = (nz + G - 1) / G, ngr = ni + C::C;
+      // per-lane source offsets of this tile (z-independent): unit u = 16 bytes at LDS offset 16 u of the plane image
+      int offi[C::NTI], offd[C::NTD];
+      const long long sy = seg1 ? p.s1y : p.s0y, sx = seg1 ? p.s1x : p.s0x;
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        if (RING && kz == 2 && slot[2] == slot[0]) continue;        // z = 0 or D-1: the reflected plane is already staged
-        const int zz = reflect_clamp(z + kz - 1, p.D);
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) store_pl(k, slot[kz], load_pl(k, n, zz, y0));
+      for (int t = 0; t < C::NTI; ++t) {
+        const int kk = l + C::NL * t < C::NDI ? l + C::NL * t : l + C::NL * (t - 1);
+        const int u = kk * 64 + lane, bp = u >> 3, jv = (u >> 1) & 3, hf = u & 1;
+        int rho = bp / IRB;
+        const int bs = bp - rho * IRB, b = bs ^ ((bs >> 1) & 1), h = 4 * b + jv;
+        rho = rho > TY + 1 ? TY + 1 : rho;
+        const int yy = reflect_clamp(y0 + rho - 1, p.H) >> sh, xx = reflect_clamp(x0 + h - 1, p.W) >> sh;
+        offi[t] = (int)(yy * sy + xx * sx) + ci0 * 2 + hf * 16;
       }
-      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < C::NTD; ++t) {
+        const int kk = l + C::NL * t < C::NDD ? l + C::NL * t : l + C::NL * (t - 1);
+        const int u = kk * 64 + lane, bp = u >> 3, jv = (u >> 1) & 3, hf = u & 1;
+        int r = bp / DRB;
+        const int bs = bp - r * DRB, b = bs ^ ((bs >> 1) & 1);
+        r = r > TY - 1 ? TY - 1 : r;
+        int yy = y0 + r, xx = x0 + 4 * b + jv;
+        yy = yy < p.H ? yy : p.H - 1;
+        xx = xx < p.W ? xx : p.W - 1;
+        offd[t] = (int)(yy * p.yy + xx * p.yx) + cot * 32 + hf * 16;
+      }
+      const char* src_n = seg1 ? p.src1 + (long long)n * p.s1n : p.src0 + (long long)n * p.s0n;
+      const long long sz = seg1 ? p.s1z : p.s0z;
+      const char* dy_n = p.dy + (long long)n * p.yn;
+      auto issue_group = [&](int j) {
+#pragma unroll
+        for (int gz = 0; gz < G; ++gz) {
+          const int q = j * G + gz;                                 // input plane sequence number: z = za - 1 + q
+          const char* plane = src_n + (long long)(reflect_clamp(za - 1 + q, p.D) >> sh) * sz;
+          char* dst = ins + (q % RI) * ISZ;
+#pragma unroll
+          for (int t = 0; t < C::NTI; ++t)
+            if (!(AMX_WT_DBG & 2))
+              __builtin_amdgcn_global_load_lds((gptr_t)(plane + offi[t]), (lptr_t)(dst + kki[t] * 1024), 16, 0, 0);
+          int d = (j - C::C) * G + gz;                              // dY plane of item j - C (before the first item: plane 0 again)
+          d = d < 0 ? 0 : d;
+          const int zz = za + d < p.D ? za + d : p.D - 1;
+          const char* dpl = dy_n + (long long)zz * p.yz;
+          char* ddst = dys + (d % RD) * DSZ;
+#pragma unroll
+          for (int t = 0; t < C::NTD; ++t)
+            if (!(AMX_WT_DBG & 2))
+              __builtin_amdgcn_global_load_lds((gptr_t)(dpl + offd[t]), (lptr_t)(ddst + kkd[t] * 1024), 16, 0, 0);
+        }
+      };
+      // the ring restarts with every run of planes: the previous run must be consumed
+      while (__builtin_amdgcn_readfirstlane(flag_min8_asm(a_done)) < Sbase) __builtin_amdgcn_s_sleep(2);
+      int next_issue = 0, next_pub = 0;
+      while (next_pub < ngr) {
+        if (next_issue < ngr) {
+          const int md = __builtin_amdgcn_readfirstlane(flag_min8_asm(a_done)) - Sbase;
+          int lim = md + C::LAG + 1;
+          lim = lim < ngr ? lim : ngr;
+          while (next_issue < lim) issue_group(next_issue++);
+        }
+        if (next_issue == next_pub) {
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        if (AMX_WT_DBG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (next_issue - next_pub - 1 > 63 / PER) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // (6-bit field: stricter than needed)
+        else WaitVm<PER, 63 / PER>::run(next_issue - next_pub - 1);     // the oldest unpublished group has landed
+        flag_store_asm(a_ready, Jbase + ++next_pub);
+      }
+      Jbase += ngr; Sbase += ni; P += nz;
     }
-    // ---- register prefetch, TWO items deep (RING; the next items are z + 1, z + 2 of the same tile): what item z + 1 needs
-    //      (its dY rows and plane z + 2) was requested during item z - 1 and is written to LDS after this item's sweep; what
-    //      item z + 2 needs is requested now.  One item deep, the ~2 us HBM latency of the request was longer than a sweep and
-    //      every item ended waiting for its loads (8800 cycles per item against 1700 of MFMAs).
-    const bool has_next = RING && item + 1 < item1 && z + 1 < p.D;
-    const bool has_next2 = has_next && item + 2 < item1 && z + 2 < p.D;
-    if (cold) ra_valid = false;
-    if (has_next && !ra_valid) {                                    // first item of a run: request item z + 1's data now (exposed once)
+  } else {
+    // ============================================ MFMA wave ============================================
+    const int li = lane & 15, g = lane >> 4;
+    const int gx = TX >= 32 ? g : (TX == 16 ? (g & 1) : 0), gr = TX >= 32 ? 0 : (TX == 16 ? (g >> 1) : g);
+    const int odd = gx & 1;                                         // parity of the group's 8-voxel block: decides the swizzled positions
+    const int ib = (li >> 2) * 32 + (li & 3) * 8;
+    // input reads of a row: P = halo x0 .. x0+3, Q = x0+4 .. x0+7 (kx = 0 as they are) and the same two voxels further, P2 = x0+2 ..
+    // x0+5, Q2 = x0+6 .. x0+9 (kx = 2 as they are; kx = 1 is four v_alignbit of P, Q and Q2's second register).  Operand tuples must
+    // be even-aligned, so forming kx = 2 from P, Q and one more read costs four v_mov per row -- and the VALU port, which the MFMAs
+    // share, is what paces this kernel (measured: 4.9 VALU per MFMA, 35 % MFMA-busy); a fourth read is free beside that.
+    // Blocks 2m, 2m+1, 2m+2 of the lane group sit at positions pos0, pos1, pos2 (swizzle); a lane's voxel of P2 / Q2 lies in the
+    // first (j < 2) or the second of the two blocks the shifted quad straddles.
+    const int jv_ = li >> 2, q4_ = li & 3;
+    const unsigned inb = lds_addr(ins) + (gr * IRB + 2 * gx) * 128;
+    const unsigned pos0 = odd ? 128 : 0, pos1 = odd ? 0 : 128, pos2 = odd ? 256 : 384;
+    const unsigned inP = inb + pos0 + ib, inQ = inb + pos1 + ib;
+    const unsigned sh2 = ((jv_ + 2) & 3) * 32 + q4_ * 8;
+    const unsigned inP2 = inb + (jv_ < 2 ? pos0 : pos1) + sh2, inQ2 = inb + (jv_ < 2 ? pos1 : pos2) + sh2;
+    const unsigned dyb = lds_addr(dys) + (gr * DRB + 2 * gx) * 128 + ib;
+    const unsigned dyP = dyb + (odd ? 128 : 0), dyQ = dyb + (odd ? 0 : 128);
+    const bool ragged = (p.H % TY) != 0 || (p.W % TX) != 0;
+    for (int P = P0; P < P1;) {
+      const int tile = P / p.D, za = P - tile * p.D;
+      const int zb = za + (P1 - P) < p.D ? za + (P1 - P) : p.D;
+      const int xt = tile % p.nxt, yt = (tile / p.nxt) % p.nyt;
+      const int y0 = yt * TY, x0 = xt * TX;
+      const int nz = zb - za, ni = (nz + G - 1) / G, ngr = ni + C::C;
+      for (int it = 0; it < ni; ++it) {
+        const int need = Jbase + it + C::C + 1;
+        while (flag_min2(ready) < need) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        // A fragments and ring offsets of the wave's K-blocks first, then their 9 rows each (a row = one (kz, ky): four reads, four
+        // v_alignbit, three MFMAs; the order of reads and MFMAs is the scheduler's -- pinning the reads two rows ahead measured slower).
+        vec8 af[C::KPW];
+        unsigned ibs[C::KPW][3];
+        bool any = false;
 #pragma unroll
-      for (int k = 0; k < NDY; ++k) ra_dy[k] = load_dy(k, n, z + 1, y0);
-      if (z + 2 < p.D)
+        for (int t = 0; t < C::KPW; ++t) {
+          const int kb = wave + 8 * t;
+          const int gz = kb / C::NKB, kbp = kb - gz * C::NKB;
+          const int r = (kbp / C::XBN) * C::RSPAN, xb = kbp % C::XBN;
+          int zl = it * G + gz;
+          const bool valid = kb < G * C::NKB && zl < nz;            // (wave-uniform)
+          any |= valid;
+          if (!valid) zl = it * G;                                  // an invalid K-block reads the item's first plane (data that has landed) against zeros
+          const unsigned ab = (zl % RD) * DSZ + (r * DRB + 8 * xb) * 128;
+          amx_u32x2 a0 = lds_read_tr16(dyP + ab), a1 = lds_read_tr16(dyQ + ab);
+          if (ragged) {                                             // voxels outside the volume contribute nothing
+            const bool rowok = y0 + r + gr < p.H;
+            const int xv = x0 + xb * 32 + gx * 8;
+            unsigned m[4];
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) ra_pl[k] = load_pl(k, n, z + 2, y0);
-    }
-    WgUnit rb_dy[NDY], rb_pl[NPL];
-    if (has_next2) {
-#pragma unroll
-      for (int k = 0; k < NDY; ++k) rb_dy[k] = load_dy(k, n, z + 2, y0);
-      if (z + 3 < p.D)
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) rb_pl[k] = load_pl(k, n, z + 3, y0);
-    }
-    // ---- K-blocks of this item: (row, xb) -> 32 voxels.  A wave owns the two K-blocks (rows r0, r0 + 1) of one x block: the four
-    //      halo rows r0 .. r0 + 3 they touch are read ONCE per kz and feed both rows (row r uses halo rows r + ky), i.e. 8 + 2 / 3
-    //      fragment reads per 18 MFMAs instead of 12 + 2 / 3 -- a third of the LDS traffic, which (with its bank conflicts) paced
-    //      this kernel.
-    const char* dyb = dys + (size_t)db * DY_BYTES;
-    const int vrows = p.H - y0 < WG_TY ? p.H - y0 : WG_TY;         // rows of this tile inside the volume (the rest hold zeros)
-    {
-      const int xb = wave % nxb, r0 = (wave / nxb) * 2;
-      if (r0 < vrows) {
-        const int X0 = xb * 32 + kg * 8;                           // multiple of 8 halves = 16 bytes
-        const vec8 af0 = *(const vec8*)(dyb + ((size_t)(r0 * 16 + m) * RS + X0) * 2);
-        const vec8 af1 = *(const vec8*)(dyb + ((size_t)((r0 + 1) * 16 + m) * RS + X0) * 2);   // zeros when r0 + 1 is outside
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-          for (int hr = 0; hr < 4; ++hr) {
-            const char* bp = ins + (size_t)slot[kz] * PLANE_BYTES + ((size_t)((r0 + hr) * 16 + m) * RS + X0) * 2;
-            const uint4 B0 = *(const uint4*)bp, B1 = *(const uint4*)(bp + 16);   // halo x = X0 .. X0 + 15  (= x - 1 ..)
-            const unsigned b0[4] = {B0.x, B0.y, B0.z, B0.w};                       // kx = 0
-            const unsigned b1[4] = {__builtin_amdgcn_alignbit(B0.y, B0.x, 16), __builtin_amdgcn_alignbit(B0.z, B0.y, 16),
-                                    __builtin_amdgcn_alignbit(B0.w, B0.z, 16), __builtin_amdgcn_alignbit(B1.x, B0.w, 16)};   // kx = 1
-            const unsigned b2[4] = {B0.y, B0.z, B0.w, B1.x};                       // kx = 2
-            if (hr < 3) {                                          // row r0, ky = hr
-              const int t0 = (kz * 3 + hr) * 3;
-              acc[t0] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b0), acc[t0]);
-              acc[t0 + 1] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
-              acc[t0 + 2] = Ops<T>::mfma(af0, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
-            }
-            if (hr > 0) {                                          // row r0 + 1, ky = hr - 1
-              const int t0 = (kz * 3 + hr - 1) * 3;
-              acc[t0] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b0), acc[t0]);
-              acc[t0 + 1] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
-              acc[t0 + 2] = Ops<T>::mfma(af1, __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
-            }
+            for (int e = 0; e < 4; ++e)
+              m[e] = rowok ? ((xv + 2 * e < p.W ? 0xffffu : 0u) | (xv + 2 * e + 1 < p.W ? 0xffff0000u : 0u)) : 0u;
+            a0[0] &= m[0]; a0[1] &= m[1]; a1[0] &= m[2]; a1[1] &= m[3];
           }
+          const unsigned vm = valid ? 0xffffffffu : 0u;
+          const unsigned av[4] = {a0[0] & vm, a0[1] & vm, a1[0] & vm, a1[1] & vm};
+          af[t] = __builtin_bit_cast(vec8, av);
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) ibs[t][kz] = ((zl + kz) % RI) * ISZ + (r * IRB + 8 * xb) * 128;
+        }
+        if (any && !(AMX_WT_DBG & 1)) {
+#pragma unroll
+          for (int t = 0; t < C::KPW; ++t)
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) {
+              const unsigned vP = inP + ibs[t][kz], vQ = inQ + ibs[t][kz], vP2 = inP2 + ibs[t][kz], vQ2 = inQ2 + ibs[t][kz];
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky) {
+                const amx_u32x2 P_ = lds_read_tr16(vP + ky * IRB * 128), Q_ = lds_read_tr16(vQ + ky * IRB * 128);
+                const amx_u32x2 P2 = lds_read_tr16(vP2 + ky * IRB * 128), Q2 = lds_read_tr16(vQ2 + ky * IRB * 128);
+                const unsigned b0[4] = {P_[0], P_[1], Q_[0], Q_[1]};                   // kx = 0
+                const unsigned b1[4] = {__builtin_amdgcn_alignbit(P_[1], P_[0], 16), __builtin_amdgcn_alignbit(Q_[0], P_[1], 16),
+                                        __builtin_amdgcn_alignbit(Q_[1], Q_[0], 16), __builtin_amdgcn_alignbit(Q2[1], Q_[1], 16)};
+                const unsigned b2[4] = {P2[0], P2[1], Q2[0], Q2[1]};                   // kx = 2
+                const int t0 = (kz * 3 + ky) * 3;
+                acc[t0] = Ops<T>::mfma(af[t], __builtin_bit_cast(vec8, b0), acc[t0]);
+                acc[t0 + 1] = Ops<T>::mfma(af[t], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+                acc[t0 + 2] = Ops<T>::mfma(af[t], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+              }
+            }
+        }
+        asm volatile("" ::: "memory");                              // LDS serves a wave's accesses in order: the flag lands behind the reads
+        if (lane == 0) flag_store(done + wave, Sbase + it + 1);
       }
+      Jbase += ngr; Sbase += ni; P += nz;
     }
-    if (has_next) {
-      // slot (z + 2) & 3 and the other dY buffer are not read by this item, and the item that read them last ended with
-      // the barrier below
-#pragma unroll
-      for (int k = 0; k < NDY; ++k) store_dy(k, db ^ 1, ra_dy[k]);
-      if (z + 2 < p.D)
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) store_pl(k, (z + 2) & 3, ra_pl[k]);
-      db ^= 1;
-      __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < NDY; ++k) ra_dy[k] = rb_dy[k];
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) ra_pl[k] = rb_pl[k];
-    ra_valid = has_next2;
   }
-  // ---- sum the 8 waves through LDS (3 rounds), wave 0 writes the partial
+  // ---- sum the 8 MFMA waves through LDS (3 rounds), wave 0 writes the partial
+  const int m = lane & 15, kg = lane >> 4;
   float* red = (float*)smem;                                        // [4 waves][27][64][4] floats = 108 KiB
   for (int half = 4; half >= 1; half >>= 1) {
     __syncthreads();
@@ -245,7 +304,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_kernel(const WgradParams p, 
       }
   }
   if (wave == 0) {
-    float* out = p.partial + ((size_t)chunk * gridDim.x + pair) * 27 * 256;
+    float* out = p.partial + ((size_t)chunk * npairs + pair) * 27 * 256;
 #pragma unroll
     for (int t = 0; t < 27; ++t)
 #pragma unroll
@@ -311,67 +370,69 @@ __global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __re
   }
 }
 
-static void wgrad_plan(int N, int D, int H, int W, int Cout, int CinPad, int* nitems, int* nchunk, int* ipc, int* nyt) {
-  const int ty = wg_ty((W + 31) / 32 * 32);
-  *nyt = (H + ty - 1) / ty;
-  *nitems = N * D * *nyt;
+// Transpose-read kernel: geometry class by row width and the split of the (tile, z) plane sequence over the workgroups.
+static int wt_class(int W) { return W <= 8 ? 3 : W <= 16 ? 2 : W <= 32 ? 1 : 0; }
+static void wt_geometry(int cls, int* ty, int* tx, int* g) {
+  static const int T[4][3] = {{8, 64, 1}, {16, 32, 1}, {16, 16, 2}, {8, 8, 4}};
+  *ty = T[cls][0]; *tx = T[cls][1]; *g = T[cls][2];
+}
+struct WtPlan { int cls, nyt, nxt, nplanes, ppc, nchunk, cpx; };
+static WtPlan wt_plan(int N, int D, int H, int W, int Cout, int CinPad) {
+  WtPlan q;
+  int ty, tx, g;
+  q.cls = wt_class(W);
+  wt_geometry(q.cls, &ty, &tx, &g);
+  q.nyt = (H + ty - 1) / ty;
+  q.nxt = (W + tx - 1) / tx;
+  q.nplanes = N * q.nyt * q.nxt * D;
   const int npairs = (Cout / 16) * (CinPad / 16);
-  // One workgroup per compute unit (139 KB of LDS each), so the grid should be ONE round of at most 256 workgroups with as many
-  // items each as that allows: 1024 workgroups (four rounds, each with its own ring fill, cross-wave reduction and 27 KB of
-  // partial sums) measured 135 us on 16 -> 16 @128^3 x 2 views against 99 us for 256, 99 -> 58 us on 32 -> 32 @64^3, 68 -> 38 us
-  // on 64 -> 64 @32^3; 257 .. 320 workgroups (a second, nearly empty round) are the worst case (tools/wgrad_time.py).
+  // one workgroup per compute unit (LDS), ONE round of at most 256 workgroups, every workgroup a contiguous run of planes
   static int target = -1;
   if (target < 0) target = exp_env("AMX_WGRAD_WGS") ? atoi(exp_env("AMX_WGRAD_WGS")) : 256;
-  int nc = target / npairs;                    // floor: never spill into a second round
-  if (nc > *nitems) nc = *nitems;
+  int nc = target / npairs;
   if (nc < 1) nc = 1;
-  *ipc = (*nitems + nc - 1) / nc;
-  *nchunk = (*nitems + *ipc - 1) / *ipc;
+  int ppc = (q.nplanes + nc - 1) / nc;
+  ppc = (ppc + g - 1) / g * g;                 // whole items
+  q.ppc = ppc;
+  q.nchunk = (q.nplanes + ppc - 1) / ppc;
+  q.cpx = (q.nchunk * npairs + 7) / 8;         // (chunk, pair) entries per XCD: at most 32, one workgroup per compute unit
+  return q;
 }
 
 size_t wgrad_scratch_bytes(int N, int D, int H, int W, int Cout, int CinPad) {
-  int nitems, nchunk, ipc, nyt;
-  wgrad_plan(N, D, H, W, Cout, CinPad, &nitems, &nchunk, &ipc, &nyt);
-  return (size_t)nchunk * (Cout / 16) * (CinPad / 16) * 27 * 256 * sizeof(float);
+  const WtPlan q = wt_plan(N, D, H, W, Cout, CinPad);
+  return (size_t)q.nchunk * (Cout / 16) * (CinPad / 16) * 27 * 256 * sizeof(float);
+}
+
+template <typename T, typename C>
+static hipError_t launch_wt(const WgradParams& p, int nwg, hipStream_t st) {
+  static DeviceOnce once;
+  if (!once.done()) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_tr_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    once.set();
+  }
+  hipLaunchKernelGGL((conv3d_wgrad_tr_kernel<T, C>), dim3(nwg), dim3(640), C::LDS, st, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, void* scratch, int precision, hipStream_t st) {
   const int CinPad = p.C0 + p.C1;
-  int nitems, nchunk, ipc, nyt;
-  wgrad_plan(p.N, p.D, p.H, p.W, p.Cout, CinPad, &nitems, &nchunk, &ipc, &nyt);
+  if (p.W > 128) return hipErrorInvalidValue;
+  const WtPlan q = wt_plan(p.N, p.D, p.H, p.W, p.Cout, CinPad);
   p.partial = (float*)scratch;
-  p.nchunk = nchunk; p.items_per_chunk = ipc; p.nitems = nitems; p.nyt = nyt;
-  const int Wp = (p.W + 31) / 32 * 32;
-  if (Wp > 128) return hipErrorInvalidValue;                       // WG_RS covers W <= 128
-  const int ty = wg_ty(Wp), rs = wg_rs(Wp);
-  const size_t dyb = (size_t)ty * 16 * rs * 2, plb = (size_t)(ty + 2) * 16 * rs * 2;
-  const size_t red = (size_t)4 * 27 * 64 * 4 * sizeof(float);
-  const bool ring = p.D >= 3;
-  size_t lds = ring ? 2 * dyb + 4 * plb : dyb + 3 * plb;
-  if (lds < red) lds = red;
+  p.nchunk = q.nchunk; p.nyt = q.nyt; p.nxt = q.nxt; p.ppc = q.ppc; p.cpx = q.cpx; p.nplanes = q.nplanes;
+  p.dbg = exp_env("AMX_WGRAD_DBG") ? atoi(exp_env("AMX_WGRAD_DBG")) : 0;
   const int npairs = (p.Cout / 16) * (CinPad / 16);
-#define AMX_WG2(T, R, TY, RS)                                                                                                \
-  {                                                                                                                          \
-    static bool done = false;                                                                                                \
-    if (!done) {                                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<T, R, TY, RS>,                                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
-      if (e != hipSuccess) return e;                                                                                         \
-      done = true;                                                                                                           \
-    }                                                                                                                        \
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<T, R, TY, RS>), dim3(npairs, nchunk), dim3(512), lds, st, p, Wp);                \
-  }
-#define AMX_WG(T, R)                                                                                                         \
-  {                                                                                                                          \
-    if (Wp <= 32) AMX_WG2(T, R, 16, 40) else if (Wp <= 64) AMX_WG2(T, R, 8, 72) else AMX_WG2(T, R, 4, 136)                   \
-  }
-  if (precision == 0) {
-    if (ring) AMX_WG(f16, true) else AMX_WG(f16, false)
-  } else {
-    if (ring) AMX_WG(bf16, true) else AMX_WG(bf16, false)
-  }
-#undef AMX_WG2
-#undef AMX_WG
+  const int nwg = 8 * q.cpx;
+  hipError_t e;
+#define AMX_WT(T)                                                                                                            \
+  (q.cls == 0 ? launch_wt<T, WtCfg<8, 64, 1>>(p, nwg, st) : q.cls == 1 ? launch_wt<T, WtCfg<16, 32, 1>>(p, nwg, st)          \
+   : q.cls == 2 ? launch_wt<T, WtCfg<16, 16, 2>>(p, nwg, st) : launch_wt<T, WtCfg<8, 8, 4>>(p, nwg, st))
+  e = precision == 0 ? AMX_WT(f16) : AMX_WT(bf16);
+#undef AMX_WT
+  if (e != hipSuccess) return e;
+  const int nchunk = q.nchunk;
   const long long E = (long long)npairs * 27 * 256;
   if (nchunk <= 16)
     hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,

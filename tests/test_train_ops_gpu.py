@@ -66,7 +66,7 @@ def test_bn_train_forward_and_backward(device, prec, shape):
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,size", [(16, 16, (8, 16, 32)), (32, 16, (6, 10, 12)), (64, 128, (4, 4, 4)), (1, 16, (8, 8, 40)),
                                             (16, 32, (2, 2, 2)), (128, 64, (8, 8, 8)),
-                                            # W a multiple of 64, H of 4, D >= 3: the transpose-read kernel (amx_wgrad_tr.hip)
+                                            # wide rows: two x tiles of the 8 x 64 geometry, ragged in y (amx_wgrad.hip)
                                             (16, 16, (5, 8, 64)), (32, 32, (3, 4, 128)), (16, 32, (9, 12, 64)), (1, 16, (4, 8, 128))])
 def test_conv_dgrad_and_wgrad(device, prec, cin, cout, size):
     dt = DT[prec]
