@@ -112,6 +112,19 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
                                      int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
                                      hipStream_t st);
 size_t mlp_backward_scratch_floats(int n, int cin, int width);
+hipError_t launch_mlp_heads_layer_forward(int nb, const float* const* x, int n, const int* k, const float* const* w, int m,
+                                          const float* const* gamma, const float* const* beta, float eps, int act, float slope,
+                                          float* const* z, float* const* y, float* const* mean, float* const* rstd,
+                                          float* const* rmean, float* const* rvar, float momentum, hipStream_t st);
+hipError_t launch_mlp_heads_layer_backward(int nb, const float* const* dy, const float* const* y, const float* const* z,
+                                           const float* const* mean, const float* const* rstd, const float* const* gamma, int act,
+                                           float slope, const float* const* x, const float* const* w, int n, const int* k, int m,
+                                           float* const* dz, float* const* dgamma, float* const* dbeta, float* const* dw,
+                                           float* const* dx, float* const* wpart, hipStream_t st);
+hipError_t launch_supcon_batch(int nb, const float* const* feat, const int* const* labels, int N, int C, float temperature, int rarity,
+                               int balance, int sqrt_mode, float* const* loss, float* const* grad, void* scratch, hipStream_t st);
+hipError_t launch_gather_labels_batch(const float* seg, int D, int H, int W, int nb, const long long* const* coords, int P, const int* dims,
+                                      int views, int* const* out, hipStream_t st);
 hipError_t launch_upcat_split(const void* dcat, void* dskip, void* dlow, int N, int Dl, int Hl, int Wl, int c0, int c1,
                               int acc_skip, int framed, int precision, hipStream_t st);
 hipError_t launch_import_input(const float* src, void* dst, int N, int Cin, long long vox, int precision, hipStream_t st);
@@ -1771,6 +1784,111 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
                                            l ? width : cin, width, dz, gamma[l] ? dgamma[l] : nullptr, gamma[l] ? dbeta[l] : nullptr,
                                            dw[l], l ? dprev : d_dx, dprev + plane, (hipStream_t)stream));
   }
+  return AMX_OK;
+}
+
+// ---- the heads / losses of ONE contrastive step as batches: n_heads chains of the same length run as one chain of launches
+int amx_mlp_heads_forward(int n_heads, const float* const* d_x, int n, const int* cin, int width, int n_layers, const float* const* w,
+                          const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                          float eps, float momentum, int act, float slope, float* const* d_z, float* const* d_y, float* const* d_mean,
+                          float* const* d_rstd, void* stream) {
+  if (!d_x || !cin || !w || !gamma || !beta || !running_mean || !running_var || !d_z || !d_y || !d_mean || !d_rstd)
+    return fail(AMX_ERR_INVALID, "null argument");
+  if (n_heads < 1 || n_heads > amx::MLP_MAXB) return fail(AMX_ERR_INVALID, "1 <= heads <= %d (got %d)", amx::MLP_MAXB, n_heads);
+  if (act != AMX_ACT_NONE && act != AMX_ACT_RELU && act != AMX_ACT_LRELU) return fail(AMX_ERR_INVALID, "unsupported activation");
+  const size_t plane = (size_t)n * width;
+  for (int h = 0; h < n_heads; ++h) {
+    if (int rc = mlp_check(n, cin[h], width, n_layers)) return rc;
+    if (!d_x[h] || !d_z[h] || !d_y[h] || !d_mean[h] || !d_rstd[h]) return fail(AMX_ERR_INVALID, "head %d: null buffer", h);
+    for (int l = 0; l < n_layers; ++l) {
+      const int i = h * n_layers + l;
+      if (!w[i] || (!gamma[i] != !beta[i]) || (!running_mean[i] != !running_var[i]))
+        return fail(AMX_ERR_INVALID, "head %d layer %d: bad parameter pointers", h, l);
+    }
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const float *x[amx::MLP_MAXB], *wl[amx::MLP_MAXB], *gl[amx::MLP_MAXB], *bl[amx::MLP_MAXB];
+    float *z[amx::MLP_MAXB], *y[amx::MLP_MAXB], *mu[amx::MLP_MAXB], *rs[amx::MLP_MAXB], *rm[amx::MLP_MAXB], *rv[amx::MLP_MAXB];
+    int k[amx::MLP_MAXB];
+    for (int h = 0; h < n_heads; ++h) {
+      const int i = h * n_layers + l;
+      x[h] = l ? d_y[h] + (l - 1) * plane : d_x[h];
+      k[h] = l ? width : cin[h];
+      wl[h] = w[i]; gl[h] = gamma[i]; bl[h] = beta[i]; rm[h] = running_mean[i]; rv[h] = running_var[i];
+      z[h] = d_z[h] + l * plane; y[h] = d_y[h] + l * plane; mu[h] = d_mean[h] + (size_t)l * width; rs[h] = d_rstd[h] + (size_t)l * width;
+    }
+    AMX_HIP(amx::launch_mlp_heads_layer_forward(n_heads, x, n, k, wl, width, gl, bl, eps, l + 1 < n_layers ? act : AMX_ACT_NONE, slope,
+                                                z, y, mu, rs, rm, rv, momentum, (hipStream_t)stream));
+  }
+  return AMX_OK;
+}
+
+int amx_mlp_heads_backward(int n_heads, const float* const* d_dy, const float* const* d_x, int n, const int* cin, int width, int n_layers,
+                           const float* const* w, const float* const* gamma, int act, float slope, const float* const* d_z,
+                           const float* const* d_y, const float* const* d_mean, const float* const* d_rstd, float* const* dw,
+                           float* const* dgamma, float* const* dbeta, float* const* d_dx, void* const* d_scratch, size_t scratch_bytes,
+                           void* stream) {
+  if (!d_dy || !d_x || !cin || !w || !gamma || !d_z || !d_y || !d_mean || !d_rstd || !dw || !dgamma || !dbeta || !d_dx || !d_scratch)
+    return fail(AMX_ERR_INVALID, "null argument");
+  if (n_heads < 1 || n_heads > amx::MLP_MAXB) return fail(AMX_ERR_INVALID, "1 <= heads <= %d (got %d)", amx::MLP_MAXB, n_heads);
+  const size_t plane = (size_t)n * width;
+  for (int h = 0; h < n_heads; ++h) {
+    if (int rc = mlp_check(n, cin[h], width, n_layers)) return rc;
+    if (scratch_bytes < amx_mlp_head_scratch_bytes(n, cin[h], width))
+      return fail(AMX_ERR_WORKSPACE, "head %d: scratch needs %zu bytes (got %zu)", h, amx_mlp_head_scratch_bytes(n, cin[h], width), scratch_bytes);
+    if (!d_dy[h] || !d_x[h] || !d_z[h] || !d_y[h] || !d_mean[h] || !d_rstd[h] || !d_scratch[h]) return fail(AMX_ERR_INVALID, "head %d: null buffer", h);
+    for (int l = 0; l < n_layers; ++l) {
+      const int i = h * n_layers + l;
+      if (!w[i] || !dw[i] || (gamma[i] && (!dgamma[i] || !dbeta[i]))) return fail(AMX_ERR_INVALID, "head %d layer %d: bad parameter pointers", h, l);
+    }
+  }
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const float *dy[amx::MLP_MAXB], *y[amx::MLP_MAXB], *z[amx::MLP_MAXB], *mu[amx::MLP_MAXB], *rs[amx::MLP_MAXB], *gl[amx::MLP_MAXB];
+    const float *x[amx::MLP_MAXB], *wl[amx::MLP_MAXB];
+    float *dz[amx::MLP_MAXB], *dg[amx::MLP_MAXB], *db[amx::MLP_MAXB], *dwl[amx::MLP_MAXB], *dx[amx::MLP_MAXB], *wpart[amx::MLP_MAXB];
+    int k[amx::MLP_MAXB];
+    for (int h = 0; h < n_heads; ++h) {
+      const int i = h * n_layers + l;
+      float* dzb = (float*)d_scratch[h];
+      float* dprev = dzb + plane;
+      dy[h] = l + 1 < n_layers ? dprev : d_dy[h];
+      y[h] = d_y[h] + l * plane; z[h] = d_z[h] + l * plane; mu[h] = d_mean[h] + (size_t)l * width; rs[h] = d_rstd[h] + (size_t)l * width;
+      gl[h] = gamma[i]; x[h] = l ? d_y[h] + (l - 1) * plane : d_x[h]; wl[h] = w[i]; k[h] = l ? width : cin[h];
+      dz[h] = dzb; dg[h] = gamma[i] ? dgamma[i] : nullptr; db[h] = gamma[i] ? dbeta[i] : nullptr; dwl[h] = dw[i];
+      dx[h] = l ? dprev : d_dx[h]; wpart[h] = dprev + plane;
+    }
+    AMX_HIP(amx::launch_mlp_heads_layer_backward(n_heads, dy, y, z, mu, rs, gl, l + 1 < n_layers ? act : AMX_ACT_NONE, slope, x, wl, n, k,
+                                                 width, dz, dg, db, dwl, dx, wpart, (hipStream_t)stream));
+  }
+  return AMX_OK;
+}
+
+int amx_supcon_loss_batch(int n_losses, const float* const* d_feat, const int* const* d_labels, int n, int c, float temperature,
+                          int weigh_rarity, int balance_denominator, int sqrt_mode, float* const* d_loss, float* const* d_grad,
+                          void* d_scratch, size_t scratch_bytes, void* stream) {
+  if (!d_feat || !d_labels || !d_loss || !d_scratch) return fail(AMX_ERR_INVALID, "null argument");
+  if (n_losses < 1 || n_losses > amx::MLP_MAXB) return fail(AMX_ERR_INVALID, "1 <= losses <= %d (got %d)", amx::MLP_MAXB, n_losses);
+  if (n < 2 || n > 16384 || c < 1 || !(temperature > 0.f)) return fail(AMX_ERR_INVALID, "bad sizes (n=%d c=%d T=%g)", n, c, temperature);
+  if (scratch_bytes < n_losses * amx::supcon_scratch_bytes(n, c))
+    return fail(AMX_ERR_WORKSPACE, "scratch needs %zu bytes (got %zu)", n_losses * amx::supcon_scratch_bytes(n, c), scratch_bytes);
+  for (int b = 0; b < n_losses; ++b) {
+    if (!d_feat[b] || !d_labels[b] || !d_loss[b]) return fail(AMX_ERR_INVALID, "loss %d: null buffer", b);
+    if (d_grad && (!d_grad[b] != !d_grad[0])) return fail(AMX_ERR_INVALID, "gradients for all losses or for none");
+  }
+  AMX_HIP(amx::launch_supcon_batch(n_losses, d_feat, d_labels, n, c, temperature, weigh_rarity, balance_denominator, sqrt_mode, d_loss,
+                                   d_grad, d_scratch, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+int amx_gather_labels_batch(const float* d_seg, int sd, int sh, int sw, int n_maps, const long long* const* d_coords, int p, const int* dims,
+                            int views, int* const* d_labels, void* stream) {
+  if (!d_seg || !d_coords || !dims || !d_labels || p < 1 || views < 1) return fail(AMX_ERR_INVALID, "gather_labels: bad arguments");
+  if (n_maps < 1 || n_maps > amx::MLP_MAXB) return fail(AMX_ERR_INVALID, "1 <= maps <= %d (got %d)", amx::MLP_MAXB, n_maps);
+  if (sd < 1 || sh < 1 || sw < 1) return fail(AMX_ERR_SHAPE, "gather_labels: non-positive shape");
+  for (int b = 0; b < n_maps; ++b)
+    if (!d_coords[b] || !d_labels[b] || dims[3 * b] < 1 || dims[3 * b + 1] < 1 || dims[3 * b + 2] < 1)
+      return fail(AMX_ERR_SHAPE, "gather_labels: map %d: bad arguments", b);
+  AMX_HIP(amx::launch_gather_labels_batch(d_seg, sd, sh, sw, n_maps, d_coords, p, dims, views, d_labels, (hipStream_t)stream));
   return AMX_OK;
 }
 

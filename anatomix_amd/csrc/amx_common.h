@@ -163,6 +163,8 @@ struct UpmergeParams {
 };
 
 // Weight-gradient launch (amx_wgrad.hip).
+constexpr int MLP_MAXB = 8;              // heads / losses per batched launch (amx_mlp.hip, amx_supcon.hip)
+
 struct WgradParams {
   const char* dy;                       // 16-bit [N][D][H][W][Cout] through byte strides (may be a framed view)
   long long yn, yz, yy, yx;
@@ -176,6 +178,8 @@ struct WgradParams {
   int nchunk, items_per_chunk, nitems, nyt;
   int nxt, ppc, cpx, nplanes;            // transpose-read kernel: x tiles, planes per chunk, (chunk, pair) entries per XCD, tiles * D
   int dbg;                               // experiment builds: 1 = no MFMA sweep, 2 = no DMA
+  float* dw;                             // nchunk == 1: the workgroup writes dW[Cout][cin_real][27] itself (no partials, no reduce launch)
+  int cin_real, accumulate;
 };
 
 }  // namespace amx

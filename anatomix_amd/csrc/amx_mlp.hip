@@ -16,6 +16,44 @@ namespace amx {
 
 constexpr int MLP_CB = 8;       // output columns per block of the column-owned kernels
 
+// Batches: the six heads of a contrastive step (and their six losses) are the same chains of small kernels on different tensors; a
+// replayed graph pays ~8 us per DEPENDENT node whatever its size, so one launch does a chain step for every head (blockIdx.y / z picks
+// the head), 6x fewer nodes on the step's critical path.  Same kernels, same arithmetic per head: bit-identical to head-by-head launches.
+struct GemmBatch {
+  int nb, splits;
+  float scale;
+  const float* A[MLP_MAXB];
+  const float* B[MLP_MAXB];
+  float* C[MLP_MAXB];
+  int M[MLP_MAXB], N[MLP_MAXB], R[MLP_MAXB], rps[MLP_MAXB];
+};
+struct BnFwdBatch {
+  const float* z[MLP_MAXB];
+  const float* gamma[MLP_MAXB];
+  const float* beta[MLP_MAXB];
+  float* y[MLP_MAXB];
+  float* mean[MLP_MAXB];
+  float* rstd[MLP_MAXB];
+  float* rmean[MLP_MAXB];
+  float* rvar[MLP_MAXB];
+};
+struct BnBwdBatch {
+  const float* dy[MLP_MAXB];
+  const float* y[MLP_MAXB];
+  const float* z[MLP_MAXB];
+  const float* mean[MLP_MAXB];
+  const float* rstd[MLP_MAXB];
+  const float* gamma[MLP_MAXB];
+  float* dz[MLP_MAXB];
+  float* dgamma[MLP_MAXB];
+  float* dbeta[MLP_MAXB];
+};
+struct ReduceBatch {
+  const float* part[MLP_MAXB];
+  float* out[MLP_MAXB];
+  int count[MLP_MAXB];
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -44,12 +82,18 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) {   // 
 // BatchNorm1d with batch statistics over the n rows of z [n][m] + activation; a block owns 8 columns for all rows, so the
 // two-pass statistics (mean, then centred sum of squares) come from registers.
 template <int RPT>
-__global__ __launch_bounds__(256) void mlp_bn_fwd_kernel(const float* __restrict__ z, int n, int m,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, int act, float slope, float* __restrict__ y,
-                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+__global__ __launch_bounds__(256) void mlp_bn_fwd_kernel(const BnFwdBatch bt, int n, int m, float eps, int act, float slope,
+                                                         float momentum) {
   __shared__ float red[4 * MLP_CB];
+  const int hb = blockIdx.y;
+  const float* __restrict__ z = bt.z[hb];
+  const float* __restrict__ gamma = bt.gamma[hb];
+  const float* __restrict__ beta = bt.beta[hb];
+  float* __restrict__ y = bt.y[hb];
+  float* __restrict__ mean_out = bt.mean[hb];
+  float* __restrict__ rstd_out = bt.rstd[hb];
+  float* __restrict__ rmean = bt.rmean[hb];
+  float* __restrict__ rvar = bt.rvar[hb];
   const int j0 = blockIdx.x * MLP_CB;
   float v[RPT][MLP_CB];
   float s[MLP_CB];
@@ -115,12 +159,18 @@ __global__ __launch_bounds__(256) void mlp_bn_fwd_kernel(const float* __restrict
 // adjoint of activation + BatchNorm1d(train):  g = dy * act'(y);  dbeta = sum g;  dgamma = sum g xh;
 // dz = rstd * gamma * (g - dbeta / n - xh * dgamma / n),  xh = (z - mean) * rstd
 template <int RPT>
-__global__ __launch_bounds__(256) void mlp_bwd_norm_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           const float* __restrict__ z, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           int act, float slope, int n, int m, float* __restrict__ dz,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void mlp_bwd_norm_kernel(const BnBwdBatch bt, int act, float slope, int n, int m) {
   __shared__ float red[4 * 2 * MLP_CB];
+  const int hb = blockIdx.y;
+  const float* __restrict__ dy = bt.dy[hb];
+  const float* __restrict__ y = bt.y[hb];
+  const float* __restrict__ z = bt.z[hb];
+  const float* __restrict__ mean = bt.mean[hb];
+  const float* __restrict__ rstd = bt.rstd[hb];
+  const float* __restrict__ gamma = bt.gamma[hb];
+  float* __restrict__ dz = bt.dz[hb];
+  float* __restrict__ dgamma = bt.dgamma[hb];
+  float* __restrict__ dbeta = bt.dbeta[hb];
   const int j0 = blockIdx.x * MLP_CB;
   float mu[MLP_CB], rs[MLP_CB];
 #pragma unroll
@@ -185,12 +235,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_norm_kernel(const float* __restri
 // registers while the current one is multiplied.  The contiguous storage dimension of every operand is a feature count
 // (multiple of 4), so all global accesses are aligned float4.  blockIdx.z splits R (partials summed by mlp_reduce_kernel).
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                       float* __restrict__ Cm, int M, int N, int R, int r_per_split,
-                                                       float scale = 1.f) {
+__global__ __launch_bounds__(256) void mlp_gemm_kernel(const GemmBatch g) {
   __shared__ float As[16][68], Bs[16][68];
+  const int hb = blockIdx.z / g.splits, sp = blockIdx.z - hb * g.splits;
+  const float* __restrict__ A = g.A[hb];
+  const float* __restrict__ B = g.B[hb];
+  float* __restrict__ Cm = g.C[hb];
+  const int M = g.M[hb], N = g.N[hb], R = g.R[hb], r_per_split = g.rps[hb];
+  const float scale = g.scale;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int rbeg = blockIdx.z * r_per_split, rend = min(R, rbeg + r_per_split);
+  if (m0 >= M || n0 >= N) return;                              // (the grid covers the largest problem of the batch)
+  const int rbeg = sp * r_per_split, rend = min(R, rbeg + r_per_split);
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   auto fetch = [&](const float* P, bool T, int o0, int O, int r0) -> float4 {
     // T == false: storage [R][O]: thread -> (r = t / 16, o = (t % 16) * 4);  T == true: storage [O][R]: (o = t / 4, r = (t % 4) * 4)
@@ -243,7 +298,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
     }
   }
-  float* Cz = Cm + (size_t)blockIdx.z * M * N;
+  float* Cz = Cm + (size_t)sp * M * N;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mm = m0 + ty * 4 + i, nn = n0 + tx * 4;
@@ -256,16 +311,21 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const float* __restrict__
 // leaves most of the 256 CUs idle (1024 x 256 x 256: 64 workgroups, each serialising 16 chunks of 256 FMAs per thread).
 // Threads 0..127 stage the A chunk, 128..255 the B chunk (one float4 each).
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                         float* __restrict__ Cm, int M, int N, int R, int r_per_split,
-                                                         float scale) {
+__global__ __launch_bounds__(256) void mlp_gemm32_kernel(const GemmBatch g) {
   // KC = 64 reduction rows per stage (four 16-row sub-chunks): a stage is one global fetch -> LDS -> two barriers round trip, and
   // with 16-row stages a 1024 x 256 x 256 product was 16 such round trips of ~1 us around 64 FMAs per thread (18 us per launch,
   // 72 launches per contrastive step: profiles/r05 step kernel stats).  Same products added in the same order: bit-identical.
   constexpr int KC = 64;
   __shared__ float As[KC][36], Bs[KC][36];
+  const int hb = blockIdx.z / g.splits, sp = blockIdx.z - hb * g.splits;
+  const float* __restrict__ A = g.A[hb];
+  const float* __restrict__ B = g.B[hb];
+  float* __restrict__ Cm = g.C[hb];
+  const int M = g.M[hb], N = g.N[hb], R = g.R[hb], r_per_split = g.rps[hb];
+  const float scale = g.scale;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int rbeg = blockIdx.z * r_per_split, rend = min(R, rbeg + r_per_split);
+  if (m0 >= M || n0 >= N) return;
+  const int rbeg = sp * r_per_split, rend = min(R, rbeg + r_per_split);
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const bool isb = threadIdx.x >= 128;
   const int t = threadIdx.x & 127;
@@ -321,7 +381,7 @@ __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict
       acc[1][1] += a.y * b.y;
     }
   }
-  float* Cz = Cm + (size_t)blockIdx.z * M * N;
+  float* Cz = Cm + (size_t)sp * M * N;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int mm = m0 + ty * 2 + i, nn = n0 + tx * 2;
@@ -330,8 +390,10 @@ __global__ __launch_bounds__(256) void mlp_gemm32_kernel(const float* __restrict
 }
 
 // out[i] = part[0][i] + part[1][i] + ... in that order
-__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int count,
-                                                         int splits) {
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceBatch rb, int splits) {
+  const float* __restrict__ part = rb.part[blockIdx.y];
+  float* __restrict__ out = rb.out[blockIdx.y];
+  const int count = rb.count[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
   float s = part[i];
@@ -342,25 +404,48 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict
 constexpr int MLP_WSPLIT = 8;   // row splits of the weight-gradient GEMM (its reduction runs over the n rows)
 
 template <bool TA, bool TB>
+static void gemm_dispatch_batch(const GemmBatch& g, hipStream_t st) {
+  int maxM = 0, maxN = 0;
+  long long wg64 = 0;
+  for (int b = 0; b < g.nb; ++b) {
+    maxM = g.M[b] > maxM ? g.M[b] : maxM;
+    maxN = g.N[b] > maxN ? g.N[b] : maxN;
+    wg64 += (long long)((g.N[b] + 63) / 64) * ((g.M[b] + 63) / 64) * g.splits;
+  }
+  // (both kernels add the same products in the same order: the choice moves time, not values)
+  if (wg64 < 200)
+    mlp_gemm32_kernel<TA, TB><<<dim3((maxN + 31) / 32, (maxM + 31) / 32, g.nb * g.splits), 256, 0, st>>>(g);
+  else
+    mlp_gemm_kernel<TA, TB><<<dim3((maxN + 63) / 64, (maxM + 63) / 64, g.nb * g.splits), 256, 0, st>>>(g);
+}
+
+template <bool TA, bool TB>
 static void gemm_dispatch(const float* A, const float* B, float* Cm, int M, int N, int R, int splits, int rps, float scale,
                           hipStream_t st) {
-  const long long wg64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * splits;
-  if (wg64 < 200)
-    mlp_gemm32_kernel<TA, TB><<<dim3((N + 31) / 32, (M + 31) / 32, splits), 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
-  else
-    mlp_gemm_kernel<TA, TB><<<dim3((N + 63) / 64, (M + 63) / 64, splits), 256, 0, st>>>(A, B, Cm, M, N, R, rps, scale);
+  GemmBatch g;
+  g.nb = 1; g.splits = splits; g.scale = scale;
+  g.A[0] = A; g.B[0] = B; g.C[0] = Cm; g.M[0] = M; g.N[0] = N; g.R[0] = R; g.rps[0] = rps;
+  gemm_dispatch_batch<TA, TB>(g, st);
 }
 
 static inline int rows_per_thread(int n) { return n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8; }
 
-hipError_t launch_mlp_layer_forward(const float* x, int n, int k, const float* w, int m, const float* gamma, const float* beta,
-                                    float eps, int act, float slope, float* z, float* y, float* mean, float* rstd, float* rmean,
-                                    float* rvar, float momentum, hipStream_t st) {
-  // z [n][m] = x [n][k] w^T [k][m]
-  gemm_dispatch<true, true>(x, w, z, n, m, k, 1, k, 1.f, st);
-  const dim3 grid(m / MLP_CB);
-#define AMX_MLP_FWD(RPT) \
-  mlp_bn_fwd_kernel<RPT><<<grid, 256, 0, st>>>(z, n, m, gamma, beta, eps, act, slope, y, mean, rstd, rmean, rvar, momentum)
+// One layer of nb heads (same rows n and width m, own input widths k[b]): z = x w^T, then BatchNorm1d(train) + activation.
+hipError_t launch_mlp_heads_layer_forward(int nb, const float* const* x, int n, const int* k, const float* const* w, int m,
+                                          const float* const* gamma, const float* const* beta, float eps, int act, float slope,
+                                          float* const* z, float* const* y, float* const* mean, float* const* rstd,
+                                          float* const* rmean, float* const* rvar, float momentum, hipStream_t st) {
+  GemmBatch g;
+  g.nb = nb; g.splits = 1; g.scale = 1.f;
+  BnFwdBatch bt;
+  for (int b = 0; b < nb; ++b) {
+    g.A[b] = x[b]; g.B[b] = w[b]; g.C[b] = z[b]; g.M[b] = n; g.N[b] = m; g.R[b] = k[b]; g.rps[b] = k[b];
+    bt.z[b] = z[b]; bt.gamma[b] = gamma[b]; bt.beta[b] = beta[b]; bt.y[b] = y[b]; bt.mean[b] = mean[b]; bt.rstd[b] = rstd[b];
+    bt.rmean[b] = rmean[b]; bt.rvar[b] = rvar[b];
+  }
+  gemm_dispatch_batch<true, true>(g, st);                      // z [n][m] = x [n][k] w^T [k][m]
+  const dim3 grid(m / MLP_CB, nb);
+#define AMX_MLP_FWD(RPT) mlp_bn_fwd_kernel<RPT><<<grid, 256, 0, st>>>(bt, n, m, eps, act, slope, momentum)
   switch (rows_per_thread(n)) {
     case 1: AMX_MLP_FWD(1); break;
     case 2: AMX_MLP_FWD(2); break;
@@ -371,17 +456,30 @@ hipError_t launch_mlp_layer_forward(const float* x, int n, int k, const float* w
   return hipGetLastError();
 }
 
+hipError_t launch_mlp_layer_forward(const float* x, int n, int k, const float* w, int m, const float* gamma, const float* beta,
+                                    float eps, int act, float slope, float* z, float* y, float* mean, float* rstd, float* rmean,
+                                    float* rvar, float momentum, hipStream_t st) {
+  return launch_mlp_heads_layer_forward(1, &x, n, &k, &w, m, &gamma, &beta, eps, act, slope, &z, &y, &mean, &rstd, &rmean, &rvar,
+                                        momentum, st);
+}
+
 size_t mlp_backward_scratch_floats(int n, int cin, int width) {
   return 2 * (size_t)n * width + (size_t)MLP_WSPLIT * width * (cin > width ? cin : width);
 }
 
-hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                                     const float* gamma, int act, float slope, const float* x, const float* w, int n, int k,
-                                     int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
-                                     hipStream_t st) {
-  const dim3 grid(m / MLP_CB);
-#define AMX_MLP_BWD(RPT) \
-  mlp_bwd_norm_kernel<RPT><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, gamma, act, slope, n, m, dz, dgamma, dbeta)
+// Adjoint of one layer of nb heads: dz (activation + BatchNorm adjoint), dW = dZ^T X (row-split + ordered sum), dX = dZ W (where asked).
+hipError_t launch_mlp_heads_layer_backward(int nb, const float* const* dy, const float* const* y, const float* const* z,
+                                           const float* const* mean, const float* const* rstd, const float* const* gamma, int act,
+                                           float slope, const float* const* x, const float* const* w, int n, const int* k, int m,
+                                           float* const* dz, float* const* dgamma, float* const* dbeta, float* const* dw,
+                                           float* const* dx, float* const* wpart, hipStream_t st) {
+  BnBwdBatch bt;
+  for (int b = 0; b < nb; ++b) {
+    bt.dy[b] = dy[b]; bt.y[b] = y[b]; bt.z[b] = z[b]; bt.mean[b] = mean[b]; bt.rstd[b] = rstd[b]; bt.gamma[b] = gamma[b];
+    bt.dz[b] = dz[b]; bt.dgamma[b] = dgamma[b]; bt.dbeta[b] = dbeta[b];
+  }
+  const dim3 grid(m / MLP_CB, nb);
+#define AMX_MLP_BWD(RPT) mlp_bwd_norm_kernel<RPT><<<grid, 256, 0, st>>>(bt, act, slope, n, m)
   switch (rows_per_thread(n)) {
     case 1: AMX_MLP_BWD(1); break;
     case 2: AMX_MLP_BWD(2); break;
@@ -392,23 +490,58 @@ hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const floa
   // dW [m][k] = dZ^T [m][n] X [n][k]: the reduction runs over the rows, split MLP_WSPLIT ways, partials summed in order
   const int splits = n >= 16 * MLP_WSPLIT ? MLP_WSPLIT : 1;
   const int rps = ((n + splits - 1) / splits + 15) / 16 * 16;
-  gemm_dispatch<false, false>(dz, x, splits > 1 ? wpart : dw, m, k, n, splits, rps, 1.f, st);
-  if (splits > 1) mlp_reduce_kernel<<<(m * k + 255) / 256, 256, 0, st>>>(wpart, dw, m * k, splits);
-  // dX [n][k] = dZ [n][m] W [m][k]
-  if (dx) gemm_dispatch<true, false>(dz, w, dx, n, k, m, 1, m, 1.f, st);
+  GemmBatch g;
+  g.nb = nb; g.splits = splits; g.scale = 1.f;
+  ReduceBatch rb;
+  int maxcount = 0;
+  for (int b = 0; b < nb; ++b) {
+    g.A[b] = dz[b]; g.B[b] = x[b]; g.C[b] = splits > 1 ? wpart[b] : dw[b]; g.M[b] = m; g.N[b] = k[b]; g.R[b] = n; g.rps[b] = rps;
+    rb.part[b] = wpart[b]; rb.out[b] = dw[b]; rb.count[b] = m * k[b];
+    maxcount = m * k[b] > maxcount ? m * k[b] : maxcount;
+  }
+  gemm_dispatch_batch<false, false>(g, st);
+  if (splits > 1) mlp_reduce_kernel<<<dim3((maxcount + 255) / 256, nb), 256, 0, st>>>(rb, splits);
+  // dX [n][k] = dZ [n][m] W [m][k]  (the heads that want it)
+  GemmBatch gx;
+  gx.nb = 0; gx.splits = 1; gx.scale = 1.f;
+  for (int b = 0; b < nb; ++b)
+    if (dx[b]) {
+      const int j = gx.nb++;
+      gx.A[j] = dz[b]; gx.B[j] = w[b]; gx.C[j] = dx[b]; gx.M[j] = n; gx.N[j] = k[b]; gx.R[j] = m; gx.rps[j] = m;
+    }
+  if (gx.nb) gemm_dispatch_batch<true, false>(gx, st);
   return hipGetLastError();
 }
 
+hipError_t launch_mlp_layer_backward(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                                     const float* gamma, int act, float slope, const float* x, const float* w, int n, int k,
+                                     int m, float* dz, float* dgamma, float* dbeta, float* dw, float* dx, float* wpart,
+                                     hipStream_t st) {
+  return launch_mlp_heads_layer_backward(1, &dy, &y, &z, &mean, &rstd, &gamma, act, slope, &x, &w, n, &k, m, &dz, &dgamma, &dbeta,
+                                         &dw, &dx, &wpart, st);
+}
+
 // C (+ z * M * N for split z) = scale * op(A) op(B) over R split `splits` ways -- the same register-tiled kernel, for the two
-// GEMMs of the contrastive loss (amx_supcon.hip).  Every contiguous storage dimension must be a multiple of 4.
+// GEMMs of the contrastive loss (amx_supcon.hip), nb problems of one shape per launch.  Every contiguous storage dimension must be a
+// multiple of 4.
+hipError_t launch_small_gemm_batch(int nb, bool ta, bool tb, const float* const* A, const float* const* B, float* const* Cm, int M,
+                                   int N, int R, int splits, float scale, hipStream_t st) {
+  const int rps = ((R + splits - 1) / splits + 15) / 16 * 16;
+  GemmBatch g;
+  g.nb = nb; g.splits = splits; g.scale = scale;
+  for (int b = 0; b < nb; ++b) {
+    g.A[b] = A[b]; g.B[b] = B[b]; g.C[b] = Cm[b]; g.M[b] = M; g.N[b] = N; g.R[b] = R; g.rps[b] = rps;
+  }
+  if (ta && tb) gemm_dispatch_batch<true, true>(g, st);
+  else if (ta) gemm_dispatch_batch<true, false>(g, st);
+  else if (tb) gemm_dispatch_batch<false, true>(g, st);
+  else gemm_dispatch_batch<false, false>(g, st);
+  return hipGetLastError();
+}
+
 hipError_t launch_small_gemm(bool ta, bool tb, const float* A, const float* B, float* Cm, int M, int N, int R, int splits,
                              float scale, hipStream_t st) {
-  const int rps = ((R + splits - 1) / splits + 15) / 16 * 16;
-  if (ta && tb) gemm_dispatch<true, true>(A, B, Cm, M, N, R, splits, rps, scale, st);
-  else if (ta) gemm_dispatch<true, false>(A, B, Cm, M, N, R, splits, rps, scale, st);
-  else if (tb) gemm_dispatch<false, true>(A, B, Cm, M, N, R, splits, rps, scale, st);
-  else gemm_dispatch<false, false>(A, B, Cm, M, N, R, splits, rps, scale, st);
-  return hipGetLastError();
+  return launch_small_gemm_batch(1, ta, tb, &A, &B, &Cm, M, N, R, splits, scale, st);
 }
 
 }  // namespace amx

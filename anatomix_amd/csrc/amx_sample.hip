@@ -159,6 +159,38 @@ hipError_t launch_gather_labels(const float* seg, int D, int H, int W, const lon
   return hipGetLastError();
 }
 
+// the same for nb feature maps of one segmentation in one launch (blockIdx.y = map): dims[3 b ..] = (d, h, w) of map b
+struct GatherLabelsBatch {
+  const long long* coords[MLP_MAXB];
+  int* out[MLP_MAXB];
+  int d[MLP_MAXB], h[MLP_MAXB], w[MLP_MAXB];
+};
+__global__ void gather_labels_batch_kernel(const float* __restrict__ seg, int D, int H, int W, const GatherLabelsBatch bt, int P, int views) {
+  const int b = blockIdx.y;
+  const long long* __restrict__ coords = bt.coords[b];
+  int* __restrict__ out = bt.out[b];
+  const int d = bt.d[b], h = bt.h[b], w = bt.w[b];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float sz = (float)D / (float)d, sy = (float)H / (float)h, sx = (float)W / (float)w;
+  int z = (int)floorf((float)coords[3 * i] * sz), y = (int)floorf((float)coords[3 * i + 1] * sy), x = (int)floorf((float)coords[3 * i + 2] * sx);
+  z = z < D - 1 ? z : D - 1;
+  y = y < H - 1 ? y : H - 1;
+  x = x < W - 1 ? x : W - 1;
+  const int lab = (int)rintf(seg[((long long)z * H + y) * W + x]);
+  for (int v = 0; v < views; ++v) out[v * P + i] = lab;
+}
+
+hipError_t launch_gather_labels_batch(const float* seg, int D, int H, int W, int nb, const long long* const* coords, int P, const int* dims,
+                                      int views, int* const* out, hipStream_t st) {
+  GatherLabelsBatch bt;
+  for (int b = 0; b < nb; ++b) {
+    bt.coords[b] = coords[b]; bt.out[b] = out[b]; bt.d[b] = dims[3 * b]; bt.h[b] = dims[3 * b + 1]; bt.w[b] = dims[3 * b + 2];
+  }
+  gather_labels_batch_kernel<<<dim3((P + 255) / 256, nb), 256, 0, st>>>(seg, D, H, W, bt, P, views);
+  return hipGetLastError();
+}
+
 // ---- sampled feature taps (the contrastive step reads 512 voxels of each tapped feature map: supcl_model.py:801-843 calls
 // netF(feat_k, num_patches, ids), pretraining_networks.py:472-480 gathers feat[:, :, x, y, z]).  Going through a dense fp32 NCDHW
 // copy of every tapped tensor costs an export pass forward and, backward, a dense zero tensor + index_put + an import pass per

@@ -131,10 +131,36 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
+// ---- batches of losses of one shape (the six layers of a contrastive step: N = views * patches rows, C = the head width): every
+// kernel below serves problem blockIdx.y; the scratch of problem b is the b-th slice of one buffer, laid out as launch_supcon lays it out.
+struct ScBatch {
+  const float* feat[MLP_MAXB];
+  const int* lab[MLP_MAXB];
+  float* loss[MLP_MAXB];
+  float* grad[MLP_MAXB];
+  char* scratch;
+  size_t stride;                                            // bytes per problem
+};
+struct ScPtrs { float *xn, *dxn, *S, *inv, *cnt, *rowloss, *wsum; };
+__host__ __device__ __forceinline__ ScPtrs sc_ptrs(char* base, int N, int C) {
+  ScPtrs p;
+  p.xn = (float*)base;
+  p.dxn = p.xn + (size_t)N * C;
+  p.S = p.dxn + (size_t)SC_KSPLIT * N * C;
+  p.inv = p.S + (size_t)N * N;
+  p.cnt = p.inv + N;
+  p.rowloss = p.cnt + N;
+  p.wsum = p.rowloss + N;
+  return p;
+}
+
 // one block per row: xn = x / max(|x|, eps); inv[i] = 1 / max(|x|, eps)
-__global__ __launch_bounds__(256) void sc_normalize_kernel(const float* __restrict__ x, float* __restrict__ xn,
-                                                          float* __restrict__ inv, int C) {
+__global__ __launch_bounds__(256) void sc_normalize_kernel(const ScBatch bt, int N, int C) {
   __shared__ float red[4];
+  const ScPtrs q = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C);
+  const float* __restrict__ x = bt.feat[blockIdx.y];
+  float* __restrict__ xn = q.xn;
+  float* __restrict__ inv = q.inv;
   const int i = blockIdx.x;
   float s = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -149,8 +175,10 @@ __global__ __launch_bounds__(256) void sc_normalize_kernel(const float* __restri
 }
 
 // one block per anchor: cnt[i] = #{j : label_j == label_i} (incl. i)
-__global__ __launch_bounds__(256) void sc_count_kernel(const int* __restrict__ lab, float* __restrict__ cnt, int N) {
+__global__ __launch_bounds__(256) void sc_count_kernel(const ScBatch bt, int N, int C) {
   __shared__ float red[4];
+  const int* __restrict__ lab = bt.lab[blockIdx.y];
+  float* __restrict__ cnt = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C).cnt;
   const int i = blockIdx.x, li = lab[i];
   float s = 0.f;
   for (int j = threadIdx.x; j < N; j += 256) s += lab[j] == li ? 1.f : 0.f;
@@ -159,9 +187,11 @@ __global__ __launch_bounds__(256) void sc_count_kernel(const int* __restrict__ l
 }
 
 // single block: wsum = sum_i r_i (rarity weights), fixed order
-__global__ __launch_bounds__(256) void sc_wsum_kernel(const float* __restrict__ cnt, float* __restrict__ wsum, int N, int rarity,
-                                                     int sqrt_mode) {
+__global__ __launch_bounds__(256) void sc_wsum_kernel(const ScBatch bt, int N, int C, int rarity, int sqrt_mode) {
   __shared__ float red[4];
+  const ScPtrs q = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C);
+  const float* __restrict__ cnt = q.cnt;
+  float* __restrict__ wsum = q.wsum;
   float s = 0.f;
   for (int i = threadIdx.x; i < N; i += 256) s += rarity ? 1.f / (sqrt_mode ? sqrtf(cnt[i]) : cnt[i]) : 1.f;
   s = block_sum(s, red);
@@ -169,10 +199,14 @@ __global__ __launch_bounds__(256) void sc_wsum_kernel(const float* __restrict__ 
 }
 
 // one block per anchor i: row statistics, loss_i, and G_i. = dL/dS_i. written over S_i.
-__global__ __launch_bounds__(256) void sc_rows_kernel(float* __restrict__ S, const int* __restrict__ lab,
-                                                     const float* __restrict__ cnt, const float* __restrict__ wsum,
-                                                     float* __restrict__ rowloss, int N, int rarity, int balance, int sqrt_mode) {
+__global__ __launch_bounds__(256) void sc_rows_kernel(const ScBatch bt, int N, int C, int rarity, int balance, int sqrt_mode) {
   __shared__ float red[4];
+  const ScPtrs q = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C);
+  float* __restrict__ S = q.S;
+  const int* __restrict__ lab = bt.lab[blockIdx.y];
+  const float* __restrict__ cnt = q.cnt;
+  const float* __restrict__ wsum = q.wsum;
+  float* __restrict__ rowloss = q.rowloss;
   const int i = blockIdx.x, li = lab[i];
   float* row = S + (long long)i * N;
   float m = -3.0e38f;
@@ -215,8 +249,10 @@ __global__ __launch_bounds__(256) void sc_rows_kernel(float* __restrict__ S, con
 }
 
 // single block: loss = sum_i rowloss[i] in index order (double)
-__global__ __launch_bounds__(256) void sc_reduce_kernel(const float* __restrict__ rowloss, float* __restrict__ loss, int N) {
+__global__ __launch_bounds__(256) void sc_reduce_kernel(const ScBatch bt, int N, int C) {
   __shared__ double part[256];
+  const float* __restrict__ rowloss = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C).rowloss;
+  float* __restrict__ loss = bt.loss[blockIdx.y];
   double s = 0.0;
   const int per = (N + 255) / 256;
   for (int k = 0; k < per; ++k) {
@@ -234,9 +270,13 @@ __global__ __launch_bounds__(256) void sc_reduce_kernel(const float* __restrict_
 
 // one block per row: dx = (dxn - xn (xn . dxn)) * inv   (the clamp max(|x|, eps) is inactive for any non-degenerate row;
 // for |x| < eps PyTorch's normalize has zero gradient through the clamp: dx = dxn / eps)
-__global__ __launch_bounds__(256) void sc_dnorm_kernel(const float* __restrict__ xn, const float* __restrict__ dxn,
-                                                      const float* __restrict__ inv, float* __restrict__ dx, int C, int N) {
+__global__ __launch_bounds__(256) void sc_dnorm_kernel(const ScBatch bt, int C, int N) {
   __shared__ float red[4];
+  const ScPtrs q = sc_ptrs(bt.scratch + blockIdx.y * bt.stride, N, C);
+  const float* __restrict__ xn = q.xn;
+  const float* __restrict__ dxn = q.dxn;
+  const float* __restrict__ inv = q.inv;
+  float* __restrict__ dx = bt.grad[blockIdx.y];
   const int i = blockIdx.x;
   auto dval = [&](int c) {                                 // the four k-quarters of sc_gemm_sym_kernel, in order
     float d = 0.f;
@@ -259,47 +299,63 @@ size_t supcon_scratch_bytes(int N, int C) {
   return ((size_t)(1 + SC_KSPLIT) * N * C + (size_t)N * N + (size_t)4 * N + 64) * sizeof(float);
 }
 
-hipError_t launch_small_gemm(bool ta, bool tb, const float* A, const float* B, float* Cm, int M, int N, int R, int splits,
-                             float scale, hipStream_t st);   // amx_mlp.hip
+hipError_t launch_small_gemm_batch(int nb, bool ta, bool tb, const float* const* A, const float* const* B, float* const* Cm, int M,
+                                   int N, int R, int splits, float scale, hipStream_t st);   // amx_mlp.hip
 
-hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
-                         int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st) {
-  float* xn = (float*)scratch;
-  float* dxn = xn + (size_t)N * C;
-  float* S = dxn + (size_t)SC_KSPLIT * N * C;
-  float* inv = S + (size_t)N * N;
-  float* cnt = inv + N;
-  float* rowloss = cnt + N;
-  float* wsum = rowloss + N;
+// nb losses of one shape: feat[b] [N][C], labels[b] [N] -> loss[b], grad[b] (nullptr for every b: no gradients); scratch: nb slices of
+// supcon_scratch_bytes(N, C).
+hipError_t launch_supcon_batch(int nb, const float* const* feat, const int* const* labels, int N, int C, float temperature, int rarity,
+                               int balance, int sqrt_mode, float* const* loss, float* const* grad, void* scratch, hipStream_t st) {
+  ScBatch bt;
+  bt.scratch = (char*)scratch;
+  bt.stride = supcon_scratch_bytes(N, C);
+  const float* xn[MLP_MAXB];
+  const float* Sc[MLP_MAXB];
+  float* S[MLP_MAXB];
+  float* dxa[MLP_MAXB];
+  float* dxb[MLP_MAXB];
+  for (int b = 0; b < nb; ++b) {
+    bt.feat[b] = feat[b]; bt.lab[b] = labels[b]; bt.loss[b] = loss[b]; bt.grad[b] = grad ? grad[b] : nullptr;
+    const ScPtrs q = sc_ptrs(bt.scratch + b * bt.stride, N, C);
+    xn[b] = q.xn; S[b] = q.S; Sc[b] = q.S; dxa[b] = q.dxn; dxb[b] = q.dxn + (size_t)2 * N * C;
+  }
+  const bool want_grad = grad && grad[0];
   const dim3 blk(256);
-  hipLaunchKernelGGL(sc_normalize_kernel, dim3(N), blk, 0, st, feat, xn, inv, C);
-  hipLaunchKernelGGL(sc_count_kernel, dim3(N), blk, 0, st, labels, cnt, N);
-  hipLaunchKernelGGL(sc_wsum_kernel, dim3(1), blk, 0, st, cnt, wsum, N, rarity, sqrt_mode);
+  hipLaunchKernelGGL(sc_normalize_kernel, dim3(N, nb), blk, 0, st, bt, N, C);
+  hipLaunchKernelGGL(sc_count_kernel, dim3(N, nb), blk, 0, st, bt, N, C);
+  hipLaunchKernelGGL(sc_wsum_kernel, dim3(1, nb), blk, 0, st, bt, N, C, rarity, sqrt_mode);
   const bool fast = !(N & 3) && !(C & 3);          // the register-tiled GEMM of amx_mlp.hip moves aligned float4s
   if (fast) {
-    hipError_t e = launch_small_gemm(true, true, xn, xn, S, N, N, C, 1, 1.f / temperature, st);   // S = xn xn^T / T
+    hipError_t e = launch_small_gemm_batch(nb, true, true, xn, xn, S, N, N, C, 1, 1.f / temperature, st);   // S = xn xn^T / T
     if (e != hipSuccess) return e;
   } else {
-    hipLaunchKernelGGL(sc_gemm_nt_kernel, dim3((N + BM - 1) / BM, (N + BM - 1) / BM), blk, 0, st, xn, xn, S, N, N, C,
-                       1.f / temperature);
+    for (int b = 0; b < nb; ++b)
+      hipLaunchKernelGGL(sc_gemm_nt_kernel, dim3((N + BM - 1) / BM, (N + BM - 1) / BM), blk, 0, st, xn[b], xn[b], S[b], N, N, C,
+                         1.f / temperature);
   }
-  hipLaunchKernelGGL(sc_rows_kernel, dim3(N), blk, 0, st, S, labels, cnt, wsum, rowloss, N, rarity, balance, sqrt_mode);
-  hipLaunchKernelGGL(sc_reduce_kernel, dim3(1), blk, 0, st, rowloss, loss, N);
-  if (grad) {
+  hipLaunchKernelGGL(sc_rows_kernel, dim3(N, nb), blk, 0, st, bt, N, C, rarity, balance, sqrt_mode);
+  hipLaunchKernelGGL(sc_reduce_kernel, dim3(1, nb), blk, 0, st, bt, N, C);
+  if (want_grad) {
     if (fast) {
       // dxn = (G + G^T) xn / T as four partial products (two row halves of G xn, two of G^T xn) that sc_dnorm adds in order
       static_assert(SC_KSPLIT == 4, "sc_dnorm sums SC_KSPLIT partials");
-      hipError_t e = launch_small_gemm(true, false, S, xn, dxn, N, C, N, 2, 1.f / temperature, st);
+      hipError_t e = launch_small_gemm_batch(nb, true, false, Sc, xn, dxa, N, C, N, 2, 1.f / temperature, st);
       if (e != hipSuccess) return e;
-      e = launch_small_gemm(false, false, S, xn, dxn + (size_t)2 * N * C, N, C, N, 2, 1.f / temperature, st);
+      e = launch_small_gemm_batch(nb, false, false, Sc, xn, dxb, N, C, N, 2, 1.f / temperature, st);
       if (e != hipSuccess) return e;
     } else {
-      hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM, SC_KSPLIT), blk, 0, st, S, xn, dxn, N, C,
-                         1.f / temperature);
+      for (int b = 0; b < nb; ++b)
+        hipLaunchKernelGGL(sc_gemm_sym_kernel, dim3((C + BM - 1) / BM, (N + BM - 1) / BM, SC_KSPLIT), blk, 0, st, Sc[b], xn[b], dxa[b], N,
+                           C, 1.f / temperature);
     }
-    hipLaunchKernelGGL(sc_dnorm_kernel, dim3(N), blk, 0, st, xn, dxn, inv, grad, C, N);
+    hipLaunchKernelGGL(sc_dnorm_kernel, dim3(N, nb), blk, 0, st, bt, C, N);
   }
   return hipGetLastError();
+}
+
+hipError_t launch_supcon(const float* feat, const int* labels, int N, int C, float temperature, int rarity, int balance,
+                         int sqrt_mode, float* loss, float* grad, void* scratch, hipStream_t st) {
+  return launch_supcon_batch(1, &feat, &labels, N, C, temperature, rarity, balance, sqrt_mode, &loss, &grad, scratch, st);
 }
 
 }  // namespace amx

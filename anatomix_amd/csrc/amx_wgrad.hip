@@ -303,7 +303,24 @@ __global__ __launch_bounds__(640) void conv3d_wgrad_tr_kernel(const WgradParams 
         acc[t] = acc[t] + o;
       }
   }
-  if (wave == 0) {
+  if (p.nchunk == 1) {
+    // the only chunk: dW itself, through LDS so that the stores follow dW's layout (a cout row of the tile is 16 x 27 contiguous floats)
+    __syncthreads();
+    if (wave == 0)
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[((kg * 4 + j) * 16 + m) * 27 + t] = acc[t][j];     // [co][ci][tap]
+    __syncthreads();
+    const int cin = p.cin_real, cib = cit * 16;
+    const int nci = cin - cib < 16 ? cin - cib : 16;                // real input channels of this tile (the rest is padding)
+    for (int e = tid; e < 16 * nci * 27; e += 640) {
+      const int co = e / (nci * 27), rest = e - co * (nci * 27);
+      float* o = p.dw + ((size_t)(cot * 16 + co) * cin + cib) * 27 + rest;
+      const float v = red[co * 16 * 27 + rest];
+      *o = p.accumulate ? *o + v : v;
+    }
+  } else if (wave == 0) {
     float* out = p.partial + ((size_t)chunk * npairs + pair) * 27 * 256;
 #pragma unroll
     for (int t = 0; t < 27; ++t)
@@ -391,6 +408,7 @@ static WtPlan wt_plan(int N, int D, int H, int W, int Cout, int CinPad) {
   if (target < 0) target = exp_env("AMX_WGRAD_WGS") ? atoi(exp_env("AMX_WGRAD_WGS")) : 256;
   int nc = target / npairs;
   if (nc < 1) nc = 1;
+  if (q.nplanes <= 4 * g) nc = 1;              // at most four items in all: one workgroup per pair writes dW itself (no partials, no reduce launch)
   int ppc = (q.nplanes + nc - 1) / nc;
   ppc = (ppc + g - 1) / g * g;                 // whole items
   q.ppc = ppc;
@@ -422,6 +440,7 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
   const WtPlan q = wt_plan(p.N, p.D, p.H, p.W, p.Cout, CinPad);
   p.partial = (float*)scratch;
   p.nchunk = q.nchunk; p.nyt = q.nyt; p.nxt = q.nxt; p.ppc = q.ppc; p.cpx = q.cpx; p.nplanes = q.nplanes;
+  p.dw = dw; p.cin_real = CinReal; p.accumulate = accumulate;
   p.dbg = exp_env("AMX_WGRAD_DBG") ? atoi(exp_env("AMX_WGRAD_DBG")) : 0;
   const int npairs = (p.Cout / 16) * (CinPad / 16);
   const int nwg = 8 * q.cpx;
@@ -434,6 +453,7 @@ hipError_t launch_wgrad(WgradParams p, int CinReal, float* dw, int accumulate, v
   if (e != hipSuccess) return e;
   const int nchunk = q.nchunk;
   const long long E = (long long)npairs * 27 * 256;
+  if (nchunk == 1) return hipGetLastError();                        // written by the kernel
   if (nchunk <= 16)
     hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, (const float*)scratch, dw, p.Cout,
                        CinReal, CinPad, nchunk, accumulate);

@@ -119,6 +119,9 @@ class _UnetTrainFn(torch.autograd.Function):
         # NCDHW copies, and the backward scatters the row gradients straight into the framed gradient buffers
         dt = _DT[model.train_precision]
         coords_of = {}
+        # hook of the sampled route (an attribute of the sampler): on_start() once the first block's kernels are enqueued -- work that
+        # does not depend on the forward (the coordinate draws) is enqueued behind them instead of in front of the whole forward
+        on_start = getattr(sampler, "on_start", None)
         # an output nobody differentiates (the network output next to sampled taps: 268 MB at 128^3) arrives as None in backward, not as a
         # dense zero tensor that would then be imported
         ctx.set_materialize_grads(False)
@@ -274,6 +277,9 @@ class _UnetTrainFn(torch.autograd.Function):
                         taps[i] = T.gather_rows(out, coords_of[i], channels_last=False)
                 blocks.append(blk)
                 ops.append(("conv", blk))
+                if on_start is not None:
+                    on_start()
+                    on_start = None
                 cur = blk["name"]
                 if model.use_skip_connection and i in model.encoder_idx:
                     skips.append(cur)
@@ -585,5 +591,7 @@ def forward_train_sampled(model, x, layers, sampler):
         coords[i] = sampler(i, shape)
         return coords[i]
 
+    if getattr(sampler, "on_start", None) is not None:
+        recording.on_start = sampler.on_start
     res = _UnetTrainFn.apply(model, x, tuple(layers), recording, *list(model.parameters()))
     return res[0], list(res[1:]), [coords[l] for l in layers], [dims[l] for l in layers]

@@ -234,9 +234,9 @@ def wgrad_scratch(x0, x1, cout):
         return _cached(("wgrad", x0.device, nbytes), lambda: torch.empty(nbytes, dtype=torch.uint8, device=x0.device))
 
 
-def conv_wgrad(dx_framed, x0, x1, cin_real, cout, out=None):
+def conv_wgrad(dx_framed, x0, x1, cin_real, cout, out=None, accumulate=False):
     """Weight gradient: fp32 [Cout, cin_real, 3, 3, 3] (``out``: preallocated result, e.g. by the caller's main stream when the
-    kernel itself is enqueued on a side stream)."""
+    kernel itself is enqueued on a side stream; ``accumulate``: added to ``out`` instead of overwriting it)."""
     lib = _lib.load()
     dev = x0.device
     n, d, h, w, c0 = x0.shape
@@ -249,7 +249,7 @@ def conv_wgrad(dx_framed, x0, x1, cin_real, cout, out=None):
         nbytes = lib.amx_conv3d_wgrad_scratch_bytes(n, d, h, w, cout, c0 + c1)
         sc = _cached(("wgrad", dev, nbytes), lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
         _lib.check(lib.amx_conv3d_wgrad(ctypes.c_void_p(view.data_ptr()), sn, sz, sy, sx, _lib.ptr(x0), c0, _lib.ptr(x1), c1,
-                                        cin_real, cout, n, d, h, w, _lib.ptr(dw), 0, _lib.ptr(sc), nbytes, _PREC[x0.dtype],
+                                        cin_real, cout, n, d, h, w, _lib.ptr(dw), 1 if accumulate else 0, _lib.ptr(sc), nbytes, _PREC[x0.dtype],
                                         _st(dev)))
     return dw
 

@@ -143,6 +143,115 @@ class _MlpHeadFn(torch.autograd.Function):
         return (dx, None) + tuple(grads)
 
 
+class _MlpHeadsFn(torch.autograd.Function):
+    """Several heads of one shape class (same rows, width, depth, activation, BatchNorm constants; own input widths) as ONE chain of
+    launches (amx_mlp_heads_forward / _backward): the contrastive step's six heads are 6 x ~20 dependent small launches otherwise,
+    and a replayed graph pays per dependent node.  Per head the same kernels in the same order: bit-identical to _MlpHeadFn."""
+
+    @staticmethod
+    def forward(ctx, specs, nparams, *args):
+        nb = len(specs)
+        xs = args[:nb]
+        lib = _lib.load()
+        dev = xs[0].device
+        layers0, act, slope = specs[0]
+        L = len(layers0)
+        n = xs[0].shape[0]
+        width = layers0[0][0].out_features
+        xcs = [x.detach().contiguous() for x in xs]
+        cins = [int(x.shape[1]) for x in xcs]
+        ws, gs, bs, rms, rvs = [], [], [], [], []
+        for layers, _, _ in specs:
+            for lin, bn in layers:
+                ws.append(lin.weight.detach().contiguous())
+                gs.append(None if bn.weight is None else bn.weight.detach())
+                bs.append(None if bn.bias is None else bn.bias.detach())
+                rms.append(bn.running_mean)
+                rvs.append(bn.running_var)
+        z = torch.empty((nb, L, n, width), dtype=torch.float32, device=dev)
+        y = torch.empty((nb, L, n, width), dtype=torch.float32, device=dev)
+        mean = torch.empty((nb, L, width), dtype=torch.float32, device=dev)
+        rstd = torch.empty((nb, L, width), dtype=torch.float32, device=dev)
+        bn0 = layers0[0][1]
+        cin_arr = (ctypes.c_int * nb)(*cins)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.amx_mlp_heads_forward(nb, _ptr_array(xcs), n, cin_arr, width, L, _ptr_array(ws), _ptr_array(gs), _ptr_array(bs),
+                                                 _ptr_array(rms), _ptr_array(rvs), float(bn0.eps), float(bn0.momentum), _lib.ACT[act],
+                                                 float(slope), _ptr_array(list(z)), _ptr_array(list(y)), _ptr_array(list(mean)),
+                                                 _ptr_array(list(rstd)), st))
+        tracked = [bn.num_batches_tracked for layers, _, _ in specs for _, bn in layers if bn.num_batches_tracked is not None]
+        if tracked:
+            torch._foreach_add_(tracked, 1)
+        ctx.specs, ctx.saved = specs, (xcs, cins, ws, gs, z, y, mean, rstd)
+        ctx.needs_dx = [x.requires_grad for x in xs]
+        return tuple(y[h, L - 1] for h in range(nb))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        specs = ctx.specs
+        xcs, cins, ws, gs, z, y, mean, rstd = ctx.saved
+        lib = _lib.load()
+        nb = len(specs)
+        layers0, act, slope = specs[0]
+        L = len(layers0)
+        dev = xcs[0].device
+        n = xcs[0].shape[0]
+        width = ws[0].shape[0]
+        dycs = [(torch.zeros((n, width), dtype=torch.float32, device=dev) if d is None else d.contiguous().float()) for d in dys]
+        dws = [torch.empty_like(w) for w in ws]
+        dgs = [None if g is None else torch.empty_like(g) for g in gs]
+        dbs = [None if g is None else torch.empty_like(g) for g in gs]
+        dxs = [torch.empty_like(x) if need else None for x, need in zip(xcs, ctx.needs_dx)]
+        cin_arr = (ctypes.c_int * nb)(*cins)
+        with torch.cuda.device(dev):
+            nbytes = max(lib.amx_mlp_head_scratch_bytes(n, c, width) for c in cins)
+            nbytes = (nbytes + 255) // 256 * 256
+            sc = torch.empty((nb, nbytes), dtype=torch.uint8, device=dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.amx_mlp_heads_backward(nb, _ptr_array(dycs), _ptr_array(xcs), n, cin_arr, width, L, _ptr_array(ws), _ptr_array(gs),
+                                                  _lib.ACT[act], float(slope), _ptr_array(list(z)), _ptr_array(list(y)),
+                                                  _ptr_array(list(mean)), _ptr_array(list(rstd)), _ptr_array(dws), _ptr_array(dgs),
+                                                  _ptr_array(dbs), _ptr_array(dxs), _ptr_array(list(sc)), nbytes, st))
+        grads = []
+        for i in range(nb * L):
+            grads.append(dws[i])
+            if gs[i] is not None:
+                grads += [dgs[i], dbs[i]]
+        return (None, None) + tuple(dxs) + tuple(grads)
+
+
+def batchable(mlps, xs):
+    """None when ``run_heads`` covers these heads as one batch, else the reason (the caller then runs them one by one)."""
+    if not 1 <= len(mlps) <= 8:
+        return "1 to 8 heads per batch"
+    for mlp, x in zip(mlps, xs):
+        why = unsupported_reason(mlp, x)
+        if why is not None:
+            return why
+    specs = [cached_spec(m) for m in mlps]
+    l0, act, slope = specs[0]
+    key = (len(l0), act, slope, l0[0][0].out_features, l0[0][1].eps, l0[0][1].momentum, xs[0].shape[0],
+           tuple(bn.weight is None for _, bn in l0))
+    for (layers, a, sl), x in zip(specs, xs):
+        if (len(layers), a, sl, layers[0][0].out_features, layers[0][1].eps, layers[0][1].momentum, x.shape[0],
+                tuple(bn.weight is None for _, bn in layers)) != key:
+            return "heads of different structure"
+    return None
+
+
+def run_heads(mlps, xs):
+    """[mlp(x) for mlp, x in zip(mlps, xs)] as one chain of launches; raises with the reason when the batch is not covered."""
+    why = batchable(mlps, xs)
+    if why is not None:
+        raise RuntimeError("projection heads as a batch: " + why)
+    specs = tuple(cached_spec(m) for m in mlps)
+    params = []
+    for layers, _, _ in specs:
+        params += head_params(layers)
+    return list(_MlpHeadsFn.apply(specs, len(params), *xs, *params))
+
+
 def head_params(layers):
     ps = []
     for lin, bn in layers:

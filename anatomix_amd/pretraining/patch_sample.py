@@ -138,11 +138,18 @@ class PatchSampleF(nn.Module):
             flat = torch.div(flat, dims[a], rounding_mode="floor")
         return torch.stack(cs[::-1], dim=1)
 
-    def forward_rows(self, rows, coords, streams=None):
+    def forward_rows(self, rows, coords, streams=None, batched=False):
         """The heads on rows that were gathered elsewhere (``model.train.forward_train_sampled``): ``rows[k]`` [views, P, C] at
-        ``coords[k]`` -- what ``forward`` computes from the dense feature maps, without the dense feature maps."""
+        ``coords[k]`` -- what ``forward`` computes from the dense feature maps, without the dense feature maps.  ``batched``: all
+        heads as ONE chain of launches when they share a structure (``mlp_head.run_heads``; same values), else layer by layer."""
         if self.use_mlp and not self.mlp_init:
             self.create_mlp([torch.zeros((1, r.shape[2], 1, 1, 1), device=r.device) for r in rows])
+        if batched and self.use_mlp:
+            mlps = [getattr(self, "mlp_%d" % k) for k in range(len(rows))]
+            xs = [r.flatten(0, 1) for r in rows]
+            if all(x.is_cuda for x in xs) and mlp_head.batchable(mlps, xs) is None:
+                ys = mlp_head.run_heads(mlps, xs)
+                return [y.view(r.shape[0], r.shape[1], -1) for y, r in zip(ys, rows)], list(coords)
         ambient = torch.cuda.current_stream(rows[0].device) if streams is not None else None
         out = []
         forked = set()

@@ -21,6 +21,12 @@ _STREAMS = {}
 # 7.45-7.50 ms per step against 7.74-7.77 with six, 7.53-7.55 with two, 7.68 with four (GPU_MAX_HW_QUEUES=8 instead: 14.4 ms).
 _HEAD_STREAMS = int(_lib.exp_env("AMX_HEAD_STREAMS", "3"))
 _PREDRAW = _lib.exp_env("AMX_NO_PREDRAW", "0") != "1"     # A/B: coordinates drawn up front on a side stream
+# A/B: the coordinate draws are enqueued behind the forward's first block instead of in front of it.  (Measured and dropped: the head +
+# loss chains started at their taps, beside the rest of the forward, on detached leaves of the rows with a second backward call for the
+# network -- 7.04 against 6.86 ms per step whether forked tap by tap or once in front of the 128^3 level: the forward's own chain changes
+# hardware queue at every fork of the replayed graph and its short deep-level kernels queue behind the heads'.)
+_LATE_DRAW = _lib.exp_env("AMX_DRAW_FIRST", "0") != "1"
+_BATCHED_HEADS = _lib.exp_env("AMX_HEAD_CHAINS", "0") != "1"   # A/B: 1 = the six per-layer chains on side streams (until round 6)
 _WEIGHTS = {}                                                # (device, nce weights, lambda, accumulation) -> weight vector on the device
 
 
@@ -61,14 +67,17 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
         tap_shapes = netG.__dict__.setdefault("_amx_tap_shapes", {})
         shapes = tap_shapes.get(skey)
         pre = {}
-        if shapes is not None and sample_ids is None and _PREDRAW and torch.cuda.is_current_stream_capturing():   # (eagerly the stream switches cost more than they return)
+        capturing = reals.is_cuda and torch.cuda.is_current_stream_capturing()
+        if shapes is not None and sample_ids is None and _PREDRAW and capturing:   # (eagerly the stream switches cost more than they return)
             side = _draw_stream(reals.device)
-            main = torch.cuda.current_stream(reals.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for l in sorted(sampled):
-                    pre[l] = netF.draw_coords(sampled[l], shapes[l], num_patches, None, reals.device)
-                    pre[l].record_stream(main)
+
+            def draw_all():
+                main = torch.cuda.current_stream(reals.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for l in sorted(sampled):
+                        pre[l] = netF.draw_coords(sampled[l], shapes[l], num_patches, None, reals.device)
+                        pre[l].record_stream(main)
             joined = []
 
             def sampler(i, shape):
@@ -78,6 +87,12 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
                 if tuple(shape) != tuple(shapes[i]):
                     raise RuntimeError("contrastive step: the tap shapes changed under a cached sampling plan")
                 return pre[i]
+            if _LATE_DRAW:
+                # a replayed graph hands its nodes to the device in capture order: six draw + filter launches in front of the forward
+                # kept the first convolution waiting for ~170 us of launch latency; behind the first block they cost nothing
+                sampler.on_start = draw_all
+            else:
+                draw_all()
         else:
             seen = {}
 
@@ -97,32 +112,45 @@ def _forward_backward(netG, netF, criterions, real_A, real_B, seg_A, nce_layers,
     # a node's backward on the stream of its forward, so the adjoint chains overlap too -- and join before the sum.
     # (only while a HIP graph is being captured: launched eagerly, the extra stream switches cost the host more than the overlap
     # returns -- 16.9 vs 15.8 ms -- while a replayed graph gets the parallel branches for free: 12.6 -> 11.8 ms)
-    streams = _layer_streams(reals.device, len(feat_sizes)) if (reals.is_cuda and _PARALLEL_HEADS and
-                                                                torch.cuda.is_current_stream_capturing()) else None
-    ambient = torch.cuda.current_stream(reals.device) if streams is not None else None
-    if sampled is not None:
-        pooled, ids = netF.forward_rows(rows, coords, streams)
+    # Inside a HIP graph the six chains run as ONE chain of batched launches (amx_mlp_heads_*, amx_supcon_loss_batch: every launch
+    # serves all layers): a replayed graph pays ~8 us per dependent node whatever its size, and six chains of ~30 small nodes on
+    # three streams were 1.5 ms of a 7 ms step.
+    stacked = None
+    capturing_now = reals.is_cuda and torch.cuda.is_current_stream_capturing()
+    if sampled is not None and _BATCHED_HEADS and capturing_now:
+        from . import supcon as _supcon
+        pooled, ids = netF.forward_rows(rows, coords, None, batched=True)
+        stacked = _supcon.batched_losses(criterions, pooled, seg_A, ids, feat_sizes)
+    if stacked is not None:
+        means = None
+        layer_losses = list(stacked.detach().unbind(0))
+        streams = None
     else:
-        pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
-    means, layer_losses = [], []
-    for k, (f_kq, sid, crit, layer, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, feat_sizes)):
-        with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
-            m = crit(f_kq, seg_A, sid, torch.Size(fsize))
-            if m.dim() != 0:                                  # (the HIP criterion returns the scalar: a mean of it would be three more launches)
-                m = m.mean()
-        means.append(m)                                       # (kept alive until after the backward: no cross-stream reuse)
-        layer_losses.append(m.detach())                       # the recorded per-layer loss IS this mean (it was reduced a second time)
-    if streams is not None:
-        for s in dict.fromkeys(streams):                      # (each distinct stream once: layers share streams)
-            ambient.wait_stream(s)
+        streams = _layer_streams(reals.device, len(feat_sizes)) if (reals.is_cuda and _PARALLEL_HEADS and capturing_now) else None
+        ambient = torch.cuda.current_stream(reals.device) if streams is not None else None
+        if sampled is not None:
+            pooled, ids = netF.forward_rows(rows, coords, streams)
+        else:
+            pooled, ids = netF(feat_kq, num_patches, sample_ids, None, False, **({"streams": streams} if streams is not None else {}))
+        means, layer_losses = [], []
+        for k, (f_kq, sid, crit, layer, fsize) in enumerate(zip(pooled, ids, criterions, nce_layers, feat_sizes)):
+            with (torch.cuda.stream(streams[k]) if streams is not None else contextlib.nullcontext()):
+                m = crit(f_kq, seg_A, sid, torch.Size(fsize))
+                if m.dim() != 0:                                  # (the HIP criterion returns the scalar: a mean of it would be three more launches)
+                    m = m.mean()
+            means.append(m)                                       # (kept alive until after the backward: no cross-stream reuse)
+            layer_losses.append(m.detach())                       # the recorded per-layer loss IS this mean (it was reduced a second time)
+        if streams is not None:
+            for s in dict.fromkeys(streams):                      # (each distinct stream once: layers share streams)
+                ambient.wait_stream(s)
     # total = sum_k mean_k * w_k * lambda_nce (supcl_model.py:815-843) as ONE weighted sum of the stacked means: the chain of scalar
     # multiplies and adds was a dozen 2-us launches on the main stream, forward and backward
     wkey = (str(reals.device), tuple(float(w) for w in nce_weights), float(lambda_nce), float(grad_accum_iters))
     wv = _WEIGHTS.get(wkey)
     if wv is None:                                            # (first built in an eager warm-up step: a host copy cannot be captured)
-        wv = _WEIGHTS[wkey] = torch.tensor([w * lambda_nce / grad_accum_iters for w in nce_weights][: len(means)], dtype=torch.float32,
+        wv = _WEIGHTS[wkey] = torch.tensor([w * lambda_nce / grad_accum_iters for w in nce_weights][: len(layer_losses)], dtype=torch.float32,
                                            device=reals.device)
-    loss = (torch.stack(means) * wv).sum()
+    loss = ((stacked if stacked is not None else torch.stack(means)) * wv).sum()
     total = loss * grad_accum_iters if grad_accum_iters != 1 else loss
     (scaler.scale(loss) if scaler is not None else loss).backward()      # supcl_model.py:624-626
     return total, layer_losses, ids, out

@@ -37,6 +37,75 @@ class _SupConHip(torch.autograd.Function):
         return (grad * gout).to(ctx.in_dtype), None, None, None, None, None
 
 
+class _SupConBatchHip(torch.autograd.Function):
+    """Several losses of one shape from ONE chain of launches (amx_supcon_loss_batch): [nb] losses, gradients kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, labels, temperature, rarity, balance, sqrt_mode, *feats):
+        lib = _lib.load()
+        nb = len(feats)
+        dev = feats[0].device
+        xs = [f.detach().float().contiguous() for f in feats]
+        n, c = xs[0].shape
+        need_grad = any(f.requires_grad for f in feats)
+        loss = torch.empty(nb, dtype=torch.float32, device=dev)
+        grad = torch.empty((nb, n, c), dtype=torch.float32, device=dev) if need_grad else None
+        with torch.cuda.device(dev):
+            per = lib.amx_supcon_scratch_bytes(n, c)
+            scratch = torch.empty(nb * per, dtype=torch.uint8, device=dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            _lib.check(lib.amx_supcon_loss_batch(nb, arr(xs), arr(list(labels)), n, c, float(temperature), int(rarity), int(balance),
+                                                 int(sqrt_mode), arr(list(loss)), None if grad is None else arr(list(grad)),
+                                                 _lib.ptr(scratch), nb * per, st))
+        ctx.save_for_backward(grad)
+        ctx.in_dtypes = [f.dtype for f in feats]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        g = grad * gout.view(-1, 1, 1)
+        return (None, None, None, None, None) + tuple(g[b].to(dt) for b, dt in enumerate(ctx.in_dtypes))
+
+
+def batched_losses(criterions, features, labels_seg, coords, ranges):
+    """[crit(f, labels_seg, c, r) for ...] as ONE tensor [len(criterions)] from one chain of launches, or None when the criteria or
+    their inputs are not of one kind (the caller then evaluates them one by one): CUDA fp32 features of one shape, 3-D coordinate
+    ranges, int64 [P, 3] device coordinates, one fp32 [1, 1, D, H, W] device segmentation, criteria of equal settings."""
+    nb = len(criterions)
+    if not (1 <= nb <= 8 and all(type(c) is SupPatchNCELoss for c in criterions)):
+        return None
+    c0 = criterions[0]
+    key = lambda c: (c.temperature, bool(c.weigh_rarity), bool(c.balance_denominator), c.weighting_mode)
+    if any(key(c) != key(c0) for c in criterions):
+        return None
+    f0 = features[0]
+    if not (f0.is_cuda and f0.dim() == 3 and all(f.is_cuda and f.device == f0.device and f.shape == f0.shape and f.dtype == torch.float32
+                                                   for f in features)):
+        return None
+    ntps, num_patches, nc = f0.shape
+    if not (labels_seg.is_cuda and labels_seg.dtype == torch.float32 and labels_seg.dim() == 5 and labels_seg.shape[:2] == (1, 1) and
+            labels_seg.device == f0.device):
+        return None
+    for c, r in zip(coords, ranges):
+        if not (len(r) == 3 and torch.is_tensor(c) and c.dtype == torch.int64 and c.is_cuda and c.device == f0.device and
+                tuple(c.shape) == (num_patches, 3)):
+            return None
+    lib = _lib.load()
+    seg = labels_seg.contiguous()
+    cs = [c.contiguous() for c in coords]
+    lab = torch.empty((nb, ntps * num_patches), dtype=torch.int32, device=f0.device)
+    dims = (ctypes.c_int * (3 * nb))(*[int(v) for r in ranges for v in r])
+    with torch.cuda.device(f0.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(f0.device).cuda_stream)
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(lib.amx_gather_labels_batch(_lib.ptr(seg), seg.shape[2], seg.shape[3], seg.shape[4], nb, arr(cs), num_patches, dims, ntps,
+                                               arr(list(lab)), st))
+    return _SupConBatchHip.apply(lab, c0.temperature, c0.weigh_rarity, c0.balance_denominator, c0.weighting_mode == "sqrt",
+                                 *[f.reshape(ntps * num_patches, nc) for f in features])
+
+
 class SupPatchNCELoss(nn.Module):
     """``SupPatchNCELoss(opt)``; ``opt`` carries nce_T, weigh_rarity, balance_denominator, weighting_mode
     (supcl_model.py:49-58).  ``forward(features [views,P,C], labels_seg [1,1,H,W,D], labels_coords [P,3], coords_range)``

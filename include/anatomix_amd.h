@@ -468,6 +468,29 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
                           const float* d_y, const float* d_mean, const float* d_rstd, float* const* dw, float* const* dgamma,
                           float* const* dbeta, float* d_dx, void* d_scratch, size_t scratch_bytes, void* stream);
 
+/* The heads and losses of ONE contrastive step as batches (supcl_model.py:801-843 walks the nce layers one by one; the chains are
+ * independent and identical in structure).  A replayed HIP graph pays per DEPENDENT node, not per byte: n_heads chains of ~30 small
+ * launches each become one chain whose every launch serves all heads (<= 8; same rows n, same width, same depth; own input widths
+ * cin[h]).  Arrays over (head, layer) are flattened [h * n_layers + l]; d_z / d_y / d_mean / d_rstd / d_scratch are per head with
+ * the single-head layouts and sizes above.  Per head the arithmetic and its order are those of amx_mlp_head_forward / _backward:
+ * bit-identical results.  amx_supcon_loss_batch: n_losses problems of one shape [n][c] (scratch: n_losses slices of
+ * amx_supcon_scratch_bytes(n, c); d_grad NULL: losses only); amx_gather_labels_batch: the class ids of n_maps feature maps of sizes
+ * dims[3 m ..] = (d, h, w) from one segmentation. */
+int amx_mlp_heads_forward(int n_heads, const float* const* d_x, int n, const int* cin, int width, int n_layers, const float* const* w,
+                          const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                          float eps, float momentum, int act, float slope, float* const* d_z, float* const* d_y, float* const* d_mean,
+                          float* const* d_rstd, void* stream);
+int amx_mlp_heads_backward(int n_heads, const float* const* d_dy, const float* const* d_x, int n, const int* cin, int width, int n_layers,
+                           const float* const* w, const float* const* gamma, int act, float slope, const float* const* d_z,
+                           const float* const* d_y, const float* const* d_mean, const float* const* d_rstd, float* const* dw,
+                           float* const* dgamma, float* const* dbeta, float* const* d_dx, void* const* d_scratch, size_t scratch_bytes,
+                           void* stream);
+int amx_supcon_loss_batch(int n_losses, const float* const* d_feat, const int* const* d_labels, int n, int c, float temperature,
+                          int weigh_rarity, int balance_denominator, int sqrt_mode, float* const* d_loss, float* const* d_grad,
+                          void* d_scratch, size_t scratch_bytes, void* stream);
+int amx_gather_labels_batch(const float* d_seg, int sd, int sh, int sw, int n_maps, const long long* const* d_coords, int p, const int* dims,
+                            int views, int* const* d_labels, void* stream);
+
 /* Patch coordinates of PatchSampleF's no-mask branch (pretraining_networks.py:443-470: `randperm(n_voxels)[:num]`, then the
  * flat ids unravelled): d_draws int64 [n_draws], values in [0, d0*d1*d2) drawn WITH replacement by the caller's generator;
  * d_coords int64 [num][3] receives the C-order coordinates of the first `num` distinct draws in draw order -- the same

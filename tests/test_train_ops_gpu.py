@@ -95,11 +95,15 @@ def test_conv_dgrad_and_wgrad(device, prec, cin, cout, size):
     dw = T.conv_wgrad(framed, xd, None, cin, cout)
     assert dw.shape == (cout, cin, 3, 3, 3)
     assert rel_l2(dw.cpu().double(), wq.grad) < 1e-5, rel_l2(dw.cpu().double(), wq.grad)      # fp32 accumulate of exact products
+    assert torch.equal(dw, T.conv_wgrad(framed, xd, None, cin, cout))                          # fixed summation order
+    base = torch.randn_like(dw)                                                                # accumulate: added to what is there
+    acc = T.conv_wgrad(framed, xd, None, cin, cout, out=base.clone(), accumulate=True)
+    assert rel_l2(acc.cpu().double(), base.cpu().double() + wq.grad) < 1e-5
 
 
 @pytest.mark.parametrize("prec", ["bf16"])
 @pytest.mark.parametrize("c0,c1,cout,size", [(16, 32, 16, (8, 8, 32)), (32, 64, 32, (4, 8, 12)), (128, 256, 128, (4, 4, 4)),
-                                              (16, 32, 16, (6, 8, 64)), (32, 64, 32, (4, 4, 128))])   # transpose-read kernel
+                                              (16, 32, 16, (6, 8, 64)), (32, 64, 32, (4, 4, 128))])
 def test_wgrad_and_dgrad_of_upsample_concat_conv(device, prec, c0, c1, cout, size):
     dt = DT[prec]
     g = torch.Generator().manual_seed(3)
