@@ -145,6 +145,8 @@ SYMBOLS = {
     "amx_mlp_heads_backward": (_I, [_I, _P, _P, _I, _P, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "amx_supcon_loss_batch": (_I, [_I, _P, _P, _I, _I, C.c_float, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "amx_gather_labels_batch": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "amx_conv3d_backward_sampled_scratch_bytes": (C.c_size_t, [_I]),
+    "amx_conv3d_backward_sampled": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _I, _P]),
     "amx_gather_rows": (_I, [_P, _I, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _P, _I, _I, _I, _P, _P]),
     "amx_scatter_rows": (_I, [_P, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _I, _P]),
     "amx_sample_coords": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

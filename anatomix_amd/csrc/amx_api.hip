@@ -138,6 +138,10 @@ hipError_t launch_gather_labels(const float* seg, int D, int H, int W, const lon
                                 int* out, hipStream_t st);
 hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long long sz, long long sy, long long sx, long long sc,
                               const long long* coords, int N, int P, int C, float* rows, hipStream_t st);
+hipError_t launch_sampled_conv_backward(const float* g, const long long* coords, const void* x, int xc, const float* w, int N, int P, int D,
+                                        int H, int W, int Cout, int Cin, float* dw, void* din, int dc, void* scratch, int precision,
+                                        hipStream_t st);
+size_t sampled_conv_backward_scratch_bytes(int P);
 hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
                                long long dx, int N, int P, int C, int accumulate, hipStream_t st);
 size_t mindssc_scratch_bytes(int H, int W, int D);
@@ -1937,6 +1941,23 @@ int amx_scatter_rows(const float* d_rows, const long long* d_coords, void* d_dst
   if (!d_rows || !d_coords || !d_dst || n < 1 || p < 1 || c < 1 || (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16))
     return fail(AMX_ERR_INVALID, "scatter_rows: bad arguments");
   AMX_HIP(amx::launch_scatter_rows(d_rows, d_coords, d_dst, precision, dst_sn, dst_sz, dst_sy, dst_sx, n, p, c, accumulate, (hipStream_t)stream));
+  return AMX_OK;
+}
+
+size_t amx_conv3d_backward_sampled_scratch_bytes(int p) { return amx::sampled_conv_backward_scratch_bytes(p); }
+
+int amx_conv3d_backward_sampled(const float* d_grows, const long long* d_coords, const void* d_x, int x_channels, const float* d_w, int n,
+                                int p, int d, int hh, int w, int cout, int cin, float* d_dw, void* d_din, int din_channels, void* d_scratch,
+                                size_t scratch_bytes, int precision, void* stream) {
+  if (!d_scratch || scratch_bytes < amx::sampled_conv_backward_scratch_bytes(p))
+    return fail(AMX_ERR_WORKSPACE, "conv3d_backward_sampled: scratch needs %zu bytes", amx::sampled_conv_backward_scratch_bytes(p));
+  if (!d_grows || !d_coords || !d_x || !d_w || !d_dw || n < 1 || p < 1) return fail(AMX_ERR_INVALID, "conv3d_backward_sampled: bad arguments");
+  if (precision != AMX_PREC_F16 && precision != AMX_PREC_BF16) return fail(AMX_ERR_INVALID, "conv3d_backward_sampled: f16 / bf16 storage");
+  if (cout < 1 || cout > 16 || cin < 1 || cin > 16 || x_channels < cin || (d_din && din_channels < cin))
+    return fail(AMX_ERR_SHAPE, "conv3d_backward_sampled: 1 <= cout, cin <= 16 (got %d, %d)", cout, cin);
+  if (d < 2 || hh < 2 || w < 2 || p > 1024) return fail(AMX_ERR_SHAPE, "conv3d_backward_sampled: sizes >= 2, at most 1024 sampled voxels");
+  AMX_HIP(amx::launch_sampled_conv_backward(d_grows, d_coords, d_x, x_channels, d_w, n, p, d, hh, w, cout, cin, d_dw, d_din, din_channels,
+                                            d_scratch, precision, (hipStream_t)stream));
   return AMX_OK;
 }
 

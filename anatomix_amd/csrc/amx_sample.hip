@@ -243,6 +243,142 @@ hipError_t launch_gather_rows(const void* src, int dtype, long long sn, long lon
   return hipGetLastError();
 }
 
+// ---- backward of a k3 reflect conv whose OUTPUT gradient is nonzero only at P sampled voxels per sample (the contrastive step taps
+// the network's output conv at 512 voxels, supcl_model.py:801-843 / pretraining_networks.py:472-480; nothing else uses that output):
+// the dense route imports the rows into a zero gradient volume and runs the full weight / data gradient over 2 x 128^3 voxels of zeros
+// (~250 us of a 6.5 ms step).  Same rounding points as the dense route: the row gradients are rounded to the storage type (what
+// scatter_rows writes), weights of the data gradient are the 16-bit packed values, sums in fp32, the data gradient rounded once.
+//   dW[co][ci][t]   = sum over (n, p) in index order of  g16[n][p][co] * x[n][r(c_p + t - 1)][ci]
+//   din[n][u][ci]   = sum over p (index order), taps t (index order) with r(c_p + t - 1) = u  of  sum_co g16[n][p][co] * w16[co][ci][t]
+// (r = reflect; din must be zero-filled by the caller -- only the <= 27 P voxels per sample that receive something are written, every
+// one of them by whoever finds it, all with the same value: deterministic).  Cout, Cin <= 16; x has xc >= Cin channels per voxel.
+constexpr int SWG = 8;                                        // sample chunks of the sampled weight gradient
+template <typename T>
+__global__ __launch_bounds__(256) void sampled_conv_wgrad_kernel(const float* __restrict__ g, const long long* __restrict__ coords,
+                                                                 const char* __restrict__ x, int xc, int N, int P, int D, int H, int W,
+                                                                 int Cout, int Cin, float* __restrict__ part, int per) {
+  // block (tap t, sample chunk k): partial[k][t][co][ci] over samples [k per, (k + 1) per) in index order
+  constexpr int CH = 128;                                      // samples staged per round (one exposed gather latency per round)
+  __shared__ float gs[CH][16], xs[CH][16];
+  const int t = blockIdx.x, kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+  const int co = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  float acc = 0.f;
+  const int total = N * P;
+  const int sbeg = blockIdx.y * per, send = sbeg + per < total ? sbeg + per : total;
+  for (int s0 = sbeg; s0 < send; s0 += CH) {
+    __syncthreads();
+#pragma unroll 8
+    for (int e = threadIdx.x; e < CH * 16; e += 256) {
+      const int sl = e >> 4, c = e & 15, sidx = s0 + sl;
+      float gv = 0.f, xv = 0.f;
+      if (sidx < send) {
+        const int n = sidx / P, p = sidx - n * P;
+        if (c < Cout) gv = (float)(T)g[(size_t)sidx * Cout + c];
+        if (c < Cin) {
+          const int z = reflect_clamp((int)coords[3 * p] + kz - 1, D), y = reflect_clamp((int)coords[3 * p + 1] + ky - 1, H),
+                    xx = reflect_clamp((int)coords[3 * p + 2] + kx - 1, W);
+          xv = (float)((const T*)x)[((((size_t)n * D + z) * H + y) * W + xx) * xc + c];
+        }
+      }
+      gs[sl][c] = gv;
+      xs[sl][c] = xv;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int sl = 0; sl < CH; ++sl) acc += gs[sl][co] * xs[sl][ci];          // (rows past the chunk hold zeros)
+  }
+  part[((size_t)blockIdx.y * 27 + t) * 256 + threadIdx.x] = acc;
+}
+
+// dW[co][ci][t] = partial[0] + partial[1] + ... in chunk order
+__global__ __launch_bounds__(256) void sampled_conv_wgrad_sum_kernel(const float* __restrict__ part, int Cout, int Cin, float* __restrict__ dw) {
+  const int t = blockIdx.x, co = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < SWG; ++k) s += part[((size_t)k * 27 + t) * 256 + threadIdx.x];
+  if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * 27 + t] = s;
+}
+
+// neighbour masks of the samples: a target voxel of sample p (one of its 27 neighbours) can only receive from samples within Chebyshev
+// distance 2 of p.  mask[p][c] bit b = sample 32 c + b is that near; one thread per (p, c).  (Searching per TARGET and per lane instead --
+// 27 P x 16 lanes, each scanning P samples -- cost 110 us at P = 512; one thread per sample scanning all others, 42 us on eight waves.)
+__global__ __launch_bounds__(256) void sampled_neighbours_kernel(const long long* __restrict__ coords, int P, unsigned* __restrict__ mask) {
+  const int nchunk = (P + 31) / 32;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * nchunk) return;
+  const int p = i / nchunk, c = i - p * nchunk;
+  const int cz = (int)coords[3 * p], cy = (int)coords[3 * p + 1], cx = (int)coords[3 * p + 2];
+  unsigned m = 0;
+#pragma unroll 8
+  for (int b = 0; b < 32; ++b) {
+    const int q = 32 * c + b;
+    if (q >= P) break;
+    const int dz = (int)coords[3 * q] - cz, dy = (int)coords[3 * q + 1] - cy, dx = (int)coords[3 * q + 2] - cx;
+    if (!(dz < -2 || dz > 2 || dy < -2 || dy > 2 || dx < -2 || dx > 2)) m |= 1u << b;
+  }
+  mask[i] = m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sampled_conv_dgrad_kernel(const float* __restrict__ g, const long long* __restrict__ coords,
+                                                                 const float* __restrict__ w, const unsigned* __restrict__ mask, int N, int P,
+                                                                 int D, int H, int W, int Cout, int Cin, char* __restrict__ din, int dc) {
+  // 16 lanes per target voxel (one input channel each), 16 targets per block.  (One thread per target with all 16 channels ran 180 us:
+  // the lanes of a wave match 27 different taps, so the product block was walked 27 times per hit with two or three lanes active.)
+  const int n = blockIdx.y;
+  const int ci = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (e >= P * 27) return;
+  const int t0 = e % 27, p0 = e / 27;
+  const int uz = reflect_clamp((int)coords[3 * p0] + t0 / 9 - 1, D), uy = reflect_clamp((int)coords[3 * p0 + 1] + (t0 / 3) % 3 - 1, H),
+            ux = reflect_clamp((int)coords[3 * p0 + 2] + t0 % 3 - 1, W);
+  const int cic = ci < Cin ? ci : 0;
+  const int nchunk = (P + 31) / 32;
+  float acc = 0.f;
+  for (int c = 0; c < nchunk; ++c) {                           // samples in index order: one summation order
+    unsigned m = mask[(size_t)p0 * nchunk + c];
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1;
+      const int p = 32 * c + b;
+      const int cz = (int)coords[3 * p], cy = (int)coords[3 * p + 1], cx = (int)coords[3 * p + 2];
+      const int dz = cz - uz, dy = cy - uy, dx = cx - ux;
+      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) continue;
+      const float* gr = g + ((size_t)n * P + p) * Cout;
+      for (int t = 0; t < 27; ++t) {
+        if (reflect_clamp(cz + t / 9 - 1, D) != uz || reflect_clamp(cy + (t / 3) % 3 - 1, H) != uy || reflect_clamp(cx + t % 3 - 1, W) != ux)
+          continue;
+        const float* wr = w + (size_t)cic * 27 + t;
+#pragma unroll 16
+        for (int co = 0; co < Cout; ++co) acc += (float)(T)gr[co] * (float)(T)wr[(size_t)co * Cin * 27];
+      }
+    }
+  }
+  if (ci < Cin) ((T*)din)[((((size_t)n * D + uz) * H + uy) * W + ux) * dc + ci] = (T)acc;
+}
+
+size_t sampled_conv_backward_scratch_bytes(int P) { return (size_t)P * ((P + 31) / 32) * sizeof(unsigned) + (size_t)SWG * 27 * 256 * sizeof(float); }
+
+hipError_t launch_sampled_conv_backward(const float* g, const long long* coords, const void* x, int xc, const float* w, int N, int P, int D,
+                                        int H, int W, int Cout, int Cin, float* dw, void* din, int dc, void* scratch, int precision,
+                                        hipStream_t st) {
+  const dim3 dgrid((P * 27 + 15) / 16, N);
+  const int nchunk = (P + 31) / 32;
+  unsigned* mask = (unsigned*)scratch;
+  float* part = (float*)(mask + (size_t)P * nchunk);
+  const int total = N * P, per = (total + SWG - 1) / SWG;
+  if (din) sampled_neighbours_kernel<<<(P * nchunk + 255) / 256, 256, 0, st>>>(coords, P, mask);
+  if (precision == 0) {
+    sampled_conv_wgrad_kernel<f16><<<dim3(27, SWG), 256, 0, st>>>(g, coords, (const char*)x, xc, N, P, D, H, W, Cout, Cin, part, per);
+    if (din) sampled_conv_dgrad_kernel<f16><<<dgrid, 256, 0, st>>>(g, coords, w, mask, N, P, D, H, W, Cout, Cin, (char*)din, dc);
+  } else {
+    sampled_conv_wgrad_kernel<bf16><<<dim3(27, SWG), 256, 0, st>>>(g, coords, (const char*)x, xc, N, P, D, H, W, Cout, Cin, part, per);
+    if (din) sampled_conv_dgrad_kernel<bf16><<<dgrid, 256, 0, st>>>(g, coords, w, mask, N, P, D, H, W, Cout, Cin, (char*)din, dc);
+  }
+  sampled_conv_wgrad_sum_kernel<<<27, 256, 0, st>>>(part, Cout, Cin, dw);
+  return hipGetLastError();
+}
+
 hipError_t launch_scatter_rows(const float* rows, const long long* coords, void* dst, int dtype, long long dn, long long dz, long long dy,
                                long long dx, int N, int P, int C, int accumulate, hipStream_t st) {
   const long long total = (long long)N * P * C;

@@ -31,6 +31,7 @@ OVERLAP_WGRAD = _lib.exp_env("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight grad
 RECOMPUTE_ACT = _lib.exp_env("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
 SPLIT_CONCAT_DGRAD = int(_lib.exp_env("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = _lib.exp_env("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
+SPARSE_OUTPUT_TAP = _lib.exp_env("AMX_DENSE_OUTPUT_TAP", "0") != "1"   # output conv tapped at sampled voxels only: its backward from the rows
 DIRECT_DGRAD = _lib.exp_env("AMX_NO_DIRECT_DGRAD", "0") != "1"   # data gradient: interior launch + shell terms instead of the framed domain + pad_fold
 PACK_ASIDE = _lib.exp_env("AMX_NO_PACK_ASIDE", "0") != "1"     # A/B: both passes' weight packing on a side stream at the start of the forward
 BATCH_PACK = _lib.exp_env("AMX_NO_BATCH_PACK", "0") != "1"     # packed weights of a pass in one launch (T.pack_batch)
@@ -410,6 +411,20 @@ class _UnetTrainFn(torch.autograd.Function):
                 g = dout
                 rows = dtap.pop(idx, None) if idx in ctx.coords_of else None
                 if g is None and rows is None:
+                    continue
+                if (g is None and SPARSE_OUTPUT_TAP and x1 is None and x0.is_cuda and blk["cout"] <= 16 and blk["cin"] <= 16
+                        and rows.shape[1] <= 1024):
+                    # the only cotangent of the output conv is 2 x 512 sampled rows: its weight and data gradient from those rows
+                    # directly (amx_conv3d_backward_sampled) instead of a dense pass over a gradient volume of zeros
+                    need_din = blk["in0"] != "x"
+                    dw, din = T.conv_backward_sampled(rows, ctx.coords_of[idx], x0, conv.weight, blk["cin"], need_din)
+                    pgrads[id(conv.weight)] = dw
+                    if conv.bias is not None:
+                        pgrads[id(conv.bias)] = rows.to(dt).float().sum((0, 1))
+                    if need_din:
+                        add_grad(blk["in0"], din)
+                    elif ctx.needs_input_grad[1]:
+                        raise NotImplementedError("input gradient through a sampled tap at a one-conv network")
                     continue
                 fr = frame((n, d, h, w), blk["cout"])
                 if g is not None:

@@ -349,6 +349,27 @@ def scatter_rows(rows, coords, dst, accumulate=False):
     return dst
 
 
+def conv_backward_sampled(grows, coords, x0, weight, cin_real, need_din=True):
+    """Backward of a k3 reflect conv (16-bit NDHWC input ``x0``, fp32 ``weight`` [Cout, cin_real, 3, 3, 3]) whose output gradient is the
+    sampled rows ``grows`` [N, P, Cout] at ``coords`` [P, 3] and zero elsewhere: (dW fp32, d input 16-bit NDHWC like x0 -- dense, zero
+    away from the samples' neighbourhoods).  amx_conv3d_backward_sampled; Cout, cin_real <= 16."""
+    lib = _lib.load()
+    grows = grows.contiguous() if grows.dtype == torch.float32 else grows.float().contiguous()
+    coords = coords.contiguous()
+    n, d, h, w, xc = x0.shape
+    p, cout = grows.shape[1], grows.shape[2]
+    wt = _as_weight(weight)
+    dw = torch.empty((cout, cin_real, 3, 3, 3), dtype=torch.float32, device=x0.device)
+    din = torch.zeros_like(x0) if need_din else None
+    with torch.cuda.device(x0.device):
+        nb = lib.amx_conv3d_backward_sampled_scratch_bytes(p)
+        sc = torch.empty(nb, dtype=torch.uint8, device=x0.device)
+        _lib.check(lib.amx_conv3d_backward_sampled(_lib.ptr(grows), _lib.ptr(coords), _lib.ptr(x0), xc, _lib.ptr(wt), n, p, d, h, w, cout,
+                                                   cin_real, _lib.ptr(dw), _lib.ptr(din), xc, _lib.ptr(sc), nb, _PREC[x0.dtype],
+                                                   _st(x0.device)))
+    return dw, din
+
+
 def import_input(x, dtype):
     """fp32 [N, Cin <= 16, D, H, W] -> 16-bit channels-last [N, D, H, W, 16] (real channels first, the rest zero) in one pass."""
     lib = _lib.load()

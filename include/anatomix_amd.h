@@ -468,6 +468,19 @@ int amx_mlp_head_backward(const float* d_dy, const float* d_x, int n, int cin, i
                           const float* d_y, const float* d_mean, const float* d_rstd, float* const* dw, float* const* dgamma,
                           float* const* dbeta, float* d_dx, void* d_scratch, size_t scratch_bytes, void* stream);
 
+/* Backward of a k3 reflect convolution whose output gradient is nonzero only at p sampled voxels per sample -- the contrastive step
+ * taps the output conv (module 65) at 512 voxels and nothing else reads the network's output (supcl_model.py:801-843): d_grows fp32
+ * [n][p][cout] at d_coords int64 [p][3]; d_x the conv's 16-bit channels-last input [n][d][h][w][x_channels]; d_w fp32
+ * [cout][cin][27].  d_dw fp32 [cout][cin][27] is written; d_din (optional) is a ZERO-FILLED 16-bit [n][d][h][w][din_channels] tensor
+ * that receives the data gradient at the <= 27 p voxels per sample it is nonzero at.  Same rounding points as scatter_rows + the dense
+ * weight / data gradient (rows rounded to the storage type, 16-bit weights in the data gradient, fp32 sums, one rounding), fixed
+ * summation order.  cout, cin <= 16.  d_scratch: amx_conv3d_backward_sampled_scratch_bytes(p) bytes (neighbour masks of the samples,
+ * partial weight-gradient sums). */
+size_t amx_conv3d_backward_sampled_scratch_bytes(int p);
+int amx_conv3d_backward_sampled(const float* d_grows, const long long* d_coords, const void* d_x, int x_channels, const float* d_w, int n,
+                                int p, int d, int hh, int w, int cout, int cin, float* d_dw, void* d_din, int din_channels, void* d_scratch,
+                                size_t scratch_bytes, int precision, void* stream);
+
 /* The heads and losses of ONE contrastive step as batches (supcl_model.py:801-843 walks the nce layers one by one; the chains are
  * independent and identical in structure).  A replayed HIP graph pays per DEPENDENT node, not per byte: n_heads chains of ~30 small
  * launches each become one chain whose every launch serves all heads (<= 8; same rows n, same width, same depth; own input widths

@@ -304,3 +304,36 @@ def test_import_input_pads_to_sixteen_channels(device, prec, cin):
     want = torch.zeros(2, 6, 10, 20, 16, dtype=dt, device=device)
     want[..., :cin] = x.permute(0, 2, 3, 4, 1).to(dt)
     assert got.shape == want.shape and got.dtype == dt and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("size,cin,cout,views,patches", [((8, 12, 16), 16, 16, 2, 64), ((6, 6, 6), 16, 5, 1, 200), ((16, 16, 32), 9, 16, 2, 512)])
+def test_sampled_output_conv_backward_equals_the_dense_route(device, prec, size, cin, cout, views, patches):
+    """amx_conv3d_backward_sampled (the output conv tapped at sampled voxels only) against the dense route it replaces: rows
+    scattered into a zero gradient volume, dense weight gradient, dense data gradient + reflect fold.  Same rounding points; the sums
+    run in another order (weight gradient: fp32 noise) and the data gradient is rounded once where the dense route rounds the padded
+    domain and the fold separately (voxels next to a face; neighbourhoods of many samples overlap at these small sizes on purpose)."""
+    dt = DT[prec]
+    g = torch.Generator().manual_seed(sum(size) + cin + cout)
+    d, h, w = size
+    nvox = d * h * w
+    flat = torch.randperm(nvox, generator=g)[:patches]
+    coords = torch.stack([flat // (h * w), (flat // w) % h, flat % w], 1).to(device)
+    x0 = torch.zeros((views, d, h, w, 16), dtype=dt, device=device)
+    x0[..., :cin] = torch.randn(views, d, h, w, cin, generator=g).to(dt).to(device)
+    wt = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).to(device)
+    rows = torch.randn(views, patches, cout, generator=g).to(device)
+    dw, din = T.conv_backward_sampled(rows, coords, x0, wt, cin)
+    dw2, din2 = T.conv_backward_sampled(rows, coords, x0, wt, cin)
+    assert torch.equal(dw, dw2) and torch.equal(din, din2)                    # fixed order, benign duplicate writes
+    cpad = (cout + 15) // 16 * 16
+    fr = T.new_framed(views, d, h, w, cpad, dt, device)
+    T.scatter_rows(rows, coords, T.interior(fr), accumulate=True)
+    dw_d = T.conv_wgrad(fr, x0, None, cin, cpad)[:cout]
+    din_d = T.pad_fold(T.conv_dgrad_framed(fr, torch.cat([wt, wt.new_zeros(cpad - cout, cin, 3, 3, 3)]) if cpad != cout else wt))
+    assert rel_l2(dw.cpu().double(), dw_d.cpu().double()) < 1e-6
+    a, b = din[..., :cin].float().cpu(), din_d[..., :cin].float().cpu()
+    assert rel_l2(a.double(), b.double()) < 2 * ULP[prec]
+    assert not din[..., cin:].any()
+    zero_d = (b == 0).all(-1)
+    assert torch.equal((a == 0).all(-1) | ~zero_d, torch.ones_like(zero_d))    # nothing written where the dense gradient is zero
