@@ -166,6 +166,14 @@ def _sampled_route(netG, netF, reals, nce_layers, num_patches):
     if not (_SAMPLED_TAPS and isinstance(netG, Unet) and type(netF) is PatchSampleF and reals.is_cuda and num_patches > 0 and
             torch.is_grad_enabled() and layers == sorted(set(layers)) and not getattr(netG, "allow_torch_path", False)):
         return None
+    # the route calls the training Function directly: only where Unet.forward would have routed the call there itself (network.py
+    # forward: batch statistics or autograd through an instance-norm network) and nobody hooked the module's __call__
+    if netG._forward_hooks or netG._forward_pre_hooks:
+        return None
+    wants_grad = reals.requires_grad or any(p.requires_grad for p in netG.parameters())
+    norm = netG._cfg["norm"]
+    if not ((norm == "batch" and (netG.training or wants_grad)) or (norm in ("instance", "instance_affine") and wants_grad)):
+        return None
     try:
         if _train.sampled_unsupported_reason(netG, reals, layers) is not None:
             return None
@@ -422,9 +430,14 @@ class GraphedContrastiveStep:
         if first:
             self._capture(real_A, real_B, seg_A)
         else:
-            self.A.copy_(real_A)
-            self.B.copy_(real_B)
-            self.seg.copy_(seg_A)
+            # one launch for the three static input buffers (three eager copies were three host-paced launches in front of every replay)
+            srcs = [real_A, real_B, seg_A]
+            dsts = [self.A, self.B, self.seg]
+            if all(t.is_cuda and t.device == d.device and t.dtype == d.dtype and t.shape == d.shape for t, d in zip(srcs, dsts)):
+                torch._foreach_copy_(dsts, srcs)
+            else:
+                for d, t in zip(dsts, srcs):
+                    d.copy_(t)
         # optimizer.step() does not run on a replay: hand the CURRENT param_groups values (lr schedulers change them every epoch,
         # base_model.py update_learning_rate) to the captured step through the optimizers' host mirrors
         for opt in self.optimizers or ():

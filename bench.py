@@ -291,7 +291,7 @@ def step_roofline(torch, dev, S):
     flops = 2.0 * 27 * 48 * 16 * n * S ** 3
     bytes_ = 2.0 * n * S ** 3 * (16 + 16) + 2.0 * n * (S // 2) ** 3 * 32 + 4.0 * 27 * 48 * 16
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv3d_wgrad<bf16> + wgrad_reduce, 16||up32 -> 16 @%d^3 x %d views" % (S, n),
+    return {"bound": "mfma", "kernel": "conv3d_wgrad_tr<bf16,8x64x1> + wgrad_reduce, 16||up32 -> 16 @%d^3 x %d views" % (S, n),
             "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
             "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}

@@ -593,3 +593,20 @@ def test_sampled_tap_route_is_bit_identical_to_the_dense_tap_route(device, monke
         # (bf16 storage: the bounds of test_backward_matches_the_rounding_point_emulation -- the d gamma / d beta sums cancel)
         assert e < (1e-5 if k == last else {"conv": 1.5e-2, "norm": 0.15, "head": 1e-5}[kind]), (k, e)
     print("sampled+rows vs sampled: worst relative gradient difference", worst)
+
+
+def test_sampled_route_is_only_taken_where_forward_would_route_to_the_training_function(device):
+    """contrastive_step's sampled-tap route calls the training Function directly; it must stand back where ``netG(...)`` would not have
+    gone there (eval mode with every parameter frozen: the inference path) and where someone hooked the module's __call__."""
+    from anatomix_amd.pretraining import step as ST
+    netG, netF, crits, (vA, vB, seg) = _step_setup(device, "bf16", 32)
+    reals = torch.cat((vA, vB), 0)
+    assert ST._sampled_route(netG, netF, reals, PI.NCE_LAYERS, 512) is not None
+    h = netG.register_forward_hook(lambda m, i, o: None)
+    assert ST._sampled_route(netG, netF, reals, PI.NCE_LAYERS, 512) is None
+    h.remove()
+    assert ST._sampled_route(netG, netF, reals, PI.NCE_LAYERS, 512) is not None
+    netG.eval()
+    for p in netG.parameters():
+        p.requires_grad_(False)
+    assert ST._sampled_route(netG, netF, reals, PI.NCE_LAYERS, 512) is None
