@@ -28,6 +28,7 @@ _DT = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "b
 
 
 OVERLAP_WGRAD = _lib.exp_env("AMX_NO_OVERLAP_WGRAD", "0") != "1"   # weight gradients on a side stream, beside the data gradient of the same block
+OVERLAP_WGRAD_MIN_W = int(_lib.exp_env("AMX_OVERLAP_WGRAD_MIN_W", "32"))   # ... of blocks at least this wide (narrower: the two joins cost what the overlap returns; 6.41 -> 6.37 ms)
 RECOMPUTE_ACT = _lib.exp_env("AMX_BN_BWD_RECOMPUTE", "1") != "0"      # norm adjoint: sign of the activation's argument from x, y not read
 SPLIT_CONCAT_DGRAD = int(_lib.exp_env("AMX_SPLIT_CONCAT_DGRAD", "1"))      # 1: the 48 -> 16 layer's data gradient as two z-march launches; 2: every concat layer
 FUSED_FOLD_SPLIT = _lib.exp_env("AMX_FUSED_FOLD_SPLIT", "1") != "0"   # concat layers: pad_fold + channel split + child sum in one pass
@@ -487,7 +488,7 @@ class _UnetTrainFn(torch.autograd.Function):
             # block touches a framed buffer (they are shared per shape).  Letting it also run beside the next block's BatchNorm
             # adjoint (second frame per shape + events) measured slower: 11.4 vs 10.7 ms per step in round 2, and again 9.04 vs 8.71 ms in
             # round 3 with the one-round weight-gradient launches (the two MFMA kernels contend; the adjoint passes lose more than the join costs).
-            if OVERLAP_WGRAD and x0.is_cuda:
+            if OVERLAP_WGRAD and x0.is_cuda and w >= OVERLAP_WGRAD_MIN_W:
                 dw = torch.empty((blk["cout"], blk["cin"], 3, 3, 3), dtype=torch.float32, device=x0.device)
                 T.wgrad_scratch(x0, x1, blk["cout"])                   # make sure the cached scratch exists (allocated here)
                 side = _side_stream(x0.device)
