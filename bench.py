@@ -294,7 +294,23 @@ def step_roofline(torch, dev, S):
     return {"bound": "mfma", "kernel": "conv3d_wgrad_tr<bf16,8x64x1> + wgrad_reduce, 16||up32 -> 16 @%d^3 x %d views" % (S, n),
             "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
-            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
+            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": wgrad_traffic(S, n)}
+
+
+def wgrad_traffic(S, n):
+    """HBM bytes per launch of the step's dominant kernel from the committed PMC summary (tools/wgrad_traffic.sh: FETCH_SIZE / WRITE_SIZE
+    in separate rocprofv3 passes, read side doubled as MI355X_MICROARCH.md prescribes); None when no summary matches the shape."""
+    import glob
+    key = "conv3d_wgrad_tr<bf16,8x64x1> 16||up32->16 @%d^3 x%d" % (S, n)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*wgrad_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if key in d:
+            return {"bytes_per_launch": d[key]["traffic"], "read": d[key]["read_corrected"], "write": d[key]["write"],
+                    "source": "profiles/" + os.path.basename(f)}
+    return None
 
 
 def parity_vs_split(torch, ctx, variant, precision, x, y):
@@ -443,7 +459,23 @@ def vit_roofline(ctx, model, batch):
                                        "the PV product), %d tokens x %d heads x %d" % (n, att.num_heads, att.head_dim),
             "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms * 1e3, 1), "flops_per_launch": flops, "bytes_per_launch": bytes_,
-            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": None}
+            "alg_intensity_flop_per_byte": round(flops / bytes_, 1), "traffic": wgrad_traffic(S, n)}
+
+
+def wgrad_traffic(S, n):
+    """HBM bytes per launch of the step's dominant kernel from the committed PMC summary (tools/wgrad_traffic.sh: FETCH_SIZE / WRITE_SIZE
+    in separate rocprofv3 passes, read side doubled as MI355X_MICROARCH.md prescribes); None when no summary matches the shape."""
+    import glob
+    key = "conv3d_wgrad_tr<bf16,8x64x1> 16||up32->16 @%d^3 x%d" % (S, n)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*wgrad_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if key in d:
+            return {"bytes_per_launch": d[key]["traffic"], "read": d[key]["read_corrected"], "write": d[key]["write"],
+                    "source": "profiles/" + os.path.basename(f)}
+    return None
 
 
 def sliding_window_parity(torch, y, vol, S, variant):
