@@ -14,7 +14,7 @@
 // (History: channels-last tiles and 16-bit gathers, 98 LDS reads + ~140 VALU per 27 MFMAs; then tiles transposed at staging with
 // 32-bit LDS writes, a z-ring and a two-deep register prefetch -- 6000 cycles per 512-voxel item whatever the layer, because the
 // register copy of the prefetch forced `vmcnt(0)` every item and the transposed writes cost as much LDS time as the sweep.  The form
-// below: 1028 -> 764 us over the 13 conv shapes of the 6 M UNet's step, every shape faster, tools/wgrad_layers.py.)
+// below: 1028 -> 685 us over the 13 conv shapes of the 6 M UNet's step, every shape faster, tools/wgrad_layers.py.)
 #include <stdlib.h>
 
 #include "amx_device.h"
@@ -27,7 +27,8 @@ namespace amx {
 // ds_write) by two loader waves, and the MFMA operands (8 consecutive voxels of one channel per lane) are formed by the
 // LDS itself: a 16-lane group that points its lanes at the four 8-byte channel quads of four consecutive voxels (128
 // contiguous bytes) receives channel (lane & 15) of those four voxels (checked in tools/ubench/tr_read_check.hip).  Per
-// K-block (32 voxels x 27 taps): 2 reads for dY, 4 reads per (kz, ky) for the input, 27 MFMAs.
+// K-block (32 voxels x 27 taps): 2 reads for dY, 4 reads per (kz, ky) for the input, 27 MFMAs; a wave's two K-blocks are
+// vertically adjacent rows and share their halo reads where the geometry allows (W > 16).
 //   * bank conflicts: the two groups served together (lanes 0-31) must lie in different 128-byte halves of the 256-byte
 //     bank row; with 8 voxels (256 B) per group they would not, so the 128-byte blocks of a row are stored swizzled,
 //     position = block ^ ((block >> 1) & 1) -- free: the DMA lane that fills a position simply fetches the swizzled source;
@@ -50,6 +51,7 @@ struct WtCfg {
   static constexpr int XBN = TX >= 32 ? TX / 32 : 1;                 // K-blocks side by side in x
   static constexpr int NKB = TY * TX / 32;                           // K-blocks per plane
   static constexpr int KPW = (G * NKB + 7) / 8;                      // K-blocks per MFMA wave and item
+  static constexpr bool SHARE = TX >= 32 && G == 1 && NKB == 16;     // a wave's two K-blocks are rows r0, r0 + 1 of one x block: shared halo rows
   static constexpr int IRB = TX == 8 ? 5 : TX / 4 + 1;               // 128-byte blocks per halo row (odd for TX = 8: groups in different rows)
   static constexpr int DRB = TX == 8 ? 3 : TX / 4;
   static constexpr int NDI = ((TY + 2) * IRB * 128 + 1023) / 1024;   // DMA instructions (1 KiB each) per input plane
@@ -231,6 +233,56 @@ __global__ __launch_bounds__(640) void conv3d_wgrad_tr_kernel(const WgradParams 
         asm volatile("" ::: "memory");
         // A fragments and ring offsets of the wave's K-blocks first, then their 9 rows each (a row = one (kz, ky): four reads, four
         // v_alignbit, three MFMAs; the order of reads and MFMAs is the scheduler's -- pinning the reads two rows ahead measured slower).
+        if constexpr (C::SHARE) {
+          // rows r0, r0 + 1 of one x block: the four halo rows r0 .. r0 + 3 of a kz are read ONCE and feed both rows (row r0 takes
+          // halo row hr as ky = hr, row r0 + 1 as ky = hr - 1): 16 reads + 16 v_alignbit per 18 MFMAs instead of 24 + 24
+          const int xb = wave % C::XBN, r0 = (wave / C::XBN) * 2, zl = it;
+          vec8 afr[2];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const unsigned ab = (zl % RD) * DSZ + ((r0 + rr) * DRB + 8 * xb) * 128;
+            amx_u32x2 a0 = lds_read_tr16(dyP + ab), a1 = lds_read_tr16(dyQ + ab);
+            if (ragged) {
+              const bool rowok = y0 + r0 + rr < p.H;
+              const int xv = x0 + xb * 32 + gx * 8;
+              unsigned m[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                m[e] = rowok ? ((xv + 2 * e < p.W ? 0xffffu : 0u) | (xv + 2 * e + 1 < p.W ? 0xffff0000u : 0u)) : 0u;
+              a0[0] &= m[0]; a0[1] &= m[1]; a1[0] &= m[2]; a1[1] &= m[3];
+            }
+            const unsigned av[4] = {a0[0], a0[1], a1[0], a1[1]};
+            afr[rr] = __builtin_bit_cast(vec8, av);
+          }
+          if (!(AMX_WT_DBG & 1)) {
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) {
+              const unsigned o = ((zl + kz) % RI) * ISZ + (r0 * IRB + 8 * xb) * 128;
+              const unsigned vP = inP + o, vQ = inQ + o, vP2 = inP2 + o, vQ2 = inQ2 + o;
+#pragma unroll
+              for (int hr = 0; hr < 4; ++hr) {
+                const amx_u32x2 P_ = lds_read_tr16(vP + hr * IRB * 128), Q_ = lds_read_tr16(vQ + hr * IRB * 128);
+                const amx_u32x2 P2 = lds_read_tr16(vP2 + hr * IRB * 128), Q2 = lds_read_tr16(vQ2 + hr * IRB * 128);
+                const unsigned b0[4] = {P_[0], P_[1], Q_[0], Q_[1]};
+                const unsigned b1[4] = {__builtin_amdgcn_alignbit(P_[1], P_[0], 16), __builtin_amdgcn_alignbit(Q_[0], P_[1], 16),
+                                        __builtin_amdgcn_alignbit(Q_[1], Q_[0], 16), __builtin_amdgcn_alignbit(Q2[1], Q_[1], 16)};
+                const unsigned b2[4] = {P2[0], P2[1], Q2[0], Q2[1]};
+                if (hr < 3) {
+                  const int t0 = (kz * 3 + hr) * 3;
+                  acc[t0] = Ops<T>::mfma(afr[0], __builtin_bit_cast(vec8, b0), acc[t0]);
+                  acc[t0 + 1] = Ops<T>::mfma(afr[0], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+                  acc[t0 + 2] = Ops<T>::mfma(afr[0], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+                }
+                if (hr > 0) {
+                  const int t0 = (kz * 3 + hr - 1) * 3;
+                  acc[t0] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b0), acc[t0]);
+                  acc[t0 + 1] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+                  acc[t0 + 2] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+                }
+              }
+            }
+          }
+        } else {
         vec8 af[C::KPW];
         unsigned ibs[C::KPW][3];
         bool any = false;
@@ -280,6 +332,7 @@ __global__ __launch_bounds__(640) void conv3d_wgrad_tr_kernel(const WgradParams 
                 acc[t0 + 2] = Ops<T>::mfma(af[t], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
               }
             }
+        }
         }
         asm volatile("" ::: "memory");                              // LDS serves a wave's accesses in order: the flag lands behind the reads
         if (lane == 0) flag_store(done + wave, Sbase + it + 1);
