@@ -377,6 +377,9 @@ class GraphedContrastiveStep:
         # bound to the stream of those steps (usually the default stream, which cannot join a capture): collect them first
         gc.collect()
         self.A, self.B, self.seg = real_A.clone(), real_B.clone(), seg_A.clone()
+        if all(t.is_cuda for t in (real_A, real_B, seg_A)):
+            # (loads the multi-tensor copy kernel now: its first use would otherwise be the first replayed step, ~30 ms late)
+            torch._foreach_copy_([self.A, self.B, self.seg], [real_A, real_B, seg_A])
         side = torch.cuda.Stream(device=self.A.device)
         side.wait_stream(torch.cuda.current_stream(self.A.device))
         with torch.cuda.stream(side):
