@@ -41,9 +41,9 @@ namespace amx {
 //     neighbouring tiles' shared halo rows and a chunk's dY (read once per cin tile) meet in one L2, and no XCD is handed
 //     more than its 32 workgroups (one per compute unit).
 // Geometry by row width: (TY, TX, G) = (8, 64, 1) for W > 32, (16, 32, 1), (16, 16, 2), (8, 8, 4) for W <= 8.
-// Measured (tools/wgrad_ab.sh, 16 -> 16 @128^3 x 2, 72 us): DMA alone 50 us, MFMA sweep alone 65 us, neither (launch, flags, the
-// cross-wave sum, the reduce launch) 22 us; the sweep runs at 54 % MFMA-busy, paced by the per-wave issue rate (7 instructions per
-// MFMA), zero bank conflicts (SQ_LDS_BANK_CONFLICT).
+// Measured (tools/wgrad_ab.sh, 16 -> 16 @128^3 x 2, 66-70 us): DMA alone 50 us, MFMA sweep alone 58 us, neither (launch, flags, the
+// cross-wave sum, the reduce launch) 22 us; the sweep runs at 64 % MFMA-busy, paced by the per-wave issue rate (~6 instructions per
+// MFMA), zero bank conflicts (SQ_LDS_BANK_CONFLICT); counter traffic 1.09x the algorithmic bytes (tools/wgrad_traffic.sh).
 template <int TY_, int TX_, int G_>
 struct WtCfg {
   static constexpr int TY = TY_, TX = TX_, G = G_;
