@@ -52,6 +52,7 @@ struct WtCfg {
   static constexpr int NKB = TY * TX / 32;                           // K-blocks per plane
   static constexpr int KPW = (G * NKB + 7) / 8;                      // K-blocks per MFMA wave and item
   static constexpr bool SHARE = TX >= 32 && G == 1 && NKB == 16;     // a wave's two K-blocks are rows r0, r0 + 1 of one x block: shared halo rows
+  static constexpr bool SHAREZ = TX == 16 && G == 2 && NKB == 8;     // ... the same rows of planes z, z + 1: shared input planes
   static constexpr int IRB = TX == 8 ? 5 : TX / 4 + 1;               // 128-byte blocks per halo row (odd for TX = 8: groups in different rows)
   static constexpr int DRB = TX == 8 ? 3 : TX / 4;
   static constexpr int NDI = ((TY + 2) * IRB * 128 + 1023) / 1024;   // DMA instructions (1 KiB each) per input plane
@@ -278,6 +279,59 @@ __global__ __launch_bounds__(640) void conv3d_wgrad_tr_kernel(const WgradParams 
                   acc[t0] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b0), acc[t0]);
                   acc[t0 + 1] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
                   acc[t0 + 2] = Ops<T>::mfma(afr[1], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+                }
+              }
+            }
+          }
+        } else if constexpr (C::SHAREZ) {
+          // the same K-block (two rows of 16) in planes z, z + 1 of the item: input planes z - 1 .. z + 2 are read once and feed both
+          // (plane offset u is kz = u for plane z, kz = u - 1 for plane z + 1)
+          const int r = wave * C::RSPAN, zl0 = it * G;
+          const bool two = zl0 + 1 < nz;                            // (wave-uniform; a last odd plane has no partner)
+          vec8 afz[2];
+#pragma unroll
+          for (int pz = 0; pz < 2; ++pz) {
+            const int zl = two ? zl0 + pz : zl0;
+            const unsigned ab = (zl % RD) * DSZ + (r * DRB) * 128;
+            amx_u32x2 a0 = lds_read_tr16(dyP + ab), a1 = lds_read_tr16(dyQ + ab);
+            if (ragged) {
+              const bool rowok = y0 + r + gr < p.H;
+              const int xv = x0 + gx * 8;
+              unsigned m[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                m[e] = rowok ? ((xv + 2 * e < p.W ? 0xffffu : 0u) | (xv + 2 * e + 1 < p.W ? 0xffff0000u : 0u)) : 0u;
+              a0[0] &= m[0]; a0[1] &= m[1]; a1[0] &= m[2]; a1[1] &= m[3];
+            }
+            const unsigned vm = (pz == 0 || two) ? 0xffffffffu : 0u;
+            const unsigned av[4] = {a0[0] & vm, a0[1] & vm, a1[0] & vm, a1[1] & vm};
+            afz[pz] = __builtin_bit_cast(vec8, av);
+          }
+          if (!(AMX_WT_DBG & 1)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (u == 3 && !two) continue;                         // plane z + 2 has not been loaded for a lone last plane
+              const unsigned o = ((zl0 + u) % RI) * ISZ + (r * IRB) * 128;
+              const unsigned vP = inP + o, vQ = inQ + o, vP2 = inP2 + o, vQ2 = inQ2 + o;
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky) {
+                const amx_u32x2 P_ = lds_read_tr16(vP + ky * IRB * 128), Q_ = lds_read_tr16(vQ + ky * IRB * 128);
+                const amx_u32x2 P2 = lds_read_tr16(vP2 + ky * IRB * 128), Q2 = lds_read_tr16(vQ2 + ky * IRB * 128);
+                const unsigned b0[4] = {P_[0], P_[1], Q_[0], Q_[1]};
+                const unsigned b1[4] = {__builtin_amdgcn_alignbit(P_[1], P_[0], 16), __builtin_amdgcn_alignbit(Q_[0], P_[1], 16),
+                                        __builtin_amdgcn_alignbit(Q_[1], Q_[0], 16), __builtin_amdgcn_alignbit(Q2[1], Q_[1], 16)};
+                const unsigned b2[4] = {P2[0], P2[1], Q2[0], Q2[1]};
+                if (u < 3) {
+                  const int t0 = (u * 3 + ky) * 3;
+                  acc[t0] = Ops<T>::mfma(afz[0], __builtin_bit_cast(vec8, b0), acc[t0]);
+                  acc[t0 + 1] = Ops<T>::mfma(afz[0], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+                  acc[t0 + 2] = Ops<T>::mfma(afz[0], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
+                }
+                if (u > 0) {
+                  const int t0 = ((u - 1) * 3 + ky) * 3;
+                  acc[t0] = Ops<T>::mfma(afz[1], __builtin_bit_cast(vec8, b0), acc[t0]);
+                  acc[t0 + 1] = Ops<T>::mfma(afz[1], __builtin_bit_cast(vec8, b1), acc[t0 + 1]);
+                  acc[t0 + 2] = Ops<T>::mfma(afz[1], __builtin_bit_cast(vec8, b2), acc[t0 + 2]);
                 }
               }
             }
